@@ -1,0 +1,113 @@
+"""ctypes binding of libfovraster_hip.so (C ABI declared in include/fovraster.h).
+
+There is NO CPU fallback: if the HIP library is missing or cannot be loaded, every rasterizer
+call raises. Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C fov-3dgs_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfovraster_hip.so")
+ABI_VERSION = 1
+
+VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
+STAGES = ("tile_levels", "preprocess", "tile_scan", "emit", "tile_sort", "render")
+VARIANT_IDS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3}
+
+RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+_FP = C.c_void_p  # device pointers are passed as raw addresses
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32),
+        ("W", C.c_int32), ("H", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("gaze_x", C.c_float), ("gaze_y", C.c_float), ("alpha", C.c_float),
+        ("stream", C.c_void_p),
+        ("background", _FP), ("means3D", _FP), ("shs", _FP), ("colors_precomp", _FP), ("opacities", _FP),
+        ("scales", _FP), ("rotations", _FP), ("cov3D_precomp", _FP), ("viewmatrix", _FP), ("projmatrix", _FP),
+        ("campos", _FP), ("shs_dcs", _FP), ("highest_levels", _FP),
+        ("out_color", _FP), ("radii", _FP), ("gaussians_count", _FP), ("contributions", _FP),
+        ("geometry_resize", RESIZE_FN), ("binning_resize", RESIZE_FN), ("image_resize", RESIZE_FN),
+        ("resize_user", C.c_void_p * 3),
+        ("num_rendered", C.c_int32), ("max_tile_instances", C.c_int32),
+        ("stage_ms", C.POINTER(C.c_float)),
+    ]
+
+
+class BackwardArgs(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("R", C.c_int32),
+        ("W", C.c_int32), ("H", C.c_int32), ("debug", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("stream", C.c_void_p),
+        ("background", _FP), ("means3D", _FP), ("shs", _FP), ("colors_precomp", _FP), ("opacities", _FP),
+        ("scales", _FP), ("rotations", _FP), ("cov3D_precomp", _FP), ("viewmatrix", _FP), ("projmatrix", _FP),
+        ("campos", _FP),
+        ("radii", _FP), ("geometry", _FP), ("binning", _FP), ("image", _FP), ("dL_dpix", _FP),
+        ("dL_dmean2D", _FP), ("dL_dconic", _FP), ("dL_dopacity", _FP), ("dL_dcolor", _FP), ("dL_dmean3D", _FP),
+        ("dL_dcov3D", _FP), ("dL_dsh", _FP), ("dL_dscale", _FP), ("dL_drot", _FP),
+        ("stage_ms", C.POINTER(C.c_float)),
+    ]
+
+
+EXPORTS = ("fr_abi_version", "fr_last_error", "fr_forward", "fr_backward", "fr_mark_visible",
+           "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
+           "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels")
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the HIP library; raise NativeLibraryError if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"fovraster: {LIB_PATH} not found -- the HIP extension is not built and there is no CPU fallback. "
+            "Run `make -C fov-3dgs_amd/csrc` (or __graft_entry__.build()).")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime, wrong arch, ...
+        raise NativeLibraryError(f"fovraster: cannot load {LIB_PATH}: {e}") from e
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise NativeLibraryError(f"fovraster: {LIB_PATH} does not export {name}")
+    lib.fr_abi_version.restype = C.c_int
+    lib.fr_last_error.restype = C.c_char_p
+    lib.fr_forward.argtypes = [C.POINTER(ForwardArgs)]
+    lib.fr_forward.restype = C.c_int
+    lib.fr_backward.argtypes = [C.POINTER(BackwardArgs)]
+    lib.fr_backward.restype = C.c_int
+    lib.fr_mark_visible.argtypes = [C.c_int32, _FP, _FP, _FP, _FP, C.c_void_p]
+    lib.fr_mark_visible.restype = C.c_int
+    for n in ("fr_geometry_bytes",):
+        getattr(lib, n).argtypes = [C.c_int32, C.c_int32]
+        getattr(lib, n).restype = C.c_size_t
+    lib.fr_image_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.fr_image_bytes.restype = C.c_size_t
+    lib.fr_binning_bytes.argtypes = [C.c_int32, C.c_int64]
+    lib.fr_binning_bytes.restype = C.c_size_t
+    for n in ("fr_image_ranges", "fr_image_final_T", "fr_image_n_contrib"):
+        getattr(lib, n).argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        getattr(lib, n).restype = C.c_void_p
+    lib.fr_binning_point_list.argtypes = [C.c_int32, C.c_int64, C.c_void_p]
+    lib.fr_binning_point_list.restype = C.c_void_p
+    lib.fr_image_tile_levels.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+    lib.fr_image_tile_levels.restype = C.c_void_p
+    if lib.fr_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"fovraster: ABI version mismatch ({lib.fr_abi_version()} != {ABI_VERSION})")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().fr_last_error().decode("utf-8", "replace")

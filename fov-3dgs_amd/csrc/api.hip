@@ -1,0 +1,178 @@
+// extern "C" entry points of libfovraster_hip.so (see include/fovraster.h for the contract and
+// for the reference interfaces each one replaces).
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace fr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+int check_launch(const char *what, hipStream_t stream, bool debug)
+{
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess && debug) e = hipStreamSynchronize(stream);
+	if (e != hipSuccess)
+	{
+		set_error("%s: %s", what, hipGetErrorString(e));
+		return FR_ERR_HIP;
+	}
+	return FR_OK;
+}
+
+#define FR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s: %s", #call, hipGetErrorString(e_)); return FR_ERR_HIP; } } while (0)
+
+static int validate_forward(const fr_forward_args *a)
+{
+	if (!a) { set_error("null args"); return FR_ERR_INVALID; }
+	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_FOV_PCHECK_OBB) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
+	if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return FR_ERR_INVALID; }
+	if (!a->out_color) { set_error("out_color is null"); return FR_ERR_INVALID; }
+	if (a->P == 0) return FR_OK;
+	if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->campos || !a->background || !a->radii)
+	{ set_error("a required pointer is null"); return FR_ERR_INVALID; }
+	if (!a->geometry_resize || !a->binning_resize || !a->image_resize) { set_error("resize callbacks are required"); return FR_ERR_INVALID; }
+	const bool fov = a->variant == FR_VARIANT_FOV_PCHECK_OBB;
+	if (fov)
+	{
+		if (!a->shs || !a->shs_dcs || !a->highest_levels) { set_error("foveated variant needs shs (rest), shs_dcs and highest_levels"); return FR_ERR_INVALID; }
+		if (a->M != 15) { set_error("foveated variant expects M=15 rest coefficients, got %d", a->M); return FR_ERR_INVALID; }
+	}
+	else
+	{
+		if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) { set_error("provide exactly one of shs / colors_precomp"); return FR_ERR_INVALID; }
+		if (a->shs && a->M < (a->D + 1) * (a->D + 1)) { set_error("M=%d too small for SH degree %d", a->M, a->D); return FR_ERR_INVALID; }
+	}
+	if (a->D < 0 || a->D > 3) { set_error("SH degree %d not in 0..3", a->D); return FR_ERR_INVALID; }
+	const bool has_sr = a->scales && a->rotations;
+	if (has_sr == (a->cov3D_precomp != nullptr)) { set_error("provide exactly one of scales+rotations / cov3D_precomp"); return FR_ERR_INVALID; }
+	if (a->variant == FR_VARIANT_PCHECK_OBB_SUM && (!a->gaussians_count || !a->contributions)) { set_error("pcheck_obb_sum needs gaussians_count and contributions"); return FR_ERR_INVALID; }
+	return FR_OK;
+}
+
+} // namespace fr
+
+using namespace fr;
+
+extern "C" {
+
+int fr_abi_version(void) { return FR_ABI_VERSION; }
+const char *fr_last_error(void) { return g_err; }
+
+size_t fr_geometry_bytes(int32_t variant, int32_t P) { return carve_geom(variant, (size_t)P, nullptr).bytes; }
+size_t fr_image_bytes(int32_t variant, int32_t W, int32_t H) { return carve_image(variant, W, H, nullptr).bytes; }
+size_t fr_binning_bytes(int32_t variant, int64_t n) { (void)variant; return carve_bin(n, nullptr).bytes; }
+
+const uint32_t *fr_image_ranges(int32_t variant, int32_t W, int32_t H, const char *image) { return (const uint32_t *)carve_image(variant, W, H, (char *)image).ranges; }
+const uint32_t *fr_binning_point_list(int32_t variant, int64_t n, const char *binning) { (void)variant; return carve_bin(n, (char *)binning).point_list; }
+const float *fr_image_final_T(int32_t variant, int32_t W, int32_t H, const char *image) { return carve_image(variant, W, H, (char *)image).final_T; }
+const uint32_t *fr_image_n_contrib(int32_t variant, int32_t W, int32_t H, const char *image) { return carve_image(variant, W, H, (char *)image).n_contrib; }
+const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image) { return carve_image(FR_VARIANT_FOV_PCHECK_OBB, W, H, (char *)image).tile_lv; }
+
+int fr_forward(fr_forward_args *a)
+{
+	int rc = validate_forward(a);
+	if (rc) return rc;
+	hipStream_t stream = (hipStream_t)a->stream;
+	a->num_rendered = 0;
+	a->max_tile_instances = 0;
+	if (a->P == 0)
+	{
+		// reference: RasterizeGaussiansCUDA returns the zero-initialised image when P == 0
+		FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, stream));
+		return FR_OK;
+	}
+	// optional per-stage timing with events on the launch stream
+	hipEvent_t ev[FR_NUM_STAGES + 1];
+	bool have[FR_NUM_STAGES + 1] = { false };
+	const bool prof = a->stage_ms != nullptr;
+	auto mark = [&](int i) { if (prof) { if (hipEventCreate(&ev[i]) == hipSuccess && hipEventRecord(ev[i], stream) == hipSuccess) have[i] = true; } };
+	auto finish_prof = [&]() {
+		if (!prof) return;
+		hipStreamSynchronize(stream);
+		for (int i = 0; i < FR_NUM_STAGES; i++)
+		{
+			float ms = 0.f;
+			if (have[i] && have[i + 1]) hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+			a->stage_ms[i] = ms;
+		}
+		for (int i = 0; i <= FR_NUM_STAGES; i++) if (have[i]) hipEventDestroy(ev[i]);
+	};
+	FwdCtx c;
+	c.a = a; c.stream = stream;
+	c.gx = (a->W + FR_TILE - 1) / FR_TILE; c.gy = (a->H + FR_TILE - 1) / FR_TILE; c.T = c.gx * c.gy;
+	c.focal_y = a->H / (2.0f * a->tanfovy);
+	c.focal_x = a->W / (2.0f * a->tanfovx);
+
+	char *gptr = a->geometry_resize(a->resize_user[0], carve_geom(a->variant, (size_t)a->P, nullptr).bytes);
+	char *iptr = a->image_resize(a->resize_user[2], carve_image(a->variant, a->W, a->H, nullptr).bytes);
+	if (!gptr || !iptr) { set_error("geometry/image resize callback returned null"); return FR_ERR_ALLOC; }
+	c.geom = carve_geom(a->variant, (size_t)a->P, gptr);
+	c.img = carve_image(a->variant, a->W, a->H, iptr);
+
+	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, sizeof(uint32_t) * (size_t)c.T, stream));
+	if (a->variant == FR_VARIANT_PCHECK_OBB_SUM)
+	{
+		FR_HIP(hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, stream));
+		FR_HIP(hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, stream));
+	}
+	mark(FR_STAGE_TILE_LEVELS);
+	if (a->variant == FR_VARIANT_FOV_PCHECK_OBB) { rc = launch_tile_levels(c); if (rc) return rc; }
+	mark(FR_STAGE_PREPROCESS);
+	rc = launch_preprocess(c); if (rc) return rc;
+	mark(FR_STAGE_TILE_SCAN);
+	rc = launch_tile_scan(c); if (rc) return rc;
+	mark(FR_STAGE_EMIT);
+
+	// the one host synchronisation of a frame: how many instances must the binning buffer hold
+	uint32_t totals[2] = { 0, 0 };
+	FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
+	FR_HIP(hipStreamSynchronize(stream));
+	if (totals[0] > 0x7fffffffu) { set_error("too many instances (%u)", totals[0]); return FR_ERR_INVALID; }
+	a->num_rendered = (int32_t)totals[0];
+	a->max_tile_instances = (int32_t)totals[1];
+
+	char *bptr = a->binning_resize(a->resize_user[1], carve_bin(totals[0], nullptr).bytes);
+	if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }
+	c.bin = carve_bin(totals[0], bptr);
+	if (totals[0] > 0) { rc = launch_emit(c); if (rc) return rc; }
+	mark(FR_STAGE_TILE_SORT);
+	if (totals[0] > 0) { rc = launch_tile_sort(c, (int)totals[0], (int)totals[1]); if (rc) return rc; }
+	mark(FR_STAGE_RENDER);
+	rc = launch_render(c);
+	mark(FR_NUM_STAGES);
+	finish_prof();
+	return rc;
+}
+
+int fr_backward(const fr_backward_args *a)
+{
+	if (!a) { set_error("null args"); return FR_ERR_INVALID; }
+	if (a->variant != FR_VARIANT_ORIGINAL && a->variant != FR_VARIANT_PCHECK_OBB_SUM)
+	{ set_error("backward exists only for the original and pcheck_obb_sum variants (the reference's inference variants have none)"); return FR_ERR_INVALID; }
+	if (a->P == 0) return FR_OK;
+	if (!a->geometry || !a->image || (a->R > 0 && !a->binning) || !a->dL_dpix || !a->radii) { set_error("missing workspace / gradient pointer"); return FR_ERR_INVALID; }
+	if (!a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor || !a->dL_dmean3D || !a->dL_dcov3D || !a->dL_dscale || !a->dL_drot)
+	{ set_error("missing gradient output pointer"); return FR_ERR_INVALID; }
+	if (a->shs && !a->dL_dsh) { set_error("dL_dsh is null"); return FR_ERR_INVALID; }
+	return launch_backward(a);
+}
+
+int fr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present, void *stream)
+{
+	(void)projmatrix;
+	if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) { set_error("bad mark_visible arguments"); return FR_ERR_INVALID; }
+	if (P == 0) return FR_OK;
+	return launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+} // extern "C"

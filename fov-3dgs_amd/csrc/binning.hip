@@ -1,0 +1,162 @@
+// Tile binning: per-tile offsets from the per-tile counters, and the per-tile depth sort.
+//
+// Replaces (reference, paths under fov3dgs/submodules/diff-gaussian-rasterization*/cuda_rasterizer/):
+//   cub::DeviceScan::InclusiveSum over tiles_touched[P] + cudaMemcpy D2H   rasterizer_impl.cu:277-281
+//   cub::DeviceRadixSort::SortPairs over (tile<<32 | depth) keys           rasterizer_impl.cu:300-308
+//   cudaMemset(ranges) + identifyTileRanges                                rasterizer_impl.cu:116-138,310-317
+//
+// MI355X design: the reference sorts D 12-byte pairs by a 45-bit key with a 6-pass global LSD
+// radix sort (~152 B of HBM traffic per instance). Here instances were already bucketed by tile
+// at emission, so (a) tile ranges fall out of an exclusive scan over T (<= 8160) counters and
+// (b) each bucket is sorted independently by one workgroup inside the CU's 160 KiB LDS:
+// one 8-byte read and one 4-byte write per instance. The sort key is (depth bits << 32 | id),
+// which reproduces the order a stable sort of the reference's keys emitted in index order gives.
+#include "common.h"
+
+namespace fr {
+
+// Single workgroup: exclusive scan of tile_count[T] -> ranges, reset the counters to serve as
+// emission cursors, publish {total, max}.
+__global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals)
+{
+	__shared__ uint32_t wave_sum[16];
+	__shared__ uint32_t carry_s;
+	__shared__ uint32_t wave_max[16];
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	if (tid == 0) carry_s = 0;
+	uint32_t vmax = 0;
+	__syncthreads();
+	for (int base = 0; base < T; base += 1024)
+	{
+		const int i = base + tid;
+		const uint32_t v = i < T ? tile_count[i] : 0u;
+		vmax = max(vmax, v);
+		// inclusive scan inside the wave
+		uint32_t s = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t n = __shfl_up(s, off);
+			if (lane >= off) s += n;
+		}
+		if (lane == 63) wave_sum[wid] = s;
+		__syncthreads();
+		uint32_t wave_off = 0, block_total = 0;
+#pragma unroll
+		for (int w = 0; w < 16; w++) { if (w < wid) wave_off += wave_sum[w]; block_total += wave_sum[w]; }
+		const uint32_t carry = carry_s;
+		const uint32_t excl = carry + wave_off + s - v;
+		if (i < T) { ranges[i] = make_uint2(excl, excl + v); tile_count[i] = 0; }
+		__syncthreads();
+		if (tid == 0) carry_s = carry + block_total;
+		__syncthreads();
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor(vmax, off));
+	if (lane == 0) wave_max[wid] = vmax;
+	__syncthreads();
+	if (tid == 0)
+	{
+		uint32_t m = 0;
+		for (int w = 0; w < 16; w++) m = max(m, wave_max[w]);
+		totals[0] = carry_s; totals[1] = m; totals[2] = 0; totals[3] = 0;
+	}
+}
+
+// All-ascending bitonic network (first step of each merge mirrors the partner index), so that
+// virtual +inf padding above n never moves: comparators whose upper index is >= n are no-ops.
+// GLOBAL: keys live in global memory and are exchanged between waves of this workgroup, so loads
+// and stores go around the per-CU L1 (agent-scope relaxed atomics = sc1 accesses).
+template <bool GLOBAL>
+__device__ __forceinline__ uint64_t key_ld(const uint64_t *p)
+{
+	if (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return *p;
+}
+template <bool GLOBAL>
+__device__ __forceinline__ void key_st(uint64_t *p, uint64_t v)
+{
+	if (GLOBAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else *p = v;
+}
+template <bool GLOBAL>
+__device__ __forceinline__ void bitonic_sort(uint64_t *keys, int n, int npow2, int tid, int nthreads)
+{
+	for (int k = 2; k <= npow2; k <<= 1)
+	{
+		// flip step: i <-> i ^ (k-1)
+		{
+			const int half = k >> 1;
+			for (int p = tid; p < (npow2 >> 1); p += nthreads)
+			{
+				const int blk = p / half, off = p - blk * half;
+				const int i = blk * k + off, l = blk * k + (k - 1 - off);
+				if (l < n)
+				{
+					const uint64_t a = key_ld<GLOBAL>(keys + i), b = key_ld<GLOBAL>(keys + l);
+					if (a > b) { key_st<GLOBAL>(keys + i, b); key_st<GLOBAL>(keys + l, a); }
+				}
+			}
+			__syncthreads();
+		}
+		for (int j = k >> 2; j > 0; j >>= 1)
+		{
+			for (int p = tid; p < (npow2 >> 1); p += nthreads)
+			{
+				const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+				const int l = i | j;
+				if (l < n)
+				{
+					const uint64_t a = key_ld<GLOBAL>(keys + i), b = key_ld<GLOBAL>(keys + l);
+					if (a > b) { key_st<GLOBAL>(keys + i, b); key_st<GLOBAL>(keys + l, a); }
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+
+// One workgroup per tile. Buckets of up to lds_cap entries are sorted in LDS; longer ones in
+// place in global memory (rare; same network).
+__global__ void __launch_bounds__(256) k_tile_sort(const uint2 *ranges, uint64_t *entries, uint32_t *point_list, int lds_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+	const uint2 rg = ranges[blockIdx.x];
+	const int n = (int)(rg.y - rg.x);
+	if (n == 0) return;
+	const int tid = threadIdx.x;
+	uint64_t *src = entries + rg.x;
+	uint32_t *dst = point_list + rg.x;
+	int npow2 = 1;
+	while (npow2 < n) npow2 <<= 1;
+	if (n <= lds_cap)
+	{
+		for (int i = tid; i < n; i += 256) skeys[i] = src[i];
+		__syncthreads();
+		bitonic_sort<false>(skeys, n, npow2, tid, 256);
+		for (int i = tid; i < n; i += 256) dst[i] = (uint32_t)skeys[i];
+	}
+	else
+	{
+		bitonic_sort<true>(src, n, npow2, tid, 256);
+		for (int i = tid; i < n; i += 256) dst[i] = (uint32_t)key_ld<true>(src + i);
+	}
+}
+
+int launch_tile_scan(FwdCtx &c)
+{
+	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals);
+	return check_launch("tile_scan", c.stream, c.a->debug);
+}
+
+int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
+{
+	(void)num_instances;
+	int cap = 64;
+	while (cap < max_tile && cap < FR_SORT_LDS_MAX) cap <<= 1;
+	const size_t lds = (size_t)cap * sizeof(uint64_t);
+	hipLaunchKernelGGL(k_tile_sort, dim3(c.T), dim3(256), lds, c.stream, c.img.ranges, c.bin.entries, c.bin.point_list, cap);
+	return check_launch("tile_sort", c.stream, c.a->debug);
+}
+
+} // namespace fr

@@ -1,0 +1,197 @@
+// Internal shared definitions of libfovraster_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/fovraster.h"
+
+#define FR_TILE 16            // tile edge in pixels (reference config.h:15-17 BLOCK_X/BLOCK_Y)
+#define FR_TILE_PIX 256
+#define FR_FOV_LEVELS 4       // RF auxiliary.h:26 fov_num
+#define FR_SORT_LDS_MAX 8192  // longest per-tile list sorted inside LDS (64 KiB of u64 keys)
+
+namespace fr {
+
+struct Mat16 { float m[16]; };
+
+// ---- workspace layouts -------------------------------------------------------------------
+// All sub-arrays are 256-byte aligned inside the caller's buffers.
+__host__ __device__ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Geometry workspace (per Gaussian). rec = 3 float4 per Gaussian:
+//   [0] = (mean2D.x, mean2D.y, conic.a, conic.b)
+//   [1] = (conic.c, opacity, r, g)          RF: (conic.c, highest_level, 0, 0)
+//   [2] = (b, depth, clamp bits, unused)
+struct GeomWS {
+	float4 *rec;        // [3P]
+	float *cov3D;       // [6P]
+	float4 *evec;       // [P]  OBB axes (e1x,e1y,e2x,e2y)      (not ORIGINAL)
+	float2 *elen;       // [P]  OBB half-lengths                 (not ORIGINAL)
+	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity)
+	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8
+	size_t bytes;
+};
+__host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
+{
+	GeomWS g; size_t off = 0;
+	g.rec = (float4 *)(base + off); off = align_up(off + P * 3 * sizeof(float4));
+	g.cov3D = (float *)(base + off); off = align_up(off + P * 6 * sizeof(float));
+	g.evec = nullptr; g.elen = nullptr; g.lvl = nullptr; g.lrange = nullptr;
+	if (variant != FR_VARIANT_ORIGINAL) {
+		g.evec = (float4 *)(base + off); off = align_up(off + P * sizeof(float4));
+		g.elen = (float2 *)(base + off); off = align_up(off + P * sizeof(float2));
+	}
+	if (variant == FR_VARIANT_FOV_PCHECK_OBB) {
+		g.lvl = (float4 *)(base + off); off = align_up(off + P * FR_FOV_LEVELS * sizeof(float4));
+		g.lrange = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
+	}
+	g.bytes = off + 256;
+	return g;
+}
+
+// Image workspace (per pixel / per tile).
+struct ImageWS {
+	float *final_T;       // [W*H]
+	uint32_t *n_contrib;  // [W*H]
+	uint2 *ranges;        // [T]
+	uint32_t *tile_count; // [T]  instance counter, then emission cursor
+	uint32_t *totals;     // [4]  {num_instances, max per tile, 0, 0}
+	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
+	size_t bytes;
+};
+__host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *base)
+{
+	ImageWS s; size_t off = 0;
+	const size_t N = (size_t)W * H;
+	const size_t T = (size_t)((W + FR_TILE - 1) / FR_TILE) * ((H + FR_TILE - 1) / FR_TILE);
+	s.final_T = (float *)(base + off); off = align_up(off + N * sizeof(float));
+	s.n_contrib = (uint32_t *)(base + off); off = align_up(off + N * sizeof(uint32_t));
+	s.ranges = (uint2 *)(base + off); off = align_up(off + T * sizeof(uint2));
+	s.tile_count = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
+	s.totals = (uint32_t *)(base + off); off = align_up(off + 4 * sizeof(uint32_t));
+	s.tile_lv = nullptr;
+	if (variant == FR_VARIANT_FOV_PCHECK_OBB) { s.tile_lv = (float *)(base + off); off = align_up(off + 5 * T * sizeof(float)); }
+	s.bytes = off + 256;
+	return s;
+}
+
+// Binning workspace (per (Gaussian,tile) instance).
+struct BinWS {
+	uint64_t *entries;    // [D] (depth bits << 32 | gaussian id), bucketed by tile
+	uint32_t *point_list; // [D] gaussian ids, sorted per tile
+	size_t bytes;
+};
+__host__ __device__ inline BinWS carve_bin(int64_t D, char *base)
+{
+	BinWS b; size_t off = 0;
+	b.entries = (uint64_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint64_t));
+	b.point_list = (uint32_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint32_t));
+	b.bytes = off + 256;
+	return b;
+}
+
+// ---- small device helpers ----------------------------------------------------------------
+// float -> int with the saturating / NaN->0 behaviour of v_cvt_i32_f32 (and of the CUDA cvt.rzi
+// the reference relies on for off-screen splats)
+__device__ __forceinline__ int f2i(float v)
+{
+	if (v != v) return 0;
+	if (v >= 2147483648.0f) return 2147483647;
+	if (v <= -2147483648.0f) return (-2147483647 - 1);
+	return (int)v;
+}
+
+// tile rectangle of a splat: reference auxiliary.h:46-56
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy,
+	int &x0, int &y0, int &x1, int &y1)
+{
+	const float r = (float)max_radius;
+	x0 = min(gx, max(0, f2i((px - r) / FR_TILE)));
+	y0 = min(gy, max(0, f2i((py - r) / FR_TILE)));
+	x1 = min(gx, max(0, f2i((px + r + (FR_TILE - 1)) / FR_TILE)));
+	y1 = min(gy, max(0, f2i((py + r + (FR_TILE - 1)) / FR_TILE)));
+}
+
+// Oriented-bounding-box vs tile separating-axis test: RS auxiliary.h:66-154.
+struct Obb {
+	float cx, cy;        // splat centre (pixels)
+	float e1x, e1y, e2x, e2y, len1, len2;
+	float vx[4], vy[4];  // box corners
+};
+__device__ __forceinline__ Obb make_obb(float cx, float cy, float4 ev, float2 el)
+{
+	Obb o; o.cx = cx; o.cy = cy; o.e1x = ev.x; o.e1y = ev.y; o.e2x = ev.z; o.e2y = ev.w; o.len1 = el.x; o.len2 = el.y;
+	const float d1x = o.len1 * o.e1x, d1y = o.len1 * o.e1y, d2x = o.len2 * o.e2x, d2y = o.len2 * o.e2y;
+	o.vx[0] = cx + d1x + d2x; o.vy[0] = cy + d1y + d2y;
+	o.vx[1] = cx - d1x + d2x; o.vy[1] = cy - d1y + d2y;
+	o.vx[2] = cx - d1x - d2x; o.vy[2] = cy - d1y - d2y;
+	o.vx[3] = cx + d1x - d2x; o.vy[3] = cy + d1y - d2y;
+	return o;
+}
+__device__ __forceinline__ bool obb_hits_tile(const Obb &o, int tx, int ty)
+{
+	const float tpx = (float)tx * (float)FR_TILE + (float)FR_TILE / 2.0f;
+	const float tpy = (float)ty * (float)FR_TILE + (float)FR_TILE / 2.0f;
+	float mn = o.vx[0] - tpx, mx = mn;
+#pragma unroll
+	for (int i = 1; i < 4; i++) { const float v = o.vx[i] - tpx; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+	if (mx < -8.0f || mn > 8.0f) return false;
+	mn = o.vy[0] - tpy; mx = mn;
+#pragma unroll
+	for (int i = 1; i < 4; i++) { const float v = o.vy[i] - tpy; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+	if (mx < -8.0f || mn > 8.0f) return false;
+	const float tvx[4] = { tpx + 8.0f - o.cx, tpx - 8.0f - o.cx, tpx - 8.0f - o.cx, tpx + 8.0f - o.cx };
+	const float tvy[4] = { tpy + 8.0f - o.cy, tpy + 8.0f - o.cy, tpy - 8.0f - o.cy, tpy - 8.0f - o.cy };
+	float d = tvx[0] * o.e1x + tvy[0] * o.e1y;
+	mn = d; mx = d;
+#pragma unroll
+	for (int i = 1; i < 4; i++) { d = tvx[i] * o.e1x + tvy[i] * o.e1y; mn = fminf(mn, d); mx = fmaxf(mx, d); }
+	if (o.len1 < mn || -o.len1 > mx) return false;
+	d = tvx[0] * o.e2x + tvy[0] * o.e2y;
+	mn = d; mx = d;
+#pragma unroll
+	for (int i = 1; i < 4; i++) { d = tvx[i] * o.e2x + tvy[i] * o.e2y; mn = fminf(mn, d); mx = fmaxf(mx, d); }
+	if (o.len2 < mn || -o.len2 > mx) return false;
+	return true;
+}
+
+// SH basis constants (reference auxiliary.h:22-39)
+#define FR_SH_C0 0.28209479177387814f
+#define FR_SH_C1 0.4886025119029199f
+#define FR_SH_C2_0 1.0925484305920792f
+#define FR_SH_C2_1 -1.0925484305920792f
+#define FR_SH_C2_2 0.31539156525252005f
+#define FR_SH_C2_3 -1.0925484305920792f
+#define FR_SH_C2_4 0.5462742152960396f
+#define FR_SH_C3_0 -0.5900435899266435f
+#define FR_SH_C3_1 2.890611442640554f
+#define FR_SH_C3_2 -0.4570457994644658f
+#define FR_SH_C3_3 0.3731763325901154f
+#define FR_SH_C3_4 -0.4570457994644658f
+#define FR_SH_C3_5 1.445305721320277f
+#define FR_SH_C3_6 -0.5900435899266435f
+
+// ---- host-side launch plumbing ------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int check_launch(const char *what, hipStream_t stream, bool debug);
+
+// stage launchers (implemented in the .hip files)
+struct FwdCtx {
+	fr_forward_args *a;
+	hipStream_t stream;
+	int gx, gy, T;
+	float focal_x, focal_y;
+	GeomWS geom;
+	ImageWS img;
+	BinWS bin;
+};
+int launch_tile_levels(FwdCtx &c);
+int launch_preprocess(FwdCtx &c);
+int launch_tile_scan(FwdCtx &c);
+int launch_emit(FwdCtx &c);
+int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile);
+int launch_render(FwdCtx &c);
+int launch_backward(const fr_backward_args *a);
+int launch_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present, hipStream_t s);
+
+} // namespace fr

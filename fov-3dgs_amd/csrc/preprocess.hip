@@ -1,0 +1,490 @@
+// Per-Gaussian stages: projection / 2D covariance / SH colour, fused tile counting with the
+// oriented-box and foveal-level culls, and instance emission into per-tile buckets.
+//
+// Replaces (reference, paths under fov3dgs/submodules/):
+//   preprocessCUDA           diff-gaussian-rasterization/cuda_rasterizer/forward.cu:155-262
+//                            …_pcheck_obb_sum/cuda_rasterizer/forward.cu:155-293, …_fov_pcheck_obb/…/forward.cu:105-238
+//   OBB_test / filter        …_pcheck_obb_sum/cuda_rasterizer/rasterizer_impl.cu:70-146, …_fov_pcheck_obb/…:264-383
+//   duplicateWithKeys        …/rasterizer_impl.cu:70-111 (R0), :150-214 (RS), :423-486 (RF)
+//   compute_tile_levels_cuda / compute_tile_level_infos_cuda   …_fov_pcheck_obb/…/rasterizer_impl.cu:120-260
+//   compute_fov_colors       …_fov_pcheck_obb/…/rasterizer_impl.cu:490-530
+//   checkFrustum             …/rasterizer_impl.cu:54-66
+//
+// MI355X design: the reference materialises a per-(Gaussian,tile) bool bitmap between a cull
+// kernel and the key-emission kernel and needs two P-long prefix scans plus two host syncs.
+// Here the cull test is evaluated inside preprocess (count phase, bumping one counter per TILE)
+// and re-evaluated in emit (no bitmap, no per-Gaussian scan); instances are bucketed by tile
+// at emission time through per-tile cursors, so no global 64-bit radix sort is needed.
+#include "common.h"
+
+namespace fr {
+
+// ---- glm-like column-major 3x3 helper; the summation order of mul() is the contract ----------
+struct M3 { float c[3][3]; };
+__device__ __forceinline__ M3 m3_cols(float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2)
+{
+	M3 m; m.c[0][0] = a0; m.c[0][1] = a1; m.c[0][2] = a2; m.c[1][0] = b0; m.c[1][1] = b1; m.c[1][2] = b2;
+	m.c[2][0] = c0; m.c[2][1] = c1; m.c[2][2] = c2; return m;
+}
+__device__ __forceinline__ M3 m3_mul(const M3 &a, const M3 &b)
+{
+	M3 r;
+#pragma unroll
+	for (int col = 0; col < 3; col++)
+#pragma unroll
+		for (int row = 0; row < 3; row++)
+			r.c[col][row] = a.c[0][row] * b.c[col][0] + a.c[1][row] * b.c[col][1] + a.c[2][row] * b.c[col][2];
+	return r;
+}
+__device__ __forceinline__ M3 m3_t(const M3 &a)
+{
+	M3 r;
+#pragma unroll
+	for (int col = 0; col < 3; col++)
+#pragma unroll
+		for (int row = 0; row < 3; row++) r.c[col][row] = a.c[row][col];
+	return r;
+}
+
+// ---- RF eccentricity level of a tile: RF rasterizer_impl.cu:86-177, auxiliary.h:55-66 ----------
+__device__ __forceinline__ void ncd2dir(float nx, float ny, float rw, float rh, float out[3])
+{
+	const float vx = (nx - 0.5f) * rw, vy = (ny - 0.5f) * rh, vz = 1.0f;
+	const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+	out[0] = vx / d; out[1] = vy / d; out[2] = vz / d;
+}
+__device__ float tile_level(int tx, int ty, int W, int H, float gaze_x, float gaze_y, float alpha)
+{
+	const float riw = 2.0f, rvd = 1.0f, sqrt_max_ps = 3.4641016151377544f;
+	const float step = (float)(((double)sqrt_max_ps - 1.) / (double)(float)(FR_FOV_LEVELS - 1));
+	const float px = (float)(tx * FR_TILE + FR_TILE / 2), py = (float)(ty * FR_TILE + FR_TILE / 2);
+	const float rih = (float)H / (float)W * riw;
+	const float nx = px / W, ny = py / H;
+	float tdir[3], gdir[3], cdir[3];
+	ncd2dir(nx, ny, riw, rih, tdir);
+	ncd2dir(gaze_x, gaze_y, riw, rih, gdir);
+	ncd2dir(0.5f, 0.5f, riw, rih, cdir);
+	const float ecc = acosf(gdir[0] * tdir[0] + gdir[1] * tdir[1] + gdir[2] * tdir[2]);
+	const float ecc_c = acosf(tdir[0] * cdir[0] + tdir[1] * cdir[1] + tdir[2] * cdir[2]);
+	const float pool = alpha * ecc * ecc;
+	const float amin = (float)((double)ecc_c - (double)pool * 0.5);
+	const float amax = (float)((double)ecc_c + (double)pool * 0.5);
+	const float ax = (float)(((double)nx - 0.5) * (double)riw), ay = (float)(((double)ny - 0.5) * (double)rih);
+	const float dist = sqrtf(ax * ax + ay * ay + rvd * rvd);
+	const float major = (tanf(amax) - tanf(amin)) * rvd;
+	const float minor = 2.0f * dist * tanf(pool * 0.5f);
+	const float area = (float)(3.14159265358979323846 * (double)major * (double)minor * (double)0.25f);
+	const float r2p = W / riw;
+	const float ps = sqrtf(area) * r2p;
+	float level;
+	if (ps <= 1) level = 0; else level = (sqrtf(ps) - 1) / step;
+	if ((double)level > ((double)(float)FR_FOV_LEVELS - 0.1)) level = (float)((double)(float)FR_FOV_LEVELS - 0.1);
+	return level;
+}
+
+// One thread per tile: level of the tile and of its 4 neighbours (recomputed instead of a second
+// kernel + global round trip), finite-difference gradients, conservative tile minimum and the
+// two-level-blend flag. out = float[5][T]: level, tile_min, grad_x, grad_y, blending.
+__global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x, float gaze_y, float alpha, float *out)
+{
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= T) return;
+	const int ty = idx / gx, tx = idx % gx;
+	const float lf = tile_level(tx, ty, W, H, gaze_x, gaze_y, alpha);
+	float right = -1, left = -1, up = -1, down = -1;
+	if (tx + 1 < gx) right = tile_level(tx + 1, ty, W, H, gaze_x, gaze_y, alpha);
+	if (tx - 1 >= 0) left = tile_level(tx - 1, ty, W, H, gaze_x, gaze_y, alpha);
+	if (ty + 1 < gy) up = tile_level(tx, ty + 1, W, H, gaze_x, gaze_y, alpha);
+	if (ty - 1 >= 0) down = tile_level(tx, ty - 1, W, H, gaze_x, gaze_y, alpha);
+	float gxv = 0, gyv = 0;
+	if (right != -1 && left != -1) gxv = (right - left) / 2.0f;
+	else if (right != -1) gxv = right - lf;
+	else if (left != -1) gxv = lf - left;
+	if (up != -1 && down != -1) gyv = (up - down) / 2.0f;
+	else if (up != -1) gyv = up - lf;
+	else if (down != -1) gyv = lf - down;
+	const float max_delta = (float)(0.5 * (double)(fabsf(gxv) + fabsf(gyv)));
+	const float tmin = lf - max_delta;
+	const float tmin_i = (float)f2i(tmin);
+	const bool blending = ((tmin - tmin_i) > 0.5f) && (tmin_i < (float)(FR_FOV_LEVELS - 1));
+	out[idx] = lf;
+	out[T + idx] = tmin;
+	out[2 * T + idx] = gxv;
+	out[3 * T + idx] = gyv;
+	out[4 * T + idx] = blending ? 1.0f : 0.0f;
+}
+
+// ---- SH colour: forward.cu:20-71 (full) and RF rasterizer_impl.cu:37-84 (rest only) -----------
+// sh points at 3*M floats of this Gaussian; REST: coefficient k is stored at slot k-1.
+template <bool REST>
+__device__ __forceinline__ void sh_colour(int deg, const float *__restrict__ sh, float dx, float dy, float dz, float out[3])
+{
+	const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+	const float x = dx / len, y = dy / len, z = dz / len;
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++)
+	{
+#define SHK(k) sh[3 * ((k) - (REST ? 1 : 0)) + ch]
+		float result = REST ? 0.0f : FR_SH_C0 * SHK(0);
+		if (deg > 0)
+		{
+			result = result - FR_SH_C1 * y * SHK(1) + FR_SH_C1 * z * SHK(2) - FR_SH_C1 * x * SHK(3);
+			if (deg > 1)
+			{
+				const float xx = x * x, yy = y * y, zz = z * z;
+				const float xy = x * y, yz = y * z, xz = x * z;
+				result = result +
+					FR_SH_C2_0 * xy * SHK(4) +
+					FR_SH_C2_1 * yz * SHK(5) +
+					FR_SH_C2_2 * (2.0f * zz - xx - yy) * SHK(6) +
+					FR_SH_C2_3 * xz * SHK(7) +
+					FR_SH_C2_4 * (xx - yy) * SHK(8);
+				if (deg > 2)
+				{
+					result = result +
+						FR_SH_C3_0 * y * (3.0f * xx - yy) * SHK(9) +
+						FR_SH_C3_1 * xy * z * SHK(10) +
+						FR_SH_C3_2 * y * (4.0f * zz - xx - yy) * SHK(11) +
+						FR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHK(12) +
+						FR_SH_C3_4 * x * (4.0f * zz - xx - yy) * SHK(13) +
+						FR_SH_C3_5 * z * (xx - yy) * SHK(14) +
+						FR_SH_C3_6 * x * (xx - 3.0f * yy) * SHK(15);
+				}
+			}
+		}
+#undef SHK
+		out[ch] = result + 0.5f;
+	}
+}
+
+struct PreArgs {
+	int P, D, M, W, H, gx, gy;
+	float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+	const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
+	const float *viewmatrix, *projmatrix, *campos;
+	const float *shs_dcs, *highest_levels;
+	const float *tile_lv; // RF float[5][T]
+	int T;
+	int *radii;
+	GeomWS geom;
+	uint32_t *tile_count;
+};
+
+// One thread per Gaussian.
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
+{
+	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
+	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= a.P) return;
+	a.radii[idx] = 0;
+
+	const float *vm = a.viewmatrix, *pm = a.projmatrix;
+	const float p[3] = { a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2] };
+	// near cull: auxiliary.h:139-164
+	const float hx = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
+	const float hy = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
+	const float hw = pm[3] * p[0] + pm[7] * p[1] + pm[11] * p[2] + pm[15];
+	const float p_w = 1.0f / (hw + 0.0000001f);
+	const float projx = hx * p_w, projy = hy * p_w;
+	float t[3];
+	t[0] = vm[0] * p[0] + vm[4] * p[1] + vm[8] * p[2] + vm[12];
+	t[1] = vm[1] * p[0] + vm[5] * p[1] + vm[9] * p[2] + vm[13];
+	t[2] = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
+	const float depth = t[2];
+	if (depth <= 0.2f) return;
+
+	// 3D covariance: forward.cu:118-152
+	float cov3D[6];
+	if (a.cov3D_precomp != nullptr)
+	{
+#pragma unroll
+		for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * idx + i];
+	}
+	else
+	{
+		const float mod = a.scale_modifier;
+		const float s0 = mod * a.scales[3 * idx], s1 = mod * a.scales[3 * idx + 1], s2 = mod * a.scales[3 * idx + 2];
+		const float4 q = ((const float4 *)a.rotations)[idx];
+		const float r = q.x, x = q.y, y = q.z, z = q.w;
+		const M3 S = m3_cols(s0, 0, 0, 0, s1, 0, 0, 0, s2);
+		const M3 R = m3_cols(
+			1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+			2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+			2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+		const M3 Mm = m3_mul(S, R);
+		const M3 Sg = m3_mul(m3_t(Mm), Mm);
+		cov3D[0] = Sg.c[0][0]; cov3D[1] = Sg.c[0][1]; cov3D[2] = Sg.c[0][2];
+		cov3D[3] = Sg.c[1][1]; cov3D[4] = Sg.c[1][2]; cov3D[5] = Sg.c[2][2];
+#pragma unroll
+		for (int i = 0; i < 6; i++) a.geom.cov3D[6 * idx + i] = cov3D[i];
+	}
+
+	// 2D covariance (EWA): forward.cu:74-113
+	float cov[3];
+	{
+		const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+		const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+		const float tx = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+		const float ty = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+		const M3 J = m3_cols(a.focal_x / t[2], 0, -(a.focal_x * tx) / (t[2] * t[2]),
+			0, a.focal_y / t[2], -(a.focal_y * ty) / (t[2] * t[2]),
+			0, 0, 0);
+		const M3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+		const M3 Tm = m3_mul(Wm, J);
+		const M3 Vrk = m3_cols(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+		const M3 c = m3_mul(m3_mul(m3_t(Tm), m3_t(Vrk)), Tm);
+		cov[0] = c.c[0][0] + 0.3f; cov[1] = c.c[0][1]; cov[2] = c.c[1][1] + 0.3f;
+	}
+	const float det = cov[0] * cov[2] - cov[1] * cov[1];
+	if (det == 0.0f) return;
+	const float det_inv = 1.f / det;
+	const float conic_a = cov[2] * det_inv, conic_b = -cov[1] * det_inv, conic_c = cov[0] * det_inv;
+	const float mid = 0.5f * (cov[0] + cov[2]);
+	const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+	const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+	const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+	// ndc2Pix is evaluated in double in the reference (auxiliary.h:41-44)
+	const float pix_x = (float)((((double)projx + 1.0) * a.W - 1.0) * 0.5);
+	const float pix_y = (float)((((double)projy + 1.0) * a.H - 1.0) * 0.5);
+	const int radius_i = f2i(my_radius);
+	int x0, y0, x1, y1;
+	get_rect(pix_x, pix_y, radius_i, a.gx, a.gy, x0, y0, x1, y1);
+	const uint32_t tnum = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+	if (tnum == 0) return;
+
+	// ---- count the tiles this splat really lands in (and bump the per-tile counters) ----
+	uint32_t count = 0;
+	float4 ev = make_float4(0, 0, 0, 0);
+	float2 el = make_float2(0, 0);
+	float hl = 0, lowest = 0, highest = 0;
+	bool be_blend = false;
+	if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
+	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
+	const float *tile_bl = FOV ? a.tile_lv + 4 * (size_t)a.T : nullptr;
+	if (!CULL)
+	{
+		for (int y = y0; y < y1; y++)
+			for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+		count = tnum;
+	}
+	else
+	{
+		if (tnum > 1)
+		{
+			// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
+			float e1x = -cov[1], e1y = cov[0] - lambda1, e2x = -cov[1], e2y = cov[0] - lambda2;
+			const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
+			e1x *= n1; e1y *= n1;
+			const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
+			e2x *= n2; e2y *= n2;
+			ev = make_float4(e1x, e1y, e2x, e2y);
+			el = make_float2(3.0f * sqrtf(lambda1), 3.0f * sqrtf(lambda2));
+		}
+		if (tnum == 1)
+		{
+			bool keep = true;
+			const int ti = y0 * a.gx + x0;
+			if (FOV)
+			{
+				const float level = tile_min[ti];
+				keep = level < (hl + 1);
+				if (keep) { lowest = level; highest = level; be_blend = tile_bl[ti] != 0.0f; }
+			}
+			if (keep) { atomicAdd(&a.tile_count[ti], 1u); count = 1; }
+		}
+		else
+		{
+			const Obb ob = make_obb(pix_x, pix_y, ev, el);
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++)
+				{
+					const int ti = y * a.gx + x;
+					bool inside = true;
+					float level = 0;
+					if (FOV) { level = tile_min[ti]; inside = level < (hl + 1); }
+					if (inside && obb_hits_tile(ob, x, y))
+					{
+						count++;
+						atomicAdd(&a.tile_count[ti], 1u);
+						if (FOV)
+						{
+							lowest = fminf(lowest, level); highest = fmaxf(highest, level);
+							be_blend = be_blend || (tile_bl[ti] != 0.0f);
+						}
+					}
+				}
+		}
+		if (count == 0) return; // culled everywhere: radii stays 0 (RS rasterizer_impl.cu:141-145)
+	}
+
+	// ---- colour ----
+	float rgb[3] = { 0, 0, 0 };
+	uint32_t clamp_bits = 0;
+	const float dirx = p[0] - a.campos[0], diry = p[1] - a.campos[1], dirz = p[2] - a.campos[2];
+	if (!FOV)
+	{
+		if (a.colors_precomp == nullptr)
+		{
+			float c[3];
+			sh_colour<false>(a.D, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, c);
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) { if (c[ch] < 0) clamp_bits |= 1u << ch; rgb[ch] = fmaxf(c[ch], 0.0f); }
+		}
+		else
+		{
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) rgb[ch] = a.colors_precomp[3 * idx + ch];
+		}
+	}
+	else
+	{
+		// RF rasterizer_impl.cu:374-381 (level range) + :490-530 (per-level colours)
+		const int lo = f2i(lowest);
+		int hi = f2i(highest);
+		if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
+		a.geom.lrange[idx] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
+		float rest[3];
+		sh_colour<true>(a.D, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, rest);
+		for (int l = lo; l <= hi; l++)
+		{
+			const float *dc = a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS + l * 3;
+			float4 v;
+			v.x = fmaxf(FR_SH_C0 * dc[0] + rest[0], 0.0f);
+			v.y = fmaxf(FR_SH_C0 * dc[1] + rest[1], 0.0f);
+			v.z = fmaxf(FR_SH_C0 * dc[2] + rest[2], 0.0f);
+			v.w = a.opacities[(size_t)idx * FR_FOV_LEVELS + l];
+			a.geom.lvl[(size_t)idx * FR_FOV_LEVELS + l] = v;
+		}
+	}
+
+	a.radii[idx] = radius_i;
+	float4 *rec = a.geom.rec + 3 * (size_t)idx;
+	rec[0] = make_float4(pix_x, pix_y, conic_a, conic_b);
+	if (FOV) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
+	else rec[1] = make_float4(conic_c, a.opacities[idx], rgb[0], rgb[1]);
+	rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), 0.0f);
+	if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
+}
+
+// One thread per Gaussian: re-walk the rect, repeat the cull test and append (depth,id) to the
+// tile's bucket through the tile cursor. Order inside a bucket is arbitrary; the per-tile sort
+// on (depth bits, id) restores the reference's stable order.
+struct EmitArgs {
+	int P, gx, gy, T;
+	const int *radii;
+	GeomWS geom;
+	const float *highest_levels;
+	const float *tile_lv;
+	const uint2 *ranges;
+	uint32_t *cursor;
+	uint64_t *entries;
+};
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_emit(const EmitArgs a)
+{
+	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
+	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= a.P) return;
+	const int radius = a.radii[idx];
+	if (!(radius > 0)) return;
+	const float4 r0 = a.geom.rec[3 * (size_t)idx];
+	const float depth = a.geom.rec[3 * (size_t)idx + 2].y;
+	const uint64_t payload = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
+	int x0, y0, x1, y1;
+	get_rect(r0.x, r0.y, radius, a.gx, a.gy, x0, y0, x1, y1);
+	const uint32_t tnum = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+	if (!CULL || tnum == 1)
+	{
+		for (int y = y0; y < y1; y++)
+			for (int x = x0; x < x1; x++)
+			{
+				const int ti = y * a.gx + x;
+				const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
+				a.entries[a.ranges[ti].x + pos] = payload;
+			}
+		return;
+	}
+	const Obb ob = make_obb(r0.x, r0.y, a.geom.evec[idx], a.geom.elen[idx]);
+	const float hl = FOV ? a.highest_levels[idx] : 0.0f;
+	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
+	for (int y = y0; y < y1; y++)
+		for (int x = x0; x < x1; x++)
+		{
+			const int ti = y * a.gx + x;
+			bool inside = true;
+			if (FOV) inside = tile_min[ti] < (hl + 1);
+			if (inside && obb_hits_tile(ob, x, y))
+			{
+				const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
+				a.entries[a.ranges[ti].x + pos] = payload;
+			}
+		}
+}
+
+__global__ void k_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present)
+{
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= P) return;
+	const float z = vm[2] * means3D[3 * idx] + vm[6] * means3D[3 * idx + 1] + vm[10] * means3D[3 * idx + 2] + vm[14];
+	present[idx] = !(z <= 0.2f);
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+int launch_tile_levels(FwdCtx &c)
+{
+	const fr_forward_args *a = c.a;
+	hipLaunchKernelGGL(k_tile_levels, dim3((c.T + 255) / 256), dim3(256), 0, c.stream,
+		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv);
+	return check_launch("tile_levels", c.stream, a->debug);
+}
+
+int launch_preprocess(FwdCtx &c)
+{
+	const fr_forward_args *a = c.a;
+	PreArgs p;
+	p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H; p.gx = c.gx; p.gy = c.gy;
+	p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.focal_x = c.focal_x; p.focal_y = c.focal_y;
+	p.scale_modifier = a->scale_modifier;
+	p.means3D = a->means3D; p.scales = a->scales; p.rotations = a->rotations; p.opacities = a->opacities;
+	p.shs = a->shs; p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
+	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
+	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.T = c.T;
+	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count;
+	const dim3 grid((a->P + 255) / 256), block(256);
+	switch (a->variant)
+	{
+	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL(k_preprocess<FR_VARIANT_ORIGINAL>, grid, block, 0, c.stream, p); break;
+	case FR_VARIANT_PCHECK_OBB_SUM: hipLaunchKernelGGL(k_preprocess<FR_VARIANT_PCHECK_OBB_SUM>, grid, block, 0, c.stream, p); break;
+	case FR_VARIANT_PCHECK_OBB: hipLaunchKernelGGL(k_preprocess<FR_VARIANT_PCHECK_OBB>, grid, block, 0, c.stream, p); break;
+	default: hipLaunchKernelGGL(k_preprocess<FR_VARIANT_FOV_PCHECK_OBB>, grid, block, 0, c.stream, p); break;
+	}
+	return check_launch("preprocess", c.stream, a->debug);
+}
+
+int launch_emit(FwdCtx &c)
+{
+	const fr_forward_args *a = c.a;
+	EmitArgs e;
+	e.P = a->P; e.gx = c.gx; e.gy = c.gy; e.T = c.T; e.radii = a->radii; e.geom = c.geom;
+	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.ranges = c.img.ranges;
+	e.cursor = c.img.tile_count; e.entries = c.bin.entries;
+	const dim3 grid((a->P + 255) / 256), block(256);
+	switch (a->variant)
+	{
+	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL(k_emit<FR_VARIANT_ORIGINAL>, grid, block, 0, c.stream, e); break;
+	case FR_VARIANT_FOV_PCHECK_OBB: hipLaunchKernelGGL(k_emit<FR_VARIANT_FOV_PCHECK_OBB>, grid, block, 0, c.stream, e); break;
+	default: hipLaunchKernelGGL(k_emit<FR_VARIANT_PCHECK_OBB>, grid, block, 0, c.stream, e); break;
+	}
+	return check_launch("emit", c.stream, a->debug);
+}
+
+int launch_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, vm, present);
+	return check_launch("mark_visible", s, false);
+}
+
+} // namespace fr

@@ -1,0 +1,368 @@
+// Per-tile front-to-back alpha blending (forward).
+//
+// Replaces (reference, paths under fov3dgs/submodules/):
+//   renderCUDA            diff-gaussian-rasterization/cuda_rasterizer/forward.cu:267-384           (ORIGINAL)
+//                         …_pcheck_obb_sum/cuda_rasterizer/forward.cu:298-430  (+ power<-4.5, counts, contributions)
+//                         …_pcheck_obb/cuda_rasterizer/forward.cu:243-384      (inference; no final_T / n_contrib)
+//   renderCUDA (RF)       …_fov_pcheck_obb/cuda_rasterizer/forward.cu:490-609  single-level tiles
+//   renderCUDA_blending   …_fov_pcheck_obb/cuda_rasterizer/forward.cu:262-476  two-level tiles
+//
+// MI355X design: a tile is blended by 256/PPL threads, each owning PPL pixels of one column
+// (rows ry, ry+16/PPL, ...). With PPL=4 a tile is ONE wave64: the per-instance record broadcast
+// out of LDS is amortised over four pixels per lane, `done` votes are wave ballots instead of
+// workgroup barriers, and each 16x4 pixel strip is skipped wave-uniformly once it saturates.
+// Instance records are gathered as 48-byte AoS (3 x b128) per Gaussian by the whole group.
+// The foveated renderer handles single-level and two-level tiles in one launch (the reference
+// launches two full grids that early-return on each other's tiles).
+#include "common.h"
+
+namespace fr {
+
+__device__ __forceinline__ float fast_exp(float p)
+{
+	// exp(p) = 2^(p*log2 e) on the transcendental unit (v_exp_f32); |rel err| ~ 2 ulp for p in [-6,0]
+	return __builtin_amdgcn_exp2f(p * 1.4426950408889634f);
+}
+
+// sum over the 64 lanes of a wave, result valid in every lane (returned through readlane 63)
+__device__ __forceinline__ float wave_sum(float x)
+{
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false)); // row_half_mirror
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false)); // row_mirror
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false)); // row_bcast15 -> rows 1,3
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xC, 0xF, false)); // row_bcast31 -> rows 2,3
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+struct RenderArgs {
+	int W, H, gx;
+	const uint2 *ranges;
+	const uint32_t *point_list;
+	const float4 *rec;
+	const float4 *lvl;      // RF
+	const float *tile_lv;   // RF float[5][T]
+	int T;
+	const float *bg;
+	float *out_color;
+	float *final_T;
+	uint32_t *n_contrib;
+	int *gaussians_count;   // RS
+	float *contributions;   // RS
+};
+
+// ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB ----------------
+template <int VARIANT, int PPL>
+__global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
+{
+	constexpr int NT = 256 / PPL;        // threads per tile
+	constexpr int RSTEP = 16 / PPL;      // row distance between a lane's pixels
+	constexpr bool CUTOFF = VARIANT != FR_VARIANT_ORIGINAL;
+	constexpr bool SUM = VARIANT == FR_VARIANT_PCHECK_OBB_SUM;
+	constexpr bool AUX = VARIANT != FR_VARIANT_PCHECK_OBB; // final_T / n_contrib kept for backward
+
+	__shared__ float4 s0[256];
+	__shared__ float4 s1[256];
+	__shared__ float s2[256];
+	__shared__ int sid[SUM ? 256 : 1];
+
+	const int tile = blockIdx.x;
+	const int tx = tile % a.gx, ty = tile / a.gx;
+	const int tid = threadIdx.x;
+	const int lx = tid & 15, ry = tid >> 4;
+	const int px = tx * FR_TILE + lx;
+	const float pxf = (float)px;
+	const uint2 range = a.ranges[tile];
+	const int n = (int)(range.y - range.x);
+
+	float T[PPL], C0[PPL], C1[PPL], C2[PPL], pyf[PPL];
+	uint32_t last[PPL];
+	bool done[PPL], inside[PPL];
+#pragma unroll
+	for (int k = 0; k < PPL; k++)
+	{
+		const int py = ty * FR_TILE + ry + k * RSTEP;
+		pyf[k] = (float)py;
+		inside[k] = px < a.W && py < a.H;
+		done[k] = !inside[k];
+		T[k] = 1.0f; C0[k] = C1[k] = C2[k] = 0.0f; last[k] = 0;
+	}
+
+	for (int base = 0; base < n; base += 256)
+	{
+		bool all_done = true;
+#pragma unroll
+		for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
+		if (__syncthreads_and(all_done)) break;
+		// cooperative gather of up to 256 instance records
+#pragma unroll
+		for (int k = 0; k < PPL; k++)
+		{
+			const int e = tid + k * NT;
+			if (base + e < n)
+			{
+				const uint32_t id = a.point_list[range.x + base + e];
+				const float4 *r = a.rec + 3 * (size_t)id;
+				s0[e] = r[0]; s1[e] = r[1]; s2[e] = r[2].x;
+				if (SUM) { sid[e] = (int)id; atomicAdd(&a.gaussians_count[id], 1); }
+			}
+		}
+		__syncthreads();
+		const int cnt = min(256, n - base);
+		for (int j = 0; j < cnt; j++)
+		{
+			bool lane_done = true;
+#pragma unroll
+			for (int k = 0; k < PPL; k++) lane_done = lane_done && done[k];
+			if (__all(lane_done)) break; // whole wave saturated: nothing left to do in this batch
+			const float4 g0 = s0[j];
+			const float4 g1 = s1[j];
+			const float dx = g0.x - pxf;
+			const float adx = g0.z * dx;         // A*dx
+			const float adx2 = adx * dx;         // A*dx*dx
+			const float bdx = g0.w * dx;         // B*dx
+			float contrib_sum = 0.0f;
+			bool any_contrib = false;
+#pragma unroll
+			for (int k = 0; k < PPL; k++)
+			{
+				if (done[k]) continue;
+				const float dy = g0.y - pyf[k];
+				const float s = fmaf(g1.x * dy, dy, adx2);            // A dx^2 + C dy^2
+				const float power = fmaf(-0.5f, s, -(bdx * dy));      // -0.5 s - B dx dy
+				if (power > 0.0f) continue;
+				if (CUTOFF && power < -4.5f) continue;
+				const float alpha = fminf(0.99f, g1.y * fast_exp(power));
+				if (alpha < 1.0f / 255.0f) continue;
+				const float test_T = T[k] * (1.0f - alpha);
+				if (test_T < 0.0001f) { done[k] = true; continue; }
+				const float w = alpha * T[k];
+				C0[k] = fmaf(g1.z, w, C0[k]);
+				C1[k] = fmaf(g1.w, w, C1[k]);
+				C2[k] = fmaf(s2[j], w, C2[k]);
+				T[k] = test_T;
+				last[k] = (uint32_t)(base + j + 1);
+				if (SUM) { contrib_sum += w; any_contrib = true; }
+			}
+			if (SUM)
+			{
+				if (__any(any_contrib))
+				{
+					const float tot = wave_sum(contrib_sum);
+					if ((tid & 63) == 0) atomicAdd(&a.contributions[sid[j]], tot);
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+	const size_t plane = (size_t)a.W * a.H;
+#pragma unroll
+	for (int k = 0; k < PPL; k++)
+	{
+		if (!inside[k]) continue;
+		const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + ry + k * RSTEP) + px;
+		if (AUX) { a.final_T[pid] = T[k]; a.n_contrib[pid] = last[k]; }
+		a.out_color[pid] = fmaf(T[k], bg0, C0[k]);
+		a.out_color[plane + pid] = fmaf(T[k], bg1, C1[k]);
+		a.out_color[2 * plane + pid] = fmaf(T[k], bg2, C2[k]);
+	}
+}
+
+// ---------------- FOV_PCHECK_OBB: single-level and two-level tiles ----------------
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
+{
+	constexpr int NT = 256 / PPL;
+	constexpr int RSTEP = 16 / PPL;
+	__shared__ float4 s0[256];   // x, y, A, B
+	__shared__ float2 s1[256];   // C, highest_level
+	__shared__ float4 sl1[256];  // level L1: r, g, b, opacity
+	__shared__ float4 sl2[256];  // level L2 (two-level tiles only)
+
+	const int tile = blockIdx.x;
+	const int tx = tile % a.gx, ty = tile / a.gx;
+	const int tid = threadIdx.x;
+	const int lx = tid & 15, ry = tid >> 4;
+	const int px = tx * FR_TILE + lx;
+	const float pxf = (float)px;
+	const uint2 range = a.ranges[tile];
+	const int n = (int)(range.y - range.x);
+	const float tlf = a.tile_lv[a.T + tile];                    // tile_min
+	const bool blending = a.tile_lv[4 * (size_t)a.T + tile] != 0.0f;
+	const int L1 = f2i(tlf);
+	const int L2 = L1 + 1;
+	const float L2f = tlf + 1.0f;
+	const float tgx = a.tile_lv[2 * (size_t)a.T + tile], tgy = a.tile_lv[3 * (size_t)a.T + tile];
+
+	float T1[PPL], T2[PPL], A0[PPL], A1[PPL], A2[PPL], B0[PPL], B1[PPL], B2[PPL], pyf[PPL], est[PPL];
+	bool d1[PPL], d2[PPL], inside[PPL];
+#pragma unroll
+	for (int k = 0; k < PPL; k++)
+	{
+		const int ly = ry + k * RSTEP;
+		const int py = ty * FR_TILE + ly;
+		pyf[k] = (float)py;
+		inside[k] = px < a.W && py < a.H;
+		T1[k] = T2[k] = 1.0f; A0[k] = A1[k] = A2[k] = B0[k] = B1[k] = B2[k] = 0.0f;
+		est[k] = tlf + ((float)lx * tgx + (float)ly * tgy) / (float)FR_TILE;
+		if (blending) { d1[k] = !inside[k] || (est[k] > (float)L2); d2[k] = !inside[k]; }
+		else { d1[k] = !inside[k]; d2[k] = true; }
+	}
+
+	for (int base = 0; base < n; base += 256)
+	{
+		bool all_done = true;
+#pragma unroll
+		for (int k = 0; k < PPL; k++) all_done = all_done && d1[k] && d2[k];
+		if (__syncthreads_and(all_done)) break;
+#pragma unroll
+		for (int k = 0; k < PPL; k++)
+		{
+			const int e = tid + k * NT;
+			if (base + e < n)
+			{
+				const uint32_t id = a.point_list[range.x + base + e];
+				const float4 *r = a.rec + 3 * (size_t)id;
+				s0[e] = r[0];
+				const float4 r1 = r[1];
+				s1[e] = make_float2(r1.x, r1.y);
+				sl1[e] = a.lvl[(size_t)id * FR_FOV_LEVELS + L1];
+				if (blending) sl2[e] = a.lvl[(size_t)id * FR_FOV_LEVELS + L2];
+			}
+		}
+		__syncthreads();
+		const int cnt = min(256, n - base);
+		for (int j = 0; j < cnt; j++)
+		{
+			bool lane_done = true;
+#pragma unroll
+			for (int k = 0; k < PPL; k++) lane_done = lane_done && d1[k] && d2[k];
+			if (__all(lane_done)) break;
+			const float4 g0 = s0[j];
+			const float2 g1 = s1[j];
+			const float4 c1 = sl1[j];
+			const float dx = g0.x - pxf;
+			const float adx2 = (g0.z * dx) * dx;
+			const float bdx = g0.w * dx;
+			if (!blending)
+			{
+#pragma unroll
+				for (int k = 0; k < PPL; k++)
+				{
+					if (d1[k]) continue;
+					const float dy = g0.y - pyf[k];
+					const float s = fmaf(g1.x * dy, dy, adx2);
+					const float power = fmaf(-0.5f, s, -(bdx * dy));
+					if (power > 0.0f || power < -4.5f) continue;
+					const float alpha = fminf(0.99f, c1.w * fast_exp(power));
+					if (alpha < 1.0f / 255.0f) continue;
+					const float test_T = T1[k] * (1.0f - alpha);
+					if (test_T < 0.0001f) { d1[k] = true; continue; }
+					const float w = alpha * T1[k];
+					A0[k] = fmaf(c1.x, w, A0[k]); A1[k] = fmaf(c1.y, w, A1[k]); A2[k] = fmaf(c1.z, w, A2[k]);
+					T1[k] = test_T;
+				}
+			}
+			else
+			{
+				const float4 c2 = sl2[j];
+				const bool l2_masked = (g1.y + 1.0f) < L2f; // Gaussian does not exist at level L2
+#pragma unroll
+				for (int k = 0; k < PPL; k++)
+				{
+					if (d1[k] && d2[k]) continue;
+					const float dy = g0.y - pyf[k];
+					const float s = fmaf(g1.x * dy, dy, adx2);
+					const float power = fmaf(-0.5f, s, -(bdx * dy));
+					if (power > 0.0f || power < -4.5f) continue;
+					const float ev = fast_exp(power);
+					if (!d1[k])
+					{
+						const float a1 = fminf(0.99f, c1.w * ev);
+						if (!(a1 < 1.0f / 255.0f))
+						{
+							const float tT = T1[k] * (1.0f - a1);
+							d1[k] = tT < 0.0001f;
+							if (!d1[k])
+							{
+								const float w = a1 * T1[k];
+								A0[k] = fmaf(c1.x, w, A0[k]); A1[k] = fmaf(c1.y, w, A1[k]); A2[k] = fmaf(c1.z, w, A2[k]);
+								T1[k] = tT;
+							}
+						}
+					}
+					if (!d2[k])
+					{
+						const float a2 = fminf(0.99f, c2.w * ev);
+						if (!((a2 < 1.0f / 255.0f) || l2_masked))
+						{
+							const float tT = T2[k] * (1.0f - a2);
+							d2[k] = tT < 0.0001f;
+							if (!d2[k])
+							{
+								const float w = a2 * T2[k];
+								B0[k] = fmaf(c2.x, w, B0[k]); B1[k] = fmaf(c2.y, w, B1[k]); B2[k] = fmaf(c2.z, w, B2[k]);
+								T2[k] = tT;
+							}
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+	const size_t plane = (size_t)a.W * a.H;
+#pragma unroll
+	for (int k = 0; k < PPL; k++)
+	{
+		if (!inside[k]) continue;
+		const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + ry + k * RSTEP) + px;
+		float o0 = fmaf(bg0, T1[k], A0[k]), o1 = fmaf(bg1, T1[k], A1[k]), o2 = fmaf(bg2, T1[k], A2[k]);
+		if (blending)
+		{
+			const float q0 = fmaf(bg0, T2[k], B0[k]), q1 = fmaf(bg1, T2[k], B1[k]), q2 = fmaf(bg2, T2[k], B2[k]);
+			float x = fabsf(est[k] - ((float)L1 + 0.5f)) / 0.5f;
+			x = fmaxf(0.0f, fminf(1.0f, x));
+			const float bT = 3 * x * x - 2 * x * x * x;
+			const float w1 = 1 - bT;
+			o0 = o0 * w1 + q0 * (1.f - w1);
+			o1 = o1 * w1 + q1 * (1.f - w1);
+			o2 = o2 * w1 + q2 * (1.f - w1);
+		}
+		a.out_color[pid] = o0;
+		a.out_color[plane + pid] = o1;
+		a.out_color[2 * plane + pid] = o2;
+	}
+}
+
+#ifndef FR_RENDER_PPL
+#define FR_RENDER_PPL 4
+#endif
+
+int launch_render(FwdCtx &c)
+{
+	const fr_forward_args *a = c.a;
+	RenderArgs r;
+	r.W = a->W; r.H = a->H; r.gx = c.gx;
+	r.ranges = c.img.ranges; r.point_list = c.bin.point_list; r.rec = c.geom.rec; r.lvl = c.geom.lvl;
+	r.tile_lv = c.img.tile_lv; r.T = c.T; r.bg = a->background; r.out_color = a->out_color;
+	r.final_T = c.img.final_T; r.n_contrib = c.img.n_contrib;
+	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions;
+	constexpr int PPL = FR_RENDER_PPL;
+	const dim3 grid(c.T), block(256 / PPL);
+	switch (a->variant)
+	{
+	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL((k_render<FR_VARIANT_ORIGINAL, PPL>), grid, block, 0, c.stream, r); break;
+	case FR_VARIANT_PCHECK_OBB_SUM: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_SUM, PPL>), grid, block, 0, c.stream, r); break;
+	case FR_VARIANT_PCHECK_OBB: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB, PPL>), grid, block, 0, c.stream, r); break;
+	default: hipLaunchKernelGGL((k_render_fov<PPL>), grid, block, 0, c.stream, r); break;
+	}
+	return check_launch("render", c.stream, a->debug);
+}
+
+} // namespace fr

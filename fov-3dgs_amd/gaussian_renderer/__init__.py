@@ -1,0 +1,64 @@
+"""render() for the non-foveated rasterizers (reference: fov3dgs/gaussian_renderer/__init__.py:19-147).
+
+Same signature and result dict; `pc` is anything exposing the GaussianModel getters
+(get_xyz, get_opacity, get_scaling, get_rotation, get_features, get_features_detach_rest,
+active_sh_degree), `viewpoint_camera` anything with the Camera/MiniCam fields.
+"""
+import math
+
+import torch
+
+from ..gaussian_wrapper import get_gs_rasterizer
+from ..rasterizer import GaussianRasterizationSettings
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, masking=False,
+           starter=None, ender=None, cuda_type="", loss_map=None):
+    """Render the scene. Background tensor (bg_color) must be on the GPU."""
+    xyz = pc.get_xyz
+    # zero tensor that makes autograd return the gradient of the 2D (screen-space) means
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx,
+        tanfovy=tanfovy,
+        bg=bg_color,
+        scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center,
+        prefiltered=False,
+        debug=bool(getattr(pipe, "debug", False)),
+    )
+    rasterizer = get_gs_rasterizer(cuda_type, raster_settings)
+
+    means3D = xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+    scales = pc.get_scaling
+    rotations = pc.get_rotation
+    shs = pc.get_features_detach_rest if masking else pc.get_features
+    if masking:
+        scales, means3D, rotations = scales.detach(), means3D.detach(), rotations.detach()
+
+    if starter is not None:
+        starter.record()
+    out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,
+                     scales=scales, rotations=rotations, cov3D_precomp=None)
+    if ender is not None:
+        ender.record()
+
+    result = {"render": out[0], "viewspace_points": screenspace_points, "visibility_filter": out[1] > 0,
+              "radii": out[1]}
+    if len(out) == 4:
+        result["gs_count"], result["contribs"] = out[2], out[3]
+    return result

@@ -1,0 +1,375 @@
+"""Host side of the drop-in boundary: the reference's autograd interface over the C ABI.
+
+Mirrors, per variant, the Python wrapper each reference extension ships
+(fov3dgs/submodules/<variant>/<pkg>/__init__.py):
+  GaussianRasterizationSettings   diff_gaussian_rasterization/__init__.py:157-169 (same 12 fields everywhere)
+  GaussianRasterizer              …/__init__.py:171-220; RS :177-226 (4 outputs); RF :203-261 (5 extra inputs)
+  _RasterizeGaussians             …/__init__.py:44-155 (argument order, saved tensors, gradient order)
+  _C.rasterize_gaussians[_backward] / mark_visible   rasterize_points.cu:35-217 -> fr_forward / fr_backward /
+                                  fr_mark_visible through ctypes (fov3dgs_amd/_native.py)
+
+All tensors must live on a ROCm device; there is no CPU path. Output / workspace tensors are
+allocated here with torch (the C library never allocates device memory).
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _native
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+def _f32(t, device):
+    """contiguous fp32 tensor on `device`, or None for the reference's 'empty tensor' placeholder."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RuntimeError(f"fovraster: expected every tensor on {device}, got one on {t.device}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(means3D):
+    if not means3D.is_cuda:
+        raise RuntimeError("fovraster: tensors must live on a ROCm GPU -- the rasterizer is a HIP extension and has no "
+                           "CPU fallback (the CPU oracle under oracle/ is test infrastructure only)")
+
+
+class _Workspaces:
+    """The three byte buffers the native call sizes through callbacks (reference: resizeFunctional)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = [torch.empty(0, dtype=torch.uint8, device=device) for _ in range(3)]
+        self.cbs = [_native.RESIZE_FN(self._make(i)) for i in range(3)]
+
+    def _make(self, i):
+        def resize(_user, nbytes):
+            if self.buf[i].numel() < nbytes:
+                self.buf[i] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return self.buf[i].data_ptr()
+        return resize
+
+
+def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05):
+    """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions])"""
+    lib = _native.load()
+    _require_gpu(means3D)
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = int(rs.image_height), int(rs.image_width)
+    a = _native.ForwardArgs()
+    keep = []
+
+    def put(name, t):
+        t = _f32(t, dev)
+        keep.append(t)
+        setattr(a, name, _ptr(t))
+        return t
+
+    with torch.cuda.device(dev):
+        color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        ws = _Workspaces(dev)
+        counts = contribs = None
+        a.variant = variant
+        a.P, a.D = P, int(rs.sh_degree)
+        sh_c = put("shs", sh)
+        a.M = 0 if sh_c is None else sh_c.size(1)
+        a.W, a.H = W, H
+        a.prefiltered, a.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+        a.tanfovx, a.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+        a.scale_modifier = float(rs.scale_modifier)
+        a.gaze_x, a.gaze_y, a.alpha = float(gaze[0]), float(gaze[1]), float(alpha)
+        a.stream = torch.cuda.current_stream(dev).cuda_stream
+        put("background", rs.bg)
+        put("means3D", means3D)
+        put("colors_precomp", colors_precomp)
+        put("opacities", opacities)
+        put("scales", scales)
+        put("rotations", rotations)
+        put("cov3D_precomp", cov3Ds_precomp)
+        put("viewmatrix", rs.viewmatrix)
+        put("projmatrix", rs.projmatrix)
+        put("campos", rs.campos)
+        put("shs_dcs", shs_dcs)
+        put("highest_levels", highest_levels)
+        a.out_color, a.radii = color.data_ptr(), radii.data_ptr()
+        if variant == _native.VARIANT_PCHECK_OBB_SUM:
+            counts = torch.zeros((P,), dtype=torch.int32, device=dev)
+            contribs = torch.zeros((P,), dtype=torch.float32, device=dev)
+            a.gaussians_count, a.contributions = counts.data_ptr(), contribs.data_ptr()
+        a.geometry_resize, a.binning_resize, a.image_resize = ws.cbs[0], ws.cbs[1], ws.cbs[2]
+        rc = lib.fr_forward(C.byref(a))
+        if rc != 0:
+            raise RuntimeError(f"fovraster forward failed ({rc}): {_native.last_error()}")
+    out = (int(a.num_rendered), color, radii, ws.buf[0], ws.buf[1], ws.buf[2])
+    if counts is not None:
+        out = out + (counts, contribs)
+    return out
+
+
+def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                     grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)"""
+    lib = _native.load()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = grad_out_color.size(1), grad_out_color.size(2)
+    a = _native.BackwardArgs()
+    keep = []
+
+    def put(name, t):
+        t = _f32(t, dev)
+        keep.append(t)
+        setattr(a, name, _ptr(t))
+        return t
+
+    with torch.cuda.device(dev):
+        sh_c = put("shs", sh)
+        M = 0 if sh_c is None else sh_c.size(1)
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
+        dL_dconic, dL_dopacity, dL_dcov3D = z(P, 2, 2), z(P, 1), z(P, 6)
+        dL_dsh, dL_dscales, dL_drotations = z(P, M, 3), z(P, 3), z(P, 4)
+        if P != 0:
+            a.variant, a.P, a.D, a.M, a.R = variant, P, int(rs.sh_degree), M, int(num_rendered)
+            a.W, a.H, a.debug = W, H, int(bool(rs.debug))
+            a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
+            a.stream = torch.cuda.current_stream(dev).cuda_stream
+            put("background", rs.bg)
+            put("means3D", means3D)
+            put("colors_precomp", colors_precomp)
+            put("opacities", opacities)
+            put("scales", scales)
+            put("rotations", rotations)
+            put("cov3D_precomp", cov3Ds_precomp)
+            put("viewmatrix", rs.viewmatrix)
+            put("projmatrix", rs.projmatrix)
+            put("campos", rs.campos)
+            put("dL_dpix", grad_out_color)
+            a.radii = radii.data_ptr()
+            a.geometry, a.binning, a.image = geomBuffer.data_ptr(), _ptr(binningBuffer if binningBuffer.numel() else None), imgBuffer.data_ptr()
+            a.dL_dmean2D, a.dL_dconic, a.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr()
+            a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D = dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr()
+            a.dL_dsh = dL_dsh.data_ptr() if M else None
+            a.dL_dscale, a.dL_drot = dL_dscales.data_ptr(), dL_drotations.data_ptr()
+            rc = lib.fr_backward(C.byref(a))
+            if rc != 0:
+                raise RuntimeError(f"fovraster backward failed ({rc}): {_native.last_error()}")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def _mark_visible(positions, rs):
+    lib = _native.load()
+    _require_gpu(positions)
+    dev = positions.device
+    P = positions.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P:
+        pos, vm, pm = _f32(positions, dev), _f32(rs.viewmatrix, dev), _f32(rs.projmatrix, dev)
+        with torch.cuda.device(dev):
+            rc = lib.fr_mark_visible(P, pos.data_ptr(), vm.data_ptr(), pm.data_ptr(), present.data_ptr(),
+                                     torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"fovraster mark_visible failed ({rc}): {_native.last_error()}")
+    return present
+
+
+def _opacities_for_backward(opacities):
+    return opacities
+
+
+def _make_plain(variant_id, with_counts, has_backward):
+    """Autograd function + module for the non-foveated variants."""
+
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                    raster_settings):
+            args = (variant_id, raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations,
+                    cov3Ds_precomp)
+            if raster_settings.debug:
+                cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
+                try:
+                    res = _forward_native(*args)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                res = _forward_native(*args)
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = res[:6]
+            ctx.raster_settings = raster_settings
+            ctx.num_rendered = num_rendered
+            ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
+                                  geomBuffer, binningBuffer, imgBuffer)
+            ctx.mark_non_differentiable(radii)
+            if with_counts:
+                ctx.mark_non_differentiable(res[6], res[7])
+                return color, radii, res[6], res[7]
+            return color, radii
+
+        @staticmethod
+        def backward(ctx, grad_out_color, *_unused):
+            if not has_backward:
+                # the reference's inference-only extension exports no backward entry point
+                raise RuntimeError("this rasterizer variant is inference-only (no backward in the reference)")
+            rs = ctx.raster_settings
+            (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
+             geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+            args = (variant_id, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                    grad_out_color, sh, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer)
+            if rs.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    res = _backward_native(*args)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise ex
+            else:
+                res = _backward_native(*args)
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = res
+            return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
+                    grad_rotations, grad_cov3Ds_precomp, None)
+
+    def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                            raster_settings):
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            with torch.no_grad():
+                return _mark_visible(positions, self.raster_settings)
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None):
+            raster_settings = self.raster_settings
+            if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+                raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                    ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            empty = torch.Tensor([])
+            shs = empty if shs is None else shs
+            colors_precomp = empty if colors_precomp is None else colors_precomp
+            scales = empty if scales is None else scales
+            rotations = empty if rotations is None else rotations
+            cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+            return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                       cov3D_precomp, raster_settings)
+
+    return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
+
+
+def _gaze_pair(gazeArray):
+    if gazeArray is None:
+        raise Exception("gazeArray is required by the foveated rasterizer")
+    if isinstance(gazeArray, torch.Tensor):
+        g = gazeArray.detach().flatten().tolist()  # the reference does two .item() syncs here
+    else:
+        g = list(gazeArray)
+    return float(g[0]), float(g[1])
+
+
+def _make_fov():
+    """Autograd function + module for the foveated (inference-only) variant."""
+    variant_id = _native.VARIANT_FOV_PCHECK_OBB
+
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                    raster_settings, shs_dcs, highest_levels, gazeArray, alpha, blending):
+            args = (variant_id, raster_settings, means3D, shs_rest, colors_precomp, opacities, scales, rotations,
+                    cov3Ds_precomp, shs_dcs, highest_levels, _gaze_pair(gazeArray), float(alpha))
+            if raster_settings.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    res = _forward_native(*args)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                res = _forward_native(*args)
+            num_rendered, color, radii = res[:3]
+            ctx.num_rendered = num_rendered
+            ctx.mark_non_differentiable(radii)
+            return color, radii
+
+        @staticmethod
+        def backward(ctx, grad_out_color, _):
+            # RF/diff_gaussian_rasterization_fov_pcheck_obb/__init__.py:128-187: the foveated extension is
+            # inference-only and hands back None for every input
+            return (None,) * 14
+
+    def rasterize_gaussians(means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations,
+                            cov3Ds_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha, blending):
+        return _RasterizeGaussians.apply(means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha,
+                                         blending)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            with torch.no_grad():
+                return _mark_visible(positions, self.raster_settings)
+
+        def forward(self, means3D, means2D, opacities, shs_rest=None, colors_precomp=None, scales=None,
+                    rotations=None, cov3D_precomp=None, shs_dcs=None, highest_levels=None, gazeArray=None,
+                    alpha=None, blending=None):
+            raster_settings = self.raster_settings
+            if (shs_rest is None and colors_precomp is None) or (shs_rest is not None and colors_precomp is not None):
+                raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                    ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            empty = torch.Tensor([])
+            shs_rest = empty if shs_rest is None else shs_rest
+            colors_precomp = empty if colors_precomp is None else colors_precomp
+            scales = empty if scales is None else scales
+            rotations = empty if rotations is None else rotations
+            cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+            return rasterize_gaussians(means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations,
+                                       cov3D_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha,
+                                       blending)
+
+    return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer

@@ -1,0 +1,165 @@
+/*
+ * fovraster.h -- C ABI of libfovraster_hip.so, the MI355X (gfx950) rasterizer library.
+ *
+ * This is the drop-in boundary for the rasterizer hot path of horizon-research/Fov-3DGS.
+ * Each entry point replaces one function of the reference's native layer (paths relative to
+ * /root/reference/fov3dgs/submodules/):
+ *
+ *   fr_forward        <-  CudaRasterizer::Rasterizer::forward
+ *                           diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:36-61      ("original")
+ *                           diff-gaussian-rasterization_pcheck_obb_sum/cuda_rasterizer/rasterizer.h (RS, + counts)
+ *                           diff-gaussian-rasterization_pcheck_obb/cuda_rasterizer/rasterizer.h     (RP)
+ *                           diff-gaussian-rasterization_fov_pcheck_obb/cuda_rasterizer/rasterizer.h:31-64 (RF)
+ *                         as called by RasterizeGaussiansCUDA (…/rasterize_points.cu:35-115; RS :35-135; RF :35-152)
+ *   fr_backward       <-  CudaRasterizer::Rasterizer::backward (…/cuda_rasterizer/rasterizer.h:63-85)
+ *                         as called by RasterizeGaussiansBackwardCUDA (…/rasterize_points.cu:117-196)
+ *   fr_mark_visible   <-  CudaRasterizer::Rasterizer::markVisible (…/rasterizer.h:24-29; rasterize_points.cu:198-217)
+ *   fr_resize_fn      <-  the std::function<char*(size_t)> buffer callbacks (…/rasterize_points.cu:27-33)
+ *
+ * Conventions: every pointer in the argument structs is a DEVICE pointer to fp32/int32 data laid
+ * out exactly as the reference's tensors (row-major, contiguous) unless stated otherwise; NULL
+ * stands for the reference's "empty tensor". The library never allocates or frees device memory:
+ * the three workspaces are obtained through the caller's resize callbacks, exactly like the
+ * reference's geometry/binning/image buffers, and must be kept alive by the caller for
+ * fr_backward. All work is enqueued on `stream` (a hipStream_t); fr_forward synchronises that
+ * stream once (to learn the number of (Gaussian,tile) instances), fr_backward never does.
+ * All functions return 0 on success or a negative FR_ERR_* code; fr_last_error() gives the message
+ * (thread-local).
+ */
+#ifndef FOVRASTER_H
+#define FOVRASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_ABI_VERSION 1
+
+/* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
+ * fov3dgs/gaussian_wrapper.py:11-23) */
+enum {
+	FR_VARIANT_ORIGINAL = 0,       /* diff-gaussian-rasterization                    */
+	FR_VARIANT_PCHECK_OBB_SUM = 1, /* …_pcheck_obb_sum (training; counts/contributions) */
+	FR_VARIANT_PCHECK_OBB = 2,     /* …_pcheck_obb (inference)                        */
+	FR_VARIANT_FOV_PCHECK_OBB = 3  /* …_fov_pcheck_obb (foveated inference)           */
+};
+
+enum {
+	FR_OK = 0,
+	FR_ERR_INVALID = -1,   /* bad argument combination (message says which) */
+	FR_ERR_HIP = -2,       /* a HIP call or kernel failed */
+	FR_ERR_ALLOC = -3,     /* a resize callback returned NULL */
+	FR_ERR_PREFILTERED = -4 /* reserved */
+};
+
+/* Workspace callback: make the buffer at least `bytes` long and return its device address.
+ * Same contract as the reference's resizeFunctional lambdas. */
+typedef char *(*fr_resize_fn)(void *user, size_t bytes);
+
+typedef struct fr_forward_args {
+	int32_t variant;
+	int32_t P;            /* number of Gaussians */
+	int32_t D;            /* active SH degree (0..3) */
+	int32_t M;            /* SH coefficients per Gaussian in `shs` (16; RF: 15 = rest only); 0 if shs == NULL */
+	int32_t W, H;         /* image size */
+	int32_t prefiltered;
+	int32_t debug;        /* != 0: synchronise + check after every launch */
+	float tanfovx, tanfovy;
+	float scale_modifier;
+	/* foveation (RF only) */
+	float gaze_x, gaze_y; /* normalised gaze in [0,1]^2 (reference passes gazeArray and .item()s it) */
+	float alpha;          /* pooling-size slope (0.05) */
+	void *stream;         /* hipStream_t */
+	/* inputs */
+	const float *background;     /* [3] */
+	const float *means3D;        /* [P,3] */
+	const float *shs;            /* [P,M,3] or NULL */
+	const float *colors_precomp; /* [P,3] or NULL */
+	const float *opacities;      /* [P,1]; RF: [P,4] per level */
+	const float *scales;         /* [P,3] or NULL */
+	const float *rotations;      /* [P,4] or NULL */
+	const float *cov3D_precomp;  /* [P,6] or NULL */
+	const float *viewmatrix;     /* [4,4] as the reference passes it (world-to-camera, transposed) */
+	const float *projmatrix;     /* [4,4] */
+	const float *campos;         /* [3] */
+	const float *shs_dcs;        /* RF: [P,4,3] per-level DC coefficient */
+	const float *highest_levels; /* RF: [P,1] float */
+	/* outputs (caller-allocated) */
+	float *out_color;            /* [3,H,W] */
+	int32_t *radii;              /* [P] */
+	int32_t *gaussians_count;    /* RS: [P], else NULL */
+	float *contributions;        /* RS: [P], else NULL */
+	/* workspaces */
+	fr_resize_fn geometry_resize;
+	fr_resize_fn binning_resize;
+	fr_resize_fn image_resize;
+	void *resize_user[3];        /* passed to the three callbacks in that order */
+	/* result */
+	int32_t num_rendered;        /* out: number of (Gaussian,tile) instances after culling */
+	int32_t max_tile_instances;  /* out: longest per-tile list */
+	/* optional profiling: HOST pointer to FR_NUM_STAGES floats, or NULL. When set, hipEvents are
+	 * recorded around every stage on `stream` and the call synchronises at the end to fill it
+	 * with per-stage milliseconds (FR_STAGE_* order). */
+	float *stage_ms;
+} fr_forward_args;
+
+enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PREPROCESS = 1, FR_STAGE_TILE_SCAN = 2, FR_STAGE_EMIT = 3,
+	FR_STAGE_TILE_SORT = 4, FR_STAGE_RENDER = 5, FR_NUM_STAGES = 6 };
+
+typedef struct fr_backward_args {
+	int32_t variant;             /* FR_VARIANT_ORIGINAL or FR_VARIANT_PCHECK_OBB_SUM */
+	int32_t P, D, M, R;          /* R = num_rendered of the forward call */
+	int32_t W, H;
+	int32_t debug;
+	float tanfovx, tanfovy;
+	float scale_modifier;
+	void *stream;
+	const float *background, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations,
+		*cov3D_precomp, *viewmatrix, *projmatrix, *campos;
+	const int32_t *radii;        /* [P] from forward */
+	const char *geometry, *binning, *image; /* the three workspaces filled by fr_forward */
+	const float *dL_dpix;        /* [3,H,W] */
+	/* outputs: caller-allocated AND ZERO-FILLED (the reference allocates them with torch::zeros,
+	 * rasterize_points.cu:171-179) */
+	float *dL_dmean2D;           /* [P,3] */
+	float *dL_dconic;            /* [P,2,2] */
+	float *dL_dopacity;          /* [P,1] */
+	float *dL_dcolor;            /* [P,3] */
+	float *dL_dmean3D;           /* [P,3] */
+	float *dL_dcov3D;            /* [P,6] */
+	float *dL_dsh;               /* [P,M,3] */
+	float *dL_dscale;            /* [P,3] */
+	float *dL_drot;              /* [P,4] */
+	float *stage_ms;             /* optional HOST pointer to 2 floats: render-backward ms, preprocess-backward ms */
+} fr_backward_args;
+
+int fr_abi_version(void);
+const char *fr_last_error(void);
+
+int fr_forward(fr_forward_args *args);
+int fr_backward(const fr_backward_args *args);
+int fr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+	uint8_t *present /* [P] bool */, void *stream);
+
+/* Bytes fr_forward will request for the geometry / image workspaces (P, W, H dependent) and for the
+ * binning workspace given a number of instances; lets a caller pre-size persistent buffers. */
+size_t fr_geometry_bytes(int32_t variant, int32_t P);
+size_t fr_image_bytes(int32_t variant, int32_t W, int32_t H);
+size_t fr_binning_bytes(int32_t variant, int64_t num_instances);
+
+/* Introspection for tests: copies of internal per-tile / per-instance state out of the workspaces.
+ * ranges: uint32 [T,2]; point_list: uint32 [num_rendered] (device pointers into the workspaces). */
+const uint32_t *fr_image_ranges(int32_t variant, int32_t W, int32_t H, const char *image);
+const uint32_t *fr_binning_point_list(int32_t variant, int64_t num_instances, const char *binning);
+const float *fr_image_final_T(int32_t variant, int32_t W, int32_t H, const char *image);
+const uint32_t *fr_image_n_contrib(int32_t variant, int32_t W, int32_t H, const char *image);
+/* RF: device pointer to float[5][T] = levels, tile_min, grad_x, grad_y, blending(0/1 as float) */
+const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOVRASTER_H */

@@ -1,0 +1,77 @@
+"""Run the HIP library on oracle-style input dicts and pull its internal state back as numpy."""
+import numpy as np
+import torch
+
+from fov3dgs_amd import _native
+from fov3dgs_amd.rasterizer import GaussianRasterizationSettings, _backward_native, _forward_native
+
+VARIANT_IDS = _native.VARIANT_IDS
+
+
+def _t(x, dev):
+    return None if x is None else torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).to(dev)
+
+
+def settings_from(cam, dev, debug=True):
+    return GaussianRasterizationSettings(
+        image_height=int(cam["image_height"]), image_width=int(cam["image_width"]), tanfovx=float(cam["tanfovx"]),
+        tanfovy=float(cam["tanfovy"]), bg=_t(cam["bg"], dev), scale_modifier=float(cam.get("scale_modifier", 1.0)),
+        viewmatrix=_t(cam["viewmatrix"], dev), projmatrix=_t(cam["projmatrix"], dev), sh_degree=int(cam["sh_degree"]),
+        campos=_t(cam["campos"], dev), prefiltered=False, debug=debug)
+
+
+def _view(buf, ptr, count, dtype):
+    off = ptr - buf.data_ptr()
+    nbytes = count * torch.empty(0, dtype=dtype).element_size()
+    assert 0 <= off and off + nbytes <= buf.numel()
+    return buf[off:off + nbytes].view(dtype)
+
+
+def hip_forward(variant, scene, cam, dev="cuda:0", debug=True):
+    """-> dict shaped like oracle.forward()'s (the subset the HIP library keeps)."""
+    lib = _native.load()
+    vid = VARIANT_IDS[variant]
+    rs = settings_from(cam, dev, debug)
+    tens = {k: _t(scene.get(k), dev) for k in ("means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
+                                                "cov3D_precomp", "shs_dcs", "highest_levels")}
+    res = _forward_native(vid, rs, tens["means3D"], tens["shs"], tens["colors_precomp"], tens["opacities"],
+                          tens["scales"], tens["rotations"], tens["cov3D_precomp"], tens["shs_dcs"],
+                          tens["highest_levels"], cam.get("gaze", (0.5, 0.5)), cam.get("alpha", 0.05))
+    torch.cuda.synchronize()
+    num_rendered, color, radii, geom, binb, img = res[:6]
+    W, H = rs.image_width, rs.image_height
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    out = {"num_rendered": num_rendered, "color": color.cpu().numpy(), "radii": radii.cpu().numpy(),
+           "_tensors": tens, "_rs": rs, "_buffers": (geom, binb, img), "_radii_t": radii}
+    rptr = lib.fr_image_ranges(vid, W, H, img.data_ptr())
+    out["ranges"] = _view(img, rptr, 2 * T, torch.int32).cpu().numpy().astype(np.uint32).reshape(T, 2)
+    if num_rendered > 0:
+        pptr = lib.fr_binning_point_list(vid, num_rendered, binb.data_ptr())
+        out["point_list"] = _view(binb, pptr, num_rendered, torch.int32).cpu().numpy().astype(np.uint32)
+    else:
+        out["point_list"] = np.zeros(0, np.uint32)
+    if variant in ("original", "pcheck_obb_sum"):
+        out["final_T"] = _view(img, lib.fr_image_final_T(vid, W, H, img.data_ptr()), W * H, torch.float32).cpu().numpy().reshape(H, W)
+        out["n_contrib"] = _view(img, lib.fr_image_n_contrib(vid, W, H, img.data_ptr()), W * H, torch.int32).cpu().numpy().astype(np.uint32).reshape(H, W)
+    if variant == "pcheck_obb_sum":
+        out["gaussians_count"], out["contributions"] = res[6].cpu().numpy(), res[7].cpu().numpy()
+    if variant == "fov_pcheck_obb":
+        lv = _view(img, lib.fr_image_tile_levels(W, H, img.data_ptr()), 5 * T, torch.float32).cpu().numpy().reshape(5, T)
+        out["tile_levels"], out["tile_min"], out["tile_gx"], out["tile_gy"] = lv[0], lv[1], lv[2], lv[3]
+        out["tile_blend"] = (lv[4] != 0).astype(np.uint8)
+    return out
+
+
+def hip_backward(variant, fwd, dL_dpix, dev="cuda:0"):
+    vid = VARIANT_IDS[variant]
+    t, rs = fwd["_tensors"], fwd["_rs"]
+    geom, binb, img = fwd["_buffers"]
+    empty = torch.Tensor([])
+    g = _backward_native(vid, rs, t["means3D"], fwd["_radii_t"], t["colors_precomp"] if t["colors_precomp"] is not None else empty,
+                         t["opacities"], t["scales"] if t["scales"] is not None else empty,
+                         t["rotations"] if t["rotations"] is not None else empty,
+                         t["cov3D_precomp"] if t["cov3D_precomp"] is not None else empty, _t(dL_dpix, dev),
+                         t["shs"] if t["shs"] is not None else empty, geom, fwd["num_rendered"], binb, img)
+    torch.cuda.synchronize()
+    names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+    return {n: v.cpu().numpy() for n, v in zip(names, g)}
