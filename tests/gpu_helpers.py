@@ -43,6 +43,9 @@ def hip_forward(variant, scene, cam, dev="cuda:0", debug=True):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     out = {"num_rendered": num_rendered, "color": color.cpu().numpy(), "radii": radii.cpu().numpy(),
            "_tensors": tens, "_rs": rs, "_buffers": (geom, binb, img), "_radii_t": radii}
+    if img.numel() == 0:  # P == 0: the library returns before touching any workspace
+        out["ranges"], out["point_list"] = np.zeros((T, 2), np.uint32), np.zeros(0, np.uint32)
+        return out
     rptr = lib.fr_image_ranges(vid, W, H, img.data_ptr())
     out["ranges"] = _view(img, rptr, 2 * T, torch.int32).cpu().numpy().astype(np.uint32).reshape(T, 2)
     if num_rendered > 0:
