@@ -34,7 +34,7 @@ class ForwardArgs(C.Structure):
         ("geometry_resize", RESIZE_FN), ("binning_resize", RESIZE_FN), ("image_resize", RESIZE_FN),
         ("resize_user", C.c_void_p * 3),
         ("num_rendered", C.c_int32), ("max_tile_instances", C.c_int32),
-        ("stage_ms", C.POINTER(C.c_float)),
+        ("stage_events", C.POINTER(C.c_void_p)),
     ]
 
 
@@ -50,11 +50,11 @@ class BackwardArgs(C.Structure):
         ("radii", _FP), ("geometry", _FP), ("binning", _FP), ("image", _FP), ("dL_dpix", _FP),
         ("dL_dmean2D", _FP), ("dL_dconic", _FP), ("dL_dopacity", _FP), ("dL_dcolor", _FP), ("dL_dmean3D", _FP),
         ("dL_dcov3D", _FP), ("dL_dsh", _FP), ("dL_dscale", _FP), ("dL_drot", _FP),
-        ("stage_ms", C.POINTER(C.c_float)),
+        ("stage_events", C.POINTER(C.c_void_p)),
     ]
 
 
-EXPORTS = ("fr_abi_version", "fr_last_error", "fr_forward", "fr_backward", "fr_mark_visible",
+EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible",
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
            "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels")
 
@@ -83,6 +83,11 @@ def load():
             raise NativeLibraryError(f"fovraster: {LIB_PATH} does not export {name}")
     lib.fr_abi_version.restype = C.c_int
     lib.fr_last_error.restype = C.c_char_p
+    lib.fr_event_create.restype = C.c_void_p
+    lib.fr_event_destroy.argtypes = [C.c_void_p]
+    lib.fr_event_destroy.restype = None
+    lib.fr_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.fr_event_elapsed_ms.restype = C.c_int
     lib.fr_forward.argtypes = [C.POINTER(ForwardArgs)]
     lib.fr_forward.restype = C.c_int
     lib.fr_backward.argtypes = [C.POINTER(BackwardArgs)]

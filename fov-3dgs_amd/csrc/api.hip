@@ -66,6 +66,21 @@ using namespace fr;
 extern "C" {
 
 int fr_abi_version(void) { return FR_ABI_VERSION; }
+
+void *fr_event_create(void)
+{
+	hipEvent_t e;
+	if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); return nullptr; }
+	return (void *)e;
+}
+void fr_event_destroy(void *event) { if (event) (void)hipEventDestroy((hipEvent_t)event); }
+int fr_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+	if (!start || !stop || !ms) { set_error("null event"); return FR_ERR_INVALID; }
+	FR_HIP(hipEventSynchronize((hipEvent_t)stop));
+	FR_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+	return FR_OK;
+}
 const char *fr_last_error(void) { return g_err; }
 
 size_t fr_geometry_bytes(int32_t variant, int32_t P) { return carve_geom(variant, (size_t)P, nullptr).bytes; }
@@ -91,22 +106,8 @@ int fr_forward(fr_forward_args *a)
 		FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, stream));
 		return FR_OK;
 	}
-	// optional per-stage timing with events on the launch stream
-	hipEvent_t ev[FR_NUM_STAGES + 1];
-	bool have[FR_NUM_STAGES + 1] = { false };
-	const bool prof = a->stage_ms != nullptr;
-	auto mark = [&](int i) { if (prof) { if (hipEventCreate(&ev[i]) == hipSuccess && hipEventRecord(ev[i], stream) == hipSuccess) have[i] = true; } };
-	auto finish_prof = [&]() {
-		if (!prof) return;
-		hipStreamSynchronize(stream);
-		for (int i = 0; i < FR_NUM_STAGES; i++)
-		{
-			float ms = 0.f;
-			if (have[i] && have[i + 1]) hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-			a->stage_ms[i] = ms;
-		}
-		for (int i = 0; i <= FR_NUM_STAGES; i++) if (have[i]) hipEventDestroy(ev[i]);
-	};
+	// optional per-stage timing: record the caller's events on the launch stream (no sync here)
+	auto mark = [&](int i) { if (a->stage_events && a->stage_events[i]) (void)hipEventRecord((hipEvent_t)a->stage_events[i], stream); };
 	FwdCtx c;
 	c.a = a; c.stream = stream;
 	c.gx = (a->W + FR_TILE - 1) / FR_TILE; c.gy = (a->H + FR_TILE - 1) / FR_TILE; c.T = c.gx * c.gy;
@@ -150,7 +151,6 @@ int fr_forward(fr_forward_args *a)
 	mark(FR_STAGE_RENDER);
 	rc = launch_render(c);
 	mark(FR_NUM_STAGES);
-	finish_prof();
 	return rc;
 }
 

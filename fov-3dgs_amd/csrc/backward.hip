@@ -467,8 +467,8 @@ int launch_backward(const fr_backward_args *a)
 	GeomWS geom = carve_geom(a->variant, (size_t)a->P, (char *)a->geometry);
 	ImageWS img = carve_image(a->variant, a->W, a->H, (char *)a->image);
 	BinWS bin = carve_bin(a->R, (char *)a->binning);
-	hipEvent_t ev[3]; bool prof = a->stage_ms != nullptr;
-	if (prof) { for (int i = 0; i < 3; i++) hipEventCreate(&ev[i]); hipEventRecord(ev[0], stream); }
+	auto mark = [&](int i) { if (a->stage_events && a->stage_events[i]) (void)hipEventRecord((hipEvent_t)a->stage_events[i], stream); };
+	mark(0);
 	if (a->R > 0)
 	{
 		BwdRenderArgs r;
@@ -483,7 +483,7 @@ int launch_backward(const fr_backward_args *a)
 		int rc = check_launch("render_bwd", stream, a->debug);
 		if (rc) return rc;
 	}
-	if (prof) hipEventRecord(ev[1], stream);
+	mark(1);
 	BwdPreArgs p;
 	p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
 	p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy;
@@ -497,14 +497,7 @@ int launch_backward(const fr_backward_args *a)
 	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
 	hipLaunchKernelGGL(k_preprocess_bwd, dim3((a->P + 255) / 256), dim3(256), 0, stream, p);
 	int rc2 = check_launch("preprocess_bwd", stream, a->debug);
-	if (prof)
-	{
-		hipEventRecord(ev[2], stream);
-		hipStreamSynchronize(stream);
-		hipEventElapsedTime(&a->stage_ms[0], ev[0], ev[1]);
-		hipEventElapsedTime(&a->stage_ms[1], ev[1], ev[2]);
-		for (int i = 0; i < 3; i++) hipEventDestroy(ev[i]);
-	}
+	mark(2);
 	return rc2;
 }
 

@@ -170,18 +170,19 @@ struct PreArgs {
 	uint32_t *tile_count;
 };
 
-// One thread per Gaussian.
-template <int VARIANT>
-__global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
+// Projection of one Gaussian: everything up to the tile rectangle.
+struct Proj {
+	bool alive;
+	float pix_x, pix_y, depth, conic_a, conic_b, conic_c;
+	float cov0, cov1, lambda1, lambda2;
+	int radius, x0, y0, x1, y1;
+	uint32_t tnum;
+};
+__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, const float p[3])
 {
-	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
-	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= a.P) return;
-	a.radii[idx] = 0;
-
+	Proj r; r.alive = false; r.tnum = 0; r.radius = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0;
+	r.pix_x = r.pix_y = r.depth = r.conic_a = r.conic_b = r.conic_c = r.cov0 = r.cov1 = r.lambda1 = r.lambda2 = 0.f;
 	const float *vm = a.viewmatrix, *pm = a.projmatrix;
-	const float p[3] = { a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2] };
 	// near cull: auxiliary.h:139-164
 	const float hx = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
 	const float hy = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
@@ -192,33 +193,33 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	t[0] = vm[0] * p[0] + vm[4] * p[1] + vm[8] * p[2] + vm[12];
 	t[1] = vm[1] * p[0] + vm[5] * p[1] + vm[9] * p[2] + vm[13];
 	t[2] = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
-	const float depth = t[2];
-	if (depth <= 0.2f) return;
+	r.depth = t[2];
+	if (r.depth <= 0.2f) return r;
 
 	// 3D covariance: forward.cu:118-152
 	float cov3D[6];
 	if (a.cov3D_precomp != nullptr)
 	{
 #pragma unroll
-		for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * idx + i];
+		for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * (size_t)idx + i];
 	}
 	else
 	{
 		const float mod = a.scale_modifier;
-		const float s0 = mod * a.scales[3 * idx], s1 = mod * a.scales[3 * idx + 1], s2 = mod * a.scales[3 * idx + 2];
+		const float s0 = mod * a.scales[3 * (size_t)idx], s1 = mod * a.scales[3 * (size_t)idx + 1], s2 = mod * a.scales[3 * (size_t)idx + 2];
 		const float4 q = ((const float4 *)a.rotations)[idx];
-		const float r = q.x, x = q.y, y = q.z, z = q.w;
+		const float rr = q.x, x = q.y, y = q.z, z = q.w;
 		const M3 S = m3_cols(s0, 0, 0, 0, s1, 0, 0, 0, s2);
 		const M3 R = m3_cols(
-			1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-			2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-			2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+			1.f - 2.f * (y * y + z * z), 2.f * (x * y - rr * z), 2.f * (x * z + rr * y),
+			2.f * (x * y + rr * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - rr * x),
+			2.f * (x * z - rr * y), 2.f * (y * z + rr * x), 1.f - 2.f * (x * x + y * y));
 		const M3 Mm = m3_mul(S, R);
 		const M3 Sg = m3_mul(m3_t(Mm), Mm);
 		cov3D[0] = Sg.c[0][0]; cov3D[1] = Sg.c[0][1]; cov3D[2] = Sg.c[0][2];
 		cov3D[3] = Sg.c[1][1]; cov3D[4] = Sg.c[1][2]; cov3D[5] = Sg.c[2][2];
 #pragma unroll
-		for (int i = 0; i < 6; i++) a.geom.cov3D[6 * idx + i] = cov3D[i];
+		for (int i = 0; i < 6; i++) a.geom.cov3D[6 * (size_t)idx + i] = cov3D[i];
 	}
 
 	// 2D covariance (EWA): forward.cu:74-113
@@ -238,21 +239,68 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		cov[0] = c.c[0][0] + 0.3f; cov[1] = c.c[0][1]; cov[2] = c.c[1][1] + 0.3f;
 	}
 	const float det = cov[0] * cov[2] - cov[1] * cov[1];
-	if (det == 0.0f) return;
+	if (det == 0.0f) return r;
 	const float det_inv = 1.f / det;
-	const float conic_a = cov[2] * det_inv, conic_b = -cov[1] * det_inv, conic_c = cov[0] * det_inv;
+	r.conic_a = cov[2] * det_inv; r.conic_b = -cov[1] * det_inv; r.conic_c = cov[0] * det_inv;
 	const float mid = 0.5f * (cov[0] + cov[2]);
-	const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-	const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-	const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+	r.lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+	r.lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+	const float my_radius = ceilf(3.f * sqrtf(fmaxf(r.lambda1, r.lambda2)));
 	// ndc2Pix is evaluated in double in the reference (auxiliary.h:41-44)
-	const float pix_x = (float)((((double)projx + 1.0) * a.W - 1.0) * 0.5);
-	const float pix_y = (float)((((double)projy + 1.0) * a.H - 1.0) * 0.5);
-	const int radius_i = f2i(my_radius);
-	int x0, y0, x1, y1;
-	get_rect(pix_x, pix_y, radius_i, a.gx, a.gy, x0, y0, x1, y1);
-	const uint32_t tnum = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
-	if (tnum == 0) return;
+	r.pix_x = (float)((((double)projx + 1.0) * a.W - 1.0) * 0.5);
+	r.pix_y = (float)((((double)projy + 1.0) * a.H - 1.0) * 0.5);
+	r.radius = f2i(my_radius);
+	get_rect(r.pix_x, r.pix_y, r.radius, a.gx, a.gy, r.x0, r.y0, r.x1, r.y1);
+	r.tnum = (uint32_t)(r.y1 - r.y0) * (uint32_t)(r.x1 - r.x0);
+	r.cov0 = cov[0]; r.cov1 = cov[1];
+	r.alive = r.tnum != 0;
+	return r;
+}
+
+// wave-wide reductions / broadcasts (64 lanes)
+__device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+	return v;
+}
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+	return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+	return v;
+}
+__device__ __forceinline__ float bcast_f(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// Splats whose rectangle covers more than FR_BIG_RECT tiles are walked by the whole wave (one tile
+// per lane and step) instead of serially by their own lane: a near-camera splat can cover all
+// 8160 tiles of a 1080p frame, which would otherwise stall its wave for milliseconds.
+#define FR_BIG_RECT 32
+
+// One thread per Gaussian.
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
+{
+	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
+	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const bool in_range = idx < a.P;
+	float p[3] = { 0.f, 0.f, 0.f };
+	Proj pr; pr.alive = false; pr.tnum = 0;
+	if (in_range)
+	{
+		a.radii[idx] = 0;
+		p[0] = a.means3D[3 * (size_t)idx]; p[1] = a.means3D[3 * (size_t)idx + 1]; p[2] = a.means3D[3 * (size_t)idx + 2];
+		pr = project_gaussian(a, idx, p);
+	}
 
 	// ---- count the tiles this splat really lands in (and bump the per-tile counters) ----
 	uint32_t count = 0;
@@ -260,32 +308,36 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	float2 el = make_float2(0, 0);
 	float hl = 0, lowest = 0, highest = 0;
 	bool be_blend = false;
-	if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
 	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
 	const float *tile_bl = FOV ? a.tile_lv + 4 * (size_t)a.T : nullptr;
-	if (!CULL)
+	if (pr.alive)
 	{
-		for (int y = y0; y < y1; y++)
-			for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
-		count = tnum;
-	}
-	else
-	{
-		if (tnum > 1)
+		if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
+		if (CULL && pr.tnum > 1)
 		{
 			// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
-			float e1x = -cov[1], e1y = cov[0] - lambda1, e2x = -cov[1], e2y = cov[0] - lambda2;
+			float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
 			const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
 			e1x *= n1; e1y *= n1;
 			const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
 			e2x *= n2; e2y *= n2;
 			ev = make_float4(e1x, e1y, e2x, e2y);
-			el = make_float2(3.0f * sqrtf(lambda1), 3.0f * sqrtf(lambda2));
+			el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
 		}
-		if (tnum == 1)
+	}
+	const bool big = pr.alive && pr.tnum > FR_BIG_RECT;
+	if (pr.alive && !big)
+	{
+		if (!CULL)
+		{
+			for (int y = pr.y0; y < pr.y1; y++)
+				for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+			count = pr.tnum;
+		}
+		else if (pr.tnum == 1)
 		{
 			bool keep = true;
-			const int ti = y0 * a.gx + x0;
+			const int ti = pr.y0 * a.gx + pr.x0;
 			if (FOV)
 			{
 				const float level = tile_min[ti];
@@ -296,9 +348,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		}
 		else
 		{
-			const Obb ob = make_obb(pix_x, pix_y, ev, el);
-			for (int y = y0; y < y1; y++)
-				for (int x = x0; x < x1; x++)
+			const Obb ob = make_obb(pr.pix_x, pr.pix_y, ev, el);
+			for (int y = pr.y0; y < pr.y1; y++)
+				for (int x = pr.x0; x < pr.x1; x++)
 				{
 					const int ti = y * a.gx + x;
 					bool inside = true;
@@ -316,8 +368,55 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					}
 				}
 		}
-		if (count == 0) return; // culled everywhere: radii stays 0 (RS rasterizer_impl.cu:141-145)
 	}
+	// wave-cooperative walk of the big rectangles
+	unsigned long long bigmask = __ballot(big);
+	while (bigmask)
+	{
+		const int L = __ffsll((long long)bigmask) - 1;
+		bigmask &= bigmask - 1;
+		const int bx0 = bcast_i(pr.x0, L), by0 = bcast_i(pr.y0, L), bx1 = bcast_i(pr.x1, L), by1 = bcast_i(pr.y1, L);
+		const int w = bx1 - bx0, tn = w * (by1 - by0);
+		uint32_t c = 0;
+		float lo = 3.0e38f, hi = 0.0f;
+		bool bl = false;
+		if (!CULL)
+		{
+			for (int t = lane; t < tn; t += 64) atomicAdd(&a.tile_count[(by0 + t / w) * a.gx + bx0 + t % w], 1u);
+			c = 0; // owner already knows count == tnum
+		}
+		else
+		{
+			const float4 bev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
+			const float2 bel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
+			const Obb ob = make_obb(bcast_f(pr.pix_x, L), bcast_f(pr.pix_y, L), bev, bel);
+			const float bhl = bcast_f(hl, L);
+			for (int t = lane; t < tn; t += 64)
+			{
+				const int x = bx0 + t % w, y = by0 + t / w;
+				const int ti = y * a.gx + x;
+				bool inside = true;
+				float level = 0;
+				if (FOV) { level = tile_min[ti]; inside = level < (bhl + 1); }
+				if (inside && obb_hits_tile(ob, x, y))
+				{
+					c++;
+					atomicAdd(&a.tile_count[ti], 1u);
+					if (FOV) { lo = fminf(lo, level); hi = fmaxf(hi, level); bl = bl || (tile_bl[ti] != 0.0f); }
+				}
+			}
+		}
+		const uint32_t ctot = CULL ? wave_add_u32(c) : 0u;
+		float lo_all = 0.f, hi_all = 0.f;
+		bool bl_any = false;
+		if (FOV) { lo_all = wave_min_f32(lo); hi_all = wave_max_f32(hi); bl_any = __any(bl); }
+		if (lane == L)
+		{
+			count = CULL ? ctot : pr.tnum;
+			if (FOV) { lowest = fminf(lowest, lo_all); highest = fmaxf(highest, hi_all); be_blend = bl_any; }
+		}
+	}
+	if (!pr.alive || count == 0) return; // culled everywhere: radii stays 0 (RS rasterizer_impl.cu:141-145)
 
 	// ---- colour ----
 	float rgb[3] = { 0, 0, 0 };
@@ -335,7 +434,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		else
 		{
 #pragma unroll
-			for (int ch = 0; ch < 3; ch++) rgb[ch] = a.colors_precomp[3 * idx + ch];
+			for (int ch = 0; ch < 3; ch++) rgb[ch] = a.colors_precomp[3 * (size_t)idx + ch];
 		}
 	}
 	else
@@ -359,18 +458,18 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		}
 	}
 
-	a.radii[idx] = radius_i;
+	a.radii[idx] = pr.radius;
 	float4 *rec = a.geom.rec + 3 * (size_t)idx;
-	rec[0] = make_float4(pix_x, pix_y, conic_a, conic_b);
-	if (FOV) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
-	else rec[1] = make_float4(conic_c, a.opacities[idx], rgb[0], rgb[1]);
-	rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), 0.0f);
+	rec[0] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
+	if (FOV) rec[1] = make_float4(pr.conic_c, hl, 0.0f, 0.0f);
+	else rec[1] = make_float4(pr.conic_c, a.opacities[idx], rgb[0], rgb[1]);
+	rec[2] = make_float4(rgb[2], pr.depth, __uint_as_float(clamp_bits), 0.0f);
 	if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
 }
 
 // One thread per Gaussian: re-walk the rect, repeat the cull test and append (depth,id) to the
 // tile's bucket through the tile cursor. Order inside a bucket is arbitrary; the per-tile sort
-// on (depth bits, id) restores the reference's stable order.
+// on (depth bits, id) restores the reference's stable order. Big rects: whole wave, as above.
 struct EmitArgs {
 	int P, gx, gy, T;
 	const int *radii;
@@ -387,41 +486,87 @@ __global__ void __launch_bounds__(256) k_emit(const EmitArgs a)
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= a.P) return;
-	const int radius = a.radii[idx];
-	if (!(radius > 0)) return;
-	const float4 r0 = a.geom.rec[3 * (size_t)idx];
-	const float depth = a.geom.rec[3 * (size_t)idx + 2].y;
-	const uint64_t payload = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
-	int x0, y0, x1, y1;
-	get_rect(r0.x, r0.y, radius, a.gx, a.gy, x0, y0, x1, y1);
-	const uint32_t tnum = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
-	if (!CULL || tnum == 1)
+	const int lane = threadIdx.x & 63;
+	int radius = 0;
+	if (idx < a.P) radius = a.radii[idx];
+	const bool alive = radius > 0;
+	int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+	uint32_t tnum = 0;
+	float cx = 0.f, cy = 0.f, hl = 0.f;
+	uint32_t depth_bits = 0;
+	float4 ev = make_float4(0, 0, 0, 0);
+	float2 el = make_float2(0, 0);
+	if (alive)
 	{
-		for (int y = y0; y < y1; y++)
-			for (int x = x0; x < x1; x++)
-			{
-				const int ti = y * a.gx + x;
-				const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
-				a.entries[a.ranges[ti].x + pos] = payload;
-			}
-		return;
+		const float4 r0 = a.geom.rec[3 * (size_t)idx];
+		cx = r0.x; cy = r0.y;
+		depth_bits = __float_as_uint(a.geom.rec[3 * (size_t)idx + 2].y);
+		get_rect(cx, cy, radius, a.gx, a.gy, x0, y0, x1, y1);
+		tnum = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+		if (CULL && tnum > 1) { ev = a.geom.evec[idx]; el = a.geom.elen[idx]; }
+		if (FOV) hl = a.highest_levels[idx];
 	}
-	const Obb ob = make_obb(r0.x, r0.y, a.geom.evec[idx], a.geom.elen[idx]);
-	const float hl = FOV ? a.highest_levels[idx] : 0.0f;
 	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
-	for (int y = y0; y < y1; y++)
-		for (int x = x0; x < x1; x++)
+	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
+	const bool big = alive && tnum > FR_BIG_RECT;
+	if (alive && !big)
+	{
+		if (!CULL || tnum == 1)
 		{
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++)
+				{
+					const int ti = y * a.gx + x;
+					const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
+					a.entries[a.ranges[ti].x + pos] = payload;
+				}
+		}
+		else
+		{
+			const Obb ob = make_obb(cx, cy, ev, el);
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++)
+				{
+					const int ti = y * a.gx + x;
+					bool inside = true;
+					if (FOV) inside = tile_min[ti] < (hl + 1);
+					if (inside && obb_hits_tile(ob, x, y))
+					{
+						const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
+						a.entries[a.ranges[ti].x + pos] = payload;
+					}
+				}
+		}
+	}
+	unsigned long long bigmask = __ballot(big);
+	while (bigmask)
+	{
+		const int L = __ffsll((long long)bigmask) - 1;
+		bigmask &= bigmask - 1;
+		const int bx0 = bcast_i(x0, L), by0 = bcast_i(y0, L), bx1 = bcast_i(x1, L), by1 = bcast_i(y1, L);
+		const int w = bx1 - bx0, tn = w * (by1 - by0);
+		const uint64_t bpay = ((uint64_t)(uint32_t)bcast_i((int)depth_bits, L) << 32) | (uint32_t)bcast_i(idx, L);
+		const float4 bev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
+		const float2 bel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
+		const Obb ob = make_obb(bcast_f(cx, L), bcast_f(cy, L), bev, bel);
+		const float bhl = bcast_f(hl, L);
+		for (int t = lane; t < tn; t += 64)
+		{
+			const int x = bx0 + t % w, y = by0 + t / w;
 			const int ti = y * a.gx + x;
 			bool inside = true;
-			if (FOV) inside = tile_min[ti] < (hl + 1);
-			if (inside && obb_hits_tile(ob, x, y))
+			if (CULL)
+			{
+				if (FOV) inside = tile_min[ti] < (bhl + 1);
+				inside = inside && obb_hits_tile(ob, x, y);
+			}
+			if (inside)
 			{
 				const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
-				a.entries[a.ranges[ti].x + pos] = payload;
+				a.entries[a.ranges[ti].x + pos] = bpay;
 			}
 		}
+	}
 }
 
 __global__ void k_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present)

@@ -60,8 +60,17 @@ def _require_gpu(means3D):
                            "CPU fallback (the CPU oracle under oracle/ is test infrastructure only)")
 
 
+_GRANULE = 32 << 20  # workspace sizes are rounded up so the caching allocator can reuse blocks
+
+
 class _Workspaces:
-    """The three byte buffers the native call sizes through callbacks (reference: resizeFunctional)."""
+    """The three byte buffers the native call sizes through callbacks (reference: resizeFunctional).
+
+    The binning buffer's size changes every frame with the instance count; un-rounded requests make
+    PyTorch's caching allocator fall through to hipMalloc (~8 ms each on MI355X), so requests are
+    rounded up to 32 MiB granules, and inference calls (no autograd graph) keep one grow-only set of
+    buffers per device alive across frames.
+    """
 
     def __init__(self, device):
         self.device = device
@@ -71,14 +80,34 @@ class _Workspaces:
     def _make(self, i):
         def resize(_user, nbytes):
             if self.buf[i].numel() < nbytes:
-                self.buf[i] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                want = (int(nbytes) * 5 // 4 + _GRANULE - 1) // _GRANULE * _GRANULE
+                self.buf[i] = torch.empty(want, dtype=torch.uint8, device=self.device)
             return self.buf[i].data_ptr()
         return resize
 
 
+_persistent_ws = {}
+
+
+def _workspaces_for(device, needs_graph):
+    """Fresh buffers when autograd will keep them for backward, a per-device persistent set otherwise."""
+    if needs_graph:
+        return _Workspaces(device)
+    ws = _persistent_ws.get(device)
+    if ws is None:
+        ws = _persistent_ws[device] = _Workspaces(device)
+    return ws
+
+
+# Set by fov3dgs_amd.profiling.StageTimer while a timed region is active: a ctypes array of
+# FR_NUM_STAGES + 1 event handles that the next forward call records on its stream.
+_stage_events_hook = None
+
+
 def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05):
-    """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions])"""
+                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False):
+    """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions])
+    persistent=True: the workspaces are the per-device grow-only set (valid until the next call)."""
     lib = _native.load()
     _require_gpu(means3D)
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -98,7 +127,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
     with torch.cuda.device(dev):
         color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-        ws = _Workspaces(dev)
+        ws = _workspaces_for(dev, not persistent)
         counts = contribs = None
         a.variant = variant
         a.P, a.D = P, int(rs.sh_degree)
@@ -128,6 +157,8 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
             contribs = torch.zeros((P,), dtype=torch.float32, device=dev)
             a.gaussians_count, a.contributions = counts.data_ptr(), contribs.data_ptr()
         a.geometry_resize, a.binning_resize, a.image_resize = ws.cbs[0], ws.cbs[1], ws.cbs[2]
+        if _stage_events_hook is not None:
+            a.stage_events = _stage_events_hook()
         rc = lib.fr_forward(C.byref(a))
         if rc != 0:
             raise RuntimeError(f"fovraster forward failed ({rc}): {_native.last_error()}")
@@ -217,17 +248,20 @@ def _make_plain(variant_id, with_counts, has_backward):
                     raster_settings):
             args = (variant_id, raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations,
                     cov3Ds_precomp)
+            keep_ws = has_backward and any(ctx.needs_input_grad)  # backward re-reads the workspaces
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
                 try:
-                    res = _forward_native(*args)
+                    res = _forward_native(*args, persistent=not keep_ws)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                res = _forward_native(*args)
+                res = _forward_native(*args, persistent=not keep_ws)
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = res[:6]
+            if not keep_ws:  # nothing will call backward: do not pin the shared workspaces
+                geomBuffer = binningBuffer = imgBuffer = torch.empty(0, dtype=torch.uint8, device=means3D.device)
             ctx.raster_settings = raster_settings
             ctx.num_rendered = num_rendered
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
@@ -320,13 +354,13 @@ def _make_fov():
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    res = _forward_native(*args)
+                    res = _forward_native(*args, persistent=True)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                res = _forward_native(*args)
+                res = _forward_native(*args, persistent=True)
             num_rendered, color, radii = res[:3]
             ctx.num_rendered = num_rendered
             ctx.mark_non_differentiable(radii)

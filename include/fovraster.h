@@ -100,10 +100,11 @@ typedef struct fr_forward_args {
 	/* result */
 	int32_t num_rendered;        /* out: number of (Gaussian,tile) instances after culling */
 	int32_t max_tile_instances;  /* out: longest per-tile list */
-	/* optional profiling: HOST pointer to FR_NUM_STAGES floats, or NULL. When set, hipEvents are
-	 * recorded around every stage on `stream` and the call synchronises at the end to fill it
-	 * with per-stage milliseconds (FR_STAGE_* order). */
-	float *stage_ms;
+	/* optional profiling: HOST pointer to FR_NUM_STAGES + 1 event handles made by fr_event_create(),
+	 * or NULL. Event i is recorded on `stream` just before stage i (FR_STAGE_* order), event
+	 * FR_NUM_STAGES after the last one; nothing is synchronised. Read the stage durations later with
+	 * fr_event_elapsed_ms(ev[i], ev[i+1]). */
+	void **stage_events;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PREPROCESS = 1, FR_STAGE_TILE_SCAN = 2, FR_STAGE_EMIT = 3,
@@ -133,11 +134,16 @@ typedef struct fr_backward_args {
 	float *dL_dsh;               /* [P,M,3] */
 	float *dL_dscale;            /* [P,3] */
 	float *dL_drot;              /* [P,4] */
-	float *stage_ms;             /* optional HOST pointer to 2 floats: render-backward ms, preprocess-backward ms */
+	void **stage_events;         /* optional: 3 event handles around render-backward and preprocess-backward */
 } fr_backward_args;
 
 int fr_abi_version(void);
 const char *fr_last_error(void);
+
+/* hipEvent wrappers so a host that only speaks the C ABI can time stages on the launch stream */
+void *fr_event_create(void);
+void fr_event_destroy(void *event);
+int fr_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 
 int fr_forward(fr_forward_args *args);
 int fr_backward(const fr_backward_args *args);

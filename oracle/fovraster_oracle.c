@@ -77,7 +77,16 @@ typedef struct {
 	const real *means3D, *scales, *rotations, *opacities, *shs;
 	const real *cov3D_precomp, *colors_precomp;
 	const real *shs_dcs, *highest_levels;
+	/* optional tile window [x0,x1) x [y0,y1) restricting binning + blending (bench cpu_baseline
+	 * sampling only; all zeros = whole frame) */
+	int32_t win[4];
 } orc_in;
+
+static int in_window(const orc_in *in, int tx, int ty)
+{
+	if (in->win[2] <= in->win[0] || in->win[3] <= in->win[1]) return 1;
+	return tx >= in->win[0] && tx < in->win[2] && ty >= in->win[1] && ty < in->win[3];
+}
 
 typedef struct {
 	/* per Gaussian */
@@ -523,7 +532,7 @@ static int64_t bin_and_sort(const orc_in *in, orc_out *o)
 			for (int y = rmin[1]; y < rmax[1]; y++)
 				for (int x = rmin[0]; x < rmax[0]; x++)
 				{
-					inst[n].tile = (uint32_t)(y * gx + x); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++;
+					if (in_window(in, x, y)) { inst[n].tile = (uint32_t)(y * gx + x); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++; }
 					count++;
 				}
 		}
@@ -539,7 +548,7 @@ static int64_t bin_and_sort(const orc_in *in, orc_out *o)
 			}
 			if (keep)
 			{
-				inst[n].tile = (uint32_t)(rmin[1] * gx + rmin[0]); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++;
+				if (in_window(in, rmin[0], rmin[1])) { inst[n].tile = (uint32_t)(rmin[1] * gx + rmin[0]); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++; }
 				count = 1;
 			}
 		}
@@ -580,7 +589,7 @@ static int64_t bin_and_sort(const orc_in *in, orc_out *o)
 								lowest = r_fmin(lowest, level); highest = r_fmax(highest, level);
 								be_blend = blending || be_blend;
 							}
-							inst[n].tile = (uint32_t)(y * gx + x); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++;
+							if (in_window(in, x, y)) { inst[n].tile = (uint32_t)(y * gx + x); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++; }
 						}
 					}
 				}
@@ -668,6 +677,7 @@ static void render_plain(const orc_in *in, orc_out *o)
 	for (int ty = 0; ty < gy; ty++)
 		for (int tx = 0; tx < gx; tx++)
 		{
+			if (!in_window(in, tx, ty)) continue;
 			const uint32_t r0 = o->ranges[2 * (ty * gx + tx)], r1 = o->ranges[2 * (ty * gx + tx) + 1];
 			const int n = (int)(r1 - r0);
 			int all_done_pos = 0, never_done = 0;
@@ -741,6 +751,7 @@ static void render_fov(const orc_in *in, orc_out *o)
 	for (int ty = 0; ty < gy; ty++)
 		for (int tx = 0; tx < gx; tx++)
 		{
+			if (!in_window(in, tx, ty)) continue;
 			const uint32_t r0 = o->ranges[2 * (ty * gx + tx)], r1 = o->ranges[2 * (ty * gx + tx) + 1];
 			const int n = (int)(r1 - r0);
 			const uint32_t cur = (uint32_t)(tx + twn * ty);

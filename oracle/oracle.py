@@ -60,7 +60,7 @@ def _structs(real):
                     ("gaze_x", real), ("gaze_y", real), ("alpha", real)] + \
                    [(n, C.c_void_p) for n in ("bg", "viewmatrix", "projmatrix", "campos", "means3D", "scales",
                                               "rotations", "opacities", "shs", "cov3D_precomp", "colors_precomp",
-                                              "shs_dcs", "highest_levels")]
+                                              "shs_dcs", "highest_levels")] + [("win", C.c_int32 * 4)]
 
     class OrcOut(C.Structure):
         _fields_ = [(n, C.c_void_p) for n in ("depths", "radii", "means2D", "cov3D", "conic", "rgb", "clamped",
@@ -121,6 +121,10 @@ def _prep_inputs(variant, scene, cam, dtype, keep):
     inp.colors_precomp = _ptr(arr(scene.get("colors_precomp")))
     inp.shs_dcs = _ptr(arr(scene.get("shs_dcs")))
     inp.highest_levels = _ptr(arr(scene.get("highest_levels")))
+    win = cam.get("tile_window")  # (x0, y0, x1, y1) in tiles; bench cpu_baseline sampling only
+    if win is not None:
+        for i in range(4):
+            inp.win[i] = int(win[i])
     return inp, OrcOut, OrcGrads, P, M, vi
 
 
