@@ -9,6 +9,9 @@
 #define FR_TILE_PIX 256
 #define FR_FOV_LEVELS 4       // RF auxiliary.h:26 fov_num
 #define FR_SORT_LDS_MAX 8192  // longest per-tile list sorted inside LDS (64 KiB of u64 keys)
+#define FR_BIN_THREADS 512    // workgroup size of the binning kernels (preprocess / emit)
+#define FR_BIN_BLOCKS 768     // persistent workgroups of the binning kernels (3 per CU)
+#define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
 
 namespace fr {
 
@@ -57,8 +60,14 @@ struct ImageWS {
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
 	uint32_t *totals;     // [4]  {num_instances, max per tile, 0, 0}
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
+	uint32_t *hist;       // [FR_BIN_BLOCKS][T] per-workgroup tile histograms (null if T too large for LDS)
 	size_t bytes;
 };
+__host__ __device__ inline int bin_blocks(int P)
+{
+	const int slabs = (P + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
+	return slabs < FR_BIN_BLOCKS ? (slabs > 0 ? slabs : 1) : FR_BIN_BLOCKS;
+}
 __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *base)
 {
 	ImageWS s; size_t off = 0;
@@ -71,6 +80,8 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.totals = (uint32_t *)(base + off); off = align_up(off + 4 * sizeof(uint32_t));
 	s.tile_lv = nullptr;
 	if (variant == FR_VARIANT_FOV_PCHECK_OBB) { s.tile_lv = (float *)(base + off); off = align_up(off + 5 * T * sizeof(float)); }
+	s.hist = nullptr;
+	if (T <= FR_LDS_HIST_MAX_TILES) { s.hist = (uint32_t *)(base + off); off = align_up(off + (size_t)FR_BIN_BLOCKS * T * sizeof(uint32_t)); }
 	s.bytes = off + 256;
 	return s;
 }

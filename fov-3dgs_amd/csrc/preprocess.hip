@@ -168,6 +168,7 @@ struct PreArgs {
 	int *radii;
 	GeomWS geom;
 	uint32_t *tile_count;
+	uint32_t *hist; // [blocks][T] per-workgroup tile histograms (LDSH)
 };
 
 // Projection of one Gaussian: everything up to the tile rectangle.
@@ -284,14 +285,27 @@ __device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgc
 // 8160 tiles of a 1080p frame, which would otherwise stall its wave for milliseconds.
 #define FR_BIG_RECT 32
 
-// One thread per Gaussian.
-template <int VARIANT>
-__global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
+// Persistent workgroups of FR_BIN_THREADS threads; slab s (FR_BIN_THREADS consecutive Gaussians)
+// belongs to workgroup s % gridDim.x -- k_emit uses the same assignment. LDSH: per-tile instance
+// counts are accumulated in an LDS-private histogram (T <= 16 Ki tiles fit the 160 KiB LDS twice
+// over) and written once per workgroup to hist[block][tile]: no global atomics at all. Otherwise
+// (huge tile grids) the counters are bumped with global atomics.
+#define BUMP_TILE(ti) do { if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
+template <int VARIANT, bool LDSH>
+__global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
 	const int lane = threadIdx.x & 63;
+	if (LDSH)
+	{
+		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
+		__syncthreads();
+	}
+	for (int base = blockIdx.x * FR_BIN_THREADS; base < a.P; base += gridDim.x * FR_BIN_THREADS)
+	{
+	const int idx = base + threadIdx.x;
 	const bool in_range = idx < a.P;
 	float p[3] = { 0.f, 0.f, 0.f };
 	Proj pr; pr.alive = false; pr.tnum = 0;
@@ -331,7 +345,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		if (!CULL)
 		{
 			for (int y = pr.y0; y < pr.y1; y++)
-				for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+				for (int x = pr.x0; x < pr.x1; x++) BUMP_TILE(y * a.gx + x);
 			count = pr.tnum;
 		}
 		else if (pr.tnum == 1)
@@ -344,7 +358,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 				keep = level < (hl + 1);
 				if (keep) { lowest = level; highest = level; be_blend = tile_bl[ti] != 0.0f; }
 			}
-			if (keep) { atomicAdd(&a.tile_count[ti], 1u); count = 1; }
+			if (keep) { BUMP_TILE(ti); count = 1; }
 		}
 		else
 		{
@@ -359,7 +373,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					if (inside && obb_hits_tile(ob, x, y))
 					{
 						count++;
-						atomicAdd(&a.tile_count[ti], 1u);
+						BUMP_TILE(ti);
 						if (FOV)
 						{
 							lowest = fminf(lowest, level); highest = fmaxf(highest, level);
@@ -382,7 +396,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		bool bl = false;
 		if (!CULL)
 		{
-			for (int t = lane; t < tn; t += 64) atomicAdd(&a.tile_count[(by0 + t / w) * a.gx + bx0 + t % w], 1u);
+			for (int t = lane; t < tn; t += 64) BUMP_TILE((by0 + t / w) * a.gx + bx0 + t % w);
 			c = 0; // owner already knows count == tnum
 		}
 		else
@@ -401,7 +415,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 				if (inside && obb_hits_tile(ob, x, y))
 				{
 					c++;
-					atomicAdd(&a.tile_count[ti], 1u);
+					BUMP_TILE(ti);
 					if (FOV) { lo = fminf(lo, level); hi = fmaxf(hi, level); bl = bl || (tile_bl[ti] != 0.0f); }
 				}
 			}
@@ -416,7 +430,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			if (FOV) { lowest = fminf(lowest, lo_all); highest = fmaxf(highest, hi_all); be_blend = bl_any; }
 		}
 	}
-	if (!pr.alive || count == 0) return; // culled everywhere: radii stays 0 (RS rasterizer_impl.cu:141-145)
+	if (!pr.alive || count == 0) continue; // culled everywhere: radii stays 0 (RS rasterizer_impl.cu:141-145)
 
 	// ---- colour ----
 	float rgb[3] = { 0, 0, 0 };
@@ -465,7 +479,15 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	else rec[1] = make_float4(pr.conic_c, a.opacities[idx], rgb[0], rgb[1]);
 	rec[2] = make_float4(rgb[2], pr.depth, __uint_as_float(clamp_bits), 0.0f);
 	if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
+	} // slab loop
+	if (LDSH)
+	{
+		__syncthreads();
+		uint32_t *out = a.hist + (size_t)blockIdx.x * a.T;
+		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) out[t] = lds_hist[t];
+	}
 }
+#undef BUMP_TILE
 
 // One thread per Gaussian: re-walk the rect, repeat the cull test and append (depth,id) to the
 // tile's bucket through the tile cursor. Order inside a bucket is arbitrary; the per-tile sort
@@ -479,14 +501,27 @@ struct EmitArgs {
 	const uint2 *ranges;
 	uint32_t *cursor;
 	uint64_t *entries;
+	const uint32_t *hist; // [blocks][T] exclusive prefix over workgroups (LDSH)
 };
-template <int VARIANT>
-__global__ void __launch_bounds__(256) k_emit(const EmitArgs a)
+// LDSH: the workgroup's write cursor of every tile lives in LDS, initialised to
+// tile start + (instances of the same tile owned by lower-numbered workgroups).
+#define NEXT_SLOT(ti) (LDSH ? atomicAdd(&lds_cur[(ti)], 1u) : a.ranges[(ti)].x + atomicAdd(&a.cursor[(ti)], 1u))
+template <int VARIANT, bool LDSH>
+__global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
 	const int lane = threadIdx.x & 63;
+	if (LDSH)
+	{
+		const uint32_t *pre = a.hist + (size_t)blockIdx.x * a.T;
+		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_cur[t] = a.ranges[t].x + pre[t];
+		__syncthreads();
+	}
+	for (int base = blockIdx.x * FR_BIN_THREADS; base < a.P; base += gridDim.x * FR_BIN_THREADS)
+	{
+	const int idx = base + threadIdx.x;
 	int radius = 0;
 	if (idx < a.P) radius = a.radii[idx];
 	const bool alive = radius > 0;
@@ -517,8 +552,7 @@ __global__ void __launch_bounds__(256) k_emit(const EmitArgs a)
 				for (int x = x0; x < x1; x++)
 				{
 					const int ti = y * a.gx + x;
-					const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
-					a.entries[a.ranges[ti].x + pos] = payload;
+					a.entries[NEXT_SLOT(ti)] = payload;
 				}
 		}
 		else
@@ -530,11 +564,7 @@ __global__ void __launch_bounds__(256) k_emit(const EmitArgs a)
 					const int ti = y * a.gx + x;
 					bool inside = true;
 					if (FOV) inside = tile_min[ti] < (hl + 1);
-					if (inside && obb_hits_tile(ob, x, y))
-					{
-						const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
-						a.entries[a.ranges[ti].x + pos] = payload;
-					}
+					if (inside && obb_hits_tile(ob, x, y)) a.entries[NEXT_SLOT(ti)] = payload;
 				}
 		}
 	}
@@ -560,13 +590,27 @@ __global__ void __launch_bounds__(256) k_emit(const EmitArgs a)
 				if (FOV) inside = tile_min[ti] < (bhl + 1);
 				inside = inside && obb_hits_tile(ob, x, y);
 			}
-			if (inside)
-			{
-				const uint32_t pos = atomicAdd(&a.cursor[ti], 1u);
-				a.entries[a.ranges[ti].x + pos] = bpay;
-			}
+			if (inside) a.entries[NEXT_SLOT(ti)] = bpay;
 		}
 	}
+	} // slab loop
+}
+#undef NEXT_SLOT
+
+// Column scan of the per-workgroup histograms: one thread per tile turns hist[b][t] into the
+// exclusive prefix over b and leaves the tile's total in tile_count[t].
+__global__ void __launch_bounds__(256) k_hist_colscan(int T, int B, uint32_t *hist, uint32_t *tile_count)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= T) return;
+	uint32_t run = 0;
+	for (int b = 0; b < B; b++)
+	{
+		const uint32_t v = hist[(size_t)b * T + t];
+		hist[(size_t)b * T + t] = run;
+		run += v;
+	}
+	tile_count[t] = run;
 }
 
 __global__ void k_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present)
@@ -597,16 +641,25 @@ int launch_preprocess(FwdCtx &c)
 	p.shs = a->shs; p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.T = c.T;
-	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count;
-	const dim3 grid((a->P + 255) / 256), block(256);
+	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;
+	const bool ldsh = c.img.hist != nullptr;
+	const int nblk = bin_blocks(a->P);
+	const dim3 grid(nblk), block(FR_BIN_THREADS);
+	const size_t lds = ldsh ? (size_t)c.T * sizeof(uint32_t) : 0;
+#define LAUNCH_PRE(V) do { if (ldsh) hipLaunchKernelGGL((k_preprocess<V, true>), grid, block, lds, c.stream, p); \
+	else hipLaunchKernelGGL((k_preprocess<V, false>), grid, block, 0, c.stream, p); } while (0)
 	switch (a->variant)
 	{
-	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL(k_preprocess<FR_VARIANT_ORIGINAL>, grid, block, 0, c.stream, p); break;
-	case FR_VARIANT_PCHECK_OBB_SUM: hipLaunchKernelGGL(k_preprocess<FR_VARIANT_PCHECK_OBB_SUM>, grid, block, 0, c.stream, p); break;
-	case FR_VARIANT_PCHECK_OBB: hipLaunchKernelGGL(k_preprocess<FR_VARIANT_PCHECK_OBB>, grid, block, 0, c.stream, p); break;
-	default: hipLaunchKernelGGL(k_preprocess<FR_VARIANT_FOV_PCHECK_OBB>, grid, block, 0, c.stream, p); break;
+	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
+	case FR_VARIANT_PCHECK_OBB_SUM: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB_SUM); break;
+	case FR_VARIANT_PCHECK_OBB: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break;
+	default: LAUNCH_PRE(FR_VARIANT_FOV_PCHECK_OBB); break;
 	}
-	return check_launch("preprocess", c.stream, a->debug);
+#undef LAUNCH_PRE
+	int rc = check_launch("preprocess", c.stream, a->debug);
+	if (rc || !ldsh) return rc;
+	hipLaunchKernelGGL(k_hist_colscan, dim3((c.T + 255) / 256), dim3(256), 0, c.stream, c.T, nblk, c.img.hist, c.img.tile_count);
+	return check_launch("hist_colscan", c.stream, a->debug);
 }
 
 int launch_emit(FwdCtx &c)
@@ -615,14 +668,19 @@ int launch_emit(FwdCtx &c)
 	EmitArgs e;
 	e.P = a->P; e.gx = c.gx; e.gy = c.gy; e.T = c.T; e.radii = a->radii; e.geom = c.geom;
 	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.ranges = c.img.ranges;
-	e.cursor = c.img.tile_count; e.entries = c.bin.entries;
-	const dim3 grid((a->P + 255) / 256), block(256);
+	e.cursor = c.img.tile_count; e.entries = c.bin.entries; e.hist = c.img.hist;
+	const bool ldsh = c.img.hist != nullptr;
+	const dim3 grid(bin_blocks(a->P)), block(FR_BIN_THREADS);
+	const size_t lds = ldsh ? (size_t)c.T * sizeof(uint32_t) : 0;
+#define LAUNCH_EMIT(V) do { if (ldsh) hipLaunchKernelGGL((k_emit<V, true>), grid, block, lds, c.stream, e); \
+	else hipLaunchKernelGGL((k_emit<V, false>), grid, block, 0, c.stream, e); } while (0)
 	switch (a->variant)
 	{
-	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL(k_emit<FR_VARIANT_ORIGINAL>, grid, block, 0, c.stream, e); break;
-	case FR_VARIANT_FOV_PCHECK_OBB: hipLaunchKernelGGL(k_emit<FR_VARIANT_FOV_PCHECK_OBB>, grid, block, 0, c.stream, e); break;
-	default: hipLaunchKernelGGL(k_emit<FR_VARIANT_PCHECK_OBB>, grid, block, 0, c.stream, e); break;
+	case FR_VARIANT_ORIGINAL: LAUNCH_EMIT(FR_VARIANT_ORIGINAL); break;
+	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_EMIT(FR_VARIANT_FOV_PCHECK_OBB); break;
+	default: LAUNCH_EMIT(FR_VARIANT_PCHECK_OBB); break;
 	}
+#undef LAUNCH_EMIT
 	return check_launch("emit", c.stream, a->debug);
 }
 
