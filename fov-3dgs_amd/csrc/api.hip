@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 namespace fr {
 
@@ -20,7 +21,10 @@ void set_error(const char *fmt, ...)
 int check_launch(const char *what, hipStream_t stream, bool debug)
 {
 	hipError_t e = hipGetLastError();
+	static const bool trace = getenv("FR_TRACE") != nullptr;
+	if (trace) { fprintf(stderr, "[fovraster] launched %s\n", what); fflush(stderr); }
 	if (e == hipSuccess && debug) e = hipStreamSynchronize(stream);
+	if (trace && debug) { fprintf(stderr, "[fovraster] %s done (%d)\n", what, (int)e); fflush(stderr); }
 	if (e != hipSuccess)
 	{
 		set_error("%s: %s", what, hipGetErrorString(e));
@@ -121,6 +125,7 @@ int fr_forward(fr_forward_args *a)
 	c.img = carve_image(a->variant, a->W, a->H, iptr);
 
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, sizeof(uint32_t) * (size_t)c.T, stream));
+	FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, sizeof(uint32_t), stream));
 	if (a->variant == FR_VARIANT_PCHECK_OBB_SUM)
 	{
 		FR_HIP(hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, stream));

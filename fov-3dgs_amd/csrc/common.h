@@ -12,6 +12,7 @@
 #define FR_BIN_THREADS 512    // workgroup size of the binning kernels (preprocess / emit)
 #define FR_BIN_BLOCKS 768     // persistent workgroups of the binning kernels (3 per CU)
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
+#define FR_MAX_SLABS_PER_BLOCK 4096 // a workgroup stops pulling slabs after this many
 
 namespace fr {
 
@@ -32,6 +33,8 @@ struct GeomWS {
 	float2 *elen;       // [P]  OBB half-lengths                 (not ORIGINAL)
 	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity)
 	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8
+	uint32_t *slab_ctr; // [1]  dynamic slab scheduler of the binning kernels
+	uint16_t *slab_owner; // [ceil(P / FR_BIN_THREADS)] workgroup that preprocessed each slab
 	size_t bytes;
 };
 __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
@@ -48,6 +51,8 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 		g.lvl = (float4 *)(base + off); off = align_up(off + P * FR_FOV_LEVELS * sizeof(float4));
 		g.lrange = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
 	}
+	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + 4);
+	g.slab_owner = (uint16_t *)(base + off); off = align_up(off + ((P + FR_BIN_THREADS - 1) / FR_BIN_THREADS + 1) * sizeof(uint16_t));
 	g.bytes = off + 256;
 	return g;
 }

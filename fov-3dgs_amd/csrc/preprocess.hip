@@ -280,10 +280,44 @@ __device__ __forceinline__ float wave_max_f32(float v)
 __device__ __forceinline__ float bcast_f(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
 __device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// Splats whose rectangle covers more than FR_BIG_RECT tiles are walked by the whole wave (one tile
-// per lane and step) instead of serially by their own lane: a near-camera splat can cover all
-// 8160 tiles of a 1080p frame, which would otherwise stall its wave for milliseconds.
-#define FR_BIG_RECT 32
+// ---- wave-balanced (Gaussian, tile) pair processing ------------------------------------------
+// The reference walks each splat's tile rectangle serially in the splat's own thread; rectangles
+// range from 1 tile to the whole frame (a near-camera splat covers all 8160 tiles at 1080p), so on
+// a wave64 most lanes idle behind the largest one. Here the rectangles of the 64 Gaussians of a
+// wave are concatenated into one list of pairs (prefix sum of the tile counts) and processed 64
+// pairs per step: lane l of step k handles pair k+l, finds the owning lane by binary search on
+// the prefix sums (ds_bpermute) and pulls the owner's parameters with shuffles. Results go back
+// to the owner through ballots: a lane's pairs are contiguous, so it masks out its own segment.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1)
+	{
+		const uint32_t n = (uint32_t)__shfl_up((int)v, off);
+		if (lane >= off) v += n;
+	}
+	return v;
+}
+// smallest lane L with incl[L] > j  (j < total)
+__device__ __forceinline__ int pair_owner(uint32_t incl, uint32_t j)
+{
+	int lo = 0, hi = 63;
+#pragma unroll
+	for (int it = 0; it < 6; it++)
+	{
+		const int mid = (lo + hi) >> 1;
+		const uint32_t v = (uint32_t)__shfl((int)incl, mid);
+		if (v > j) hi = mid; else lo = mid + 1;
+	}
+	return lo;
+}
+// bits [a, b) of a 64-bit mask, for 0 <= a <= b <= 64
+__device__ __forceinline__ unsigned long long seg_mask(int a, int b)
+{
+	if (b <= a) return 0ull;
+	const unsigned long long hi = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+	return hi & ~((1ull << a) - 1ull);
+}
 
 // Persistent workgroups of FR_BIN_THREADS threads; slab s (FR_BIN_THREADS consecutive Gaussians)
 // belongs to workgroup s % gridDim.x -- k_emit uses the same assignment. LDSH: per-tile instance
@@ -303,9 +337,26 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
 		__syncthreads();
 	}
-	for (int base = blockIdx.x * FR_BIN_THREADS; base < a.P; base += gridDim.x * FR_BIN_THREADS)
+	// LDSH: slabs are pulled from a global counter (a few near-camera splats make some slabs 100x more
+	// expensive than others); the owner of every slab is recorded because k_emit must replay the same
+	// slab -> workgroup assignment (its bucket offsets are per workgroup).
+	__shared__ int s_slab;
+	const int nslabs = (a.P + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
+	int pulled = 0;
+	for (int sstat = blockIdx.x; ; sstat += gridDim.x)
 	{
-	const int idx = base + threadIdx.x;
+	int slab = sstat;
+	if (LDSH)
+	{
+		__syncthreads();
+		if (threadIdx.x == 0) s_slab = pulled < FR_MAX_SLABS_PER_BLOCK ? (int)atomicAdd(a.geom.slab_ctr, 1u) : nslabs;
+		__syncthreads();
+		slab = __builtin_amdgcn_readfirstlane(s_slab);
+		pulled++;
+		if (slab < nslabs && threadIdx.x == 0) a.geom.slab_owner[slab] = (uint16_t)blockIdx.x;
+	}
+	if (slab >= nslabs) break;
+	const int idx = slab * FR_BIN_THREADS + threadIdx.x;
 	const bool in_range = idx < a.P;
 	float p[3] = { 0.f, 0.f, 0.f };
 	Proj pr; pr.alive = false; pr.tnum = 0;
@@ -339,98 +390,83 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 			el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
 		}
 	}
-	const bool big = pr.alive && pr.tnum > FR_BIG_RECT;
-	if (pr.alive && !big)
+	// single-tile splats need no box test (RS rasterizer_impl.cu:99-102); handle them in place
+	if (pr.alive && pr.tnum == 1)
 	{
-		if (!CULL)
+		bool keep = true;
+		const int ti = pr.y0 * a.gx + pr.x0;
+		if (FOV)
 		{
-			for (int y = pr.y0; y < pr.y1; y++)
-				for (int x = pr.x0; x < pr.x1; x++) BUMP_TILE(y * a.gx + x);
-			count = pr.tnum;
+			const float level = tile_min[ti];
+			keep = level < (hl + 1);
+			if (keep) { lowest = level; highest = level; be_blend = tile_bl[ti] != 0.0f; }
 		}
-		else if (pr.tnum == 1)
+		if (keep) { BUMP_TILE(ti); count = 1; }
+	}
+	// everything else: wave-balanced pair loop
+	{
+		const uint32_t my_n = (pr.alive && pr.tnum > 1) ? pr.tnum : 0u;
+		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
+		const uint32_t excl = incl - my_n;
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		uint32_t lvmask = 0; // FOV: bit l = some kept tile has int(level) == l; bit 4 = some kept tile blends
+		for (uint32_t k = 0; k < total; k += 64)
 		{
-			bool keep = true;
-			const int ti = pr.y0 * a.gx + pr.x0;
+			const uint32_t j = k + lane;
+			const bool valid = j < total;
+			const int owner = pair_owner(incl, valid ? j : total - 1);
+			const uint32_t local = (valid ? j : total - 1) - (uint32_t)__shfl((int)excl, owner);
+			const int ox0 = __shfl(pr.x0, owner), oy0 = __shfl(pr.y0, owner), ow = __shfl(pr.x1, owner) - ox0;
+			const int x = ox0 + (int)(local % (uint32_t)ow), y = oy0 + (int)(local / (uint32_t)ow);
+			const int ti = y * a.gx + x;
+			bool pass = valid;
+			uint32_t m = 0;
+			if (CULL)
+			{
+				const float4 oev = make_float4(__shfl(ev.x, owner), __shfl(ev.y, owner), __shfl(ev.z, owner), __shfl(ev.w, owner));
+				const float2 oel = make_float2(__shfl(el.x, owner), __shfl(el.y, owner));
+				const float ocx = __shfl(pr.pix_x, owner), ocy = __shfl(pr.pix_y, owner);
+				float level = 0.f;
+				if (FOV)
+				{
+					const float ohl = __shfl(hl, owner);
+					level = valid ? tile_min[ti] : 0.f;
+					pass = pass && (level < (ohl + 1));
+				}
+				if (pass)
+				{
+					const Obb ob = make_obb(ocx, ocy, oev, oel);
+					pass = obb_hits_tile(ob, x, y);
+				}
+				if (FOV && pass) m = (1u << min(max(f2i(level), 0), 3)) | ((tile_bl[ti] != 0.0f) ? 16u : 0u);
+			}
+			if (pass) BUMP_TILE(ti);
+			// hand the results back to the owners: my pairs of this step are lanes [seg_a, seg_b)
+			const int seg_a = (int)max((long long)excl - (long long)k, 0ll);
+			const int seg_b = (int)min((long long)incl - (long long)k, 64ll);
+			const unsigned long long mine = seg_mask(seg_a, seg_b);
+			count += (uint32_t)__popcll(__ballot(pass) & mine);
 			if (FOV)
 			{
-				const float level = tile_min[ti];
-				keep = level < (hl + 1);
-				if (keep) { lowest = level; highest = level; be_blend = tile_bl[ti] != 0.0f; }
+#pragma unroll
+				for (int bit = 0; bit < 5; bit++)
+					if (__ballot((m >> bit) & 1u) & mine) lvmask |= 1u << bit;
 			}
-			if (keep) { BUMP_TILE(ti); count = 1; }
 		}
-		else
+		if (FOV && my_n != 0 && count != 0)
 		{
-			const Obb ob = make_obb(pr.pix_x, pr.pix_y, ev, el);
-			for (int y = pr.y0; y < pr.y1; y++)
-				for (int x = pr.x0; x < pr.x1; x++)
-				{
-					const int ti = y * a.gx + x;
-					bool inside = true;
-					float level = 0;
-					if (FOV) { level = tile_min[ti]; inside = level < (hl + 1); }
-					if (inside && obb_hits_tile(ob, x, y))
-					{
-						count++;
-						BUMP_TILE(ti);
-						if (FOV)
-						{
-							lowest = fminf(lowest, level); highest = fmaxf(highest, level);
-							be_blend = be_blend || (tile_bl[ti] != 0.0f);
-						}
-					}
-				}
+			// int(lowest) / int(highest) of RF rasterizer_impl.cu:374-381 from the per-level bits: truncation is
+			// monotone, so int(min(levels)) == min(int(level)); lowest starts at the Gaussian's own level
+			const int lo_bit = __ffs((int)(lvmask & 15u)) - 1, hi_bit = 31 - __clz((int)(lvmask & 15u));
+			lowest = fminf(lowest, (float)lo_bit);
+			highest = fmaxf(highest, (float)hi_bit);
+			be_blend = (lvmask & 16u) != 0;
 		}
 	}
-	// wave-cooperative walk of the big rectangles
-	unsigned long long bigmask = __ballot(big);
-	while (bigmask)
+	// NOTE: no divergent `continue` in this loop -- it carries workgroup barriers, and hipcc re-runs the
+	// loop header (barrier included) for the lanes that continue, which deadlocks the workgroup.
+	if (pr.alive && count != 0) // else culled everywhere: radii stays 0 (RS rasterizer_impl.cu:141-145)
 	{
-		const int L = __ffsll((long long)bigmask) - 1;
-		bigmask &= bigmask - 1;
-		const int bx0 = bcast_i(pr.x0, L), by0 = bcast_i(pr.y0, L), bx1 = bcast_i(pr.x1, L), by1 = bcast_i(pr.y1, L);
-		const int w = bx1 - bx0, tn = w * (by1 - by0);
-		uint32_t c = 0;
-		float lo = 3.0e38f, hi = 0.0f;
-		bool bl = false;
-		if (!CULL)
-		{
-			for (int t = lane; t < tn; t += 64) BUMP_TILE((by0 + t / w) * a.gx + bx0 + t % w);
-			c = 0; // owner already knows count == tnum
-		}
-		else
-		{
-			const float4 bev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
-			const float2 bel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
-			const Obb ob = make_obb(bcast_f(pr.pix_x, L), bcast_f(pr.pix_y, L), bev, bel);
-			const float bhl = bcast_f(hl, L);
-			for (int t = lane; t < tn; t += 64)
-			{
-				const int x = bx0 + t % w, y = by0 + t / w;
-				const int ti = y * a.gx + x;
-				bool inside = true;
-				float level = 0;
-				if (FOV) { level = tile_min[ti]; inside = level < (bhl + 1); }
-				if (inside && obb_hits_tile(ob, x, y))
-				{
-					c++;
-					BUMP_TILE(ti);
-					if (FOV) { lo = fminf(lo, level); hi = fmaxf(hi, level); bl = bl || (tile_bl[ti] != 0.0f); }
-				}
-			}
-		}
-		const uint32_t ctot = CULL ? wave_add_u32(c) : 0u;
-		float lo_all = 0.f, hi_all = 0.f;
-		bool bl_any = false;
-		if (FOV) { lo_all = wave_min_f32(lo); hi_all = wave_max_f32(hi); bl_any = __any(bl); }
-		if (lane == L)
-		{
-			count = CULL ? ctot : pr.tnum;
-			if (FOV) { lowest = fminf(lowest, lo_all); highest = fmaxf(highest, hi_all); be_blend = bl_any; }
-		}
-	}
-	if (!pr.alive || count == 0) continue; // culled everywhere: radii stays 0 (RS rasterizer_impl.cu:141-145)
 
 	// ---- colour ----
 	float rgb[3] = { 0, 0, 0 };
@@ -479,6 +515,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 	else rec[1] = make_float4(pr.conic_c, a.opacities[idx], rgb[0], rgb[1]);
 	rec[2] = make_float4(rgb[2], pr.depth, __uint_as_float(clamp_bits), 0.0f);
 	if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
+	} // visible
 	} // slab loop
 	if (LDSH)
 	{
@@ -519,9 +556,23 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_cur[t] = a.ranges[t].x + pre[t];
 		__syncthreads();
 	}
-	for (int base = blockIdx.x * FR_BIN_THREADS; base < a.P; base += gridDim.x * FR_BIN_THREADS)
+	// replay preprocess's slab -> workgroup assignment
+	__shared__ uint32_t s_nmine;
+	__shared__ uint32_t s_mine[FR_MAX_SLABS_PER_BLOCK];
+	const int nslabs = (a.P + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
+	if (LDSH)
 	{
-	const int idx = base + threadIdx.x;
+		if (threadIdx.x == 0) s_nmine = 0;
+		__syncthreads();
+		for (int sl = threadIdx.x; sl < nslabs; sl += FR_BIN_THREADS)
+			if (a.geom.slab_owner[sl] == (uint16_t)blockIdx.x) s_mine[atomicAdd(&s_nmine, 1u)] = (uint32_t)sl;
+		__syncthreads();
+	}
+	const int nmine = LDSH ? (int)s_nmine : (nslabs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+	for (int it = 0; it < nmine; it++)
+	{
+	const int slab = LDSH ? (int)s_mine[it] : (int)blockIdx.x + it * (int)gridDim.x;
+	const int idx = slab * FR_BIN_THREADS + threadIdx.x;
 	int radius = 0;
 	if (idx < a.P) radius = a.radii[idx];
 	const bool alive = radius > 0;
@@ -543,54 +594,40 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	}
 	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
 	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
-	const bool big = alive && tnum > FR_BIG_RECT;
-	if (alive && !big)
+	if (alive && tnum == 1) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
 	{
-		if (!CULL || tnum == 1)
+		const uint32_t my_n = (alive && tnum > 1) ? tnum : 0u;
+		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
+		const uint32_t excl = incl - my_n;
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		for (uint32_t k = 0; k < total; k += 64)
 		{
-			for (int y = y0; y < y1; y++)
-				for (int x = x0; x < x1; x++)
-				{
-					const int ti = y * a.gx + x;
-					a.entries[NEXT_SLOT(ti)] = payload;
-				}
-		}
-		else
-		{
-			const Obb ob = make_obb(cx, cy, ev, el);
-			for (int y = y0; y < y1; y++)
-				for (int x = x0; x < x1; x++)
-				{
-					const int ti = y * a.gx + x;
-					bool inside = true;
-					if (FOV) inside = tile_min[ti] < (hl + 1);
-					if (inside && obb_hits_tile(ob, x, y)) a.entries[NEXT_SLOT(ti)] = payload;
-				}
-		}
-	}
-	unsigned long long bigmask = __ballot(big);
-	while (bigmask)
-	{
-		const int L = __ffsll((long long)bigmask) - 1;
-		bigmask &= bigmask - 1;
-		const int bx0 = bcast_i(x0, L), by0 = bcast_i(y0, L), bx1 = bcast_i(x1, L), by1 = bcast_i(y1, L);
-		const int w = bx1 - bx0, tn = w * (by1 - by0);
-		const uint64_t bpay = ((uint64_t)(uint32_t)bcast_i((int)depth_bits, L) << 32) | (uint32_t)bcast_i(idx, L);
-		const float4 bev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
-		const float2 bel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
-		const Obb ob = make_obb(bcast_f(cx, L), bcast_f(cy, L), bev, bel);
-		const float bhl = bcast_f(hl, L);
-		for (int t = lane; t < tn; t += 64)
-		{
-			const int x = bx0 + t % w, y = by0 + t / w;
+			const uint32_t j = k + lane;
+			const bool valid = j < total;
+			const int owner = pair_owner(incl, valid ? j : total - 1);
+			const uint32_t local = (valid ? j : total - 1) - (uint32_t)__shfl((int)excl, owner);
+			const int ox0 = __shfl(x0, owner), oy0 = __shfl(y0, owner), ow = __shfl(x1, owner) - ox0;
+			const int x = ox0 + (int)(local % (uint32_t)ow), y = oy0 + (int)(local / (uint32_t)ow);
 			const int ti = y * a.gx + x;
-			bool inside = true;
+			const uint64_t opay = ((uint64_t)(uint32_t)__shfl((int)depth_bits, owner) << 32) | (uint32_t)__shfl(idx, owner);
+			bool pass = valid;
 			if (CULL)
 			{
-				if (FOV) inside = tile_min[ti] < (bhl + 1);
-				inside = inside && obb_hits_tile(ob, x, y);
+				const float4 oev = make_float4(__shfl(ev.x, owner), __shfl(ev.y, owner), __shfl(ev.z, owner), __shfl(ev.w, owner));
+				const float2 oel = make_float2(__shfl(el.x, owner), __shfl(el.y, owner));
+				const float ocx = __shfl(cx, owner), ocy = __shfl(cy, owner);
+				if (FOV)
+				{
+					const float ohl = __shfl(hl, owner);
+					pass = pass && (tile_min[valid ? ti : 0] < (ohl + 1));
+				}
+				if (pass)
+				{
+					const Obb ob = make_obb(ocx, ocy, oev, oel);
+					pass = obb_hits_tile(ob, x, y);
+				}
 			}
-			if (inside) a.entries[NEXT_SLOT(ti)] = bpay;
+			if (pass) a.entries[NEXT_SLOT(ti)] = opay;
 		}
 	}
 	} // slab loop
