@@ -125,7 +125,7 @@ int fr_forward(fr_forward_args *a)
 	c.img = carve_image(a->variant, a->W, a->H, iptr);
 
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, sizeof(uint32_t) * (size_t)c.T, stream));
-	FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, sizeof(uint32_t), stream));
+	FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, 4 * sizeof(uint32_t), stream));
 	if (a->variant == FR_VARIANT_PCHECK_OBB_SUM)
 	{
 		FR_HIP(hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, stream));

@@ -33,7 +33,8 @@ struct GeomWS {
 	float2 *elen;       // [P]  OBB half-lengths                 (not ORIGINAL)
 	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity)
 	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8
-	uint32_t *slab_ctr; // [1]  dynamic slab scheduler of the binning kernels
+	uint32_t *slab_ctr; // [4]  {slab scheduler of k_bin, number of entries in vis_list, 0, 0}
+	uint32_t *vis_list; // [P]  indices of the Gaussians that survive projection (unordered)
 	uint16_t *slab_owner; // [ceil(P / FR_BIN_THREADS)] workgroup that preprocessed each slab
 	size_t bytes;
 };
@@ -51,7 +52,8 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 		g.lvl = (float4 *)(base + off); off = align_up(off + P * FR_FOV_LEVELS * sizeof(float4));
 		g.lrange = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
 	}
-	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + 4);
+	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + 16);
+	g.vis_list = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
 	g.slab_owner = (uint16_t *)(base + off); off = align_up(off + ((P + FR_BIN_THREADS - 1) / FR_BIN_THREADS + 1) * sizeof(uint16_t));
 	g.bytes = off + 256;
 	return g;

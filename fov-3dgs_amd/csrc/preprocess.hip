@@ -169,6 +169,7 @@ struct PreArgs {
 	GeomWS geom;
 	uint32_t *tile_count;
 	uint32_t *hist; // [blocks][T] per-workgroup tile histograms (LDSH)
+	int write_cov3D; // keep the 3D covariances for the backward pass (training variants only)
 };
 
 // Projection of one Gaussian: everything up to the tile rectangle.
@@ -219,8 +220,11 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, cons
 		const M3 Sg = m3_mul(m3_t(Mm), Mm);
 		cov3D[0] = Sg.c[0][0]; cov3D[1] = Sg.c[0][1]; cov3D[2] = Sg.c[0][2];
 		cov3D[3] = Sg.c[1][1]; cov3D[4] = Sg.c[1][2]; cov3D[5] = Sg.c[2][2];
+		if (a.write_cov3D)
+		{
 #pragma unroll
-		for (int i = 0; i < 6; i++) a.geom.cov3D[6 * (size_t)idx + i] = cov3D[i];
+			for (int i = 0; i < 6; i++) a.geom.cov3D[6 * (size_t)idx + i] = cov3D[i];
+		}
 	}
 
 	// 2D covariance (EWA): forward.cu:74-113
@@ -319,6 +323,83 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 	return hi & ~((1ull << a) - 1ull);
 }
 
+// Stage 1: projection, covariance, conic, radius, tile rectangle -- memory-streaming, one thread per
+// Gaussian, grid-stride over 1024-wide chunks. Survivors are appended to vis_list so that the binning
+// and colour stages below run on dense waves (typically 10-20 % of a scene is on screen). The append
+// is staged through an LDS list and flushed with ONE global atomic per flush: a single device-scope
+// counter saturates at ~90 atomics/us on MI355X, so one atomic per wave (94 k per frame at 6 M
+// Gaussians) would cost a millisecond.
+#define FR_PROJ_THREADS 1024
+#define FR_PROJ_LIST 8192
+template <int VARIANT>
+__global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
+{
+	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
+	__shared__ uint32_t s_list[FR_PROJ_LIST];
+	__shared__ uint32_t s_n, s_base;
+	const int lane = threadIdx.x & 63;
+	if (threadIdx.x == 0) s_n = 0;
+	__syncthreads();
+	for (int chunk = blockIdx.x; chunk * FR_PROJ_THREADS < a.P; chunk += gridDim.x)
+	{
+		const int idx = chunk * FR_PROJ_THREADS + threadIdx.x;
+		Proj pr; pr.alive = false; pr.tnum = 0;
+		if (idx < a.P)
+		{
+			const float p[3] = { a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2] };
+			pr = project_gaussian(a, idx, p);
+			a.radii[idx] = pr.alive ? pr.radius : 0;
+		}
+		if (pr.alive)
+		{
+			float4 *rec = a.geom.rec + 3 * (size_t)idx;
+			rec[0] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
+			rec[1] = make_float4(pr.conic_c, 0.f, 0.f, 0.f);
+			rec[2] = make_float4(0.f, pr.depth, 0.f, 0.f);
+			if (CULL)
+			{
+				float4 ev = make_float4(0, 0, 0, 0);
+				float2 el = make_float2(0, 0);
+				if (pr.tnum > 1)
+				{
+					// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
+					float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
+					const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
+					e1x *= n1; e1y *= n1;
+					const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
+					e2x *= n2; e2y *= n2;
+					ev = make_float4(e1x, e1y, e2x, e2y);
+					el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
+				}
+				a.geom.evec[idx] = ev; a.geom.elen[idx] = el;
+			}
+		}
+		// wave-aggregated append to the LDS list
+		const unsigned long long m = __ballot(pr.alive);
+		if (m)
+		{
+			uint32_t base = 0;
+			const int leader = __ffsll((long long)m) - 1;
+			if (lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+			base = (uint32_t)__shfl((int)base, leader);
+			if (pr.alive) s_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+		}
+		__syncthreads();
+		const uint32_t n = s_n;
+		const bool last = (chunk + (int)gridDim.x) * FR_PROJ_THREADS >= a.P;
+		if (n + FR_PROJ_THREADS > FR_PROJ_LIST || last)
+		{
+			if (threadIdx.x == 0) s_base = n ? atomicAdd(a.geom.slab_ctr + 1, n) : 0u;
+			__syncthreads();
+			const uint32_t gbase = s_base;
+			for (uint32_t i = threadIdx.x; i < n; i += FR_PROJ_THREADS) a.geom.vis_list[gbase + i] = s_list[i];
+			__syncthreads();
+			if (threadIdx.x == 0) s_n = 0;
+		}
+		__syncthreads();
+	}
+}
+
 // Persistent workgroups of FR_BIN_THREADS threads; slab s (FR_BIN_THREADS consecutive Gaussians)
 // belongs to workgroup s % gridDim.x -- k_emit uses the same assignment. LDSH: per-tile instance
 // counts are accumulated in an LDS-private histogram (T <= 16 Ki tiles fit the 160 KiB LDS twice
@@ -326,7 +407,7 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 // (huge tile grids) the counters are bumped with global atomics.
 #define BUMP_TILE(ti) do { if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
 template <int VARIANT, bool LDSH>
-__global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
+__global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
@@ -341,7 +422,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 	// expensive than others); the owner of every slab is recorded because k_emit must replay the same
 	// slab -> workgroup assignment (its bucket offsets are per workgroup).
 	__shared__ int s_slab;
-	const int nslabs = (a.P + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
+	const int V = (int)a.geom.slab_ctr[1]; // entries of vis_list
+	const int nslabs = (V + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
 	int pulled = 0;
 	for (int sstat = blockIdx.x; ; sstat += gridDim.x)
 	{
@@ -356,15 +438,21 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 		if (slab < nslabs && threadIdx.x == 0) a.geom.slab_owner[slab] = (uint16_t)blockIdx.x;
 	}
 	if (slab >= nslabs) break;
-	const int idx = slab * FR_BIN_THREADS + threadIdx.x;
-	const bool in_range = idx < a.P;
-	float p[3] = { 0.f, 0.f, 0.f };
-	Proj pr; pr.alive = false; pr.tnum = 0;
-	if (in_range)
+	const int item = slab * FR_BIN_THREADS + threadIdx.x;
+	int idx = 0;
+	Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0; pr.pix_x = pr.pix_y = 0.f;
+	float4 r1 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
+	if (item < V)
 	{
-		a.radii[idx] = 0;
-		p[0] = a.means3D[3 * (size_t)idx]; p[1] = a.means3D[3 * (size_t)idx + 1]; p[2] = a.means3D[3 * (size_t)idx + 2];
-		pr = project_gaussian(a, idx, p);
+		idx = (int)a.geom.vis_list[item];
+		const float4 *rec = a.geom.rec + 3 * (size_t)idx;
+		const float4 r0 = rec[0];
+		r1 = rec[1]; r2 = rec[2];
+		pr.pix_x = r0.x; pr.pix_y = r0.y;
+		pr.radius = a.radii[idx];
+		get_rect(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, pr.x0, pr.y0, pr.x1, pr.y1);
+		pr.tnum = (uint32_t)(pr.y1 - pr.y0) * (uint32_t)(pr.x1 - pr.x0);
+		pr.alive = true;
 	}
 
 	// ---- count the tiles this splat really lands in (and bump the per-tile counters) ----
@@ -378,17 +466,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 	if (pr.alive)
 	{
 		if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
-		if (CULL && pr.tnum > 1)
-		{
-			// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
-			float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
-			const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
-			e1x *= n1; e1y *= n1;
-			const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
-			e2x *= n2; e2y *= n2;
-			ev = make_float4(e1x, e1y, e2x, e2y);
-			el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
-		}
+		if (CULL && pr.tnum > 1) { ev = a.geom.evec[idx]; el = a.geom.elen[idx]; }
 	}
 	// single-tile splats need no box test (RS rasterizer_impl.cu:99-102); handle them in place
 	if (pr.alive && pr.tnum == 1)
@@ -405,7 +483,11 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 	}
 	// everything else: wave-balanced pair loop
 	{
+#ifdef FR_EXP_NOPAIRS
+		const uint32_t my_n = 0u; if (pr.alive && pr.tnum > 1) count = 1;
+#else
 		const uint32_t my_n = (pr.alive && pr.tnum > 1) ? pr.tnum : 0u;
+#endif
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -465,13 +547,18 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 	}
 	// NOTE: no divergent `continue` in this loop -- it carries workgroup barriers, and hipcc re-runs the
 	// loop header (barrier included) for the lanes that continue, which deadlocks the workgroup.
-	if (pr.alive && count != 0) // else culled everywhere: radii stays 0 (RS rasterizer_impl.cu:141-145)
+	if (pr.alive && count == 0) a.radii[idx] = 0; // culled everywhere (RS rasterizer_impl.cu:141-145)
+#ifdef FR_EXP_NOCOLOR
+	if (false)
+#else
+	if (pr.alive && count != 0)
+#endif
 	{
-
 	// ---- colour ----
 	float rgb[3] = { 0, 0, 0 };
 	uint32_t clamp_bits = 0;
-	const float dirx = p[0] - a.campos[0], diry = p[1] - a.campos[1], dirz = p[2] - a.campos[2];
+	const float dirx = a.means3D[3 * (size_t)idx] - a.campos[0], diry = a.means3D[3 * (size_t)idx + 1] - a.campos[1],
+		dirz = a.means3D[3 * (size_t)idx + 2] - a.campos[2];
 	if (!FOV)
 	{
 		if (a.colors_precomp == nullptr)
@@ -507,14 +594,10 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_preprocess(const PreArgs a)
 			a.geom.lvl[(size_t)idx * FR_FOV_LEVELS + l] = v;
 		}
 	}
-
-	a.radii[idx] = pr.radius;
 	float4 *rec = a.geom.rec + 3 * (size_t)idx;
-	rec[0] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
-	if (FOV) rec[1] = make_float4(pr.conic_c, hl, 0.0f, 0.0f);
-	else rec[1] = make_float4(pr.conic_c, a.opacities[idx], rgb[0], rgb[1]);
-	rec[2] = make_float4(rgb[2], pr.depth, __uint_as_float(clamp_bits), 0.0f);
-	if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
+	if (FOV) rec[1] = make_float4(r1.x, hl, 0.0f, 0.0f);
+	else rec[1] = make_float4(r1.x, a.opacities[idx], rgb[0], rgb[1]);
+	rec[2] = make_float4(rgb[2], r2.y, __uint_as_float(clamp_bits), 0.0f);
 	} // visible
 	} // slab loop
 	if (LDSH)
@@ -559,7 +642,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	// replay preprocess's slab -> workgroup assignment
 	__shared__ uint32_t s_nmine;
 	__shared__ uint32_t s_mine[FR_MAX_SLABS_PER_BLOCK];
-	const int nslabs = (a.P + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
+	const int V = (int)a.geom.slab_ctr[1];
+	const int nslabs = (V + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
 	if (LDSH)
 	{
 		if (threadIdx.x == 0) s_nmine = 0;
@@ -572,9 +656,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	for (int it = 0; it < nmine; it++)
 	{
 	const int slab = LDSH ? (int)s_mine[it] : (int)blockIdx.x + it * (int)gridDim.x;
-	const int idx = slab * FR_BIN_THREADS + threadIdx.x;
-	int radius = 0;
-	if (idx < a.P) radius = a.radii[idx];
+	const int item = slab * FR_BIN_THREADS + threadIdx.x;
+	int idx = 0, radius = 0;
+	if (item < V) { idx = (int)a.geom.vis_list[item]; radius = a.radii[idx]; }
 	const bool alive = radius > 0;
 	int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
 	uint32_t tnum = 0;
@@ -634,20 +718,33 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 }
 #undef NEXT_SLOT
 
-// Column scan of the per-workgroup histograms: one thread per tile turns hist[b][t] into the
-// exclusive prefix over b and leaves the tile's total in tile_count[t].
+// Column scan of the per-workgroup histograms: hist[b][t] becomes the exclusive prefix over b, the
+// tile's total goes to tile_count[t]. A workgroup owns 16 tiles; 16 row groups walk B/16 rows each
+// (two passes), which keeps ~16x more loads in flight than one thread per tile walking all B rows.
 __global__ void __launch_bounds__(256) k_hist_colscan(int T, int B, uint32_t *hist, uint32_t *tile_count)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= T) return;
+	__shared__ uint32_t s_part[16][17];
+	const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+	const int t = blockIdx.x * 16 + c;
+	const int R = (B + 15) / 16;
+	const int r0 = g * R, r1 = min(B, r0 + R);
+	uint32_t sum = 0;
+	if (t < T)
+		for (int r = r0; r < r1; r++) sum += hist[(size_t)r * T + t];
+	s_part[g][c] = sum;
+	__syncthreads();
 	uint32_t run = 0;
-	for (int b = 0; b < B; b++)
+	for (int k = 0; k < g; k++) run += s_part[k][c];
+	if (t < T)
 	{
-		const uint32_t v = hist[(size_t)b * T + t];
-		hist[(size_t)b * T + t] = run;
-		run += v;
+		for (int r = r0; r < r1; r++)
+		{
+			const uint32_t v = hist[(size_t)r * T + t];
+			hist[(size_t)r * T + t] = run;
+			run += v;
+		}
+		if (g == 15) tile_count[t] = run;
 	}
-	tile_count[t] = run;
 }
 
 __global__ void k_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present)
@@ -679,12 +776,24 @@ int launch_preprocess(FwdCtx &c)
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.T = c.T;
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;
+	p.write_cov3D = (a->variant == FR_VARIANT_ORIGINAL || a->variant == FR_VARIANT_PCHECK_OBB_SUM) ? 1 : 0;
+	{
+		const int pchunks = (a->P + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS;
+		const dim3 pgrid(pchunks < 1024 ? pchunks : 1024), pblock(FR_PROJ_THREADS);
+		switch (a->variant)
+		{
+		case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL(k_project<FR_VARIANT_ORIGINAL>, pgrid, pblock, 0, c.stream, p); break;
+		default: hipLaunchKernelGGL(k_project<FR_VARIANT_PCHECK_OBB>, pgrid, pblock, 0, c.stream, p); break;
+		}
+		int prc = check_launch("project", c.stream, a->debug);
+		if (prc) return prc;
+	}
 	const bool ldsh = c.img.hist != nullptr;
 	const int nblk = bin_blocks(a->P);
 	const dim3 grid(nblk), block(FR_BIN_THREADS);
 	const size_t lds = ldsh ? (size_t)c.T * sizeof(uint32_t) : 0;
-#define LAUNCH_PRE(V) do { if (ldsh) hipLaunchKernelGGL((k_preprocess<V, true>), grid, block, lds, c.stream, p); \
-	else hipLaunchKernelGGL((k_preprocess<V, false>), grid, block, 0, c.stream, p); } while (0)
+#define LAUNCH_PRE(V) do { if (ldsh) hipLaunchKernelGGL((k_bin<V, true>), grid, block, lds, c.stream, p); \
+	else hipLaunchKernelGGL((k_bin<V, false>), grid, block, 0, c.stream, p); } while (0)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
@@ -695,7 +804,7 @@ int launch_preprocess(FwdCtx &c)
 #undef LAUNCH_PRE
 	int rc = check_launch("preprocess", c.stream, a->debug);
 	if (rc || !ldsh) return rc;
-	hipLaunchKernelGGL(k_hist_colscan, dim3((c.T + 255) / 256), dim3(256), 0, c.stream, c.T, nblk, c.img.hist, c.img.tile_count);
+	hipLaunchKernelGGL(k_hist_colscan, dim3((c.T + 15) / 16), dim3(256), 0, c.stream, c.T, nblk, c.img.hist, c.img.tile_count);
 	return check_launch("hist_colscan", c.stream, a->debug);
 }
 
