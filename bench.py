@@ -213,8 +213,15 @@ def main():
     }
     dominant = max(("preprocess", "render", "tile_sort", "emit"), key=lambda k: mean_ms[k])
     achieved = alg_bytes[dominant] / (mean_ms[dominant] * 1e-3) / 1e9
+    traffic = None
+    try:  # HBM bytes per launch of that kernel from the committed PMC pass (profiles/), if it exists
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["kernels"]
+        kname = {"render": "k_render_fov", "preprocess": "k_bin", "tile_sort": "k_tile_sort", "emit": "k_emit"}[dominant]
+        traffic = int((2 * pmc[kname]["FETCH_SIZE_KiB"] + pmc[kname]["WRITE_SIZE_KiB"]) * 1024)
+    except Exception:
+        pass
     roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     algorithmic_bytes=int(alg_bytes[dominant]), kernel_ms=round(mean_ms[dominant], 4),
                     per_kernel={k: dict(ms=round(mean_ms[k], 4), alg_GBs=round(alg_bytes[k] / max(mean_ms[k], 1e-9) / 1e6, 1))
                                 for k in _native.STAGES})

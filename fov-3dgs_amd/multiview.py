@@ -45,9 +45,11 @@ def gather_images(image, dst=0, async_op=False):
 def all_gather_images(image, async_op=False):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return None, image.unsqueeze(0)
-    out = torch.empty((dist.get_world_size(),) + tuple(image.shape), dtype=image.dtype, device=image.device)
-    work = dist.all_gather_into_tensor(out, image.contiguous(), async_op=async_op)
-    return (work if async_op else None), out
+    world = dist.get_world_size()
+    # concatenated layout [world*C, H, W] (accepted by both RCCL and gloo), viewed as [world, C, H, W]
+    flat = torch.empty((world * image.shape[0],) + tuple(image.shape[1:]), dtype=image.dtype, device=image.device)
+    work = dist.all_gather_into_tensor(flat, image.contiguous(), async_op=async_op)
+    return (work if async_op else None), flat.view((world,) + tuple(image.shape))
 
 
 def allreduce_gradients(params, bucket_bytes=256 << 20):
