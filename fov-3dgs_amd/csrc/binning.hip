@@ -17,13 +17,15 @@ namespace fr {
 
 // Single workgroup: exclusive scan of tile_count[T] -> ranges, reset the counters to serve as
 // emission cursors, publish {total, max}.
-__global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals)
+__global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals, uint32_t *tile_order)
 {
+	__shared__ uint32_t bucket[34];
 	__shared__ uint32_t wave_sum[16];
 	__shared__ uint32_t carry_s;
 	__shared__ uint32_t wave_max[16];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	if (tid == 0) carry_s = 0;
+	if (tid < 34) bucket[tid] = 0;
 	uint32_t vmax = 0;
 	__syncthreads();
 	for (int base = 0; base < T; base += 1024)
@@ -31,6 +33,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		const int i = base + tid;
 		const uint32_t v = i < T ? tile_count[i] : 0u;
 		vmax = max(vmax, v);
+		if (i < T) atomicAdd(&bucket[v ? 32 - __clz((int)v) : 0], 1u); // bucket b: 2^(b-1) <= v < 2^b
 		// inclusive scan inside the wave
 		uint32_t s = v;
 #pragma unroll
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		for (int w = 0; w < 16; w++) { if (w < wid) wave_off += wave_sum[w]; block_total += wave_sum[w]; }
 		const uint32_t carry = carry_s;
 		const uint32_t excl = carry + wave_off + s - v;
-		if (i < T) { ranges[i] = make_uint2(excl, excl + v); tile_count[i] = 0; }
+		if (i < T) ranges[i] = make_uint2(excl, excl + v);
 		__syncthreads();
 		if (tid == 0) carry_s = carry + block_total;
 		__syncthreads();
@@ -60,6 +63,19 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		uint32_t m = 0;
 		for (int w = 0; w < 16; w++) m = max(m, wave_max[w]);
 		totals[0] = carry_s; totals[1] = m; totals[2] = 0; totals[3] = 0;
+		// bucket start offsets, longest lists first
+		uint32_t run = 0;
+		for (int b = 32; b >= 0; b--) { const uint32_t c = bucket[b]; bucket[b] = run; run += c; }
+	}
+	__syncthreads();
+	// longest-processing-time-first order for the per-tile kernels (sort, blend): a frame's critical
+	// path is its longest tile list, so those workgroups must start first. tile_count doubles as the
+	// emission cursor in the global-atomics fallback and is reset here.
+	for (int i = tid; i < T; i += 1024)
+	{
+		const uint32_t v = tile_count[i];
+		tile_order[atomicAdd(&bucket[v ? 32 - __clz((int)v) : 0], 1u)] = (uint32_t)i;
+		tile_count[i] = 0;
 	}
 }
 
@@ -118,10 +134,10 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int n, int npow2, i
 
 // One workgroup per tile. Buckets of up to lds_cap entries are sorted in LDS; longer ones in
 // place in global memory (rare; same network).
-__global__ void __launch_bounds__(256) k_tile_sort(const uint2 *ranges, uint64_t *entries, uint32_t *point_list, int lds_cap)
+__global__ void __launch_bounds__(256) k_tile_sort(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries, uint32_t *point_list, int lds_cap)
 {
 	extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
-	const uint2 rg = ranges[blockIdx.x];
+	const uint2 rg = ranges[tile_order[blockIdx.x]];
 	const int n = (int)(rg.y - rg.x);
 	if (n == 0) return;
 	const int tid = threadIdx.x;
@@ -145,7 +161,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(const uint2 *ranges, uint64_t
 
 int launch_tile_scan(FwdCtx &c)
 {
-	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals);
+	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals, c.img.tile_order);
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 
@@ -155,7 +171,7 @@ int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
 	int cap = 64;
 	while (cap < max_tile && cap < FR_SORT_LDS_MAX) cap <<= 1;
 	const size_t lds = (size_t)cap * sizeof(uint64_t);
-	hipLaunchKernelGGL(k_tile_sort, dim3(c.T), dim3(256), lds, c.stream, c.img.ranges, c.bin.entries, c.bin.point_list, cap);
+	hipLaunchKernelGGL(k_tile_sort, dim3(c.T), dim3(256), lds, c.stream, c.img.ranges, c.img.tile_order, c.bin.entries, c.bin.point_list, cap);
 	return check_launch("tile_sort", c.stream, c.a->debug);
 }
 

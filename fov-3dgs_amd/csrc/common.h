@@ -66,6 +66,7 @@ struct ImageWS {
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
 	uint32_t *totals;     // [4]  {num_instances, max per tile, 0, 0}
+	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
 	uint32_t *hist;       // [FR_BIN_BLOCKS][T] per-workgroup tile histograms (null if T too large for LDS)
 	size_t bytes;
@@ -85,6 +86,7 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.ranges = (uint2 *)(base + off); off = align_up(off + T * sizeof(uint2));
 	s.tile_count = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.totals = (uint32_t *)(base + off); off = align_up(off + 4 * sizeof(uint32_t));
+	s.tile_order = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.tile_lv = nullptr;
 	if (variant == FR_VARIANT_FOV_PCHECK_OBB) { s.tile_lv = (float *)(base + off); off = align_up(off + 5 * T * sizeof(float)); }
 	s.hist = nullptr;

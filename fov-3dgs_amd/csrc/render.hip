@@ -43,6 +43,7 @@ struct RenderArgs {
 	const float4 *rec;
 	const float4 *lvl;      // RF
 	const float *tile_lv;   // RF float[5][T]
+	const uint32_t *tile_order; // tiles sorted by descending list length (longest first), or null
 	int T;
 	const float *bg;
 	float *out_color;
@@ -53,21 +54,27 @@ struct RenderArgs {
 };
 
 // ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB ----------------
+// Instances are staged NT (= threads of the group) at a time: with PPL = 4 that is 64 records = 2.3 KiB of
+// LDS per wave, so occupancy is bounded by registers, not LDS. The records of the NEXT batch are
+// prefetched into registers before the current batch is blended (the point_list -> record gather is two
+// dependent global loads). RS semantics that depend on the reference's 256-entry batches
+// (gaussians_count: +1 per entry of every batch a still-live tile fetches, RS forward.cu:349-361) are kept
+// by taking the "tile finished" decision only at multiples of 256 entries.
 template <int VARIANT, int PPL>
 __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 {
-	constexpr int NT = 256 / PPL;        // threads per tile
+	constexpr int NT = 256 / PPL;        // threads per tile == staging batch
 	constexpr int RSTEP = 16 / PPL;      // row distance between a lane's pixels
 	constexpr bool CUTOFF = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool SUM = VARIANT == FR_VARIANT_PCHECK_OBB_SUM;
 	constexpr bool AUX = VARIANT != FR_VARIANT_PCHECK_OBB; // final_T / n_contrib kept for backward
 
-	__shared__ float4 s0[256];
-	__shared__ float4 s1[256];
-	__shared__ float s2[256];
-	__shared__ int sid[SUM ? 256 : 1];
+	__shared__ float4 s0[NT];
+	__shared__ float4 s1[NT];
+	__shared__ float s2[NT];
+	__shared__ int sid[SUM ? NT : 1];
 
-	const int tile = blockIdx.x;
+	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
 	const int tx = tile % a.gx, ty = tile / a.gx;
 	const int tid = threadIdx.x;
 	const int lx = tid & 15, ry = tid >> 4;
@@ -89,27 +96,44 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 		T[k] = 1.0f; C0[k] = C1[k] = C2[k] = 0.0f; last[k] = 0;
 	}
 
-	for (int base = 0; base < n; base += 256)
+	// prefetch registers
+	uint32_t pid = 0;
+	float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
+	float p2 = 0.f;
+	if (tid < n)
+	{
+		pid = a.point_list[range.x + tid];
+		const float4 *r = a.rec + 3 * (size_t)pid;
+		p0 = r[0]; p1 = r[1]; p2 = r[2].x;
+	}
+	bool finished = false; // SUM: every pixel saturated, only counting until the next 256 boundary
+	for (int base = 0; base < n; base += NT)
 	{
 		bool all_done = true;
 #pragma unroll
 		for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
-		if (__syncthreads_and(all_done)) break;
-		// cooperative gather of up to 256 instance records
-#pragma unroll
-		for (int k = 0; k < PPL; k++)
+		const bool wg_done = __syncthreads_and(all_done) != 0; // also fences the LDS reuse
+		if (SUM)
 		{
-			const int e = tid + k * NT;
-			if (base + e < n)
-			{
-				const uint32_t id = a.point_list[range.x + base + e];
-				const float4 *r = a.rec + 3 * (size_t)id;
-				s0[e] = r[0]; s1[e] = r[1]; s2[e] = r[2].x;
-				if (SUM) { sid[e] = (int)id; atomicAdd(&a.gaussians_count[id], 1); }
-			}
+			if ((base & 255) == 0) { if (wg_done) break; }
+			finished = wg_done;
+		}
+		else if (wg_done) break;
+		if (base + tid < n)
+		{
+			s0[tid] = p0; s1[tid] = p1; s2[tid] = p2;
+			if (SUM) { sid[tid] = (int)pid; atomicAdd(&a.gaussians_count[pid], 1); }
+		}
+		if (base + NT + tid < n)
+		{
+			pid = a.point_list[range.x + base + NT + tid];
+			const float4 *r = a.rec + 3 * (size_t)pid;
+			p0 = r[0]; p1 = r[1]; p2 = r[2].x;
 		}
 		__syncthreads();
-		const int cnt = min(256, n - base);
+		// SUM && finished: nothing left to blend, the loop only keeps counting (no `continue` here: this
+		// loop carries barriers, see the note in k_bin)
+		const int cnt = (SUM && finished) ? 0 : min(NT, n - base);
 		for (int j = 0; j < cnt; j++)
 		{
 			bool lane_done = true;
@@ -119,9 +143,8 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 			const float4 g0 = s0[j];
 			const float4 g1 = s1[j];
 			const float dx = g0.x - pxf;
-			const float adx = g0.z * dx;         // A*dx
-			const float adx2 = adx * dx;         // A*dx*dx
-			const float bdx = g0.w * dx;         // B*dx
+			const float adx2 = (g0.z * dx) * dx;     // A*dx*dx
+			const float bdx = g0.w * dx;             // B*dx
 			float contrib_sum = 0.0f;
 			bool any_contrib = false;
 #pragma unroll
@@ -154,7 +177,6 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 				}
 			}
 		}
-		__syncthreads();
 	}
 
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
@@ -163,11 +185,11 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	for (int k = 0; k < PPL; k++)
 	{
 		if (!inside[k]) continue;
-		const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + ry + k * RSTEP) + px;
-		if (AUX) { a.final_T[pid] = T[k]; a.n_contrib[pid] = last[k]; }
-		a.out_color[pid] = fmaf(T[k], bg0, C0[k]);
-		a.out_color[plane + pid] = fmaf(T[k], bg1, C1[k]);
-		a.out_color[2 * plane + pid] = fmaf(T[k], bg2, C2[k]);
+		const size_t pid2 = (size_t)a.W * (size_t)(ty * FR_TILE + ry + k * RSTEP) + px;
+		if (AUX) { a.final_T[pid2] = T[k]; a.n_contrib[pid2] = last[k]; }
+		a.out_color[pid2] = fmaf(T[k], bg0, C0[k]);
+		a.out_color[plane + pid2] = fmaf(T[k], bg1, C1[k]);
+		a.out_color[2 * plane + pid2] = fmaf(T[k], bg2, C2[k]);
 	}
 }
 
@@ -177,12 +199,12 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 {
 	constexpr int NT = 256 / PPL;
 	constexpr int RSTEP = 16 / PPL;
-	__shared__ float4 s0[256];   // x, y, A, B
-	__shared__ float2 s1[256];   // C, highest_level
-	__shared__ float4 sl1[256];  // level L1: r, g, b, opacity
-	__shared__ float4 sl2[256];  // level L2 (two-level tiles only)
+	__shared__ float4 s0[NT];   // x, y, A, B
+	__shared__ float2 s1[NT];   // C, highest_level
+	__shared__ float4 sl1[NT];  // level L1: r, g, b, opacity
+	__shared__ float4 sl2[NT];  // level L2 (two-level tiles only)
 
-	const int tile = blockIdx.x;
+	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
 	const int tx = tile % a.gx, ty = tile / a.gx;
 	const int tid = threadIdx.x;
 	const int lx = tid & 15, ry = tid >> 4;
@@ -212,29 +234,30 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 		else { d1[k] = !inside[k]; d2[k] = true; }
 	}
 
-	for (int base = 0; base < n; base += 256)
+	// prefetch registers
+	float4 p0 = make_float4(0, 0, 0, 0), pl1 = p0, pl2 = p0;
+	float2 p1 = make_float2(0, 0);
+	auto fetch = [&](int e)
+	{
+		const uint32_t id = a.point_list[range.x + e];
+		const float4 *r = a.rec + 3 * (size_t)id;
+		p0 = r[0];
+		const float4 r1 = r[1];
+		p1 = make_float2(r1.x, r1.y);
+		pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + L1];
+		if (blending) pl2 = a.lvl[(size_t)id * FR_FOV_LEVELS + L2];
+	};
+	if (tid < n) fetch(tid);
+	for (int base = 0; base < n; base += NT)
 	{
 		bool all_done = true;
 #pragma unroll
 		for (int k = 0; k < PPL; k++) all_done = all_done && d1[k] && d2[k];
 		if (__syncthreads_and(all_done)) break;
-#pragma unroll
-		for (int k = 0; k < PPL; k++)
-		{
-			const int e = tid + k * NT;
-			if (base + e < n)
-			{
-				const uint32_t id = a.point_list[range.x + base + e];
-				const float4 *r = a.rec + 3 * (size_t)id;
-				s0[e] = r[0];
-				const float4 r1 = r[1];
-				s1[e] = make_float2(r1.x, r1.y);
-				sl1[e] = a.lvl[(size_t)id * FR_FOV_LEVELS + L1];
-				if (blending) sl2[e] = a.lvl[(size_t)id * FR_FOV_LEVELS + L2];
-			}
-		}
+		if (base + tid < n) { s0[tid] = p0; s1[tid] = p1; sl1[tid] = pl1; if (blending) sl2[tid] = pl2; }
+		if (base + NT + tid < n) fetch(base + NT + tid);
 		__syncthreads();
-		const int cnt = min(256, n - base);
+		const int cnt = min(NT, n - base);
 		for (int j = 0; j < cnt; j++)
 		{
 			bool lane_done = true;
@@ -312,7 +335,6 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 				}
 			}
 		}
-		__syncthreads();
 	}
 
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
@@ -350,7 +372,7 @@ int launch_render(FwdCtx &c)
 	RenderArgs r;
 	r.W = a->W; r.H = a->H; r.gx = c.gx;
 	r.ranges = c.img.ranges; r.point_list = c.bin.point_list; r.rec = c.geom.rec; r.lvl = c.geom.lvl;
-	r.tile_lv = c.img.tile_lv; r.T = c.T; r.bg = a->background; r.out_color = a->out_color;
+	r.tile_lv = c.img.tile_lv; r.tile_order = c.img.tile_order; r.T = c.T; r.bg = a->background; r.out_color = a->out_color;
 	r.final_T = c.img.final_T; r.n_contrib = c.img.n_contrib;
 	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions;
 	constexpr int PPL = FR_RENDER_PPL;
