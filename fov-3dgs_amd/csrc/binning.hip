@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		for (int w = 0; w < 16; w++) { if (w < wid) wave_off += wave_sum[w]; block_total += wave_sum[w]; }
 		const uint32_t carry = carry_s;
 		const uint32_t excl = carry + wave_off + s - v;
-		if (i < T) ranges[i] = make_uint2(excl, excl + v);
+		if (i < T) ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u); // empty tiles stay (0,0) like the reference's memset
 		__syncthreads();
 		if (tid == 0) carry_s = carry + block_total;
 		__syncthreads();

@@ -163,6 +163,25 @@ def test_long_tile_lists_use_global_sort_path():
     check_image(got["color"], want["color"])
 
 
+@pytest.mark.parametrize("variant", ("pcheck_obb", "fov_pcheck_obb"))
+def test_huge_tile_grid_uses_global_counter_path(variant):
+    """More than 16384 tiles (4096x2160 -> 34560): the per-workgroup LDS histograms do not fit and the
+    binning kernels fall back to global per-tile counters / cursors."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    cloud = syn.scene_1k(P=1500, seed=12)
+    cloud._scaling += 0.5
+    cam = syn.camera_1k(4096, 2160, 70.0)
+    fov = syn.foveation_layers(cloud, seed=13) if variant == "fov_pcheck_obb" else None
+    scene, cd = scene_dict(cloud, variant, fov), cam_dict(cam, gaze=(0.6, 0.4))
+    want = orc.forward(variant, scene, cd)
+    got = hip_forward(variant, scene, cd)
+    assert got["num_rendered"] == want["num_rendered"]
+    np.testing.assert_array_equal(got["ranges"], want["ranges"])
+    np.testing.assert_array_equal(got["point_list"], want["point_list"])
+    check_image(got["color"], want["color"])
+
+
 def test_autograd_module_end_to_end():
     """render() entry point + autograd: grads reach the raw parameters and match the oracle chain."""
     _need_gpu()
