@@ -132,31 +132,105 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *keys, int n, int npow2, i
 	}
 }
 
-// One workgroup per tile. Buckets of up to lds_cap entries are sorted in LDS; longer ones in
-// place in global memory (rare; same network).
-__global__ void __launch_bounds__(256) k_tile_sort(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries, uint32_t *point_list, int lds_cap)
+// ---- per-tile merge sort in LDS -------------------------------------------------------------
+// One workgroup per tile, THREADS x ITEMS keys of capacity. Every thread sorts ITEMS consecutive keys
+// in registers (odd-even transposition network), then log2(n / ITEMS) merge passes follow: a thread
+// finds its ITEMS-long slice of the merged output by a merge-path binary search and merges it
+// sequentially out of LDS into registers; results are written back in place after a barrier.
+// LDS traffic is O(n log n) (vs O(n log^2 n) for the bitonic network), which is what bounds a CU that
+// hosts several tiles at once. Keys are unique (the id is part of the key), so no stability issue.
+template <int ITEMS>
+__device__ __forceinline__ void reg_sort(uint64_t (&k)[ITEMS])
 {
-	extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+#pragma unroll
+	for (int r = 0; r < ITEMS; r++)
+#pragma unroll
+		for (int i = (r & 1); i + 1 < ITEMS; i += 2)
+		{
+			const uint64_t lo = k[i] < k[i + 1] ? k[i] : k[i + 1];
+			const uint64_t hi = k[i] < k[i + 1] ? k[i + 1] : k[i];
+			k[i] = lo; k[i + 1] = hi;
+		}
+}
+
+template <int THREADS, int ITEMS>
+__global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, const uint32_t *tile_order, const uint64_t *entries,
+	uint32_t *point_list, int n_lo)
+{
+	extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
 	const uint2 rg = ranges[tile_order[blockIdx.x]];
 	const int n = (int)(rg.y - rg.x);
-	if (n == 0) return;
+	if (n <= n_lo || n > THREADS * ITEMS) return; // another size class sorts this tile
+	const int tid = threadIdx.x;
+	const uint64_t *src = entries + rg.x;
+	uint32_t *dst = point_list + rg.x;
+	// active capacity: ITEMS * 2^k >= n
+	int runs = 1;
+	while (runs * ITEMS < n) runs <<= 1;
+	const int nact = runs * ITEMS;
+	for (int i = tid; i < nact; i += THREADS) sk[i] = i < n ? src[i] : ~0ull;
+	__syncthreads();
+	const bool act = tid < runs;
+	uint64_t k[ITEMS];
+	const int o = tid * ITEMS;
+	if (act)
+	{
+#pragma unroll
+		for (int i = 0; i < ITEMS; i++) k[i] = sk[o + i];
+		reg_sort<ITEMS>(k);
+#pragma unroll
+		for (int i = 0; i < ITEMS; i++) sk[o + i] = k[i];
+	}
+	__syncthreads();
+	for (int L = ITEMS; L < nact; L <<= 1)
+	{
+		if (act)
+		{
+			const int base = o & ~(2 * L - 1);
+			const int d = o - base;                      // outputs before mine inside this pair of runs
+			const uint64_t *A = sk + base, *B = sk + base + L;
+			int lo = max(0, d - L), hi = min(d, L);
+			while (lo < hi)
+			{
+				const int mid = (lo + hi) >> 1;
+				if (A[mid] < B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+			}
+			int i = lo, j = d - lo;
+			uint64_t av = i < L ? A[i] : ~0ull, bv = j < L ? B[j] : ~0ull;
+#pragma unroll
+			for (int t = 0; t < ITEMS; t++)
+			{
+				const bool ta = av <= bv;
+				k[t] = ta ? av : bv;
+				if (ta) { i++; av = i < L ? A[i] : ~0ull; }
+				else { j++; bv = j < L ? B[j] : ~0ull; }
+			}
+		}
+		__syncthreads();
+		if (act)
+		{
+#pragma unroll
+			for (int t = 0; t < ITEMS; t++) sk[o + t] = k[t];
+		}
+		__syncthreads();
+	}
+	for (int i = tid; i < n; i += THREADS) dst[i] = (uint32_t)sk[i];
+}
+
+// Lists longer than the largest LDS class: bitonic network in place in global memory (rare).
+__global__ void __launch_bounds__(256) k_tile_sort_global(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries,
+	uint32_t *point_list, int n_lo)
+{
+	const uint2 rg = ranges[tile_order[blockIdx.x]];
+	const int n = (int)(rg.y - rg.x);
+	if (n <= n_lo) return;
 	const int tid = threadIdx.x;
 	uint64_t *src = entries + rg.x;
 	uint32_t *dst = point_list + rg.x;
 	int npow2 = 1;
 	while (npow2 < n) npow2 <<= 1;
-	if (n <= lds_cap)
-	{
-		for (int i = tid; i < n; i += 256) skeys[i] = src[i];
-		__syncthreads();
-		bitonic_sort<false>(skeys, n, npow2, tid, 256);
-		for (int i = tid; i < n; i += 256) dst[i] = (uint32_t)skeys[i];
-	}
-	else
-	{
-		bitonic_sort<true>(src, n, npow2, tid, 256);
-		for (int i = tid; i < n; i += 256) dst[i] = (uint32_t)key_ld<true>(src + i);
-	}
+	bitonic_sort<true>(src, n, npow2, tid, 256);
+	for (int i = tid; i < n; i += 256) dst[i] = (uint32_t)key_ld<true>(src + i);
 }
 
 int launch_tile_scan(FwdCtx &c)
@@ -168,10 +242,19 @@ int launch_tile_scan(FwdCtx &c)
 int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
 {
 	(void)num_instances;
-	int cap = 64;
-	while (cap < max_tile && cap < FR_SORT_LDS_MAX) cap <<= 1;
-	const size_t lds = (size_t)cap * sizeof(uint64_t);
-	hipLaunchKernelGGL(k_tile_sort, dim3(c.T), dim3(256), lds, c.stream, c.img.ranges, c.img.tile_order, c.bin.entries, c.bin.point_list, cap);
+	const dim3 grid(c.T);
+	const uint2 *rg = c.img.ranges;
+	const uint32_t *ord = c.img.tile_order;
+	// size classes (tile_order is longest-first, so the big classes start first on the chip)
+	if (max_tile > 16384)
+		hipLaunchKernelGGL(k_tile_sort_global, grid, dim3(256), 0, c.stream, rg, ord, c.bin.entries, c.bin.point_list, 16384);
+	if (max_tile > 8192)
+		hipLaunchKernelGGL((k_tile_msort<1024, 16>), grid, dim3(1024), 16384 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 8192);
+	if (max_tile > 2048)
+		hipLaunchKernelGGL((k_tile_msort<1024, 8>), grid, dim3(1024), 8192 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 2048);
+	if (max_tile > 512)
+		hipLaunchKernelGGL((k_tile_msort<256, 8>), grid, dim3(256), 2048 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 512);
+	hipLaunchKernelGGL((k_tile_msort<64, 8>), grid, dim3(64), 512 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 0);
 	return check_launch("tile_sort", c.stream, c.a->debug);
 }
 

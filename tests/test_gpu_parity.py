@@ -147,17 +147,19 @@ def test_edge_cases():
     check_image(got["color"], want["color"])
 
 
-def test_long_tile_lists_use_global_sort_path():
-    """Per-tile lists longer than the LDS sort capacity (8192) fall back to the in-place global sort."""
+@pytest.mark.parametrize("P", (700, 3000, 9000, 18000))
+def test_tile_sort_size_classes(P):
+    """Every size class of the per-tile sort: <=512 (one wave), <=2048, <=8192, <=16384 entries in LDS,
+    and the in-place global-memory network beyond that."""
     _need_gpu()
     from tests.gpu_helpers import hip_forward
-    cloud = syn.scene_1k(P=9000, seed=9)
+    cloud = syn.scene_1k(P=P, seed=9)
     cloud._xyz[:, :2] *= 0.02      # pile everything onto a few tiles
     cloud._opacity -= 3.5          # faint, so nothing saturates early
     cam = syn.camera_1k(64, 64)
     scene, cd = scene_dict(cloud, "original"), cam_dict(cam)
     want = orc.forward("original", scene, cd)
-    assert (want["ranges"][:, 1] - want["ranges"][:, 0]).max() > 8192
+    assert (want["ranges"][:, 1] - want["ranges"][:, 0]).max() > 0.9 * P
     got = hip_forward("original", scene, cd)
     np.testing.assert_array_equal(got["point_list"], want["point_list"])
     check_image(got["color"], want["color"])
