@@ -140,12 +140,13 @@ int fr_forward(fr_forward_args *a)
 	mark(FR_STAGE_EMIT);
 
 	// the one host synchronisation of a frame: how many instances must the binning buffer hold
-	uint32_t totals[2] = { 0, 0 };
+	uint32_t totals[4] = { 0, 0, 0, 0 };
 	FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
 	FR_HIP(hipStreamSynchronize(stream));
 	if (totals[0] > 0x7fffffffu) { set_error("too many instances (%u)", totals[0]); return FR_ERR_INVALID; }
 	a->num_rendered = (int32_t)totals[0];
 	a->max_tile_instances = (int32_t)totals[1];
+	c.heavy4 = (int)totals[2]; c.heavy2 = (int)totals[3];
 
 	char *bptr = a->binning_resize(a->resize_user[1], carve_bin(totals[0], nullptr).bytes);
 	if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }

@@ -229,13 +229,12 @@ struct BwdPreArgs {
 	const float *cov3D_ws;
 	const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
 	float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+	const uint32_t *vis_list;  // forward's compact list of projected Gaussians
+	const uint32_t *vis_count; // its length (device)
 };
 
-__global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
+__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx)
 {
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= a.P) return;
-	if (!(a.radii[idx] > 0)) return;
 	const float *vm = a.viewmatrix, *proj = a.projmatrix;
 	const float m[3] = { a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2] };
 	const float *cov3D = a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : a.cov3D_ws + 6 * (size_t)idx;
@@ -456,6 +455,18 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 	}
 }
 
+// Grid-stride over the forward pass's visible list: dense waves instead of one thread per Gaussian with
+// ~90 % of the lanes returning immediately. Entries culled after projection (radii reset to 0) are skipped.
+__global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
+{
+	const int V = (int)*a.vis_count;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x)
+	{
+		const int idx = (int)a.vis_list[i];
+		if (a.radii[idx] > 0) preprocess_bwd_one(a, idx);
+	}
+}
+
 #ifndef FR_BWD_PPL
 #define FR_BWD_PPL 4
 #endif
@@ -495,7 +506,9 @@ int launch_backward(const fr_backward_args *a)
 	p.radii = a->radii; p.rec = geom.rec; p.cov3D_ws = geom.cov3D;
 	p.dL_dmean2D = a->dL_dmean2D; p.dL_dconic = a->dL_dconic; p.dL_dcolor = a->dL_dcolor;
 	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
-	hipLaunchKernelGGL(k_preprocess_bwd, dim3((a->P + 255) / 256), dim3(256), 0, stream, p);
+	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1;
+	const int pblocks = (a->P + 255) / 256;
+	hipLaunchKernelGGL(k_preprocess_bwd, dim3(pblocks < 2048 ? pblocks : 2048), dim3(256), 0, stream, p);
 	int rc2 = check_launch("preprocess_bwd", stream, a->debug);
 	mark(2);
 	return rc2;

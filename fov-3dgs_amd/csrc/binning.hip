@@ -62,7 +62,10 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 	{
 		uint32_t m = 0;
 		for (int w = 0; w < 16; w++) m = max(m, wave_max[w]);
-		totals[0] = carry_s; totals[1] = m; totals[2] = 0; totals[3] = 0;
+		// bucket b holds lists with 2^(b-1) <= n < 2^b: n >= 2048 <=> b >= 12, 512 <= n < 2048 <=> b in {10, 11}
+		uint32_t h4 = 0;
+		for (int b = 12; b <= 32; b++) h4 += bucket[b];
+		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11];
 		// bucket start offsets, longest lists first
 		uint32_t run = 0;
 		for (int b = 32; b >= 0; b--) { const uint32_t c = bucket[b]; bucket[b] = run; run += c; }

@@ -65,7 +65,7 @@ struct ImageWS {
 	uint32_t *n_contrib;  // [W*H]
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
-	uint32_t *totals;     // [4]  {num_instances, max per tile, 0, 0}
+	uint32_t *totals;     // [4]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047}
 	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
 	uint32_t *hist;       // [FR_BIN_BLOCKS][T] per-workgroup tile histograms (null if T too large for LDS)
@@ -200,6 +200,7 @@ struct FwdCtx {
 	fr_forward_args *a;
 	hipStream_t stream;
 	int gx, gy, T;
+	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
 	float focal_x, focal_y;
 	GeomWS geom;
 	ImageWS img;
