@@ -36,6 +36,33 @@ __device__ __forceinline__ float wave_sum(float x)
 	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// power = -0.5 (A dx^2 + C dy^2) - B dx dy for two rows at once (packed fp32: v_pk_mul/v_pk_fma)
+__device__ __forceinline__ v2f power2(v2f dy, float C, float adx2, float bdx)
+{
+	const v2f cdy = C * dy;
+	const v2f s = __builtin_elementwise_fma(cdy, dy, (v2f){ adx2, adx2 });
+	const v2f nb = -(bdx * dy);
+	return __builtin_elementwise_fma((v2f){ -0.5f, -0.5f }, s, nb);
+}
+
+// One pixel's front-to-back update for one splat, fully predicated (no lane-divergent branch: hipcc turns
+// nested divergent ifs on bool state into long chains of scalar mask merges).
+__device__ __forceinline__ void blend_px(bool hit, float alpha, float cr, float cg, float cb,
+	float &T, float &C0, float &C1, float &C2, bool &done, float &w_out, bool &acc_out)
+{
+	const float test_T = T * (1.0f - alpha);
+	const bool live = hit && !(alpha < 1.0f / 255.0f);
+	const bool sat = live && (test_T < 0.0001f);
+	const bool acc = live && !sat;
+	const float w = acc ? alpha * T : 0.0f;
+	C0 = fmaf(cr, w, C0); C1 = fmaf(cg, w, C1); C2 = fmaf(cb, w, C2);
+	T = acc ? test_T : T;
+	done = done || sat;
+	w_out = w; acc_out = acc;
+}
+
 struct RenderArgs {
 	int W, H, gx;
 	const uint2 *ranges;
@@ -134,39 +161,37 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 		// SUM && finished: nothing left to blend, the loop only keeps counting (no `continue` here: this
 		// loop carries barriers, see the note in k_bin)
 		const int cnt = (SUM && finished) ? 0 : min(NT, n - base);
+		static_assert(PPL == 4, "the packed inner loop handles four rows per lane");
+		const v2f py01 = { pyf[0], pyf[1] }, py23 = { pyf[2], pyf[3] };
 		for (int j = 0; j < cnt; j++)
 		{
-			bool lane_done = true;
-#pragma unroll
-			for (int k = 0; k < PPL; k++) lane_done = lane_done && done[k];
-			if (__all(lane_done)) break; // whole wave saturated: nothing left to do in this batch
+			if (__all(done[0] && done[1] && done[2] && done[3])) break; // wave saturated
 			const float4 g0 = s0[j];
 			const float4 g1 = s1[j];
 			const float dx = g0.x - pxf;
 			const float adx2 = (g0.z * dx) * dx;     // A*dx*dx
 			const float bdx = g0.w * dx;             // B*dx
+			const v2f pw01 = power2(g0.y - py01, g1.x, adx2, bdx);
+			const v2f pw23 = power2(g0.y - py23, g1.x, adx2, bdx);
+			const float pw[4] = { pw01.x, pw01.y, pw23.x, pw23.y };
+			bool hit[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) hit[k] = !done[k] && !(pw[k] > 0.0f) && !(CUTOFF && pw[k] < -4.5f);
+			if (!__any(hit[0] || hit[1] || hit[2] || hit[3])) continue; // splat misses every live pixel of the tile
+			const float cb = s2[j];
 			float contrib_sum = 0.0f;
 			bool any_contrib = false;
 #pragma unroll
-			for (int k = 0; k < PPL; k++)
+			for (int k = 0; k < 4; k++)
 			{
-				if (done[k]) continue;
-				const float dy = g0.y - pyf[k];
-				const float s = fmaf(g1.x * dy, dy, adx2);            // A dx^2 + C dy^2
-				const float power = fmaf(-0.5f, s, -(bdx * dy));      // -0.5 s - B dx dy
-				if (power > 0.0f) continue;
-				if (CUTOFF && power < -4.5f) continue;
-				const float alpha = fminf(0.99f, g1.y * fast_exp(power));
-				if (alpha < 1.0f / 255.0f) continue;
-				const float test_T = T[k] * (1.0f - alpha);
-				if (test_T < 0.0001f) { done[k] = true; continue; }
-				const float w = alpha * T[k];
-				C0[k] = fmaf(g1.z, w, C0[k]);
-				C1[k] = fmaf(g1.w, w, C1[k]);
-				C2[k] = fmaf(s2[j], w, C2[k]);
-				T[k] = test_T;
-				last[k] = (uint32_t)(base + j + 1);
-				if (SUM) { contrib_sum += w; any_contrib = true; }
+				if (__any(hit[k]))   // wave-uniform: skip the exp for strips the splat does not reach
+				{
+					const float alpha = fminf(0.99f, g1.y * fast_exp(pw[k]));
+					float w; bool acc;
+					blend_px(hit[k], alpha, g1.z, g1.w, cb, T[k], C0[k], C1[k], C2[k], done[k], w, acc);
+					last[k] = acc ? (uint32_t)(base + j + 1) : last[k];
+					if (SUM) { contrib_sum += w; any_contrib = any_contrib || acc; }
+				}
 			}
 			if (SUM)
 			{
@@ -258,79 +283,53 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 		if (base + NT + tid < n) fetch(base + NT + tid);
 		__syncthreads();
 		const int cnt = min(NT, n - base);
+		static_assert(PPL == 4, "the packed inner loop handles four rows per lane");
+		const v2f py01 = { pyf[0], pyf[1] }, py23 = { pyf[2], pyf[3] };
 		for (int j = 0; j < cnt; j++)
 		{
 			bool lane_done = true;
 #pragma unroll
-			for (int k = 0; k < PPL; k++) lane_done = lane_done && d1[k] && d2[k];
+			for (int k = 0; k < 4; k++) lane_done = lane_done && d1[k] && d2[k];
 			if (__all(lane_done)) break;
 			const float4 g0 = s0[j];
 			const float2 g1 = s1[j];
-			const float4 c1 = sl1[j];
 			const float dx = g0.x - pxf;
 			const float adx2 = (g0.z * dx) * dx;
 			const float bdx = g0.w * dx;
+			const v2f pw01 = power2(g0.y - py01, g1.x, adx2, bdx);
+			const v2f pw23 = power2(g0.y - py23, g1.x, adx2, bdx);
+			const float pw[4] = { pw01.x, pw01.y, pw23.x, pw23.y };
+			bool hit[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) hit[k] = !(d1[k] && d2[k]) && !(pw[k] > 0.0f || pw[k] < -4.5f);
+			if (!__any(hit[0] || hit[1] || hit[2] || hit[3])) continue;
+			const float4 c1 = sl1[j];
 			if (!blending)
 			{
 #pragma unroll
-				for (int k = 0; k < PPL; k++)
+				for (int k = 0; k < 4; k++)
 				{
-					if (d1[k]) continue;
-					const float dy = g0.y - pyf[k];
-					const float s = fmaf(g1.x * dy, dy, adx2);
-					const float power = fmaf(-0.5f, s, -(bdx * dy));
-					if (power > 0.0f || power < -4.5f) continue;
-					const float alpha = fminf(0.99f, c1.w * fast_exp(power));
-					if (alpha < 1.0f / 255.0f) continue;
-					const float test_T = T1[k] * (1.0f - alpha);
-					if (test_T < 0.0001f) { d1[k] = true; continue; }
-					const float w = alpha * T1[k];
-					A0[k] = fmaf(c1.x, w, A0[k]); A1[k] = fmaf(c1.y, w, A1[k]); A2[k] = fmaf(c1.z, w, A2[k]);
-					T1[k] = test_T;
+					if (__any(hit[k]))
+					{
+						const float alpha = fminf(0.99f, c1.w * fast_exp(pw[k]));
+						float w; bool acc;
+						blend_px(hit[k], alpha, c1.x, c1.y, c1.z, T1[k], A0[k], A1[k], A2[k], d1[k], w, acc);
+					}
 				}
 			}
 			else
 			{
 				const float4 c2 = sl2[j];
-				const bool l2_masked = (g1.y + 1.0f) < L2f; // Gaussian does not exist at level L2
+				const bool l2_ok = !((g1.y + 1.0f) < L2f); // the Gaussian exists at level L2
 #pragma unroll
-				for (int k = 0; k < PPL; k++)
+				for (int k = 0; k < 4; k++)
 				{
-					if (d1[k] && d2[k]) continue;
-					const float dy = g0.y - pyf[k];
-					const float s = fmaf(g1.x * dy, dy, adx2);
-					const float power = fmaf(-0.5f, s, -(bdx * dy));
-					if (power > 0.0f || power < -4.5f) continue;
-					const float ev = fast_exp(power);
-					if (!d1[k])
+					if (__any(hit[k]))
 					{
-						const float a1 = fminf(0.99f, c1.w * ev);
-						if (!(a1 < 1.0f / 255.0f))
-						{
-							const float tT = T1[k] * (1.0f - a1);
-							d1[k] = tT < 0.0001f;
-							if (!d1[k])
-							{
-								const float w = a1 * T1[k];
-								A0[k] = fmaf(c1.x, w, A0[k]); A1[k] = fmaf(c1.y, w, A1[k]); A2[k] = fmaf(c1.z, w, A2[k]);
-								T1[k] = tT;
-							}
-						}
-					}
-					if (!d2[k])
-					{
-						const float a2 = fminf(0.99f, c2.w * ev);
-						if (!((a2 < 1.0f / 255.0f) || l2_masked))
-						{
-							const float tT = T2[k] * (1.0f - a2);
-							d2[k] = tT < 0.0001f;
-							if (!d2[k])
-							{
-								const float w = a2 * T2[k];
-								B0[k] = fmaf(c2.x, w, B0[k]); B1[k] = fmaf(c2.y, w, B1[k]); B2[k] = fmaf(c2.z, w, B2[k]);
-								T2[k] = tT;
-							}
-						}
+						const float ev = fast_exp(pw[k]);
+						float w; bool acc;
+						blend_px(hit[k] && !d1[k], fminf(0.99f, c1.w * ev), c1.x, c1.y, c1.z, T1[k], A0[k], A1[k], A2[k], d1[k], w, acc);
+						blend_px(hit[k] && !d2[k] && l2_ok, fminf(0.99f, c2.w * ev), c2.x, c2.y, c2.z, T2[k], B0[k], B1[k], B2[k], d2[k], w, acc);
 					}
 				}
 			}
