@@ -302,6 +302,35 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 	}
 	return v;
 }
+// inclusive prefix maximum over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips)
+__device__ __forceinline__ int wave_scan_max_i32(int v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp((-2147483647 - 1), v, 0x111, 0xF, 0xF, false)); // row_shr:1
+	v = max(v, __builtin_amdgcn_update_dpp((-2147483647 - 1), v, 0x112, 0xF, 0xF, false)); // row_shr:2
+	v = max(v, __builtin_amdgcn_update_dpp((-2147483647 - 1), v, 0x114, 0xF, 0xF, false)); // row_shr:4
+	v = max(v, __builtin_amdgcn_update_dpp((-2147483647 - 1), v, 0x118, 0xF, 0xF, false)); // row_shr:8
+	v = max(v, __builtin_amdgcn_update_dpp((-2147483647 - 1), v, 0x142, 0xA, 0xF, false)); // row_bcast15 -> rows 1,3
+	v = max(v, __builtin_amdgcn_update_dpp((-2147483647 - 1), v, 0x143, 0xC, 0xF, false)); // row_bcast31 -> rows 2,3
+	return v;
+}
+// Owner lane of every pair of the current step: each lane whose segment [seg_a, seg_b) is non-empty drops
+// its lane id at position seg_a of a 64-entry LDS row; a prefix maximum spreads it over the segment
+// (segments are disjoint, ordered by lane). Two LDS writes + one read + six DPP ops, instead of a six-deep
+// chain of dependent ds_bpermute in a binary search.
+__device__ __forceinline__ int pair_owner_scan(int *row, int lane, int seg_a, int seg_b)
+{
+	// lanes talk to each other through LDS here: wave-scope fences + wave barrier make that defined (without
+	// them the compiler forwards this lane's own -1 to the load)
+	row[lane] = -1;
+	if (seg_b > seg_a) row[seg_a] = lane;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	const int m = row[lane];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	return wave_scan_max_i32(m);
+}
 // smallest lane L with incl[L] > j  (j < total)
 __device__ __forceinline__ int pair_owner(uint32_t incl, uint32_t j)
 {
@@ -422,6 +451,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// expensive than others); the owner of every slab is recorded because k_emit must replay the same
 	// slab -> workgroup assignment (its bucket offsets are per workgroup).
 	__shared__ int s_slab;
+	__shared__ int s_own[FR_BIN_THREADS];
 	const int V = (int)a.geom.slab_ctr[1]; // entries of vis_list
 	const int nslabs = (V + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
 	int pulled = 0;
@@ -496,9 +526,11 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		{
 			const uint32_t j = k + lane;
 			const bool valid = j < total;
-			const int owner = pair_owner(incl, valid ? j : total - 1);
+			const int seg_a = (int)max((long long)excl - (long long)k, 0ll);
+			const int seg_b = (int)min((long long)incl - (long long)k, 64ll);
+			const int owner = max(pair_owner_scan(s_own + (threadIdx.x & ~63), lane, seg_a, seg_b), 0);
 			const uint32_t local = (valid ? j : total - 1) - (uint32_t)__shfl((int)excl, owner);
-			const int ox0 = __shfl(pr.x0, owner), oy0 = __shfl(pr.y0, owner), ow = __shfl(pr.x1, owner) - ox0;
+			const int ox0 = __shfl(pr.x0, owner), oy0 = __shfl(pr.y0, owner), ow = max(__shfl(pr.x1, owner) - ox0, 1);
 			const int x = ox0 + (int)(local % (uint32_t)ow), y = oy0 + (int)(local / (uint32_t)ow);
 			const int ti = y * a.gx + x;
 			bool pass = valid;
@@ -524,8 +556,6 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			}
 			if (pass) BUMP_TILE(ti);
 			// hand the results back to the owners: my pairs of this step are lanes [seg_a, seg_b)
-			const int seg_a = (int)max((long long)excl - (long long)k, 0ll);
-			const int seg_b = (int)min((long long)incl - (long long)k, 64ll);
 			const unsigned long long mine = seg_mask(seg_a, seg_b);
 			count += (uint32_t)__popcll(__ballot(pass) & mine);
 			if (FOV)
@@ -642,6 +672,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	// replay preprocess's slab -> workgroup assignment
 	__shared__ uint32_t s_nmine;
 	__shared__ uint32_t s_mine[FR_MAX_SLABS_PER_BLOCK];
+	__shared__ int s_own[FR_BIN_THREADS];
 	const int V = (int)a.geom.slab_ctr[1];
 	const int nslabs = (V + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
 	if (LDSH)
@@ -688,9 +719,11 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 		{
 			const uint32_t j = k + lane;
 			const bool valid = j < total;
-			const int owner = pair_owner(incl, valid ? j : total - 1);
+			const int seg_a = (int)max((long long)excl - (long long)k, 0ll);
+			const int seg_b = (int)min((long long)incl - (long long)k, 64ll);
+			const int owner = max(pair_owner_scan(s_own + (threadIdx.x & ~63), lane, seg_a, seg_b), 0);
 			const uint32_t local = (valid ? j : total - 1) - (uint32_t)__shfl((int)excl, owner);
-			const int ox0 = __shfl(x0, owner), oy0 = __shfl(y0, owner), ow = __shfl(x1, owner) - ox0;
+			const int ox0 = __shfl(x0, owner), oy0 = __shfl(y0, owner), ow = max(__shfl(x1, owner) - ox0, 1);
 			const int x = ox0 + (int)(local % (uint32_t)ow), y = oy0 + (int)(local / (uint32_t)ow);
 			const int ti = y * a.gx + x;
 			const uint64_t opay = ((uint64_t)(uint32_t)__shfl((int)depth_bits, owner) << 32) | (uint32_t)__shfl(idx, owner);
