@@ -31,6 +31,7 @@ __device__ __forceinline__ float wave_sum_b(float x)
 struct BwdRenderArgs {
 	int W, H, gx;
 	const uint2 *ranges;
+	const uint32_t *tile_order;
 	const uint32_t *point_list;
 	const float4 *rec;
 	const float *bg;
@@ -48,12 +49,12 @@ __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 {
 	constexpr int NT = 256 / PPL;
 	constexpr int RSTEP = 16 / PPL;
-	__shared__ float4 s0[256];
-	__shared__ float4 s1[256];
-	__shared__ float s2[256];
-	__shared__ int sid[256];
+	__shared__ float4 s0[NT];
+	__shared__ float4 s1[NT];
+	__shared__ float s2[NT];
+	__shared__ int sid[NT];
 
-	const int tile = blockIdx.x;
+	const int tile = (int)a.tile_order[blockIdx.x]; // longest lists first
 	const int tx = tile % a.gx, ty = tile / a.gx;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
@@ -100,21 +101,27 @@ __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 	const int tile_last = tile_last_s; // entries [0, tile_last) can contribute
 	if (tile_last == 0) return;
 
-	// walk the list back to front, starting at the tile's deepest contributor
-	for (int top = tile_last; top > 0; top -= 256)
+	// walk the list back to front, starting at the tile's deepest contributor; NT (= 64) entries per batch,
+	// the next batch's records are prefetched into registers while this one is processed
+	uint32_t pid = 0;
+	float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
+	float p2 = 0.f;
+	if (tid < tile_last)
+	{
+		pid = a.point_list[range.x + tile_last - 1 - tid];
+		const float4 *r = a.rec + 3 * (size_t)pid;
+		p0 = r[0]; p1 = r[1]; p2 = r[2].x;
+	}
+	for (int top = tile_last; top > 0; top -= NT)
 	{
 		__syncthreads();
-		const int cnt = min(256, top);
-#pragma unroll
-		for (int k = 0; k < PPL; k++)
+		const int cnt = min(NT, top);
+		if (tid < cnt) { s0[tid] = p0; s1[tid] = p1; s2[tid] = p2; sid[tid] = (int)pid; }
+		if (top - NT - tid > 0)
 		{
-			const int e = tid + k * NT; // e-th entry from the back of this batch
-			if (e < cnt)
-			{
-				const uint32_t id = a.point_list[range.x + top - 1 - e];
-				const float4 *r = a.rec + 3 * (size_t)id;
-				s0[e] = r[0]; s1[e] = r[1]; s2[e] = r[2].x; sid[e] = (int)id;
-			}
+			pid = a.point_list[range.x + top - NT - 1 - tid];
+			const float4 *r = a.rec + 3 * (size_t)pid;
+			p0 = r[0]; p1 = r[1]; p2 = r[2].x;
 		}
 		__syncthreads();
 		for (int j = 0; j < cnt; j++)
@@ -483,7 +490,7 @@ int launch_backward(const fr_backward_args *a)
 	if (a->R > 0)
 	{
 		BwdRenderArgs r;
-		r.W = a->W; r.H = a->H; r.gx = gx; r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec;
+		r.W = a->W; r.H = a->H; r.gx = gx; r.ranges = img.ranges; r.tile_order = img.tile_order; r.point_list = bin.point_list; r.rec = geom.rec;
 		r.bg = a->background; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.dL_dpix = a->dL_dpix;
 		r.dL_dmean2D = a->dL_dmean2D; r.dL_dconic = a->dL_dconic; r.dL_dopacity = a->dL_dopacity; r.dL_dcolor = a->dL_dcolor;
 		constexpr int PPL = FR_BWD_PPL;
