@@ -12,8 +12,10 @@ LIB_PATH = os.path.join(HERE, "libfovraster_hip.so")
 ABI_VERSION = 1
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
+VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC = 4, 5
 STAGES = ("tile_levels", "preprocess", "tile_scan", "emit", "tile_sort", "render")
-VARIANT_IDS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3}
+VARIANT_IDS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3, "pcheck_obb_max": 4,
+               "pcheck_obb_loss_weighted_max_count": 5}
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -35,6 +37,7 @@ class ForwardArgs(C.Structure):
         ("resize_user", C.c_void_p * 3),
         ("num_rendered", C.c_int32), ("max_tile_instances", C.c_int32),
         ("stage_events", C.POINTER(C.c_void_p)),
+        ("loss_map", _FP),
     ]
 
 

@@ -38,7 +38,7 @@ int check_launch(const char *what, hipStream_t stream, bool debug)
 static int validate_forward(const fr_forward_args *a)
 {
 	if (!a) { set_error("null args"); return FR_ERR_INVALID; }
-	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_FOV_PCHECK_OBB) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
+	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_PCHECK_OBB_LWMC) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
 	if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return FR_ERR_INVALID; }
 	if (!a->out_color) { set_error("out_color is null"); return FR_ERR_INVALID; }
 	if (a->P == 0) return FR_OK;
@@ -59,7 +59,8 @@ static int validate_forward(const fr_forward_args *a)
 	if (a->D < 0 || a->D > 3) { set_error("SH degree %d not in 0..3", a->D); return FR_ERR_INVALID; }
 	const bool has_sr = a->scales && a->rotations;
 	if (has_sr == (a->cov3D_precomp != nullptr)) { set_error("provide exactly one of scales+rotations / cov3D_precomp"); return FR_ERR_INVALID; }
-	if (a->variant == FR_VARIANT_PCHECK_OBB_SUM && (!a->gaussians_count || !a->contributions)) { set_error("pcheck_obb_sum needs gaussians_count and contributions"); return FR_ERR_INVALID; }
+	if (has_stats(a->variant) && (!a->gaussians_count || !a->contributions)) { set_error("this variant needs gaussians_count and contributions"); return FR_ERR_INVALID; }
+	if (a->variant == FR_VARIANT_PCHECK_OBB_LWMC && !a->loss_map) { set_error("pcheck_obb_loss_weighted_max_count needs loss_map"); return FR_ERR_INVALID; }
 	return FR_OK;
 }
 
@@ -126,7 +127,7 @@ int fr_forward(fr_forward_args *a)
 
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, sizeof(uint32_t) * (size_t)c.T, stream));
 	FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, 4 * sizeof(uint32_t), stream));
-	if (a->variant == FR_VARIANT_PCHECK_OBB_SUM)
+	if (has_stats(a->variant))
 	{
 		FR_HIP(hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, stream));
 		FR_HIP(hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, stream));
@@ -163,8 +164,8 @@ int fr_forward(fr_forward_args *a)
 int fr_backward(const fr_backward_args *a)
 {
 	if (!a) { set_error("null args"); return FR_ERR_INVALID; }
-	if (a->variant != FR_VARIANT_ORIGINAL && a->variant != FR_VARIANT_PCHECK_OBB_SUM)
-	{ set_error("backward exists only for the original and pcheck_obb_sum variants (the reference's inference variants have none)"); return FR_ERR_INVALID; }
+	if (!has_backward(a->variant))
+	{ set_error("backward exists only for the original and pcheck_obb_sum/_max/_loss_weighted_max_count variants (the reference's inference variants have none)"); return FR_ERR_INVALID; }
 	if (a->P == 0) return FR_OK;
 	if (!a->geometry || !a->image || (a->R > 0 && !a->binning) || !a->dL_dpix || !a->radii) { set_error("missing workspace / gradient pointer"); return FR_ERR_INVALID; }
 	if (!a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor || !a->dL_dmean3D || !a->dL_dcov3D || !a->dL_dscale || !a->dL_drot)

@@ -16,7 +16,9 @@
 
 namespace fr {
 
-struct Mat16 { float m[16]; };
+// variant traits
+__host__ __device__ inline bool has_stats(int v) { return v == FR_VARIANT_PCHECK_OBB_SUM || v == FR_VARIANT_PCHECK_OBB_MAX || v == FR_VARIANT_PCHECK_OBB_LWMC; }
+__host__ __device__ inline bool has_backward(int v) { return v == FR_VARIANT_ORIGINAL || has_stats(v); }
 
 // ---- workspace layouts -------------------------------------------------------------------
 // All sub-arrays are 256-byte aligned inside the caller's buffers.

@@ -809,7 +809,7 @@ int launch_preprocess(FwdCtx &c)
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.T = c.T;
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;
-	p.write_cov3D = (a->variant == FR_VARIANT_ORIGINAL || a->variant == FR_VARIANT_PCHECK_OBB_SUM) ? 1 : 0;
+	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
 	{
 		const int pchunks = (a->P + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS;
 		const dim3 pgrid(pchunks < 1024 ? pchunks : 1024), pblock(FR_PROJ_THREADS);
@@ -830,9 +830,8 @@ int launch_preprocess(FwdCtx &c)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
-	case FR_VARIANT_PCHECK_OBB_SUM: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB_SUM); break;
-	case FR_VARIANT_PCHECK_OBB: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break;
-	default: LAUNCH_PRE(FR_VARIANT_FOV_PCHECK_OBB); break;
+	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_PRE(FR_VARIANT_FOV_PCHECK_OBB); break;
+	default: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
 	}
 #undef LAUNCH_PRE
 	int rc = check_launch("preprocess", c.stream, a->debug);

@@ -76,8 +76,9 @@ struct RenderArgs {
 	float *out_color;
 	float *final_T;
 	uint32_t *n_contrib;
-	int *gaussians_count;   // RS
-	float *contributions;   // RS
+	int *gaussians_count;   // RS / MAX / LWMC
+	float *contributions;   // RS / MAX / LWMC
+	const float *loss_map;  // LWMC
 };
 
 // ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB ----------------
@@ -93,13 +94,17 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	constexpr int NT = 256 / PPL;        // threads per tile == staging batch
 	constexpr int RSTEP = 16 / PPL;      // row distance between a lane's pixels
 	constexpr bool CUTOFF = VARIANT != FR_VARIANT_ORIGINAL;
-	constexpr bool SUM = VARIANT == FR_VARIANT_PCHECK_OBB_SUM;
+	constexpr bool SUM = VARIANT == FR_VARIANT_PCHECK_OBB_SUM;   // contributions += alpha*T, count per fetched entry
+	constexpr bool PMAX = VARIANT == FR_VARIANT_PCHECK_OBB_MAX;  // contributions = max alpha*T, count per in-support pixel
+	constexpr bool LWMC = VARIANT == FR_VARIANT_PCHECK_OBB_LWMC; // per-pixel loss to its max-contribution Gaussian
+	constexpr bool FETCHCNT = SUM || LWMC;                       // gaussians_count per fetched entry (256-batches)
+	constexpr bool NEEDID = SUM || PMAX || LWMC;
 	constexpr bool AUX = VARIANT != FR_VARIANT_PCHECK_OBB; // final_T / n_contrib kept for backward
 
 	__shared__ float4 s0[NT];
 	__shared__ float4 s1[NT];
 	__shared__ float s2[NT];
-	__shared__ int sid[SUM ? NT : 1];
+	__shared__ int sid[NEEDID ? NT : 1];
 
 	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
 	const int tx = tile % a.gx, ty = tile / a.gx;
@@ -122,6 +127,10 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 		done[k] = !inside[k];
 		T[k] = 1.0f; C0[k] = C1[k] = C2[k] = 0.0f; last[k] = 0;
 	}
+	float best_w[LWMC ? PPL : 1];   // LWMC forward.cu:347-348: running max contribution per pixel ...
+	int best_id[LWMC ? PPL : 1];    // ... and whose it is (defaults to Gaussian 0, as in the reference)
+#pragma unroll
+	for (int k = 0; k < (LWMC ? PPL : 1); k++) { best_w[k] = 0.0f; best_id[k] = 0; }
 
 	// prefetch registers
 	uint32_t pid = 0;
@@ -140,7 +149,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 #pragma unroll
 		for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
 		const bool wg_done = __syncthreads_and(all_done) != 0; // also fences the LDS reuse
-		if (SUM)
+		if (FETCHCNT)
 		{
 			if ((base & 255) == 0) { if (wg_done) break; }
 			finished = wg_done;
@@ -149,7 +158,8 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 		if (base + tid < n)
 		{
 			s0[tid] = p0; s1[tid] = p1; s2[tid] = p2;
-			if (SUM) { sid[tid] = (int)pid; atomicAdd(&a.gaussians_count[pid], 1); }
+			if (NEEDID) sid[tid] = (int)pid;
+			if (FETCHCNT) atomicAdd(&a.gaussians_count[pid], 1);
 		}
 		if (base + NT + tid < n)
 		{
@@ -160,7 +170,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 		__syncthreads();
 		// SUM && finished: nothing left to blend, the loop only keeps counting (no `continue` here: this
 		// loop carries barriers, see the note in k_bin)
-		const int cnt = (SUM && finished) ? 0 : min(NT, n - base);
+		const int cnt = (FETCHCNT && finished) ? 0 : min(NT, n - base);
 		static_assert(PPL == 4, "the packed inner loop handles four rows per lane");
 		const v2f py01 = { pyf[0], pyf[1] }, py23 = { pyf[2], pyf[3] };
 		for (int j = 0; j < cnt; j++)
@@ -179,8 +189,14 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 			for (int k = 0; k < 4; k++) hit[k] = !done[k] && !(pw[k] > 0.0f) && !(CUTOFF && pw[k] < -4.5f);
 			if (!__any(hit[0] || hit[1] || hit[2] || hit[3])) continue; // splat misses every live pixel of the tile
 			const float cb = s2[j];
-			float contrib_sum = 0.0f;
+			float contrib_sum = 0.0f, contrib_max = 0.0f;
 			bool any_contrib = false;
+			if (PMAX)
+			{
+				// …_max forward.cu:381: +1 for every live pixel inside the splat's support (before the alpha test)
+				const int c = __popcll(__ballot(hit[0])) + __popcll(__ballot(hit[1])) + __popcll(__ballot(hit[2])) + __popcll(__ballot(hit[3]));
+				if ((tid & 63) == 0) atomicAdd(&a.gaussians_count[sid[j]], c);
+			}
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 			{
@@ -191,6 +207,8 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 					blend_px(hit[k], alpha, g1.z, g1.w, cb, T[k], C0[k], C1[k], C2[k], done[k], w, acc);
 					last[k] = acc ? (uint32_t)(base + j + 1) : last[k];
 					if (SUM) { contrib_sum += w; any_contrib = any_contrib || acc; }
+					if (PMAX) { contrib_max = fmaxf(contrib_max, w); any_contrib = any_contrib || acc; }
+					if (LWMC) { const bool better = acc && (w > best_w[k]); best_w[k] = better ? w : best_w[k]; best_id[k] = better ? sid[j] : best_id[k]; }
 				}
 			}
 			if (SUM)
@@ -199,6 +217,17 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 				{
 					const float tot = wave_sum(contrib_sum);
 					if ((tid & 63) == 0) atomicAdd(&a.contributions[sid[j]], tot);
+				}
+			}
+			if (PMAX)
+			{
+				if (__any(any_contrib))
+				{
+					// atomicMaxFloat of the reference; values are >= 0, so the integer order of the bit patterns is the float order
+					float m = contrib_max;
+#pragma unroll
+					for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+					if ((tid & 63) == 0) atomicMax((unsigned int *)&a.contributions[sid[j]], __float_as_uint(m));
 				}
 			}
 		}
@@ -212,6 +241,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 		if (!inside[k]) continue;
 		const size_t pid2 = (size_t)a.W * (size_t)(ty * FR_TILE + ry + k * RSTEP) + px;
 		if (AUX) { a.final_T[pid2] = T[k]; a.n_contrib[pid2] = last[k]; }
+		if (LWMC) atomicAdd(&a.contributions[best_id[k]], a.loss_map[pid2]); // …_count forward.cu:435
 		a.out_color[pid2] = fmaf(T[k], bg0, C0[k]);
 		a.out_color[plane + pid2] = fmaf(T[k], bg1, C1[k]);
 		a.out_color[2 * plane + pid2] = fmaf(T[k], bg2, C2[k]);
@@ -373,7 +403,7 @@ int launch_render(FwdCtx &c)
 	r.ranges = c.img.ranges; r.point_list = c.bin.point_list; r.rec = c.geom.rec; r.lvl = c.geom.lvl;
 	r.tile_lv = c.img.tile_lv; r.tile_order = c.img.tile_order; r.T = c.T; r.bg = a->background; r.out_color = a->out_color;
 	r.final_T = c.img.final_T; r.n_contrib = c.img.n_contrib;
-	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions;
+	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions; r.loss_map = a->loss_map;
 	constexpr int PPL = FR_RENDER_PPL;
 	const dim3 grid(c.T), block(256 / PPL);
 	switch (a->variant)
@@ -381,6 +411,8 @@ int launch_render(FwdCtx &c)
 	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL((k_render<FR_VARIANT_ORIGINAL, PPL>), grid, block, 0, c.stream, r); break;
 	case FR_VARIANT_PCHECK_OBB_SUM: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_SUM, PPL>), grid, block, 0, c.stream, r); break;
 	case FR_VARIANT_PCHECK_OBB: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB, PPL>), grid, block, 0, c.stream, r); break;
+	case FR_VARIANT_PCHECK_OBB_MAX: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_MAX, PPL>), grid, block, 0, c.stream, r); break;
+	case FR_VARIANT_PCHECK_OBB_LWMC: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_LWMC, PPL>), grid, block, 0, c.stream, r); break;
 	default: hipLaunchKernelGGL((k_render_fov<PPL>), grid, block, 0, c.stream, r); break;
 	}
 	return check_launch("render", c.stream, a->debug);

@@ -52,8 +52,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     if starter is not None:
         starter.record()
-    out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,
-                     scales=scales, rotations=rotations, cov3D_precomp=None)
+    if cuda_type == "pcheck_obb_loss_weighted_max_count":
+        out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,
+                         scales=scales, rotations=rotations, cov3D_precomp=None, loss_map=loss_map)
+    else:
+        out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,
+                         scales=scales, rotations=rotations, cov3D_precomp=None)
     if ender is not None:
         ender.record()
 

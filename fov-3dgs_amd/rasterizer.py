@@ -105,7 +105,7 @@ _stage_events_hook = None
 
 
 def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False):
+                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None):
     """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions])
     persistent=True: the workspaces are the per-device grow-only set (valid until the next call)."""
     lib = _native.load()
@@ -152,7 +152,8 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         put("shs_dcs", shs_dcs)
         put("highest_levels", highest_levels)
         a.out_color, a.radii = color.data_ptr(), radii.data_ptr()
-        if variant == _native.VARIANT_PCHECK_OBB_SUM:
+        put("loss_map", loss_map)
+        if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC):
             counts = torch.zeros((P,), dtype=torch.int32, device=dev)
             contribs = torch.zeros((P,), dtype=torch.float32, device=dev)
             a.gaussians_count, a.contributions = counts.data_ptr(), contribs.data_ptr()
@@ -239,26 +240,31 @@ def _opacities_for_backward(opacities):
     return opacities
 
 
-def _make_plain(variant_id, with_counts, has_backward):
-    """Autograd function + module for the non-foveated variants."""
+def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
+    """Autograd function + module for the non-foveated variants. takes_loss_map: the
+    …_loss_weighted_max_count extension has one extra input (`loss_map`, a [3,H,W] or [H,W] tensor)."""
 
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    raster_settings):
+                    raster_settings, loss_map=None):
             args = (variant_id, raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations,
                     cov3Ds_precomp)
             keep_ws = has_backward and any(ctx.needs_input_grad)  # backward re-reads the workspaces
+            if takes_loss_map:
+                if loss_map is None or loss_map.numel() < raster_settings.image_height * raster_settings.image_width:
+                    raise Exception("loss_map with at least image_height*image_width values is required")
+            ctx.n_inputs = 10 if takes_loss_map else 9
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
                 try:
-                    res = _forward_native(*args, persistent=not keep_ws)
+                    res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                res = _forward_native(*args, persistent=not keep_ws)
+                res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map)
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = res[:6]
             if not keep_ws:  # nothing will call backward: do not pin the shared workspaces
                 geomBuffer = binningBuffer = imgBuffer = torch.empty(0, dtype=torch.uint8, device=means3D.device)
@@ -294,11 +300,15 @@ def _make_plain(variant_id, with_counts, has_backward):
                 res = _backward_native(*args)
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations) = res
-            return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
-                    grad_rotations, grad_cov3Ds_precomp, None)
+            grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
+                     grad_rotations, grad_cov3Ds_precomp, None)
+            return grads + (None,) * (ctx.n_inputs - 9)
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                            raster_settings):
+                            raster_settings, loss_map=None):
+        if takes_loss_map:
+            return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                             cov3Ds_precomp, raster_settings, loss_map)
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                          cov3Ds_precomp, raster_settings)
 
@@ -312,7 +322,7 @@ def _make_plain(variant_id, with_counts, has_backward):
                 return _mark_visible(positions, self.raster_settings)
 
         def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                    cov3D_precomp=None):
+                    cov3D_precomp=None, loss_map=None):
             raster_settings = self.raster_settings
             if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
                 raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -326,7 +336,7 @@ def _make_plain(variant_id, with_counts, has_backward):
             rotations = empty if rotations is None else rotations
             cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings)
+                                       cov3D_precomp, raster_settings, loss_map)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
 

@@ -44,7 +44,12 @@ enum {
 	FR_VARIANT_ORIGINAL = 0,       /* diff-gaussian-rasterization                    */
 	FR_VARIANT_PCHECK_OBB_SUM = 1, /* …_pcheck_obb_sum (training; counts/contributions) */
 	FR_VARIANT_PCHECK_OBB = 2,     /* …_pcheck_obb (inference)                        */
-	FR_VARIANT_FOV_PCHECK_OBB = 3  /* …_fov_pcheck_obb (foveated inference)           */
+	FR_VARIANT_FOV_PCHECK_OBB = 3, /* …_fov_pcheck_obb (foveated inference)           */
+	/* pruning-metric variants of the training rasterizer (prune.py / metric_mask_learn.py); forward
+	 * statistics differ from …_sum, backward is identical */
+	FR_VARIANT_PCHECK_OBB_MAX = 4, /* …_pcheck_obb_max: count per in-support pixel, contributions = max alpha*T */
+	FR_VARIANT_PCHECK_OBB_LWMC = 5 /* …_pcheck_obb_loss_weighted_max_count: per-pixel loss credited to its
+	                                * max-contribution Gaussian */
 };
 
 enum {
@@ -105,13 +110,15 @@ typedef struct fr_forward_args {
 	 * FR_NUM_STAGES after the last one; nothing is synchronised. Read the stage durations later with
 	 * fr_event_elapsed_ms(ev[i], ev[i+1]). */
 	void **stage_events;
+	const float *loss_map;       /* LWMC: [>= H*W] per-pixel weights (the reference passes a [3,H,W] map and reads
+	                              * its first plane, …_loss_weighted_max_count/cuda_rasterizer/forward.cu:435) */
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PREPROCESS = 1, FR_STAGE_TILE_SCAN = 2, FR_STAGE_EMIT = 3,
 	FR_STAGE_TILE_SORT = 4, FR_STAGE_RENDER = 5, FR_NUM_STAGES = 6 };
 
 typedef struct fr_backward_args {
-	int32_t variant;             /* FR_VARIANT_ORIGINAL or FR_VARIANT_PCHECK_OBB_SUM */
+	int32_t variant;             /* ORIGINAL, PCHECK_OBB_SUM, PCHECK_OBB_MAX or PCHECK_OBB_LWMC */
 	int32_t P, D, M, R;          /* R = num_rendered of the forward call */
 	int32_t W, H;
 	int32_t debug;

@@ -64,7 +64,9 @@ typedef float real;
 #define BLOCK_SIZE 256
 #define FOV_NUM 4 /* RF auxiliary.h:26 */
 
-enum { ORC_R0 = 0, ORC_RS = 1, ORC_RP = 2, ORC_RF = 3 };
+enum { ORC_R0 = 0, ORC_RS = 1, ORC_RP = 2, ORC_RF = 3, ORC_RMAX = 4, ORC_LWMC = 5 };
+/* ORC_RMAX = …_pcheck_obb_max, ORC_LWMC = …_pcheck_obb_loss_weighted_max_count: RS with different
+ * per-Gaussian statistics (pruning metrics of prune.py / metric_mask_learn.py); same backward as RS. */
 
 typedef struct {
 	int32_t variant;
@@ -77,6 +79,7 @@ typedef struct {
 	const real *means3D, *scales, *rotations, *opacities, *shs;
 	const real *cov3D_precomp, *colors_precomp;
 	const real *shs_dcs, *highest_levels;
+	const real *loss_map; /* LWMC: per-pixel weights, first H*W values are used */
 	/* optional tile window [x0,x1) x [y0,y1) restricting binning + blending (bench cpu_baseline
 	 * sampling only; all zeros = whole frame) */
 	int32_t win[4];
@@ -339,7 +342,7 @@ static int preprocess(const orc_in *in, orc_out *o)
 	const real focal_y = H / ((real)2.0 * in->tanfovy); /* R0 rasterizer_impl.cu:222-223 */
 	const real focal_x = W / ((real)2.0 * in->tanfovx);
 	const int with_eigen = in->variant != ORC_R0;
-	const int with_sh = (in->variant == ORC_R0 || in->variant == ORC_RS || in->variant == ORC_RP);
+	const int with_sh = in->variant != ORC_RF;
 	for (int idx = 0; idx < P; idx++)
 	{
 		o->radii[idx] = 0;
@@ -669,7 +672,8 @@ static void render_plain(const orc_in *in, orc_out *o)
 	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 	const int cutoff = variant != ORC_R0;
 	double *contrib = NULL;
-	if (variant == ORC_RS)
+	const int stats = (variant == ORC_RS || variant == ORC_RMAX || variant == ORC_LWMC);
+	if (stats)
 	{
 		contrib = (double *)calloc((size_t)in->P, sizeof(double));
 		memset(o->gaussians_count, 0, sizeof(int32_t) * (size_t)in->P);
@@ -690,6 +694,8 @@ static void render_plain(const orc_in *in, orc_out *o)
 					real T = 1, C[3] = { 0, 0, 0 };
 					uint32_t contributor = 0, last_contributor = 0;
 					int done_pos = -1;
+					int max_point_idx = 0;          /* LWMC forward.cu:347-348 (quirk: defaults to Gaussian 0) */
+					real max_point_contrib = 0;
 					for (int j = 0; j < n; j++)
 					{
 						contributor++;
@@ -699,6 +705,7 @@ static void render_plain(const orc_in *in, orc_out *o)
 						const real power = (real)-0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
 						if (power > (real)0) continue;
 						if (cutoff && power < (real)-4.5f) continue;
+						if (variant == ORC_RMAX) o->gaussians_count[g] += 1; /* …_max forward.cu:381: per pixel in support */
 						const real alpha = r_fmin((real)0.99f, in->opacities[g] * r_exp(power));
 						if (alpha < (real)1.0f / (real)255.0f) continue;
 						const real test_T = T * (1 - alpha);
@@ -710,7 +717,9 @@ static void render_plain(const orc_in *in, orc_out *o)
 						}
 						else
 							for (int ch = 0; ch < 3; ch++) C[ch] += o->rgb[3 * g + ch] * alpha * T;
-						if (contrib) contrib[g] += (double)(alpha * T);
+						if (variant == ORC_RS) contrib[g] += (double)(alpha * T);
+						else if (variant == ORC_RMAX) { if ((double)(alpha * T) > contrib[g]) contrib[g] = (double)(alpha * T); } /* atomicMaxFloat, …_max forward.cu:400 */
+						else if (variant == ORC_LWMC) { const real cv = alpha * T; if (cv > max_point_contrib) { max_point_contrib = cv; max_point_idx = (int)g; } }
 						T = test_T;
 						last_contributor = contributor;
 					}
@@ -721,9 +730,10 @@ static void render_plain(const orc_in *in, orc_out *o)
 						o->final_T[pid] = T;
 						o->n_contrib[pid] = last_contributor;
 					}
+					if (variant == ORC_LWMC) contrib[max_point_idx] += (double)in->loss_map[pid]; /* …_count forward.cu:435 */
 					for (int ch = 0; ch < 3; ch++) o->color[(size_t)ch * H * W + pid] = C[ch] + T * in->bg[ch];
 				}
-			if (variant == ORC_RS)
+			if (variant == ORC_RS || variant == ORC_LWMC)
 			{
 				/* RS forward.cu:349-361: +1 per list entry fetched by a batch that a still-live
 				 * tile loads; the vote happens once per 256-entry batch. */
@@ -1149,7 +1159,7 @@ static void backward_cov3D(const real scale[3], real mod, const real rot[4], con
 int orc_backward(const orc_in *in, const orc_out *o, orc_grads *g)
 {
 	const int P = in->P, M = in->M;
-	if (in->variant != ORC_R0 && in->variant != ORC_RS) return -2;
+	if (in->variant == ORC_RP || in->variant == ORC_RF) return -2;
 	memset(g->dL_dmean2D, 0, sizeof(real) * 3 * (size_t)P);
 	memset(g->dL_dconic, 0, sizeof(real) * 4 * (size_t)P);
 	memset(g->dL_dopacity, 0, sizeof(real) * (size_t)P);

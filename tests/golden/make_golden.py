@@ -107,21 +107,26 @@ def part_a():
 def part_b():
     from tests.helpers import small_case
     from oracle import oracle as orc
-    for variant in ("original", "pcheck_obb_sum", "pcheck_obb", "fov_pcheck_obb"):
+    for variant in ("original", "pcheck_obb_sum", "pcheck_obb", "fov_pcheck_obb", "pcheck_obb_max",
+                    "pcheck_obb_loss_weighted_max_count"):
         scene, cam = small_case(variant)
         o = orc.forward(variant, scene, cam)
         keep = {k: o[k] for k in ("color", "radii", "point_list", "ranges", "depths", "means2D", "conic",
                                   "tiles_touched")}
         keep["num_rendered"] = np.int64(o["num_rendered"])
-        if variant in ("original", "pcheck_obb_sum"):
+        stats = variant in ("pcheck_obb_sum", "pcheck_obb_max", "pcheck_obb_loss_weighted_max_count")
+        if variant == "original" or variant == "pcheck_obb_sum":
             keep["final_T"], keep["n_contrib"] = o["final_T"], o["n_contrib"]
             rng = np.random.default_rng(7)
             dpix = rng.normal(size=o["color"].shape).astype(np.float32)
             g = orc.backward(variant, scene, cam, o, dpix)
             keep["dL_dpix"] = dpix
             keep.update({"g_" + k: v for k, v in g.items()})
-        if variant == "pcheck_obb_sum":
+        if stats:
             keep["gaussians_count"], keep["contributions"] = o["gaussians_count"], o["contributions"]
+            if variant != "pcheck_obb_sum":  # same image/lists as pcheck_obb_sum: keep the fixture small
+                for k in ("color", "point_list", "ranges", "depths", "means2D", "conic"):
+                    keep.pop(k)
         if variant == "fov_pcheck_obb":
             for k in ("tile_levels", "tile_min", "tile_blend", "tile_gx", "tile_gy", "level_ranges"):
                 keep[k] = o[k]

@@ -36,7 +36,8 @@ def hip_forward(variant, scene, cam, dev="cuda:0", debug=True):
                                                 "cov3D_precomp", "shs_dcs", "highest_levels")}
     res = _forward_native(vid, rs, tens["means3D"], tens["shs"], tens["colors_precomp"], tens["opacities"],
                           tens["scales"], tens["rotations"], tens["cov3D_precomp"], tens["shs_dcs"],
-                          tens["highest_levels"], cam.get("gaze", (0.5, 0.5)), cam.get("alpha", 0.05))
+                          tens["highest_levels"], cam.get("gaze", (0.5, 0.5)), cam.get("alpha", 0.05),
+                          loss_map=_t(scene.get("loss_map"), dev))
     torch.cuda.synchronize()
     num_rendered, color, radii, geom, binb, img = res[:6]
     W, H = rs.image_width, rs.image_height
@@ -53,10 +54,10 @@ def hip_forward(variant, scene, cam, dev="cuda:0", debug=True):
         out["point_list"] = _view(binb, pptr, num_rendered, torch.int32).cpu().numpy().astype(np.uint32)
     else:
         out["point_list"] = np.zeros(0, np.uint32)
-    if variant in ("original", "pcheck_obb_sum"):
+    if variant in ("original", "pcheck_obb_sum", "pcheck_obb_max", "pcheck_obb_loss_weighted_max_count"):
         out["final_T"] = _view(img, lib.fr_image_final_T(vid, W, H, img.data_ptr()), W * H, torch.float32).cpu().numpy().reshape(H, W)
         out["n_contrib"] = _view(img, lib.fr_image_n_contrib(vid, W, H, img.data_ptr()), W * H, torch.int32).cpu().numpy().astype(np.uint32).reshape(H, W)
-    if variant == "pcheck_obb_sum":
+    if variant in ("pcheck_obb_sum", "pcheck_obb_max", "pcheck_obb_loss_weighted_max_count"):
         out["gaussians_count"], out["contributions"] = res[6].cpu().numpy(), res[7].cpu().numpy()
     if variant == "fov_pcheck_obb":
         lv = _view(img, lib.fr_image_tile_levels(W, H, img.data_ptr()), 5 * T, torch.float32).cpu().numpy().reshape(5, T)

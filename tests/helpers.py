@@ -66,4 +66,8 @@ def small_case(variant, P=3000, seed=3, bg=(0.1, 0.2, 0.3), gaze=(0.4, 0.55), al
     cloud = small_cloud(P, seed)
     cam = small_camera(width, height)
     fov = syn.foveation_layers(cloud, seed=seed + 1) if variant == FOV_VARIANT else None
-    return scene_dict(cloud, variant, fov), cam_dict(cam, bg=bg, gaze=gaze, alpha=alpha)
+    scene = scene_dict(cloud, variant, fov)
+    if variant == "pcheck_obb_loss_weighted_max_count":
+        # the callers pass a [3,H,W] map (prune.py:80); only its first plane is read
+        scene["loss_map"] = np.random.default_rng(seed + 7).random((3, height, width)).astype(np.float32)
+    return scene, cam_dict(cam, bg=bg, gaze=gaze, alpha=alpha)

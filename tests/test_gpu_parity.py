@@ -81,6 +81,32 @@ def test_forward_matches_frozen_fixture(variant):
     check_image(got["color"], g["color"])
 
 
+@pytest.mark.parametrize("variant", ("pcheck_obb_max", "pcheck_obb_loss_weighted_max_count"))
+def test_pruning_metric_variants(variant):
+    """the two pruning-metric flavours of the training rasterizer."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_backward, hip_forward
+    scene, cam = small_case(variant)
+    want = orc.forward(variant, scene, cam)
+    got = hip_forward(variant, scene, cam)
+    assert got["num_rendered"] == want["num_rendered"]
+    np.testing.assert_array_equal(got["point_list"], want["point_list"])
+    check_image(got["color"], want["color"])
+    assert np.mean(got["gaussians_count"] != want["gaussians_count"]) <= 2e-3
+    if variant == "pcheck_obb_max":
+        check_grad(got["contributions"], want["contributions"], "contributions(max)", rtol=1e-5)
+    else:
+        # a pixel whose two best contributions are within an ulp may credit the other Gaussian
+        np.testing.assert_allclose(got["contributions"].sum(), want["contributions"].sum(), rtol=1e-5)
+        assert np.mean(np.abs(got["contributions"] - want["contributions"]) > 1e-3) <= 2e-3
+    rng = np.random.default_rng(7)
+    dpix = rng.normal(size=want["color"].shape).astype(np.float32)
+    wb = orc.backward(variant, scene, cam, want, dpix)
+    gb = hip_backward(variant, got, dpix)
+    for k in ("dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot", "dL_dopacity"):
+        check_grad(gb[k].reshape(wb[k].shape), wb[k], k)
+
+
 @pytest.mark.parametrize("variant", ("original", "pcheck_obb_sum"))
 def test_backward_matches_oracle(variant):
     _need_gpu()

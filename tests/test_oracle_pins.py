@@ -213,6 +213,26 @@ def test_frozen_fixture(variant):
             np.testing.assert_allclose(v, g["g_" + k], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("variant", ("pcheck_obb_max", "pcheck_obb_loss_weighted_max_count"))
+def test_pruning_metric_variants(variant):
+    """Same image / lists as pcheck_obb_sum, different per-Gaussian statistics; frozen fixture + invariants."""
+    g = _g(f"oracle_{variant}.npz")
+    scene, cam = small_case(variant)
+    o = orc.forward(variant, scene, cam)
+    ref = orc.forward("pcheck_obb_sum", {k: v for k, v in scene.items() if k != "loss_map"}, cam)
+    np.testing.assert_array_equal(o["color"], ref["color"])
+    np.testing.assert_array_equal(o["point_list"], ref["point_list"])
+    np.testing.assert_array_equal(o["gaussians_count"], g["gaussians_count"])
+    np.testing.assert_allclose(o["contributions"], g["contributions"], rtol=1e-6, atol=1e-7)
+    if variant == "pcheck_obb_max":
+        # max over pixels of alpha*T is bounded by 0.99 and only set where something contributed
+        assert o["contributions"].max() <= 0.99 + 1e-6 and np.all(o["gaussians_count"][o["contributions"] > 0] > 0)
+    else:
+        # every pixel credits its loss to exactly one Gaussian; fetch counts are those of pcheck_obb_sum
+        np.testing.assert_allclose(o["contributions"].sum(), scene["loss_map"][0].sum(), rtol=1e-5)
+        np.testing.assert_array_equal(o["gaussians_count"], ref["gaussians_count"])
+
+
 def test_edge_cases():
     # empty cloud
     scene, cam = small_case("original", P=50)
