@@ -12,7 +12,7 @@
 #define FR_BIN_THREADS 512    // workgroup size of the binning kernels (preprocess / emit)
 #define FR_BIN_BLOCKS 768     // persistent workgroups of the binning kernels (3 per CU)
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
-#define FR_MAX_SLABS_PER_BLOCK 4096 // a workgroup stops pulling slabs after this many
+#define FR_SLAB_CTR_WORDS 288 // header line + eight 128-byte counter lines
 
 namespace fr {
 
@@ -35,9 +35,11 @@ struct GeomWS {
 	float2 *elen;       // [P]  OBB half-lengths                 (not ORIGINAL)
 	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity)
 	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8
-	uint32_t *slab_ctr; // [4]  {slab scheduler of k_bin, number of entries in vis_list, 0, 0}
+	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {-, number of entries in vis_list, ...}; k_bin's eight slab pull
+	                    // counters live at [32 * (1 + r)], one 128-byte line each
 	uint32_t *vis_list; // [P]  indices of the Gaussians that survive projection (unordered)
-	uint16_t *slab_owner; // [ceil(P / FR_BIN_THREADS)] workgroup that preprocessed each slab
+	int32_t *slab_next;   // [ceil(P / 64)] per-wave chains of the 64-entry vis_list slabs k_bin's waves pulled ...
+	int32_t *wave_head;   // [FR_BIN_BLOCKS * FR_BIN_THREADS / 64] ... and the last slab of every wave (-1: none)
 	size_t bytes;
 };
 __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
@@ -54,9 +56,10 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 		g.lvl = (float4 *)(base + off); off = align_up(off + P * FR_FOV_LEVELS * sizeof(float4));
 		g.lrange = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
 	}
-	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + 16);
+	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + FR_SLAB_CTR_WORDS * sizeof(uint32_t));
 	g.vis_list = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
-	g.slab_owner = (uint16_t *)(base + off); off = align_up(off + ((P + FR_BIN_THREADS - 1) / FR_BIN_THREADS + 1) * sizeof(uint16_t));
+	g.slab_next = (int32_t *)(base + off); off = align_up(off + ((P + 63) / 64 + 1) * sizeof(int32_t));
+	g.wave_head = (int32_t *)(base + off); off = align_up(off + FR_BIN_BLOCKS * (FR_BIN_THREADS / 64) * sizeof(int32_t));
 	g.bytes = off + 256;
 	return g;
 }
@@ -67,6 +70,7 @@ struct ImageWS {
 	uint32_t *n_contrib;  // [W*H]
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
+	uint32_t *lv_bbox;    // [5][4] RF: box of the tiles with tile_min < k as {gx - x0, gy - y0, x1, y1} (0 = empty), k = 0..4
 	uint32_t *totals;     // [4]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047}
 	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
@@ -87,6 +91,7 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.n_contrib = (uint32_t *)(base + off); off = align_up(off + N * sizeof(uint32_t));
 	s.ranges = (uint2 *)(base + off); off = align_up(off + T * sizeof(uint2));
 	s.tile_count = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
+	s.lv_bbox = (uint32_t *)(base + off); off = align_up(off + 5 * 4 * sizeof(uint32_t));
 	s.totals = (uint32_t *)(base + off); off = align_up(off + 4 * sizeof(uint32_t));
 	s.tile_order = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.tile_lv = nullptr;
@@ -132,6 +137,52 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 	y0 = min(gy, max(0, f2i((py - r) / FR_TILE)));
 	x1 = min(gx, max(0, f2i((px + r + (FR_TILE - 1)) / FR_TILE)));
 	y1 = min(gy, max(0, f2i((py + r + (FR_TILE - 1)) / FR_TILE)));
+}
+
+// Rectangle of tiles the binning kernels WALK for one splat. The reference walks getRect()'s rectangle
+// (the 3-sigma circle) and then rejects tiles with the OBB test (RS rasterizer_impl.cu:99-123) and, in RF,
+// the level test tile_min < highest_level + 1 (RF rasterizer_impl.cu:349-372). A tile outside the
+// axis-aligned box of the OBB's corners fails the first two axes of that OBB test, and a tile outside the
+// bounding box of {tiles with tile_min < ceil(highest_level + 1)} fails the level test, so clipping the walk
+// to both boxes (with a safety margin far above float rounding) drops only pairs that would be rejected
+// anyway: results are unchanged, a third to a half of the pairs are never visited, and splats whose
+// clipped rectangle is empty are culled before they reach the binning kernels at all.
+// boxtest: the splat's FULL rectangle has more than one tile, i.e. the reference applies the OBB test.
+struct WalkRect { int x0, y0, x1, y1; uint32_t tnum; bool boxtest; };
+template <bool CULL, bool FOV>
+__device__ __forceinline__ WalkRect walk_rect(float px, float py, int radius, int gx, int gy, float4 ev, float2 el,
+	float hl, const uint32_t *__restrict__ lv_bbox)
+{
+	WalkRect w;
+	get_rect(px, py, radius, gx, gy, w.x0, w.y0, w.x1, w.y1);
+	w.boxtest = CULL && ((uint32_t)(w.y1 - w.y0) * (uint32_t)(w.x1 - w.x0) > 1u);
+	if (w.boxtest)
+	{
+		// obb_hits_tile keeps tile tx only if min(vx) - 16 <= 16 tx <= max(vx) (up to rounding)
+		const float hx = fabsf(el.x * ev.x) + fabsf(el.y * ev.z), hy = fabsf(el.x * ev.y) + fabsf(el.y * ev.w);
+		if (hx < 1e30f) // false for NaN axes (degenerate covariance): the reference's test then rejects nothing here
+		{
+			const float d = 0.01f + 1e-4f * (fabsf(px) + hx);
+			const float lo = floorf((px - hx - d) * (1.0f / FR_TILE)) - 1.0f, hi = floorf((px + hx + d) * (1.0f / FR_TILE)) + 1.0f;
+			w.x0 = max(w.x0, (int)fmaxf(lo, -1e6f)); w.x1 = min(w.x1, (int)fminf(hi, 1e6f));
+		}
+		if (hy < 1e30f)
+		{
+			const float d = 0.01f + 1e-4f * (fabsf(py) + hy);
+			const float lo = floorf((py - hy - d) * (1.0f / FR_TILE)) - 1.0f, hi = floorf((py + hy + d) * (1.0f / FR_TILE)) + 1.0f;
+			w.y0 = max(w.y0, (int)fmaxf(lo, -1e6f)); w.y1 = min(w.y1, (int)fminf(hi, 1e6f));
+		}
+	}
+	if (FOV)
+	{
+		const int k = (int)fminf(fmaxf(ceilf(hl + 1.0f), 0.0f), 4.0f); // NaN -> 0: nothing passes `level < NaN`
+		const uint4 b = ((const uint4 *)lv_bbox)[k];
+		w.x0 = max(w.x0, gx - (int)b.x); w.y0 = max(w.y0, gy - (int)b.y);
+		w.x1 = min(w.x1, (int)b.z); w.y1 = min(w.y1, (int)b.w);
+	}
+	if (w.x1 <= w.x0 || w.y1 <= w.y0) { w.x1 = w.x0; w.y1 = w.y0; w.tnum = 0; }
+	else w.tnum = (uint32_t)(w.y1 - w.y0) * (uint32_t)(w.x1 - w.x0);
+	return w;
 }
 
 // Oriented-bounding-box vs tile separating-axis test: RS auxiliary.h:66-154.

@@ -85,11 +85,13 @@ __device__ float tile_level(int tx, int ty, int W, int H, float gaze_x, float ga
 // One thread per tile: level of the tile and of its 4 neighbours (recomputed instead of a second
 // kernel + global round trip), finite-difference gradients, conservative tile minimum and the
 // two-level-blend flag. out = float[5][T]: level, tile_min, grad_x, grad_y, blending.
-__global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x, float gaze_y, float alpha, float *out)
+// lv_bbox[k] (zeroed by the caller): bounding box of the tiles with tile_min < k, see walk_rect().
+__global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x, float gaze_y, float alpha, float *out,
+	uint32_t *lv_bbox)
 {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= T) return;
-	const int ty = idx / gx, tx = idx % gx;
+	const bool live = idx < T;
+	const int ty = live ? idx / gx : 0, tx = live ? idx % gx : 0;
 	const float lf = tile_level(tx, ty, W, H, gaze_x, gaze_y, alpha);
 	float right = -1, left = -1, up = -1, down = -1;
 	if (tx + 1 < gx) right = tile_level(tx + 1, ty, W, H, gaze_x, gaze_y, alpha);
@@ -107,11 +109,26 @@ __global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x,
 	const float tmin = lf - max_delta;
 	const float tmin_i = (float)f2i(tmin);
 	const bool blending = ((tmin - tmin_i) > 0.5f) && (tmin_i < (float)(FR_FOV_LEVELS - 1));
-	out[idx] = lf;
-	out[T + idx] = tmin;
-	out[2 * T + idx] = gxv;
-	out[3 * T + idx] = gyv;
-	out[4 * T + idx] = blending ? 1.0f : 0.0f;
+	if (live)
+	{
+		out[idx] = lf;
+		out[T + idx] = tmin;
+		out[2 * T + idx] = gxv;
+		out[3 * T + idx] = gyv;
+		out[4 * T + idx] = blending ? 1.0f : 0.0f;
+	}
+	for (int k = 0; k <= FR_FOV_LEVELS; k++)
+	{
+		const bool in = live && tmin < (float)k;
+		uint32_t v[4] = { in ? (uint32_t)(gx - tx) : 0u, in ? (uint32_t)(gy - ty) : 0u, in ? (uint32_t)(tx + 1) : 0u, in ? (uint32_t)(ty + 1) : 0u };
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+		{
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) v[c] = max(v[c], (uint32_t)__shfl_xor((int)v[c], off));
+			if ((threadIdx.x & 63) == 0 && v[c] != 0) atomicMax(&lv_bbox[4 * k + c], v[c]);
+		}
+	}
 }
 
 // ---- SH colour: forward.cu:20-71 (full) and RF rasterizer_impl.cu:37-84 (rest only) -----------
@@ -164,6 +181,7 @@ struct PreArgs {
 	const float *viewmatrix, *projmatrix, *campos;
 	const float *shs_dcs, *highest_levels;
 	const float *tile_lv; // RF float[5][T]
+	const uint32_t *lv_bbox; // RF [5][4], see walk_rect()
 	int T;
 	int *radii;
 	GeomWS geom;
@@ -364,6 +382,7 @@ template <int VARIANT>
 __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
+	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	__shared__ uint32_t s_list[FR_PROJ_LIST];
 	__shared__ uint32_t s_n, s_base;
 	const int lane = threadIdx.x & 63;
@@ -377,32 +396,37 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		{
 			const float p[3] = { a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2] };
 			pr = project_gaussian(a, idx, p);
-			a.radii[idx] = pr.alive ? pr.radius : 0;
 		}
 		if (pr.alive)
 		{
-			float4 *rec = a.geom.rec + 3 * (size_t)idx;
-			rec[0] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
-			rec[1] = make_float4(pr.conic_c, 0.f, 0.f, 0.f);
-			rec[2] = make_float4(0.f, pr.depth, 0.f, 0.f);
-			if (CULL)
+			float4 ev = make_float4(0, 0, 0, 0);
+			float2 el = make_float2(0, 0);
+			if (CULL && pr.tnum > 1)
 			{
-				float4 ev = make_float4(0, 0, 0, 0);
-				float2 el = make_float2(0, 0);
-				if (pr.tnum > 1)
-				{
-					// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
-					float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
-					const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
-					e1x *= n1; e1y *= n1;
-					const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
-					e2x *= n2; e2y *= n2;
-					ev = make_float4(e1x, e1y, e2x, e2y);
-					el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
-				}
-				a.geom.evec[idx] = ev; a.geom.elen[idx] = el;
+				// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
+				float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
+				const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
+				e1x *= n1; e1y *= n1;
+				const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
+				e2x *= n2; e2y *= n2;
+				ev = make_float4(e1x, e1y, e2x, e2y);
+				el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
+			}
+			// splats whose clipped walk rectangle is empty land in no tile: the reference zeroes their radius
+			// after its rectangle walk (RS rasterizer_impl.cu:141-145), here they never reach k_bin
+			const WalkRect w = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el,
+				FOV ? a.highest_levels[idx] : 0.0f, a.lv_bbox);
+			pr.alive = w.tnum != 0;
+			if (pr.alive)
+			{
+				float4 *rec = a.geom.rec + 3 * (size_t)idx;
+				rec[0] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
+				rec[1] = make_float4(pr.conic_c, 0.f, 0.f, 0.f);
+				rec[2] = make_float4(0.f, pr.depth, 0.f, 0.f);
+				if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
 			}
 		}
+		if (idx < a.P) a.radii[idx] = pr.alive ? pr.radius : 0;
 		// wave-aggregated append to the LDS list
 		const unsigned long long m = __ballot(pr.alive);
 		if (m)
@@ -447,31 +471,69 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
 		__syncthreads();
 	}
-	// LDSH: slabs are pulled from a global counter (a few near-camera splats make some slabs 100x more
-	// expensive than others); the owner of every slab is recorded because k_emit must replay the same
-	// slab -> workgroup assignment (its bucket offsets are per workgroup).
-	__shared__ int s_slab;
+	// Work unit = a "slab" of 64 consecutive vis_list entries, handled by ONE wave; there is no workgroup
+	// barrier inside the loop (a few near-camera splats make some slabs 100x more expensive than others,
+	// and waiting for the slowest wave of a workgroup at every slab cost a quarter of the kernel).
+	// LDSH: waves pull slabs dynamically from eight counters (slab s belongs to counter s % 8; a wave
+	// starts at its workgroup's counter and steals from the others when that one runs dry: one counter
+	// serves only ~90 pulls/us; no peeking at the counters with atomic loads -- those slowed every memory
+	// access of the kernel down by 2x). Every wave leaves the chain of slabs it pulled behind (slab_next,
+	// wave_head): k_emit must replay the same slab -> workgroup assignment because its bucket offsets are
+	// per workgroup.
 	__shared__ int s_own[FR_BIN_THREADS];
 	const int V = (int)a.geom.slab_ctr[1]; // entries of vis_list
-	const int nslabs = (V + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
-	int pulled = 0;
-	for (int sstat = blockIdx.x; ; sstat += gridDim.x)
+	const int nslabs = (V + 63) / 64;
+	const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
+	const int nwaves = (int)gridDim.x * (FR_BIN_THREADS / 64);
+	int region = (int)blockIdx.x & 7;
+	int chain = -1; // last slab this wave pulled
+#ifdef FR_BIN_TIMERS
+	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_x; int tm_n = 0;
+#define TM_BEGIN() tm_x = wall_clock64()
+#define TM_END(acc) do { const uint64_t now_ = wall_clock64(); acc += now_ - tm_x; tm_x = now_; } while (0)
+#else
+#define TM_BEGIN()
+#define TM_END(acc)
+#endif
+	for (int sstat = wave_gid; ; sstat += nwaves)
 	{
+	TM_BEGIN();
 	int slab = sstat;
 	if (LDSH)
 	{
-		__syncthreads();
-		if (threadIdx.x == 0) s_slab = pulled < FR_MAX_SLABS_PER_BLOCK ? (int)atomicAdd(a.geom.slab_ctr, 1u) : nslabs;
-		__syncthreads();
-		slab = __builtin_amdgcn_readfirstlane(s_slab);
-		pulled++;
-		if (slab < nslabs && threadIdx.x == 0) a.geom.slab_owner[slab] = (uint16_t)blockIdx.x;
+		int got = -1;
+		if (lane == 0)
+		{
+			for (int tries = 0; tries < 8 && got < 0; tries++)
+			{
+				const int r = (region + tries) & 7;
+				const int nr = (nslabs - r + 7) >> 3;
+				uint32_t *ctr = a.geom.slab_ctr + 32 * (1 + r);
+				const int li = (int)atomicAdd(ctr, 1u);
+				if (li < nr) { got = li * 8 + r; region = r; }
+			}
+		}
+		slab = __builtin_amdgcn_readfirstlane(got);
+		if (slab < 0) break;
+		if (lane == 0) a.geom.slab_next[slab] = chain;
+		chain = slab;
 	}
-	if (slab >= nslabs) break;
-	const int item = slab * FR_BIN_THREADS + threadIdx.x;
+	else if (slab >= nslabs) break;
+	TM_END(tm_s);
+#ifdef FR_BIN_TIMERS
+	tm_n++;
+#endif
+	const int item = slab * 64 + lane;
 	int idx = 0;
 	Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0; pr.pix_x = pr.pix_y = 0.f;
 	float4 r1 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
+	uint32_t count = 0;
+	float4 ev = make_float4(0, 0, 0, 0);
+	float2 el = make_float2(0, 0);
+	float hl = 0, lowest = 0, highest = 0;
+	bool be_blend = false, boxtest = false;
+	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
+	const float *tile_bl = FOV ? a.tile_lv + 4 * (size_t)a.T : nullptr;
 	if (item < V)
 	{
 		idx = (int)a.geom.vis_list[item];
@@ -480,26 +542,17 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		r1 = rec[1]; r2 = rec[2];
 		pr.pix_x = r0.x; pr.pix_y = r0.y;
 		pr.radius = a.radii[idx];
-		get_rect(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, pr.x0, pr.y0, pr.x1, pr.y1);
-		pr.tnum = (uint32_t)(pr.y1 - pr.y0) * (uint32_t)(pr.x1 - pr.x0);
+		if (CULL) { ev = a.geom.evec[idx]; el = a.geom.elen[idx]; }
+		if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
+		const WalkRect w = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, hl, a.lv_bbox);
+		pr.x0 = w.x0; pr.y0 = w.y0; pr.x1 = w.x1; pr.y1 = w.y1; pr.tnum = w.tnum; boxtest = w.boxtest;
 		pr.alive = true;
 	}
 
 	// ---- count the tiles this splat really lands in (and bump the per-tile counters) ----
-	uint32_t count = 0;
-	float4 ev = make_float4(0, 0, 0, 0);
-	float2 el = make_float2(0, 0);
-	float hl = 0, lowest = 0, highest = 0;
-	bool be_blend = false;
-	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
-	const float *tile_bl = FOV ? a.tile_lv + 4 * (size_t)a.T : nullptr;
-	if (pr.alive)
-	{
-		if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
-		if (CULL && pr.tnum > 1) { ev = a.geom.evec[idx]; el = a.geom.elen[idx]; }
-	}
 	// single-tile splats need no box test (RS rasterizer_impl.cu:99-102); handle them in place
-	if (pr.alive && pr.tnum == 1)
+	const bool in_place = pr.alive && pr.tnum == 1 && !boxtest;
+	if (in_place)
 	{
 		bool keep = true;
 		const int ti = pr.y0 * a.gx + pr.x0;
@@ -511,12 +564,13 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		if (keep) { BUMP_TILE(ti); count = 1; }
 	}
+	TM_END(tm_l);
 	// everything else: wave-balanced pair loop
 	{
 #ifdef FR_EXP_NOPAIRS
-		const uint32_t my_n = 0u; if (pr.alive && pr.tnum > 1) count = 1;
+		const uint32_t my_n = 0u; if (pr.alive && !in_place) count = 1;
 #else
-		const uint32_t my_n = (pr.alive && pr.tnum > 1) ? pr.tnum : 0u;
+		const uint32_t my_n = (pr.alive && !in_place) ? pr.tnum : 0u;
 #endif
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
@@ -575,8 +629,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			be_blend = (lvmask & 16u) != 0;
 		}
 	}
-	// NOTE: no divergent `continue` in this loop -- it carries workgroup barriers, and hipcc re-runs the
-	// loop header (barrier included) for the lanes that continue, which deadlocks the workgroup.
+	TM_END(tm_p);
 	if (pr.alive && count == 0) a.radii[idx] = 0; // culled everywhere (RS rasterizer_impl.cu:141-145)
 #ifdef FR_EXP_NOCOLOR
 	if (false)
@@ -629,9 +682,19 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	else rec[1] = make_float4(r1.x, a.opacities[idx], rgb[0], rgb[1]);
 	rec[2] = make_float4(rgb[2], r2.y, __uint_as_float(clamp_bits), 0.0f);
 	} // visible
+	TM_END(tm_c);
 	} // slab loop
+#ifdef FR_BIN_TIMERS
+	if (lane == 0)
+	{
+		float *d = a.geom.cov3D + (size_t)wave_gid * 8;
+		d[0] = (float)(wall_clock64() - tm0); d[1] = (float)tm_s; d[2] = (float)tm_l; d[3] = (float)tm_p; d[4] = (float)tm_c;
+		d[5] = (float)tm_n; d[6] = (float)(tm0 & 0xffffff); d[7] = (float)(wall_clock64() & 0xffffff);
+	}
+#endif
 	if (LDSH)
 	{
+		if (lane == 0) a.geom.wave_head[wave_gid] = chain;
 		__syncthreads();
 		uint32_t *out = a.hist + (size_t)blockIdx.x * a.T;
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) out[t] = lds_hist[t];
@@ -648,6 +711,7 @@ struct EmitArgs {
 	GeomWS geom;
 	const float *highest_levels;
 	const float *tile_lv;
+	const uint32_t *lv_bbox;
 	const uint2 *ranges;
 	uint32_t *cursor;
 	uint64_t *entries;
@@ -669,30 +733,18 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_cur[t] = a.ranges[t].x + pre[t];
 		__syncthreads();
 	}
-	// replay preprocess's slab -> workgroup assignment
-	__shared__ uint32_t s_nmine;
-	__shared__ uint32_t s_mine[FR_MAX_SLABS_PER_BLOCK];
 	__shared__ int s_own[FR_BIN_THREADS];
 	const int V = (int)a.geom.slab_ctr[1];
-	const int nslabs = (V + FR_BIN_THREADS - 1) / FR_BIN_THREADS;
-	if (LDSH)
+	const int nslabs = (V + 63) / 64; // wave-sized slabs, as in k_bin
+	auto process = [&](const int slab)
 	{
-		if (threadIdx.x == 0) s_nmine = 0;
-		__syncthreads();
-		for (int sl = threadIdx.x; sl < nslabs; sl += FR_BIN_THREADS)
-			if (a.geom.slab_owner[sl] == (uint16_t)blockIdx.x) s_mine[atomicAdd(&s_nmine, 1u)] = (uint32_t)sl;
-		__syncthreads();
-	}
-	const int nmine = LDSH ? (int)s_nmine : (nslabs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-	for (int it = 0; it < nmine; it++)
-	{
-	const int slab = LDSH ? (int)s_mine[it] : (int)blockIdx.x + it * (int)gridDim.x;
-	const int item = slab * FR_BIN_THREADS + threadIdx.x;
+	const int item = slab * 64 + lane;
 	int idx = 0, radius = 0;
 	if (item < V) { idx = (int)a.geom.vis_list[item]; radius = a.radii[idx]; }
 	const bool alive = radius > 0;
-	int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+	int x0 = 0, y0 = 0, x1 = 0;
 	uint32_t tnum = 0;
+	bool boxtest = false;
 	float cx = 0.f, cy = 0.f, hl = 0.f;
 	uint32_t depth_bits = 0;
 	float4 ev = make_float4(0, 0, 0, 0);
@@ -702,16 +754,17 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 		const float4 r0 = a.geom.rec[3 * (size_t)idx];
 		cx = r0.x; cy = r0.y;
 		depth_bits = __float_as_uint(a.geom.rec[3 * (size_t)idx + 2].y);
-		get_rect(cx, cy, radius, a.gx, a.gy, x0, y0, x1, y1);
-		tnum = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
-		if (CULL && tnum > 1) { ev = a.geom.evec[idx]; el = a.geom.elen[idx]; }
+		if (CULL) { ev = a.geom.evec[idx]; el = a.geom.elen[idx]; }
 		if (FOV) hl = a.highest_levels[idx];
+		const WalkRect w = walk_rect<CULL, FOV>(cx, cy, radius, a.gx, a.gy, ev, el, hl, a.lv_bbox);
+		x0 = w.x0; y0 = w.y0; x1 = w.x1; tnum = w.tnum; boxtest = w.boxtest;
 	}
 	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
 	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
-	if (alive && tnum == 1) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
+	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_bin's level test, no box test (single-tile splat)
+	if (in_place) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
 	{
-		const uint32_t my_n = (alive && tnum > 1) ? tnum : 0u;
+		const uint32_t my_n = (alive && !in_place) ? tnum : 0u;
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -747,7 +800,25 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 			if (pass) a.entries[NEXT_SLOT(ti)] = opay;
 		}
 	}
-	} // slab loop
+	}; // process(slab)
+	if (LDSH)
+	{
+		// replay k_bin's slab -> wave assignment (the bucket offsets are per workgroup) by walking the
+		// chain that wave left behind
+		int slab = a.geom.wave_head[(int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6)];
+		while (slab >= 0)
+		{
+			const int next = a.geom.slab_next[slab];
+			process(slab);
+			slab = next;
+		}
+	}
+	else
+	{
+		const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
+		const int nwaves = (int)gridDim.x * (FR_BIN_THREADS / 64);
+		for (int slab = wave_gid; slab < nslabs; slab += nwaves) process(slab);
+	}
 }
 #undef NEXT_SLOT
 
@@ -793,7 +864,7 @@ int launch_tile_levels(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	hipLaunchKernelGGL(k_tile_levels, dim3((c.T + 255) / 256), dim3(256), 0, c.stream,
-		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv);
+		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv, c.img.lv_bbox);
 	return check_launch("tile_levels", c.stream, a->debug);
 }
 
@@ -807,7 +878,7 @@ int launch_preprocess(FwdCtx &c)
 	p.means3D = a->means3D; p.scales = a->scales; p.rotations = a->rotations; p.opacities = a->opacities;
 	p.shs = a->shs; p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
-	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.T = c.T;
+	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.lv_bbox = c.img.lv_bbox; p.T = c.T;
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
 	{
@@ -845,7 +916,7 @@ int launch_emit(FwdCtx &c)
 	const fr_forward_args *a = c.a;
 	EmitArgs e;
 	e.P = a->P; e.gx = c.gx; e.gy = c.gy; e.T = c.T; e.radii = a->radii; e.geom = c.geom;
-	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.ranges = c.img.ranges;
+	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.lv_bbox = c.img.lv_bbox; e.ranges = c.img.ranges;
 	e.cursor = c.img.tile_count; e.entries = c.bin.entries; e.hist = c.img.hist;
 	const bool ldsh = c.img.hist != nullptr;
 	const dim3 grid(bin_blocks(a->P)), block(FR_BIN_THREADS);

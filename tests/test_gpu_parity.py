@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN, cam_dict, scene_dict, small_case, syn
+from tests.helpers import GOLDEN, cam_dict, scene_dict, small_camera, small_case, small_cloud, syn
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -66,6 +66,34 @@ def test_forward_matches_oracle(variant):
         np.testing.assert_allclose(got["tile_levels"], want["tile_levels"], atol=2e-5)
         np.testing.assert_allclose(got["tile_min"], want["tile_min"], atol=2e-5)
         np.testing.assert_array_equal(got["tile_blend"], want["tile_blend"])
+
+
+@pytest.mark.parametrize("variant,gaze", [("pcheck_obb", (0.5, 0.5)), ("fov_pcheck_obb", (0.08, 0.9)),
+                                          ("fov_pcheck_obb", (0.7, 0.3)), ("fov_pcheck_obb", (1.4, -0.2))])
+def test_clipped_walk_rectangles(variant, gaze):
+    """The binning kernels walk getRect() clipped to the OBB's axis-aligned box and to the box of the tiles
+    whose level passes (common.h walk_rect); the instance lists must stay the reference's bit for bit.
+    Needle-shaped, diagonal and frame-filling splats on a 1280x720 frame, gaze near a corner / off screen."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    cloud = small_cloud(6000, seed=11, big_fraction=0.3)
+    g = torch.Generator().manual_seed(5)
+    needle = torch.randperm(6000, generator=g)[:2500]
+    cloud._scaling[needle, 0] += 2.5   # up to ~100:1 aspect ratios
+    cloud._scaling[needle, 1] -= 1.5
+    cloud._scaling[needle[:40]] += 2.0  # a few cover most of the frame
+    cam = small_camera(1280, 720)
+    fov = syn.foveation_layers(cloud, seed=12) if variant == "fov_pcheck_obb" else None
+    scene = scene_dict(cloud, variant, fov)
+    cd = cam_dict(cam, bg=(0.0, 0.1, 0.0), gaze=gaze)
+    want = orc.forward(variant, scene, cd)
+    got = hip_forward(variant, scene, cd)
+    assert want["num_rendered"] > 50000
+    assert got["num_rendered"] == want["num_rendered"]
+    np.testing.assert_array_equal(got["radii"], want["radii"])
+    np.testing.assert_array_equal(got["ranges"], want["ranges"])
+    np.testing.assert_array_equal(got["point_list"], want["point_list"])
+    check_image(got["color"], want["color"])
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

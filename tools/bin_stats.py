@@ -22,8 +22,12 @@ geom = r[3]
 P = xyz.shape[0]
 off = ((P * 48 + 255) // 256) * 256
 dbg = geom[off:off + 768 * 8 * 8 * 4].view(torch.float32).view(768 * 8, 8).cpu().numpy()
-tot, pairs, steps, slabs, mx = dbg[:, 0] * 10, dbg[:, 1] * 10, dbg[:, 2], dbg[:, 3], dbg[:, 4]
-print("waves", len(tot), "wave total ns: mean %.0f p50 %.0f p99 %.0f max %.0f" % (tot.mean(), np.percentile(tot, 50), np.percentile(tot, 99), tot.max()))
-print("pairs ns: mean %.0f p99 %.0f max %.0f ; frac of total %.2f" % (pairs.mean(), np.percentile(pairs, 99), pairs.max(), pairs.sum() / tot.sum()))
-print("steps per wave: mean %.1f p99 %.0f max %.0f ; slabs per wave mean %.2f max %.0f ; max steps in one slab %.0f" % (steps.mean(), np.percentile(steps, 99), steps.max(), slabs.mean(), slabs.max(), mx.max()))
-print("ns per step %.1f" % (pairs.sum() / max(steps.sum(), 1)))
+tot, sched, load, pairs, col, pulled = [dbg[:, i] * (10 if i < 5 else 1) for i in range(6)]
+print("waves", len(tot), "wave total us: mean %.0f max %.0f" % (tot.mean() / 1e3, tot.max() / 1e3))
+for name, v in (("sched+barrier", sched), ("load", load), ("pairs", pairs), ("colour+write", col)):
+    print("  %-14s mean %.1f us  frac %.2f" % (name, v.mean() / 1e3, v.sum() / tot.sum()))
+print("slabs per wave mean %.2f max %d" % (pulled.mean(), pulled.max()))
+t0 = dbg[:, 6].astype(np.int64); t1 = dbg[:, 7].astype(np.int64)
+base = t0.min(); st = (t0 - base) % (1 << 24); en = (t1 - base) % (1 << 24)
+print("start spread us: max %.1f ; end us: min %.1f mean %.1f max %.1f" % (st.max() / 100, en.min() / 100, en.mean() / 100, en.max() / 100))
+print("wave total pct 50/90/99: %s" % np.percentile(tot / 1e3, [50, 90, 99]).round(0))
