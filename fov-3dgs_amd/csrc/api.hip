@@ -125,7 +125,7 @@ int fr_forward(fr_forward_args *a)
 	c.geom = carve_geom(a->variant, (size_t)a->P, gptr);
 	c.img = carve_image(a->variant, a->W, a->H, iptr);
 
-	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 20) - (char *)c.img.tile_count), stream)); // + lv_bbox
+	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
 	FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
 	if (has_stats(a->variant))
 	{

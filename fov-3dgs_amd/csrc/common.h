@@ -12,6 +12,7 @@
 #define FR_BIN_THREADS 512    // workgroup size of the binning kernels (preprocess / emit)
 #define FR_BIN_BLOCKS 768     // persistent workgroups of the binning kernels (3 per CU)
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
+#define FR_LV_BBOX_STRIDE 32  // words between the level boxes of ImageWS::lv_bbox (one 128-byte line each)
 #define FR_SLAB_CTR_WORDS 288 // header line + eight 128-byte counter lines
 
 namespace fr {
@@ -70,7 +71,7 @@ struct ImageWS {
 	uint32_t *n_contrib;  // [W*H]
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
-	uint32_t *lv_bbox;    // [5][4] RF: box of the tiles with tile_min < k as {gx - x0, gy - y0, x1, y1} (0 = empty), k = 0..4
+	uint32_t *lv_bbox;    // [5][FR_LV_BBOX_STRIDE] RF: box of the tiles with tile_min < k as {gx - x0, gy - y0, x1, y1} (0 = empty), k = 0..4
 	uint32_t *totals;     // [4]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047}
 	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
@@ -91,7 +92,7 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.n_contrib = (uint32_t *)(base + off); off = align_up(off + N * sizeof(uint32_t));
 	s.ranges = (uint2 *)(base + off); off = align_up(off + T * sizeof(uint2));
 	s.tile_count = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
-	s.lv_bbox = (uint32_t *)(base + off); off = align_up(off + 5 * 4 * sizeof(uint32_t));
+	s.lv_bbox = (uint32_t *)(base + off); off = align_up(off + 5 * FR_LV_BBOX_STRIDE * sizeof(uint32_t));
 	s.totals = (uint32_t *)(base + off); off = align_up(off + 4 * sizeof(uint32_t));
 	s.tile_order = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.tile_lv = nullptr;
@@ -176,7 +177,7 @@ __device__ __forceinline__ WalkRect walk_rect(float px, float py, int radius, in
 	if (FOV)
 	{
 		const int k = (int)fminf(fmaxf(ceilf(hl + 1.0f), 0.0f), 4.0f); // NaN -> 0: nothing passes `level < NaN`
-		const uint4 b = ((const uint4 *)lv_bbox)[k];
+		const uint4 b = *(const uint4 *)(lv_bbox + k * FR_LV_BBOX_STRIDE);
 		w.x0 = max(w.x0, gx - (int)b.x); w.y0 = max(w.y0, gy - (int)b.y);
 		w.x1 = min(w.x1, (int)b.z); w.y1 = min(w.y1, (int)b.w);
 	}

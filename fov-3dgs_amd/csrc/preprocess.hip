@@ -117,6 +117,11 @@ __global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x,
 		out[3 * T + idx] = gyv;
 		out[4 * T + idx] = blending ? 1.0f : 0.0f;
 	}
+	// bounding boxes: wave reduction -> LDS -> one global atomic per workgroup and component (a cache line
+	// takes only ~90 atomics/us, so every box has its own line: FR_LV_BBOX_STRIDE)
+	__shared__ uint32_t s_bb[(FR_FOV_LEVELS + 1) * 4];
+	if (threadIdx.x < (FR_FOV_LEVELS + 1) * 4) s_bb[threadIdx.x] = 0;
+	__syncthreads();
 	for (int k = 0; k <= FR_FOV_LEVELS; k++)
 	{
 		const bool in = live && tmin < (float)k;
@@ -126,52 +131,60 @@ __global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x,
 		{
 #pragma unroll
 			for (int off = 32; off > 0; off >>= 1) v[c] = max(v[c], (uint32_t)__shfl_xor((int)v[c], off));
-			if ((threadIdx.x & 63) == 0 && v[c] != 0) atomicMax(&lv_bbox[4 * k + c], v[c]);
+			if ((threadIdx.x & 63) == 0 && v[c] != 0) atomicMax(&s_bb[4 * k + c], v[c]);
 		}
 	}
+	__syncthreads();
+	if (threadIdx.x < (FR_FOV_LEVELS + 1) * 4 && s_bb[threadIdx.x] != 0)
+		atomicMax(&lv_bbox[(threadIdx.x >> 2) * FR_LV_BBOX_STRIDE + (threadIdx.x & 3)], s_bb[threadIdx.x]);
 }
 
 // ---- SH colour: forward.cu:20-71 (full) and RF rasterizer_impl.cu:37-84 (rest only) -----------
 // sh points at 3*M floats of this Gaussian; REST: coefficient k is stored at slot k-1.
+// Every lane reads its own Gaussian, i.e. its own cache lines, and a CU's address unit handles such a
+// scattered access lane by lane: 48 dword loads per Gaussian made this the slowest part of k_bin. The
+// coefficients are therefore fetched 16 bytes at a time (dword-aligned: 45 floats per Gaussian in RF) and
+// folded into the three channel sums in the reference's order (term k is basis_k * coefficient, summed
+// k = 0..15 left to right), so the result is bit-identical to the scalar formulation.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 template <bool REST>
 __device__ __forceinline__ void sh_colour(int deg, const float *__restrict__ sh, float dx, float dy, float dz, float out[3])
 {
 	const float len = sqrtf(dx * dx + dy * dy + dz * dz);
 	const float x = dx / len, y = dy / len, z = dz / len;
+	const float xx = x * x, yy = y * y, zz = z * z;
+	const float xy = x * y, yz = y * z, xz = x * z;
+	// basis_k with the association of the reference's expressions; terms 1 and 3 are subtracted there
+	const float basis[16] = {
+		FR_SH_C0, -(FR_SH_C1 * y), FR_SH_C1 * z, -(FR_SH_C1 * x),
+		FR_SH_C2_0 * xy, FR_SH_C2_1 * yz, FR_SH_C2_2 * (2.0f * zz - xx - yy), FR_SH_C2_3 * xz, FR_SH_C2_4 * (xx - yy),
+		FR_SH_C3_0 * y * (3.0f * xx - yy), FR_SH_C3_1 * xy * z, FR_SH_C3_2 * y * (4.0f * zz - xx - yy),
+		FR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), FR_SH_C3_4 * x * (4.0f * zz - xx - yy),
+		FR_SH_C3_5 * z * (xx - yy), FR_SH_C3_6 * x * (xx - 3.0f * yy) };
+	constexpr int SKIP = REST ? 1 : 0;
+	const int nfl = 3 * ((deg + 1) * (deg + 1) - SKIP); // floats in use
+	float acc[3] = { 0.0f, 0.0f, 0.0f };
 #pragma unroll
-	for (int ch = 0; ch < 3; ch++)
+	for (int q = 0; q < 12; q++)
 	{
-#define SHK(k) sh[3 * ((k) - (REST ? 1 : 0)) + ch]
-		float result = REST ? 0.0f : FR_SH_C0 * SHK(0);
-		if (deg > 0)
+		if (4 * q + 4 <= nfl)
 		{
-			result = result - FR_SH_C1 * y * SHK(1) + FR_SH_C1 * z * SHK(2) - FR_SH_C1 * x * SHK(3);
-			if (deg > 1)
+			const f4u v = *(const f4u *)(sh + 4 * q);
+#pragma unroll
+			for (int j = 0; j < 4; j++) { const int i = 4 * q + j; acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * v[j]; }
+		}
+		else
+		{
+#pragma unroll
+			for (int j = 0; j < 4; j++)
 			{
-				const float xx = x * x, yy = y * y, zz = z * z;
-				const float xy = x * y, yz = y * z, xz = x * z;
-				result = result +
-					FR_SH_C2_0 * xy * SHK(4) +
-					FR_SH_C2_1 * yz * SHK(5) +
-					FR_SH_C2_2 * (2.0f * zz - xx - yy) * SHK(6) +
-					FR_SH_C2_3 * xz * SHK(7) +
-					FR_SH_C2_4 * (xx - yy) * SHK(8);
-				if (deg > 2)
-				{
-					result = result +
-						FR_SH_C3_0 * y * (3.0f * xx - yy) * SHK(9) +
-						FR_SH_C3_1 * xy * z * SHK(10) +
-						FR_SH_C3_2 * y * (4.0f * zz - xx - yy) * SHK(11) +
-						FR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHK(12) +
-						FR_SH_C3_4 * x * (4.0f * zz - xx - yy) * SHK(13) +
-						FR_SH_C3_5 * z * (xx - yy) * SHK(14) +
-						FR_SH_C3_6 * x * (xx - 3.0f * yy) * SHK(15);
-				}
+				const int i = 4 * q + j;
+				if (i < nfl) acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * sh[i];
 			}
 		}
-#undef SHK
-		out[ch] = result + 0.5f;
 	}
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) out[ch] = acc[ch] + 0.5f;
 }
 
 struct PreArgs {
@@ -181,7 +194,8 @@ struct PreArgs {
 	const float *viewmatrix, *projmatrix, *campos;
 	const float *shs_dcs, *highest_levels;
 	const float *tile_lv; // RF float[5][T]
-	const uint32_t *lv_bbox; // RF [5][4], see walk_rect()
+	const uint32_t *lv_bbox; // RF [5][FR_LV_BBOX_STRIDE], see walk_rect()
+	int lds_tiles;           // RF: tile_min and the blend flags are staged in LDS (see k_bin)
 	int T;
 	int *radii;
 	GeomWS geom;
@@ -371,26 +385,43 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 }
 
 // Stage 1: projection, covariance, conic, radius, tile rectangle -- memory-streaming, one thread per
-// Gaussian, grid-stride over 1024-wide chunks. Survivors are appended to vis_list so that the binning
-// and colour stages below run on dense waves (typically 10-20 % of a scene is on screen). The append
-// is staged through an LDS list and flushed with ONE global atomic per flush: a single device-scope
-// counter saturates at ~90 atomics/us on MI355X, so one atomic per wave (94 k per frame at 6 M
-// Gaussians) would cost a millisecond.
-#define FR_PROJ_THREADS 1024
-#define FR_PROJ_LIST 8192
+// Gaussian, persistent waves striding over 64-wide chunks. Survivors are appended to vis_list so that
+// the binning and colour stages below run on dense waves (typically 10-20 % of a scene is on screen).
+// Every WAVE stages its survivors in an LDS list of its own and flushes it with one global atomic per
+// ~450 entries: a single device-scope counter saturates at ~90 atomics/us on MI355X, so one atomic per
+// wave and chunk (94 k per frame at 6 M Gaussians) would cost a millisecond -- and no workgroup barrier
+// is needed, so the waves of a CU drift apart and overlap their load and ALU phases.
+#define FR_PROJ_THREADS 256
+#define FR_PROJ_WLIST 512
 template <int VARIANT>
 __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
-	__shared__ uint32_t s_list[FR_PROJ_LIST];
-	__shared__ uint32_t s_n, s_base;
+	__shared__ uint32_t s_list[FR_PROJ_THREADS / 64][FR_PROJ_WLIST];
 	const int lane = threadIdx.x & 63;
-	if (threadIdx.x == 0) s_n = 0;
-	__syncthreads();
-	for (int chunk = blockIdx.x; chunk * FR_PROJ_THREADS < a.P; chunk += gridDim.x)
+	uint32_t *list = s_list[threadIdx.x >> 6];
+	uint32_t n = 0; // entries staged by this wave (wave-uniform)
+	auto flush = [&]()
 	{
-		const int idx = chunk * FR_PROJ_THREADS + threadIdx.x;
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd(a.geom.slab_ctr + 1, n);
+		base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+		// the list was written by other lanes of this wave
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		for (uint32_t i = lane; i < n; i += 64) a.geom.vis_list[base + i] = list[i];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		n = 0;
+	};
+	const int nchunks = (a.P + 63) / 64;
+	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
+	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
+	for (int chunk = wave_gid; chunk < nchunks; chunk += nwaves)
+	{
+		const int idx = chunk * 64 + lane;
 		Proj pr; pr.alive = false; pr.tnum = 0;
 		if (idx < a.P)
 		{
@@ -427,30 +458,12 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 			}
 		}
 		if (idx < a.P) a.radii[idx] = pr.alive ? pr.radius : 0;
-		// wave-aggregated append to the LDS list
 		const unsigned long long m = __ballot(pr.alive);
-		if (m)
-		{
-			uint32_t base = 0;
-			const int leader = __ffsll((long long)m) - 1;
-			if (lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
-			base = (uint32_t)__shfl((int)base, leader);
-			if (pr.alive) s_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
-		}
-		__syncthreads();
-		const uint32_t n = s_n;
-		const bool last = (chunk + (int)gridDim.x) * FR_PROJ_THREADS >= a.P;
-		if (n + FR_PROJ_THREADS > FR_PROJ_LIST || last)
-		{
-			if (threadIdx.x == 0) s_base = n ? atomicAdd(a.geom.slab_ctr + 1, n) : 0u;
-			__syncthreads();
-			const uint32_t gbase = s_base;
-			for (uint32_t i = threadIdx.x; i < n; i += FR_PROJ_THREADS) a.geom.vis_list[gbase + i] = s_list[i];
-			__syncthreads();
-			if (threadIdx.x == 0) s_n = 0;
-		}
-		__syncthreads();
+		if (pr.alive) list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+		n += (uint32_t)__popcll(m);
+		if (n > FR_PROJ_WLIST - 64) flush();
 	}
+	if (n) flush();
 }
 
 // Persistent workgroups of FR_BIN_THREADS threads; slab s (FR_BIN_THREADS consecutive Gaussians)
@@ -466,11 +479,28 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
 	const int lane = threadIdx.x & 63;
-	if (LDSH)
+	// RF: every pair step looks its tile's level (and, if kept, its blend flag) up; from global memory those
+	// were two dependent ~1 us round trips in a loop that a near-camera splat runs a hundred times. When they
+	// fit beside the histogram, the workgroup keeps tile_min (float) and the blend flags (one bit) in LDS.
+	float *lds_tmin = (float *)(lds_hist + (LDSH ? a.T : 0));
+	uint32_t *lds_blend = (uint32_t *)(lds_tmin + a.T);
+	const bool ldst = FOV && a.lds_tiles;
+	if (ldst)
 	{
-		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
-		__syncthreads();
+		const float *gmin = a.tile_lv + a.T, *gbl = a.tile_lv + 4 * (size_t)a.T;
+		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_tmin[t] = gmin[t];
+		for (int w = threadIdx.x; w * 32 < a.T; w += FR_BIN_THREADS)
+		{
+			uint32_t bits = 0;
+			for (int b = 0; b < 32 && w * 32 + b < a.T; b++) bits |= (gbl[w * 32 + b] != 0.0f ? 1u : 0u) << b;
+			lds_blend[w] = bits;
+		}
 	}
+	if (LDSH)
+		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
+	__syncthreads();
+#define TILE_MIN(ti) (ldst ? lds_tmin[(ti)] : tile_min[(ti)])
+#define TILE_BLENDS(ti) (ldst ? ((lds_blend[(ti) >> 5] >> ((ti) & 31)) & 1u) != 0u : tile_bl[(ti)] != 0.0f)
 	// Work unit = a "slab" of 64 consecutive vis_list entries, handled by ONE wave; there is no workgroup
 	// barrier inside the loop (a few near-camera splats make some slabs 100x more expensive than others,
 	// and waiting for the slowest wave of a workgroup at every slab cost a quarter of the kernel).
@@ -488,7 +518,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	int region = (int)blockIdx.x & 7;
 	int chain = -1; // last slab this wave pulled
 #ifdef FR_BIN_TIMERS
-	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_x; int tm_n = 0;
+	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0;
 #define TM_BEGIN() tm_x = wall_clock64()
 #define TM_END(acc) do { const uint64_t now_ = wall_clock64(); acc += now_ - tm_x; tm_x = now_; } while (0)
 #else
@@ -558,9 +588,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		const int ti = pr.y0 * a.gx + pr.x0;
 		if (FOV)
 		{
-			const float level = tile_min[ti];
+			const float level = TILE_MIN(ti);
 			keep = level < (hl + 1);
-			if (keep) { lowest = level; highest = level; be_blend = tile_bl[ti] != 0.0f; }
+			if (keep) { lowest = level; highest = level; be_blend = TILE_BLENDS(ti); }
 		}
 		if (keep) { BUMP_TILE(ti); count = 1; }
 	}
@@ -576,6 +606,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 		uint32_t lvmask = 0; // FOV: bit l = some kept tile has int(level) == l; bit 4 = some kept tile blends
+#ifdef FR_BIN_TIMERS
+		tm_steps += (int)((total + 63) / 64);
+#endif
 		for (uint32_t k = 0; k < total; k += 64)
 		{
 			const uint32_t j = k + lane;
@@ -598,7 +631,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 				if (FOV)
 				{
 					const float ohl = __shfl(hl, owner);
-					level = valid ? tile_min[ti] : 0.f;
+					level = valid ? TILE_MIN(ti) : 0.f;
 					pass = pass && (level < (ohl + 1));
 				}
 				if (pass)
@@ -606,7 +639,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 					const Obb ob = make_obb(ocx, ocy, oev, oel);
 					pass = obb_hits_tile(ob, x, y);
 				}
-				if (FOV && pass) m = (1u << min(max(f2i(level), 0), 3)) | ((tile_bl[ti] != 0.0f) ? 16u : 0u);
+				if (FOV && pass) m = (1u << min(max(f2i(level), 0), 3)) | (TILE_BLENDS(ti) ? 16u : 0u);
 			}
 			if (pass) BUMP_TILE(ti);
 			// hand the results back to the owners: my pairs of this step are lanes [seg_a, seg_b)
@@ -666,6 +699,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		a.geom.lrange[idx] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
 		float rest[3];
 		sh_colour<true>(a.D, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, rest);
+#ifdef FR_BIN_TIMERS
+		{ const uint64_t now_ = wall_clock64(); if (rest[0] != 123.f) tm_sh += now_ - tm_x; }
+#endif
 		for (int l = lo; l <= hi; l++)
 		{
 			const float *dc = a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS + l * 3;
@@ -689,7 +725,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	{
 		float *d = a.geom.cov3D + (size_t)wave_gid * 8;
 		d[0] = (float)(wall_clock64() - tm0); d[1] = (float)tm_s; d[2] = (float)tm_l; d[3] = (float)tm_p; d[4] = (float)tm_c;
-		d[5] = (float)tm_n; d[6] = (float)(tm0 & 0xffffff); d[7] = (float)(wall_clock64() & 0xffffff);
+		d[5] = (float)tm_n; d[6] = (float)tm_sh; d[7] = (float)tm_steps;
 	}
 #endif
 	if (LDSH)
@@ -701,6 +737,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	}
 }
 #undef BUMP_TILE
+#undef TILE_MIN
+#undef TILE_BLENDS
 
 // One thread per Gaussian: re-walk the rect, repeat the cull test and append (depth,id) to the
 // tile's bucket through the tile cursor. Order inside a bucket is arbitrary; the per-tile sort
@@ -712,6 +750,7 @@ struct EmitArgs {
 	const float *highest_levels;
 	const float *tile_lv;
 	const uint32_t *lv_bbox;
+	int lds_tiles;
 	const uint2 *ranges;
 	uint32_t *cursor;
 	uint64_t *entries;
@@ -727,12 +766,19 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
 	const int lane = threadIdx.x & 63;
+	float *lds_tmin = (float *)(lds_cur + (LDSH ? a.T : 0)); // RF: tile_min staged in LDS, as in k_bin
+	const bool ldst = FOV && a.lds_tiles;
+	if (ldst)
+	{
+		const float *gmin = a.tile_lv + a.T;
+		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_tmin[t] = gmin[t];
+	}
 	if (LDSH)
 	{
 		const uint32_t *pre = a.hist + (size_t)blockIdx.x * a.T;
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_cur[t] = a.ranges[t].x + pre[t];
-		__syncthreads();
 	}
+	__syncthreads();
 	__shared__ int s_own[FR_BIN_THREADS];
 	const int V = (int)a.geom.slab_ctr[1];
 	const int nslabs = (V + 63) / 64; // wave-sized slabs, as in k_bin
@@ -789,7 +835,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 				if (FOV)
 				{
 					const float ohl = __shfl(hl, owner);
-					pass = pass && (tile_min[valid ? ti : 0] < (ohl + 1));
+					pass = pass && ((ldst ? lds_tmin[valid ? ti : 0] : tile_min[valid ? ti : 0]) < (ohl + 1));
 				}
 				if (pass)
 				{
@@ -860,6 +906,10 @@ __global__ void k_mark_visible(int P, const float *means3D, const float *vm, uin
 }
 
 // ---- launchers -------------------------------------------------------------------------------
+// bytes of the RF tile table in LDS: tile_min floats + one blend bit per tile
+static inline size_t lds_tile_table_bytes(int T) { return (size_t)T * sizeof(float) + (size_t)((T + 31) / 32) * sizeof(uint32_t); }
+#define FR_LDS_TILE_TABLE_BUDGET (76u * 1024u) // two workgroups per CU (160 KiB) with their static LDS
+
 int launch_tile_levels(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
@@ -872,6 +922,7 @@ int launch_preprocess(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	PreArgs p;
+	p.lds_tiles = 0;
 	p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H; p.gx = c.gx; p.gy = c.gy;
 	p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.focal_x = c.focal_x; p.focal_y = c.focal_y;
 	p.scale_modifier = a->scale_modifier;
@@ -883,10 +934,11 @@ int launch_preprocess(FwdCtx &c)
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
 	{
 		const int pchunks = (a->P + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS;
-		const dim3 pgrid(pchunks < 1024 ? pchunks : 1024), pblock(FR_PROJ_THREADS);
+		const dim3 pgrid(pchunks < 2048 ? pchunks : 2048), pblock(FR_PROJ_THREADS); // 8 workgroups per CU
 		switch (a->variant)
 		{
 		case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL(k_project<FR_VARIANT_ORIGINAL>, pgrid, pblock, 0, c.stream, p); break;
+		case FR_VARIANT_FOV_PCHECK_OBB: hipLaunchKernelGGL(k_project<FR_VARIANT_FOV_PCHECK_OBB>, pgrid, pblock, 0, c.stream, p); break;
 		default: hipLaunchKernelGGL(k_project<FR_VARIANT_PCHECK_OBB>, pgrid, pblock, 0, c.stream, p); break;
 		}
 		int prc = check_launch("project", c.stream, a->debug);
@@ -895,7 +947,15 @@ int launch_preprocess(FwdCtx &c)
 	const bool ldsh = c.img.hist != nullptr;
 	const int nblk = bin_blocks(a->P);
 	const dim3 grid(nblk), block(FR_BIN_THREADS);
-	const size_t lds = ldsh ? (size_t)c.T * sizeof(uint32_t) : 0;
+	// LDS per workgroup: tile histogram (+ RF: tile_min and blend bits when two workgroups still fit a CU)
+	p.lds_tiles = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
+	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
+	if (lds > 64u * 1024u)
+	{
+		static const hipError_t once = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_FOV_PCHECK_OBB, true>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
+	}
 #define LAUNCH_PRE(V) do { if (ldsh) hipLaunchKernelGGL((k_bin<V, true>), grid, block, lds, c.stream, p); \
 	else hipLaunchKernelGGL((k_bin<V, false>), grid, block, 0, c.stream, p); } while (0)
 	switch (a->variant)
@@ -920,7 +980,14 @@ int launch_emit(FwdCtx &c)
 	e.cursor = c.img.tile_count; e.entries = c.bin.entries; e.hist = c.img.hist;
 	const bool ldsh = c.img.hist != nullptr;
 	const dim3 grid(bin_blocks(a->P)), block(FR_BIN_THREADS);
-	const size_t lds = ldsh ? (size_t)c.T * sizeof(uint32_t) : 0;
+	e.lds_tiles = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
+	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (e.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
+	if (lds > 64u * 1024u)
+	{
+		static const hipError_t once = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, true>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_emit): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
+	}
 #define LAUNCH_EMIT(V) do { if (ldsh) hipLaunchKernelGGL((k_emit<V, true>), grid, block, lds, c.stream, e); \
 	else hipLaunchKernelGGL((k_emit<V, false>), grid, block, 0, c.stream, e); } while (0)
 	switch (a->variant)

@@ -13,9 +13,14 @@ with torch.no_grad():
     rest = cloud.get_rest_features.contiguous()
 rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev),
                                       1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
-E = torch.Tensor([]); vid = 3
+E = torch.Tensor([]); vid = 3 if len(sys.argv) < 2 else 2
+with torch.no_grad():
+    full, opa = cloud.get_features.contiguous(), cloud.get_opacity.contiguous()
 for i in range(3):
-    r = rz._forward_native(vid, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], syn.lissajous_gaze(20, 90), 0.05)
+    if vid == 3:
+        r = rz._forward_native(vid, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], syn.lissajous_gaze(20, 90), 0.05)
+    else:
+        r = rz._forward_native(vid, rs, xyz, full, E, opa, sc, rot, E, None, None, (0.5, 0.5), 0.05)
 torch.cuda.synchronize()
 geom = r[3]
 # cov3D sits right after rec (3P float4, 256-aligned)
@@ -27,7 +32,9 @@ print("waves", len(tot), "wave total us: mean %.0f max %.0f" % (tot.mean() / 1e3
 for name, v in (("sched+barrier", sched), ("load", load), ("pairs", pairs), ("colour+write", col)):
     print("  %-14s mean %.1f us  frac %.2f" % (name, v.mean() / 1e3, v.sum() / tot.sum()))
 print("slabs per wave mean %.2f max %d" % (pulled.mean(), pulled.max()))
-t0 = dbg[:, 6].astype(np.int64); t1 = dbg[:, 7].astype(np.int64)
-base = t0.min(); st = (t0 - base) % (1 << 24); en = (t1 - base) % (1 << 24)
-print("start spread us: max %.1f ; end us: min %.1f mean %.1f max %.1f" % (st.max() / 100, en.min() / 100, en.mean() / 100, en.max() / 100))
+print("  sh (lane 0 of each wave) mean %.1f us" % (dbg[:, 6].mean() * 10 / 1e3))
 print("wave total pct 50/90/99: %s" % np.percentile(tot / 1e3, [50, 90, 99]).round(0))
+steps = dbg[:, 7]
+print("pair steps per wave mean %.1f max %d total %.2fM pairs<=%.1fM; us/step %.2f" % (steps.mean(), steps.max(), steps.sum() / 1e6, steps.sum() * 64 / 1e6, pairs.sum() / 1e3 / steps.sum()))
+w = int(np.argmax(tot))
+print("slowest wave: tot %.0f sched %.0f load %.0f pairs %.0f colour %.0f us, slabs %d steps %d" % (tot[w] / 1e3, sched[w] / 1e3, load[w] / 1e3, pairs[w] / 1e3, col[w] / 1e3, pulled[w], steps[w]))
