@@ -247,7 +247,7 @@ def main():
         tr = cloud.requires_grad_(True)
         target = torch.rand(3, H, W, device=dev)
         ts = []
-        for it in range(8):
+        for it in range(14):
             for p in tr.parameters():
                 p.grad = None
             torch.cuda.synchronize()

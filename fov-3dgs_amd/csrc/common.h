@@ -140,6 +140,15 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 	y1 = min(gy, max(0, f2i((py + r + (FR_TILE - 1)) / FR_TILE)));
 }
 
+// same with a fractional radius (conservative early-out of k_project)
+__device__ __forceinline__ void get_rect_f(float px, float py, float r, int gx, int gy, int &x0, int &y0, int &x1, int &y1)
+{
+	x0 = min(gx, max(0, f2i((px - r) / FR_TILE)));
+	y0 = min(gy, max(0, f2i((py - r) / FR_TILE)));
+	x1 = min(gx, max(0, f2i((px + r + (FR_TILE - 1)) / FR_TILE)));
+	y1 = min(gy, max(0, f2i((py + r + (FR_TILE - 1)) / FR_TILE)));
+}
+
 // Rectangle of tiles the binning kernels WALK for one splat. The reference walks getRect()'s rectangle
 // (the 3-sigma circle) and then rejects tiles with the OBB test (RS rasterizer_impl.cu:99-123) and, in RF,
 // the level test tile_min < highest_level + 1 (RF rasterizer_impl.cu:349-372). A tile outside the

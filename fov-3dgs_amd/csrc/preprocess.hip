@@ -212,7 +212,9 @@ struct Proj {
 	int radius, x0, y0, x1, y1;
 	uint32_t tnum;
 };
-__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, const float p[3])
+// sc / q: the Gaussian's raw scales and rotation (unused with cov3D_precomp); hl: RF highest level.
+template <bool FOV>
+__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, const float p[3], const float sc[3], float4 q, float hl)
 {
 	Proj r; r.alive = false; r.tnum = 0; r.radius = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0;
 	r.pix_x = r.pix_y = r.depth = r.conic_a = r.conic_b = r.conic_c = r.cov0 = r.cov1 = r.lambda1 = r.lambda2 = 0.f;
@@ -230,18 +232,72 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, cons
 	r.depth = t[2];
 	if (r.depth <= 0.2f) return r;
 
-	// 3D covariance: forward.cu:118-152
+	// Jacobian of the projection and T = W * J (EWA, forward.cu:74-113); needed by the early-out below
+	const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+	const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+	const float tx = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+	const float ty = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+	const M3 J = m3_cols(a.focal_x / t[2], 0, -(a.focal_x * tx) / (t[2] * t[2]),
+		0, a.focal_y / t[2], -(a.focal_y * ty) / (t[2] * t[2]),
+		0, 0, 0);
+	const M3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+	const M3 Tm = m3_mul(Wm, J);
+	// ndc2Pix is evaluated in double in the reference (auxiliary.h:41-44)
+	r.pix_x = (float)((((double)projx + 1.0) * a.W - 1.0) * 0.5);
+	r.pix_y = (float)((((double)projy + 1.0) * a.H - 1.0) * 0.5);
+
+	float s0 = 0, s1 = 0, s2 = 0;
 	float cov3D[6];
+	float rho; // upper bound of the spectral norm of the 3D covariance
 	if (a.cov3D_precomp != nullptr)
 	{
 #pragma unroll
 		for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+		rho = fabsf(cov3D[0]) + fabsf(cov3D[3]) + fabsf(cov3D[5]) + 2.0f * (fabsf(cov3D[1]) + fabsf(cov3D[2]) + fabsf(cov3D[4]));
 	}
 	else
 	{
 		const float mod = a.scale_modifier;
-		const float s0 = mod * a.scales[3 * (size_t)idx], s1 = mod * a.scales[3 * (size_t)idx + 1], s2 = mod * a.scales[3 * (size_t)idx + 2];
-		const float4 q = ((const float4 *)a.rotations)[idx];
+		s0 = mod * sc[0]; s1 = mod * sc[1]; s2 = mod * sc[2];
+		// Sigma = M^T M with M = S R, and R = (1 - 2|v|^2) I + 2 v v^T + 2 r [v]x has the singular values 1 and
+		// sqrt((1 - 2|v|^2)^2 + 4 r^2 |v|^2) (= 1 for a unit quaternion; the reference does not normalise here)
+		const float vv = q.y * q.y + q.z * q.z + q.w * q.w;
+		const float smax = fmaxf(fabsf(s0), fmaxf(fabsf(s1), fabsf(s2)));
+		rho = smax * smax * fmaxf(1.0f, (1.0f - 2.0f * vv) * (1.0f - 2.0f * vv) + 4.0f * q.x * q.x * vv);
+	}
+	// Conservative visibility test (more than half of the Gaussians in front of the camera of a room-scale scene
+	// cannot reach the frame): every entry of the 2D covariance is bounded by B = rho |T|_F^2 (+0.3 on the
+	// diagonal), hence lambda1 <= 2.42 B + 1.05 and the radius by r_ub below; getRect is monotone in the radius,
+	// so an empty rectangle for r_ub means an empty rectangle for the true radius and the reference drops the
+	// splat as well (forward.cu:229-231); RF: the same for the rectangle clipped to the level box, see
+	// walk_rect(). NaN/inf anywhere makes the test pass and the full path decide. (A wave leaves early only
+	// if all its 64 Gaussians fail, but then it skips two thirds of the arithmetic.)
+	{
+		float tf = 0.0f;
+#pragma unroll
+		for (int i = 0; i < 3; i++)
+#pragma unroll
+			for (int j = 0; j < 3; j++) tf += Tm.c[i][j] * Tm.c[i][j];
+		const float lam_ub = 2.42f * (rho * tf) + 1.05f;
+		const float r_ub = ceilf(3.0f * sqrtf(lam_ub)) * 1.01f + 2.0f;
+		if (r_ub < 1e9f)
+		{
+			int x0, y0, x1, y1;
+			get_rect_f(r.pix_x, r.pix_y, r_ub, a.gx, a.gy, x0, y0, x1, y1);
+			if (FOV)
+			{
+				const int k = (int)fminf(fmaxf(ceilf(hl + 1.0f), 0.0f), 4.0f);
+				const uint4 b = *(const uint4 *)(a.lv_bbox + k * FR_LV_BBOX_STRIDE);
+				x0 = max(x0, a.gx - (int)b.x); y0 = max(y0, a.gy - (int)b.y);
+				x1 = min(x1, (int)b.z); y1 = min(y1, (int)b.w);
+			}
+			if (x1 <= x0 || y1 <= y0) return r;
+		}
+	}
+
+	// 3D covariance: forward.cu:118-152
+	if (a.cov3D_precomp == nullptr)
+	{
 		const float rr = q.x, x = q.y, y = q.z, z = q.w;
 		const M3 S = m3_cols(s0, 0, 0, 0, s1, 0, 0, 0, s2);
 		const M3 R = m3_cols(
@@ -262,15 +318,6 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, cons
 	// 2D covariance (EWA): forward.cu:74-113
 	float cov[3];
 	{
-		const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
-		const float txtz = t[0] / t[2], tytz = t[1] / t[2];
-		const float tx = fminf(limx, fmaxf(-limx, txtz)) * t[2];
-		const float ty = fminf(limy, fmaxf(-limy, tytz)) * t[2];
-		const M3 J = m3_cols(a.focal_x / t[2], 0, -(a.focal_x * tx) / (t[2] * t[2]),
-			0, a.focal_y / t[2], -(a.focal_y * ty) / (t[2] * t[2]),
-			0, 0, 0);
-		const M3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
-		const M3 Tm = m3_mul(Wm, J);
 		const M3 Vrk = m3_cols(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
 		const M3 c = m3_mul(m3_mul(m3_t(Tm), m3_t(Vrk)), Tm);
 		cov[0] = c.c[0][0] + 0.3f; cov[1] = c.c[0][1]; cov[2] = c.c[1][1] + 0.3f;
@@ -283,9 +330,6 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, cons
 	r.lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
 	r.lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
 	const float my_radius = ceilf(3.f * sqrtf(fmaxf(r.lambda1, r.lambda2)));
-	// ndc2Pix is evaluated in double in the reference (auxiliary.h:41-44)
-	r.pix_x = (float)((((double)projx + 1.0) * a.W - 1.0) * 0.5);
-	r.pix_y = (float)((((double)projy + 1.0) * a.H - 1.0) * 0.5);
 	r.radius = f2i(my_radius);
 	get_rect(r.pix_x, r.pix_y, r.radius, a.gx, a.gy, r.x0, r.y0, r.x1, r.y1);
 	r.tnum = (uint32_t)(r.y1 - r.y0) * (uint32_t)(r.x1 - r.x0);
@@ -416,18 +460,38 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		__builtin_amdgcn_wave_barrier();
 		n = 0;
 	};
+	// The inputs of the NEXT chunk are fetched while the current one is projected: the kernel is a chain of
+	// load -> ~700 instructions -> store per chunk, and with ~5 waves per SIMD nothing else hides the loads.
+	struct Raw { float p[3], sc[3]; float4 q; float hl; };
+	const bool have_sr = a.cov3D_precomp == nullptr;
+	auto fetch = [&](const int idx)
+	{
+		Raw w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0); w.hl = 0.f;
+		if (idx < a.P)
+		{
+#pragma unroll
+			for (int i = 0; i < 3; i++) w.p[i] = a.means3D[3 * (size_t)idx + i];
+			if (have_sr)
+			{
+#pragma unroll
+				for (int i = 0; i < 3; i++) w.sc[i] = a.scales[3 * (size_t)idx + i];
+				w.q = ((const float4 *)a.rotations)[idx];
+			}
+			if (FOV) w.hl = a.highest_levels[idx];
+		}
+		return w;
+	};
 	const int nchunks = (a.P + 63) / 64;
 	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
 	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
+	Raw nxt = fetch(wave_gid < nchunks ? wave_gid * 64 + lane : a.P);
 	for (int chunk = wave_gid; chunk < nchunks; chunk += nwaves)
 	{
 		const int idx = chunk * 64 + lane;
+		const Raw cur = nxt;
+		nxt = fetch(chunk + nwaves < nchunks ? (chunk + nwaves) * 64 + lane : a.P);
 		Proj pr; pr.alive = false; pr.tnum = 0;
-		if (idx < a.P)
-		{
-			const float p[3] = { a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2] };
-			pr = project_gaussian(a, idx, p);
-		}
+		if (idx < a.P) pr = project_gaussian<FOV>(a, idx, cur.p, cur.sc, cur.q, cur.hl);
 		if (pr.alive)
 		{
 			float4 ev = make_float4(0, 0, 0, 0);
@@ -446,7 +510,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 			// splats whose clipped walk rectangle is empty land in no tile: the reference zeroes their radius
 			// after its rectangle walk (RS rasterizer_impl.cu:141-145), here they never reach k_bin
 			const WalkRect w = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el,
-				FOV ? a.highest_levels[idx] : 0.0f, a.lv_bbox);
+				cur.hl, a.lv_bbox);
 			pr.alive = w.tnum != 0;
 			if (pr.alive)
 			{
