@@ -12,6 +12,7 @@
 #define FR_BIN_THREADS 512    // workgroup size of the binning kernels (preprocess / emit)
 #define FR_BIN_BLOCKS 768     // persistent workgroups of the binning kernels (3 per CU)
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
+#define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_LV_BBOX_STRIDE 32  // words between the level boxes of ImageWS::lv_bbox (one 128-byte line each)
 #define FR_SLAB_CTR_WORDS 288 // header line + eight 128-byte counter lines
 
@@ -196,45 +197,42 @@ __device__ __forceinline__ WalkRect walk_rect(float px, float py, int radius, in
 }
 
 // Oriented-bounding-box vs tile separating-axis test: RS auxiliary.h:66-154.
+// The reference takes min/max over the four box corners (x, then y) and over the four tile corners projected on
+// the two box axes. Rounding is monotone, so the min/max of fl(u_i - t) is fl(min/max u_i - t) and the min/max of
+// fl(a_i + b_j) over all sign combinations is fl(min/max a + min/max b): the corner extremes are formed once per
+// splat and each axis needs two products per coordinate instead of four dot products -- same bits, half the work.
 struct Obb {
 	float cx, cy;        // splat centre (pixels)
 	float e1x, e1y, e2x, e2y, len1, len2;
-	float vx[4], vy[4];  // box corners
+	float vxmin, vxmax, vymin, vymax; // extremes of the box corners
 };
 __device__ __forceinline__ Obb make_obb(float cx, float cy, float4 ev, float2 el)
 {
 	Obb o; o.cx = cx; o.cy = cy; o.e1x = ev.x; o.e1y = ev.y; o.e2x = ev.z; o.e2y = ev.w; o.len1 = el.x; o.len2 = el.y;
-	const float d1x = o.len1 * o.e1x, d1y = o.len1 * o.e1y, d2x = o.len2 * o.e2x, d2y = o.len2 * o.e2y;
-	o.vx[0] = cx + d1x + d2x; o.vy[0] = cy + d1y + d2y;
-	o.vx[1] = cx - d1x + d2x; o.vy[1] = cy - d1y + d2y;
-	o.vx[2] = cx - d1x - d2x; o.vy[2] = cy - d1y - d2y;
-	o.vx[3] = cx + d1x - d2x; o.vy[3] = cy + d1y - d2y;
+	const float d1x = fabsf(o.len1 * o.e1x), d1y = fabsf(o.len1 * o.e1y), d2x = fabsf(o.len2 * o.e2x), d2y = fabsf(o.len2 * o.e2y);
+	// corners are cx +- d1x +- d2x (RS auxiliary.h:75-86), summed in that order
+	o.vxmax = cx + d1x + d2x; o.vxmin = cx - d1x - d2x;
+	o.vymax = cy + d1y + d2y; o.vymin = cy - d1y - d2y;
 	return o;
 }
 __device__ __forceinline__ bool obb_hits_tile(const Obb &o, int tx, int ty)
 {
 	const float tpx = (float)tx * (float)FR_TILE + (float)FR_TILE / 2.0f;
 	const float tpy = (float)ty * (float)FR_TILE + (float)FR_TILE / 2.0f;
-	float mn = o.vx[0] - tpx, mx = mn;
-#pragma unroll
-	for (int i = 1; i < 4; i++) { const float v = o.vx[i] - tpx; mn = fminf(mn, v); mx = fmaxf(mx, v); }
-	if (mx < -8.0f || mn > 8.0f) return false;
-	mn = o.vy[0] - tpy; mx = mn;
-#pragma unroll
-	for (int i = 1; i < 4; i++) { const float v = o.vy[i] - tpy; mn = fminf(mn, v); mx = fmaxf(mx, v); }
-	if (mx < -8.0f || mn > 8.0f) return false;
-	const float tvx[4] = { tpx + 8.0f - o.cx, tpx - 8.0f - o.cx, tpx - 8.0f - o.cx, tpx + 8.0f - o.cx };
-	const float tvy[4] = { tpy + 8.0f - o.cy, tpy + 8.0f - o.cy, tpy - 8.0f - o.cy, tpy - 8.0f - o.cy };
-	float d = tvx[0] * o.e1x + tvy[0] * o.e1y;
-	mn = d; mx = d;
-#pragma unroll
-	for (int i = 1; i < 4; i++) { d = tvx[i] * o.e1x + tvy[i] * o.e1y; mn = fminf(mn, d); mx = fmaxf(mx, d); }
-	if (o.len1 < mn || -o.len1 > mx) return false;
-	d = tvx[0] * o.e2x + tvy[0] * o.e2y;
-	mn = d; mx = d;
-#pragma unroll
-	for (int i = 1; i < 4; i++) { d = tvx[i] * o.e2x + tvy[i] * o.e2y; mn = fminf(mn, d); mx = fmaxf(mx, d); }
-	if (o.len2 < mn || -o.len2 > mx) return false;
+	if ((o.vxmax - tpx) < -8.0f || (o.vxmin - tpx) > 8.0f) return false;
+	if ((o.vymax - tpy) < -8.0f || (o.vymin - tpy) > 8.0f) return false;
+	// tile corners relative to the splat centre: x in {xp, xm}, y in {yp, ym}
+	const float xp = tpx + 8.0f - o.cx, xm = tpx - 8.0f - o.cx, yp = tpy + 8.0f - o.cy, ym = tpy - 8.0f - o.cy;
+	{
+		const float ap = xp * o.e1x, am = xm * o.e1x, bp = yp * o.e1y, bm = ym * o.e1y;
+		const float mn = fminf(ap, am) + fminf(bp, bm), mx = fmaxf(ap, am) + fmaxf(bp, bm);
+		if (o.len1 < mn || -o.len1 > mx) return false;
+	}
+	{
+		const float ap = xp * o.e2x, am = xm * o.e2x, bp = yp * o.e2y, bm = ym * o.e2y;
+		const float mn = fminf(ap, am) + fminf(bp, bm), mx = fmaxf(ap, am) + fmaxf(bp, bm);
+		if (o.len2 < mn || -o.len2 > mx) return false;
+	}
 	return true;
 }
 

@@ -140,7 +140,7 @@ __global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x,
 }
 
 // ---- SH colour: forward.cu:20-71 (full) and RF rasterizer_impl.cu:37-84 (rest only) -----------
-// sh points at 3*M floats of this Gaussian; REST: coefficient k is stored at slot k-1.
+// sh points at the navail = 3*M floats of this Gaussian; REST: coefficient k is stored at slot k-1.
 // Every lane reads its own Gaussian, i.e. its own cache lines, and a CU's address unit handles such a
 // scattered access lane by lane: 48 dword loads per Gaussian made this the slowest part of k_bin. The
 // coefficients are therefore fetched 16 bytes at a time (dword-aligned: 45 floats per Gaussian in RF) and
@@ -148,7 +148,7 @@ __global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x,
 // k = 0..15 left to right), so the result is bit-identical to the scalar formulation.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 template <bool REST>
-__device__ __forceinline__ void sh_colour(int deg, const float *__restrict__ sh, float dx, float dy, float dz, float out[3])
+__device__ __forceinline__ void sh_colour(int deg, int navail, const float *__restrict__ sh, float dx, float dy, float dz, float out[3])
 {
 	const float len = sqrtf(dx * dx + dy * dy + dz * dz);
 	const float x = dx / len, y = dy / len, z = dz / len;
@@ -164,22 +164,38 @@ __device__ __forceinline__ void sh_colour(int deg, const float *__restrict__ sh,
 	constexpr int SKIP = REST ? 1 : 0;
 	const int nfl = 3 * ((deg + 1) * (deg + 1) - SKIP); // floats in use
 	float acc[3] = { 0.0f, 0.0f, 0.0f };
-#pragma unroll
-	for (int q = 0; q < 12; q++)
+	if (navail >= 48 - 3 * SKIP)
 	{
-		if (4 * q + 4 <= nfl)
-		{
-			const f4u v = *(const f4u *)(sh + 4 * q);
+		// usual case (M = 16 coefficients allocated): every chunk is fetched unconditionally, so the loads are
+		// issued back to back and cost ONE memory round trip; chunks beyond the active degree are ignored
+		f4u v[12];
 #pragma unroll
-			for (int j = 0; j < 4; j++) { const int i = 4 * q + j; acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * v[j]; }
-		}
-		else
-		{
+		for (int q = 0; q < 11; q++) v[q] = *(const f4u *)(sh + 4 * q);
+		if (REST) v[11] = (f4u){ sh[44], 0.0f, 0.0f, 0.0f };
+		else v[11] = *(const f4u *)(sh + 44);
 #pragma unroll
-			for (int j = 0; j < 4; j++)
+		for (int i = 0; i < 48 - 3 * SKIP; i++)
+			if (i < nfl) acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * v[i / 4][i % 4];
+	}
+	else
+	{
+#pragma unroll
+		for (int q = 0; q < 12; q++)
+		{
+			if (4 * q + 4 <= nfl)
 			{
-				const int i = 4 * q + j;
-				if (i < nfl) acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * sh[i];
+				const f4u v = *(const f4u *)(sh + 4 * q);
+#pragma unroll
+				for (int j = 0; j < 4; j++) { const int i = 4 * q + j; acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * v[j]; }
+			}
+			else
+			{
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+				{
+					const int i = 4 * q + j;
+					if (i < nfl) acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * sh[i];
+				}
 			}
 		}
 	}
@@ -661,15 +677,65 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	TM_END(tm_l);
 	// everything else: wave-balanced pair loop
 	{
+		uint32_t lvmask = 0; // FOV: bit l = some kept tile has int(level) == l; bit 4 = some kept tile blends
+		// Splats with at least a wave's worth of tiles are walked by the whole wave ONE AT A TIME: the owner is
+		// wave-uniform (scalar registers), so a step needs no owner search and no shuffles and is ~3x shorter
+		// than a step of the mixed loop below. A frame-filling splat is 128 such steps and sits on the
+		// kernel's critical path.
+		const bool big = pr.alive && !in_place && pr.tnum >= FR_BIG_TNUM;
+		if (__ballot(big)) __builtin_amdgcn_s_setprio(3);
+		for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1)
+		{
+			const int L = __ffsll((long long)bigm) - 1;
+			const int ox0 = bcast_i(pr.x0, L), oy0 = bcast_i(pr.y0, L), ow = bcast_i(pr.x1, L) - ox0;
+			const uint32_t on = (uint32_t)bcast_i((int)pr.tnum, L);
+			const float4 oev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
+			const float2 oel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
+			const Obb ob = make_obb(bcast_f(pr.pix_x, L), bcast_f(pr.pix_y, L), oev, oel);
+			const float olim = bcast_f(hl, L) + 1;
+			const float rw = 1.0f / (float)ow;
+			uint32_t cnt = 0, bits = 0;
+#ifdef FR_BIN_TIMERS
+			tm_steps += (int)((on + 63) / 64);
+#endif
+			for (uint32_t k = 0; k < on; k += 64)
+			{
+				const uint32_t j = k + lane;
+				const bool valid = j < on;
+				int ry = (int)(((float)j + 0.5f) * rw); // j / ow for j < 2^23, fixed up below
+				int rx = (int)j - ry * ow;
+				if (rx < 0) { ry--; rx += ow; } else if (rx >= ow) { ry++; rx -= ow; }
+				const int x = ox0 + rx, y = oy0 + ry;
+				const int ti = valid ? y * a.gx + x : 0;
+				bool pass = valid;
+				uint32_t m = 0;
+				if (CULL)
+				{
+					float level = 0.f;
+					if (FOV) { level = TILE_MIN(ti); pass = pass && (level < olim); }
+					pass = pass && obb_hits_tile(ob, x, y);
+					if (FOV && pass) m = (1u << min(max(f2i(level), 0), 3)) | (TILE_BLENDS(ti) ? 16u : 0u);
+				}
+				if (pass) BUMP_TILE(ti);
+				cnt += (uint32_t)__popcll(__ballot(pass));
+				if (FOV)
+				{
+#pragma unroll
+					for (int bit = 0; bit < 5; bit++)
+						if (__ballot((m >> bit) & 1u)) bits |= 1u << bit;
+				}
+			}
+			if (lane == L) { count = cnt; lvmask = bits; }
+		}
+		__builtin_amdgcn_s_setprio(0);
 #ifdef FR_EXP_NOPAIRS
 		const uint32_t my_n = 0u; if (pr.alive && !in_place) count = 1;
 #else
-		const uint32_t my_n = (pr.alive && !in_place) ? pr.tnum : 0u;
+		const uint32_t my_n = (pr.alive && !in_place && !big) ? pr.tnum : 0u;
 #endif
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		uint32_t lvmask = 0; // FOV: bit l = some kept tile has int(level) == l; bit 4 = some kept tile blends
 #ifdef FR_BIN_TIMERS
 		tm_steps += (int)((total + 63) / 64);
 #endif
@@ -716,7 +782,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 					if (__ballot((m >> bit) & 1u) & mine) lvmask |= 1u << bit;
 			}
 		}
-		if (FOV && my_n != 0 && count != 0)
+		if (FOV && (my_n != 0 || big) && count != 0)
 		{
 			// int(lowest) / int(highest) of RF rasterizer_impl.cu:374-381 from the per-level bits: truncation is
 			// monotone, so int(min(levels)) == min(int(level)); lowest starts at the Gaussian's own level
@@ -744,7 +810,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		if (a.colors_precomp == nullptr)
 		{
 			float c[3];
-			sh_colour<false>(a.D, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, c);
+			sh_colour<false>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, c);
 #pragma unroll
 			for (int ch = 0; ch < 3; ch++) { if (c[ch] < 0) clamp_bits |= 1u << ch; rgb[ch] = fmaxf(c[ch], 0.0f); }
 		}
@@ -761,20 +827,30 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		int hi = f2i(highest);
 		if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
 		a.geom.lrange[idx] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
+		// all four levels' DC colours (12 floats) and opacities are fetched with the SH coefficients: one round trip
+		const f4u *dcp = (const f4u *)(a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
+		const f4u dc0 = dcp[0], dc1 = dcp[1], dc2 = dcp[2];
+		const f4u opl = *(const f4u *)(a.opacities + (size_t)idx * FR_FOV_LEVELS);
+		const float dcs[12] = { dc0.x, dc0.y, dc0.z, dc0.w, dc1.x, dc1.y, dc1.z, dc1.w, dc2.x, dc2.y, dc2.z, dc2.w };
+		const float ops[4] = { opl.x, opl.y, opl.z, opl.w };
 		float rest[3];
-		sh_colour<true>(a.D, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, rest);
+		sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, rest);
 #ifdef FR_BIN_TIMERS
 		{ const uint64_t now_ = wall_clock64(); if (rest[0] != 123.f) tm_sh += now_ - tm_x; }
 #endif
-		for (int l = lo; l <= hi; l++)
+		static_assert(FR_FOV_LEVELS == 4, "level data is fetched as float4s");
+#pragma unroll
+		for (int l = 0; l < FR_FOV_LEVELS; l++)
 		{
-			const float *dc = a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS + l * 3;
-			float4 v;
-			v.x = fmaxf(FR_SH_C0 * dc[0] + rest[0], 0.0f);
-			v.y = fmaxf(FR_SH_C0 * dc[1] + rest[1], 0.0f);
-			v.z = fmaxf(FR_SH_C0 * dc[2] + rest[2], 0.0f);
-			v.w = a.opacities[(size_t)idx * FR_FOV_LEVELS + l];
-			a.geom.lvl[(size_t)idx * FR_FOV_LEVELS + l] = v;
+			if (l >= lo && l <= hi)
+			{
+				float4 v;
+				v.x = fmaxf(FR_SH_C0 * dcs[3 * l] + rest[0], 0.0f);
+				v.y = fmaxf(FR_SH_C0 * dcs[3 * l + 1] + rest[1], 0.0f);
+				v.z = fmaxf(FR_SH_C0 * dcs[3 * l + 2] + rest[2], 0.0f);
+				v.w = ops[l];
+				a.geom.lvl[(size_t)idx * FR_FOV_LEVELS + l] = v;
+			}
 		}
 	}
 	float4 *rec = a.geom.rec + 3 * (size_t)idx;
@@ -874,7 +950,38 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_bin's level test, no box test (single-tile splat)
 	if (in_place) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
 	{
-		const uint32_t my_n = (alive && !in_place) ? tnum : 0u;
+		// big splats: whole wave, wave-uniform owner (see k_bin)
+		const bool big = alive && !in_place && tnum >= FR_BIG_TNUM;
+		for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1)
+		{
+			const int L = __ffsll((long long)bigm) - 1;
+			const int ox0 = bcast_i(x0, L), oy0 = bcast_i(y0, L), ow = bcast_i(x1, L) - ox0;
+			const uint32_t on = (uint32_t)bcast_i((int)tnum, L);
+			const float4 oev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
+			const float2 oel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
+			const Obb ob = make_obb(bcast_f(cx, L), bcast_f(cy, L), oev, oel);
+			const float olim = bcast_f(hl, L) + 1;
+			const uint64_t opay = ((uint64_t)(uint32_t)bcast_i((int)depth_bits, L) << 32) | (uint32_t)bcast_i(idx, L);
+			const float rw = 1.0f / (float)ow;
+			for (uint32_t k = 0; k < on; k += 64)
+			{
+				const uint32_t j = k + lane;
+				const bool valid = j < on;
+				int ry = (int)(((float)j + 0.5f) * rw);
+				int rx = (int)j - ry * ow;
+				if (rx < 0) { ry--; rx += ow; } else if (rx >= ow) { ry++; rx -= ow; }
+				const int x = ox0 + rx, y = oy0 + ry;
+				const int ti = valid ? y * a.gx + x : 0;
+				bool pass = valid;
+				if (CULL)
+				{
+					if (FOV) pass = pass && ((ldst ? lds_tmin[ti] : tile_min[ti]) < olim);
+					pass = pass && obb_hits_tile(ob, x, y);
+				}
+				if (pass) a.entries[NEXT_SLOT(ti)] = opay;
+			}
+		}
+		const uint32_t my_n = (alive && !in_place && !big) ? tnum : 0u;
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
