@@ -13,6 +13,8 @@
 #define FR_BIN_BLOCKS 768     // persistent workgroups of the binning kernels (3 per CU)
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
+#define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop
+#define FR_GIANT_MAX 64         // giant splats a workgroup can set aside (more: handled like big ones)
 #define FR_LV_BBOX_STRIDE 32  // words between the level boxes of ImageWS::lv_bbox (one 128-byte line each)
 #define FR_SLAB_CTR_WORDS 288 // header line + eight 128-byte counter lines
 

@@ -578,6 +578,14 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	}
 	if (LDSH)
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
+	// "giant" splats (FR_GIANT_TNUM+ tiles, up to the whole frame = 128 wave steps) are set aside here and walked
+	// by ALL waves of the workgroup after the slab loop: left to the wave that met them they were the kernel's
+	// critical path
+	__shared__ int s_gidx[FR_GIANT_MAX];
+	__shared__ uint32_t s_gcount[FR_GIANT_MAX], s_gmask[FR_GIANT_MAX];
+	__shared__ uint32_t s_ng;
+	if (threadIdx.x < FR_GIANT_MAX) { s_gcount[threadIdx.x] = 0; s_gmask[threadIdx.x] = 0; }
+	if (threadIdx.x == 0) s_ng = 0;
 	__syncthreads();
 #define TILE_MIN(ti) (ldst ? lds_tmin[(ti)] : tile_min[(ti)])
 #define TILE_BLENDS(ti) (ldst ? ((lds_blend[(ti) >> 5] >> ((ti) & 31)) & 1u) != 0u : tile_bl[(ti)] != 0.0f)
@@ -597,6 +605,110 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	const int nwaves = (int)gridDim.x * (FR_BIN_THREADS / 64);
 	int region = (int)blockIdx.x & 7;
 	int chain = -1; // last slab this wave pulled
+	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
+	const float *tile_bl = FOV ? a.tile_lv + 4 * (size_t)a.T : nullptr;
+	// Wave-uniform walk of ONE splat's rectangle: lanes take tiles k0 + lane, k0 + lane + kstep, ... of the on
+	// tiles; returns the number of tiles kept and (RF) their level bits. No owner search, no shuffles.
+	auto walk_uniform = [&](const int ox0, const int oy0, const int ow, const uint32_t on, const Obb &ob, const float olim,
+		const uint32_t k0, const uint32_t kstep, uint32_t &cnt, uint32_t &bits)
+	{
+		const float rw = 1.0f / (float)ow;
+		for (uint32_t k = k0; k < on; k += kstep)
+		{
+			const uint32_t j = k + lane;
+			const bool valid = j < on;
+			int ry = (int)(((float)j + 0.5f) * rw); // j / ow for j < 2^23, fixed up below
+			int rx = (int)j - ry * ow;
+			if (rx < 0) { ry--; rx += ow; } else if (rx >= ow) { ry++; rx -= ow; }
+			const int x = ox0 + rx, y = oy0 + ry;
+			const int ti = valid ? y * a.gx + x : 0;
+			bool pass = valid;
+			uint32_t m = 0;
+			if (CULL)
+			{
+				float level = 0.f;
+				if (FOV) { level = TILE_MIN(ti); pass = pass && (level < olim); }
+				pass = pass && obb_hits_tile(ob, x, y);
+				if (FOV && pass) m = (1u << min(max(f2i(level), 0), 3)) | (TILE_BLENDS(ti) ? 16u : 0u);
+			}
+			if (pass) BUMP_TILE(ti);
+			cnt += (uint32_t)__popcll(__ballot(pass));
+			if (FOV)
+			{
+#pragma unroll
+				for (int bit = 0; bit < 5; bit++)
+					if (__ballot((m >> bit) & 1u)) bits |= 1u << bit;
+			}
+		}
+	};
+	// int(lowest) / int(highest) of RF rasterizer_impl.cu:374-381 from the per-level bits: truncation is
+	// monotone, so int(min(levels)) == min(int(level)); lowest starts at the Gaussian's own level
+	auto range_from_mask = [&](const uint32_t lvmask, float &lowest, float &highest, bool &be_blend)
+	{
+		const int lo_bit = __ffs((int)(lvmask & 15u)) - 1, hi_bit = 31 - __clz((int)(lvmask & 15u));
+		lowest = fminf(lowest, (float)lo_bit);
+		highest = fmaxf(highest, (float)hi_bit);
+		be_blend = (lvmask & 16u) != 0;
+	};
+	// Per-Gaussian epilogue once its tile count is known: radius of culled-everywhere splats, colour(s), final record.
+	auto finish = [&](const int idx, const uint32_t count, const float hl, const float lowest, const float highest,
+		const bool be_blend, const float conic_c, const float depth)
+	{
+		if (count == 0) { a.radii[idx] = 0; return; } // culled everywhere (RS rasterizer_impl.cu:141-145)
+		float rgb[3] = { 0, 0, 0 };
+		uint32_t clamp_bits = 0;
+		const float dirx = a.means3D[3 * (size_t)idx] - a.campos[0], diry = a.means3D[3 * (size_t)idx + 1] - a.campos[1],
+			dirz = a.means3D[3 * (size_t)idx + 2] - a.campos[2];
+		if (!FOV)
+		{
+			if (a.colors_precomp == nullptr)
+			{
+				float c[3];
+				sh_colour<false>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, c);
+#pragma unroll
+				for (int ch = 0; ch < 3; ch++) { if (c[ch] < 0) clamp_bits |= 1u << ch; rgb[ch] = fmaxf(c[ch], 0.0f); }
+			}
+			else
+			{
+#pragma unroll
+				for (int ch = 0; ch < 3; ch++) rgb[ch] = a.colors_precomp[3 * (size_t)idx + ch];
+			}
+		}
+		else
+		{
+			// RF rasterizer_impl.cu:374-381 (level range) + :490-530 (per-level colours)
+			const int lo = f2i(lowest);
+			int hi = f2i(highest);
+			if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
+			a.geom.lrange[idx] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
+			// all four levels' DC colours (12 floats) and opacities are fetched with the SH coefficients: one round trip
+			const f4u *dcp = (const f4u *)(a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
+			const f4u dc0 = dcp[0], dc1 = dcp[1], dc2 = dcp[2];
+			const f4u opl = *(const f4u *)(a.opacities + (size_t)idx * FR_FOV_LEVELS);
+			const float dcs[12] = { dc0.x, dc0.y, dc0.z, dc0.w, dc1.x, dc1.y, dc1.z, dc1.w, dc2.x, dc2.y, dc2.z, dc2.w };
+			const float ops[4] = { opl.x, opl.y, opl.z, opl.w };
+			float rest[3];
+			sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, rest);
+			static_assert(FR_FOV_LEVELS == 4, "level data is fetched as float4s");
+#pragma unroll
+			for (int l = 0; l < FR_FOV_LEVELS; l++)
+			{
+				if (l >= lo && l <= hi)
+				{
+					float4 v;
+					v.x = fmaxf(FR_SH_C0 * dcs[3 * l] + rest[0], 0.0f);
+					v.y = fmaxf(FR_SH_C0 * dcs[3 * l + 1] + rest[1], 0.0f);
+					v.z = fmaxf(FR_SH_C0 * dcs[3 * l + 2] + rest[2], 0.0f);
+					v.w = ops[l];
+					a.geom.lvl[(size_t)idx * FR_FOV_LEVELS + l] = v;
+				}
+			}
+		}
+		float4 *rec = a.geom.rec + 3 * (size_t)idx;
+		if (FOV) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
+		else rec[1] = make_float4(conic_c, a.opacities[idx], rgb[0], rgb[1]);
+		rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), 0.0f);
+	};
 #ifdef FR_BIN_TIMERS
 	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0;
 #define TM_BEGIN() tm_x = wall_clock64()
@@ -642,8 +754,6 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	float2 el = make_float2(0, 0);
 	float hl = 0, lowest = 0, highest = 0;
 	bool be_blend = false, boxtest = false;
-	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
-	const float *tile_bl = FOV ? a.tile_lv + 4 * (size_t)a.T : nullptr;
 	if (item < V)
 	{
 		idx = (int)a.geom.vis_list[item];
@@ -682,7 +792,13 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		// wave-uniform (scalar registers), so a step needs no owner search and no shuffles and is ~3x shorter
 		// than a step of the mixed loop below. A frame-filling splat is 128 such steps and sits on the
 		// kernel's critical path.
-		const bool big = pr.alive && !in_place && pr.tnum >= FR_BIG_TNUM;
+		bool deferred = false;
+		if (pr.alive && !in_place && pr.tnum >= FR_GIANT_TNUM)
+		{
+			const uint32_t slot = atomicAdd(&s_ng, 1u);
+			if (slot < FR_GIANT_MAX) { s_gidx[slot] = idx; deferred = true; }
+		}
+		const bool big = pr.alive && !in_place && !deferred && pr.tnum >= FR_BIG_TNUM;
 		if (__ballot(big)) __builtin_amdgcn_s_setprio(3);
 		for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1)
 		{
@@ -692,46 +808,18 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			const float4 oev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
 			const float2 oel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
 			const Obb ob = make_obb(bcast_f(pr.pix_x, L), bcast_f(pr.pix_y, L), oev, oel);
-			const float olim = bcast_f(hl, L) + 1;
-			const float rw = 1.0f / (float)ow;
 			uint32_t cnt = 0, bits = 0;
 #ifdef FR_BIN_TIMERS
 			tm_steps += (int)((on + 63) / 64);
 #endif
-			for (uint32_t k = 0; k < on; k += 64)
-			{
-				const uint32_t j = k + lane;
-				const bool valid = j < on;
-				int ry = (int)(((float)j + 0.5f) * rw); // j / ow for j < 2^23, fixed up below
-				int rx = (int)j - ry * ow;
-				if (rx < 0) { ry--; rx += ow; } else if (rx >= ow) { ry++; rx -= ow; }
-				const int x = ox0 + rx, y = oy0 + ry;
-				const int ti = valid ? y * a.gx + x : 0;
-				bool pass = valid;
-				uint32_t m = 0;
-				if (CULL)
-				{
-					float level = 0.f;
-					if (FOV) { level = TILE_MIN(ti); pass = pass && (level < olim); }
-					pass = pass && obb_hits_tile(ob, x, y);
-					if (FOV && pass) m = (1u << min(max(f2i(level), 0), 3)) | (TILE_BLENDS(ti) ? 16u : 0u);
-				}
-				if (pass) BUMP_TILE(ti);
-				cnt += (uint32_t)__popcll(__ballot(pass));
-				if (FOV)
-				{
-#pragma unroll
-					for (int bit = 0; bit < 5; bit++)
-						if (__ballot((m >> bit) & 1u)) bits |= 1u << bit;
-				}
-			}
+			walk_uniform(ox0, oy0, ow, on, ob, bcast_f(hl, L) + 1, 0u, 64u, cnt, bits);
 			if (lane == L) { count = cnt; lvmask = bits; }
 		}
 		__builtin_amdgcn_s_setprio(0);
 #ifdef FR_EXP_NOPAIRS
-		const uint32_t my_n = 0u; if (pr.alive && !in_place) count = 1;
+		const uint32_t my_n = 0u; if (pr.alive && !in_place && !deferred) count = 1;
 #else
-		const uint32_t my_n = (pr.alive && !in_place && !big) ? pr.tnum : 0u;
+		const uint32_t my_n = (pr.alive && !in_place && !big && !deferred) ? pr.tnum : 0u;
 #endif
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
@@ -782,95 +870,53 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 					if (__ballot((m >> bit) & 1u) & mine) lvmask |= 1u << bit;
 			}
 		}
-		if (FOV && (my_n != 0 || big) && count != 0)
-		{
-			// int(lowest) / int(highest) of RF rasterizer_impl.cu:374-381 from the per-level bits: truncation is
-			// monotone, so int(min(levels)) == min(int(level)); lowest starts at the Gaussian's own level
-			const int lo_bit = __ffs((int)(lvmask & 15u)) - 1, hi_bit = 31 - __clz((int)(lvmask & 15u));
-			lowest = fminf(lowest, (float)lo_bit);
-			highest = fmaxf(highest, (float)hi_bit);
-			be_blend = (lvmask & 16u) != 0;
-		}
+		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
+		TM_END(tm_p);
+		if (pr.alive && !deferred) finish(idx, count, hl, lowest, highest, be_blend, r1.x, r2.y);
 	}
-	TM_END(tm_p);
-	if (pr.alive && count == 0) a.radii[idx] = 0; // culled everywhere (RS rasterizer_impl.cu:141-145)
-#ifdef FR_EXP_NOCOLOR
-	if (false)
-#else
-	if (pr.alive && count != 0)
-#endif
-	{
-	// ---- colour ----
-	float rgb[3] = { 0, 0, 0 };
-	uint32_t clamp_bits = 0;
-	const float dirx = a.means3D[3 * (size_t)idx] - a.campos[0], diry = a.means3D[3 * (size_t)idx + 1] - a.campos[1],
-		dirz = a.means3D[3 * (size_t)idx + 2] - a.campos[2];
-	if (!FOV)
-	{
-		if (a.colors_precomp == nullptr)
-		{
-			float c[3];
-			sh_colour<false>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, c);
-#pragma unroll
-			for (int ch = 0; ch < 3; ch++) { if (c[ch] < 0) clamp_bits |= 1u << ch; rgb[ch] = fmaxf(c[ch], 0.0f); }
-		}
-		else
-		{
-#pragma unroll
-			for (int ch = 0; ch < 3; ch++) rgb[ch] = a.colors_precomp[3 * (size_t)idx + ch];
-		}
-	}
-	else
-	{
-		// RF rasterizer_impl.cu:374-381 (level range) + :490-530 (per-level colours)
-		const int lo = f2i(lowest);
-		int hi = f2i(highest);
-		if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
-		a.geom.lrange[idx] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
-		// all four levels' DC colours (12 floats) and opacities are fetched with the SH coefficients: one round trip
-		const f4u *dcp = (const f4u *)(a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
-		const f4u dc0 = dcp[0], dc1 = dcp[1], dc2 = dcp[2];
-		const f4u opl = *(const f4u *)(a.opacities + (size_t)idx * FR_FOV_LEVELS);
-		const float dcs[12] = { dc0.x, dc0.y, dc0.z, dc0.w, dc1.x, dc1.y, dc1.z, dc1.w, dc2.x, dc2.y, dc2.z, dc2.w };
-		const float ops[4] = { opl.x, opl.y, opl.z, opl.w };
-		float rest[3];
-		sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, rest);
-#ifdef FR_BIN_TIMERS
-		{ const uint64_t now_ = wall_clock64(); if (rest[0] != 123.f) tm_sh += now_ - tm_x; }
-#endif
-		static_assert(FR_FOV_LEVELS == 4, "level data is fetched as float4s");
-#pragma unroll
-		for (int l = 0; l < FR_FOV_LEVELS; l++)
-		{
-			if (l >= lo && l <= hi)
-			{
-				float4 v;
-				v.x = fmaxf(FR_SH_C0 * dcs[3 * l] + rest[0], 0.0f);
-				v.y = fmaxf(FR_SH_C0 * dcs[3 * l + 1] + rest[1], 0.0f);
-				v.z = fmaxf(FR_SH_C0 * dcs[3 * l + 2] + rest[2], 0.0f);
-				v.w = ops[l];
-				a.geom.lvl[(size_t)idx * FR_FOV_LEVELS + l] = v;
-			}
-		}
-	}
-	float4 *rec = a.geom.rec + 3 * (size_t)idx;
-	if (FOV) rec[1] = make_float4(r1.x, hl, 0.0f, 0.0f);
-	else rec[1] = make_float4(r1.x, a.opacities[idx], rgb[0], rgb[1]);
-	rec[2] = make_float4(rgb[2], r2.y, __uint_as_float(clamp_bits), 0.0f);
-	} // visible
 	TM_END(tm_c);
 	} // slab loop
+#ifdef FR_BIN_TIMERS
+	const uint64_t tm_loop_end = wall_clock64();
+#endif
+	if (LDSH && lane == 0) a.geom.wave_head[wave_gid] = chain;
+	// ---- giant splats: every wave of the workgroup takes every (FR_BIN_THREADS / 64)-th step ----
+	__syncthreads();
+	const int ng = min((int)s_ng, FR_GIANT_MAX);
+	for (int g = 0; g < ng; g++)
+	{
+		const int gi = s_gidx[g];
+		const float4 r0 = a.geom.rec[3 * (size_t)gi];
+		float4 gev = make_float4(0, 0, 0, 0); float2 gel = make_float2(0, 0);
+		if (CULL) { gev = a.geom.evec[gi]; gel = a.geom.elen[gi]; }
+		const float ghl = FOV ? a.highest_levels[gi] : 0.0f;
+		const WalkRect w = walk_rect<CULL, FOV>(r0.x, r0.y, a.radii[gi], a.gx, a.gy, gev, gel, ghl, a.lv_bbox);
+		const Obb ob = make_obb(r0.x, r0.y, gev, gel);
+		uint32_t cnt = 0, bits = 0;
+		walk_uniform(w.x0, w.y0, w.x1 - w.x0, w.tnum, ob, ghl + 1, (uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_BIN_THREADS, cnt, bits);
+		if (lane == 0) { atomicAdd(&s_gcount[g], cnt); if (FOV) atomicOr(&s_gmask[g], bits); }
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < ng)
+	{
+		const int gi = s_gidx[threadIdx.x];
+		const uint32_t gcount = s_gcount[threadIdx.x];
+		const float ghl = FOV ? a.highest_levels[gi] : 0.0f;
+		float lowest = ghl, highest = 0.0f;
+		bool be_blend = false;
+		if (FOV && gcount != 0) range_from_mask(s_gmask[threadIdx.x], lowest, highest, be_blend);
+		finish(gi, gcount, ghl, lowest, highest, be_blend, a.geom.rec[3 * (size_t)gi + 1].x, a.geom.rec[3 * (size_t)gi + 2].y);
+	}
 #ifdef FR_BIN_TIMERS
 	if (lane == 0)
 	{
 		float *d = a.geom.cov3D + (size_t)wave_gid * 8;
-		d[0] = (float)(wall_clock64() - tm0); d[1] = (float)tm_s; d[2] = (float)tm_l; d[3] = (float)tm_p; d[4] = (float)tm_c;
+		d[0] = (float)(wall_clock64() - tm0); d[1] = (float)(tm_loop_end - tm0); d[2] = (float)tm_l; d[3] = (float)tm_p; d[4] = (float)tm_c;
 		d[5] = (float)tm_n; d[6] = (float)tm_sh; d[7] = (float)tm_steps;
 	}
 #endif
 	if (LDSH)
 	{
-		if (lane == 0) a.geom.wave_head[wave_gid] = chain;
 		__syncthreads();
 		uint32_t *out = a.hist + (size_t)blockIdx.x * a.T;
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) out[t] = lds_hist[t];
@@ -920,6 +966,33 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	}
 	__syncthreads();
 	__shared__ int s_own[FR_BIN_THREADS];
+	__shared__ int s_gidx[FR_GIANT_MAX]; // giant splats, walked by the whole workgroup at the end (see k_bin)
+	__shared__ uint32_t s_ng;
+	if (threadIdx.x == 0) s_ng = 0;
+	__syncthreads();
+	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
+	auto walk_uniform = [&](const int ox0, const int oy0, const int ow, const uint32_t on, const Obb &ob, const float olim,
+		const uint64_t opay, const uint32_t k0, const uint32_t kstep)
+	{
+		const float rw = 1.0f / (float)ow;
+		for (uint32_t k = k0; k < on; k += kstep)
+		{
+			const uint32_t j = k + lane;
+			const bool valid = j < on;
+			int ry = (int)(((float)j + 0.5f) * rw);
+			int rx = (int)j - ry * ow;
+			if (rx < 0) { ry--; rx += ow; } else if (rx >= ow) { ry++; rx -= ow; }
+			const int x = ox0 + rx, y = oy0 + ry;
+			const int ti = valid ? y * a.gx + x : 0;
+			bool pass = valid;
+			if (CULL)
+			{
+				if (FOV) pass = pass && ((ldst ? lds_tmin[ti] : tile_min[ti]) < olim);
+				pass = pass && obb_hits_tile(ob, x, y);
+			}
+			if (pass) a.entries[NEXT_SLOT(ti)] = opay;
+		}
+	};
 	const int V = (int)a.geom.slab_ctr[1];
 	const int nslabs = (V + 63) / 64; // wave-sized slabs, as in k_bin
 	auto process = [&](const int slab)
@@ -945,43 +1018,29 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 		const WalkRect w = walk_rect<CULL, FOV>(cx, cy, radius, a.gx, a.gy, ev, el, hl, a.lv_bbox);
 		x0 = w.x0; y0 = w.y0; x1 = w.x1; tnum = w.tnum; boxtest = w.boxtest;
 	}
-	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
 	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
 	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_bin's level test, no box test (single-tile splat)
 	if (in_place) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
 	{
+		bool deferred = false;
+		if (alive && !in_place && tnum >= FR_GIANT_TNUM)
+		{
+			const uint32_t slot = atomicAdd(&s_ng, 1u);
+			if (slot < FR_GIANT_MAX) { s_gidx[slot] = idx; deferred = true; }
+		}
 		// big splats: whole wave, wave-uniform owner (see k_bin)
-		const bool big = alive && !in_place && tnum >= FR_BIG_TNUM;
+		const bool big = alive && !in_place && !deferred && tnum >= FR_BIG_TNUM;
 		for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1)
 		{
 			const int L = __ffsll((long long)bigm) - 1;
 			const int ox0 = bcast_i(x0, L), oy0 = bcast_i(y0, L), ow = bcast_i(x1, L) - ox0;
-			const uint32_t on = (uint32_t)bcast_i((int)tnum, L);
 			const float4 oev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
 			const float2 oel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
 			const Obb ob = make_obb(bcast_f(cx, L), bcast_f(cy, L), oev, oel);
-			const float olim = bcast_f(hl, L) + 1;
 			const uint64_t opay = ((uint64_t)(uint32_t)bcast_i((int)depth_bits, L) << 32) | (uint32_t)bcast_i(idx, L);
-			const float rw = 1.0f / (float)ow;
-			for (uint32_t k = 0; k < on; k += 64)
-			{
-				const uint32_t j = k + lane;
-				const bool valid = j < on;
-				int ry = (int)(((float)j + 0.5f) * rw);
-				int rx = (int)j - ry * ow;
-				if (rx < 0) { ry--; rx += ow; } else if (rx >= ow) { ry++; rx -= ow; }
-				const int x = ox0 + rx, y = oy0 + ry;
-				const int ti = valid ? y * a.gx + x : 0;
-				bool pass = valid;
-				if (CULL)
-				{
-					if (FOV) pass = pass && ((ldst ? lds_tmin[ti] : tile_min[ti]) < olim);
-					pass = pass && obb_hits_tile(ob, x, y);
-				}
-				if (pass) a.entries[NEXT_SLOT(ti)] = opay;
-			}
+			walk_uniform(ox0, oy0, ow, (uint32_t)bcast_i((int)tnum, L), ob, bcast_f(hl, L) + 1, opay, 0u, 64u);
 		}
-		const uint32_t my_n = (alive && !in_place && !big) ? tnum : 0u;
+		const uint32_t my_n = (alive && !in_place && !big && !deferred) ? tnum : 0u;
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1035,6 +1094,20 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 		const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
 		const int nwaves = (int)gridDim.x * (FR_BIN_THREADS / 64);
 		for (int slab = wave_gid; slab < nslabs; slab += nwaves) process(slab);
+	}
+	__syncthreads();
+	const int ng = min((int)s_ng, FR_GIANT_MAX);
+	for (int g = 0; g < ng; g++)
+	{
+		const int gi = s_gidx[g];
+		const float4 r0 = a.geom.rec[3 * (size_t)gi];
+		float4 gev = make_float4(0, 0, 0, 0); float2 gel = make_float2(0, 0);
+		if (CULL) { gev = a.geom.evec[gi]; gel = a.geom.elen[gi]; }
+		const float ghl = FOV ? a.highest_levels[gi] : 0.0f;
+		const WalkRect w = walk_rect<CULL, FOV>(r0.x, r0.y, a.radii[gi], a.gx, a.gy, gev, gel, ghl, a.lv_bbox);
+		const Obb ob = make_obb(r0.x, r0.y, gev, gel);
+		const uint64_t opay = ((uint64_t)__float_as_uint(a.geom.rec[3 * (size_t)gi + 2].y) << 32) | (uint32_t)gi;
+		walk_uniform(w.x0, w.y0, w.x1 - w.x0, w.tnum, ob, ghl + 1, opay, (uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_BIN_THREADS);
 	}
 }
 #undef NEXT_SLOT

@@ -87,6 +87,15 @@ __device__ __forceinline__ void blend2(Px2 &s, bool in_x, bool in_y, v2f e, floa
 	blend2(s, in_x, in_y, e, c, w, ax, ay);
 }
 
+// Rows of a tile are dealt to the waves of its workgroup in contiguous bands (16 / waves rows each); inside a
+// band a lane owns rows r, r + 4, ... of its column: a small splat then misses the other band's wave entirely.
+template <int PPL>
+__device__ __forceinline__ int tile_row(int tid, int k)
+{
+	constexpr int NW = 256 / PPL / 64; // waves per tile
+	return (tid >> 6) * (16 / NW) + ((tid >> 4) & 3) + 4 * k;
+}
+
 struct RenderArgs {
 	int W, H, gx;
 	const uint2 *ranges;
@@ -116,7 +125,6 @@ template <int VARIANT, int PPL>
 __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 {
 	constexpr int NT = 256 / PPL;        // threads per tile == staging batch
-	constexpr int RSTEP = 16 / PPL;      // row distance between a lane's pixels
 	constexpr bool CUTOFF = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool SUM = VARIANT == FR_VARIANT_PCHECK_OBB_SUM;   // contributions += alpha*T, count per fetched entry
 	constexpr bool PMAX = VARIANT == FR_VARIANT_PCHECK_OBB_MAX;  // contributions = max alpha*T, count per in-support pixel
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
 	const int tx = tile % a.gx, ty = tile / a.gx;
 	const int tid = threadIdx.x;
-	const int lx = tid & 15, ry = tid >> 4;
+	const int lx = tid & 15;
 	const int px = tx * FR_TILE + lx;
 	const float pxf = (float)px;
 	const uint2 range = a.ranges[tile];
@@ -149,7 +157,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 #pragma unroll
 	for (int k = 0; k < PPL; k++)
 	{
-		const int py = ty * FR_TILE + ry + k * RSTEP;
+		const int py = ty * FR_TILE + tile_row<PPL>(tid, k);
 		pyf[k] = (float)py;
 		inside[k] = px < a.W && py < a.H;
 		S[k >> 1].T[k & 1] = inside[k] ? 1.0f : -1.0f;
@@ -285,7 +293,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	for (int k = 0; k < PPL; k++)
 	{
 		if (!inside[k]) continue;
-		const size_t pid2 = (size_t)a.W * (size_t)(ty * FR_TILE + ry + k * RSTEP) + px;
+		const size_t pid2 = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
 		const float Tk = fabsf(S[k >> 1].T[k & 1]);
 		if (AUX) { a.final_T[pid2] = Tk; a.n_contrib[pid2] = last[k]; }
 		if (LWMC) atomicAdd(&a.contributions[best_id[k]], a.loss_map[pid2]); // …_count forward.cu:435
@@ -300,7 +308,6 @@ template <int PPL>
 __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 {
 	constexpr int NT = 256 / PPL;
-	constexpr int RSTEP = 16 / PPL;
 	__shared__ float4 s0[NT];   // x, y, A, B
 	__shared__ float2 s1[NT];   // C, highest_level
 	__shared__ float4 sl1[NT];  // level L1: r, g, b, opacity
@@ -309,7 +316,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
 	const int tx = tile % a.gx, ty = tile / a.gx;
 	const int tid = threadIdx.x;
-	const int lx = tid & 15, ry = tid >> 4;
+	const int lx = tid & 15;
 	const int px = tx * FR_TILE + lx;
 	const float pxf = (float)px;
 	const uint2 range = a.ranges[tile];
@@ -332,7 +339,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 #pragma unroll
 	for (int k = 0; k < PPL; k++)
 	{
-		const int ly = ry + k * RSTEP;
+		const int ly = tile_row<PPL>(tid, k);
 		const int py = ty * FR_TILE + ly;
 		pyf[k] = (float)py;
 		inside[k] = px < a.W && py < a.H;
@@ -439,7 +446,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 	for (int k = 0; k < PPL; k++)
 	{
 		if (!inside[k]) continue;
-		const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + ry + k * RSTEP) + px;
+		const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
 		const float t1 = fabsf(S1[k >> 1].T[k & 1]), t2 = fabsf(S2[k >> 1].T[k & 1]);
 		float o0 = fmaf(bg0, t1, S1[k >> 1].C0[k & 1]), o1 = fmaf(bg1, t1, S1[k >> 1].C1[k & 1]), o2 = fmaf(bg2, t1, S1[k >> 1].C2[k & 1]);
 		if (blending)

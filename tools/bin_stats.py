@@ -29,7 +29,8 @@ off = ((P * 48 + 255) // 256) * 256
 dbg = geom[off:off + 768 * 8 * 8 * 4].view(torch.float32).view(768 * 8, 8).cpu().numpy()
 tot, sched, load, pairs, col, pulled = [dbg[:, i] * (10 if i < 5 else 1) for i in range(6)]
 print("waves", len(tot), "wave total us: mean %.0f max %.0f" % (tot.mean() / 1e3, tot.max() / 1e3))
-for name, v in (("sched+barrier", sched), ("load", load), ("pairs", pairs), ("colour+write", col)):
+print("  slab loop end: mean %.1f p99 %.1f max %.1f us" % (sched.mean() / 1e3, np.percentile(sched, 99) / 1e3, sched.max() / 1e3))
+for name, v in ( ("load", load), ("pairs", pairs), ("colour+write", col)):
     print("  %-14s mean %.1f us  frac %.2f" % (name, v.mean() / 1e3, v.sum() / tot.sum()))
 print("slabs per wave mean %.2f max %d" % (pulled.mean(), pulled.max()))
 print("  sh (lane 0 of each wave) mean %.1f us" % (dbg[:, 6].mean() * 10 / 1e3))
