@@ -87,6 +87,43 @@ __device__ __forceinline__ void blend2(Px2 &s, bool in_x, bool in_y, v2f e, floa
 	blend2(s, in_x, in_y, e, c, w, ax, ay);
 }
 
+// Can the splat reach the pixel rectangle [X0, X1] x [Y0, Y1] at all? power = -q/2 with the convex quadratic
+// q = A dx^2 + 2 B dx dy + C dy^2, whose minimum over a box not containing the centre lies on one of the four
+// edges (1-D minimiser clamped to the edge). Returns false only if every pixel of the rectangle is certain to be
+// skipped by the blend (power below `thr` by a margin far above float rounding); degenerate conics are kept.
+// This is evaluated ONCE per staged entry and wave band by the lane that stages the entry, so that the waves
+// iterate only over entries that can touch their band: the 3-sigma box of the binning stage also admits tiles
+// that only the box corners reach, and a two-wave tile halves the footprint once more.
+__device__ __forceinline__ bool splat_reaches(float gx, float gy, float A, float B, float C, float thr,
+	float X0, float X1, float Y0, float Y1)
+{
+	const float ax = X0 - gx, bx = X1 - gx, ay = Y0 - gy, by = Y1 - gy;
+	if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f) || !(ax == ax) || !(ay == ay)) return true;
+	if (ax <= 0.0f && bx >= 0.0f && ay <= 0.0f && by >= 0.0f) return true;
+	const float iA = 1.0f / A, iC = 1.0f / C;
+	float qmin = 3.0e38f;
+#pragma unroll
+	for (int e = 0; e < 2; e++)
+	{
+		const float dx = e ? bx : ax;
+		const float dy = fminf(fmaxf(-(B * dx) * iC, ay), by);
+		qmin = fminf(qmin, (A * dx + 2.0f * B * dy) * dx + C * dy * dy);
+		const float ey = e ? by : ay;
+		const float ex = fminf(fmaxf(-(B * ey) * iA, ax), bx);
+		qmin = fminf(qmin, (A * ex + 2.0f * B * ey) * ex + C * ey * ey);
+	}
+	const float mx = fmaxf(fabsf(ax), fabsf(bx)), my = fmaxf(fabsf(ay), fabsf(by));
+	const float mag = A * mx * mx + C * my * my + 2.0f * fabsf(B) * mx * my;
+	return !(-0.5f * qmin < thr - (2e-5f * mag + 1e-3f));
+}
+
+// a wave-uniform 64-bit value moved to scalar registers (loop control on it then runs on the scalar unit)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
+
 // Rows of a tile are dealt to the waves of its workgroup in contiguous bands (16 / waves rows each); inside a
 // band a lane owns rows r, r + 4, ... of its column: a small splat then misses the other band's wave entirely.
 template <int PPL>
@@ -137,6 +174,8 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	__shared__ float4 s1[NT];
 	__shared__ float s2[NT];
 	__shared__ int sid[NEEDID ? NT : 1];
+	constexpr int NW = NT / 64;  // waves per tile, each owning a band of 16 / NW rows
+	__shared__ unsigned long long s_reach[NW][NW]; // [band][staging wave]: staged entries that can touch the band
 
 	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
 	const int tx = tile % a.gx, ty = tile / a.gx;
@@ -193,11 +232,27 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 			finished = wg_done;
 		}
 		else if (wg_done) break;
-		if (base + tid < n)
+		const bool staged = base + tid < n;
+		if (staged)
 		{
 			s0[tid] = p0; s1[tid] = p1; s2[tid] = p2;
 			if (NEEDID) sid[tid] = (int)pid;
 			if (FETCHCNT) atomicAdd(&a.gaussians_count[pid], 1);
+		}
+		{
+			// which bands can this entry touch at all (see splat_reaches)? alpha < 1/255 (forward.cu:336) <=> power <
+			// -ln(255 opacity); the _max flavour counts pixels BEFORE the alpha test, so only the support cutoff applies
+			const float thr_a = -__logf(255.0f * p1.y) - 0.01f;
+			const float thr = PMAX ? -4.5f : (CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a);
+#pragma unroll
+			for (int w = 0; w < NW; w++)
+			{
+				const float Y0 = (float)(ty * FR_TILE + w * (16 / NW));
+				const bool reach = staged && splat_reaches(p0.x, p0.y, p0.z, p0.w, p1.x, thr,
+					(float)(tx * FR_TILE), (float)(tx * FR_TILE + 15), Y0, Y0 + (float)(16 / NW - 1));
+				const unsigned long long m = __ballot(reach);
+				if ((tid & 63) == 0) s_reach[w][tid >> 6] = m;
+			}
 		}
 		if (base + NT + tid < n)
 		{
@@ -208,16 +263,19 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 		__syncthreads();
 		// SUM && finished: nothing left to blend, the loop only keeps counting (no `continue` here: this
 		// loop carries barriers, see the note in k_bin)
-		const int cnt = (FETCHCNT && finished) ? 0 : min(NT, n - base);
+		const bool blend_batch = !(FETCHCNT && finished);
 		v2f pyp[HP];
 #pragma unroll
 		for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
-		for (int j = 0; j < cnt; j++)
+		bool stop = !blend_batch;
+		for (int sw = 0; sw < NW && !stop; sw++)
+		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; rm &= rm - 1)
 		{
+			const int j = sw * 64 + __builtin_ctzll(rm);
 			float tmax = -1.0f;
 #pragma unroll
 			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(S[h].T.x, S[h].T.y));
-			if (!__any(tmax > 0.0f)) break; // wave saturated
+			if (!__any(tmax > 0.0f)) { stop = true; break; } // wave saturated
 			const float4 g0 = s0[j];
 			const float4 g1 = s1[j];
 			const float dx = g0.x - pxf;
@@ -312,6 +370,8 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 	__shared__ float2 s1[NT];   // C, highest_level
 	__shared__ float4 sl1[NT];  // level L1: r, g, b, opacity
 	__shared__ float4 sl2[NT];  // level L2 (two-level tiles only)
+	constexpr int NW = NT / 64;  // waves per tile, each owning a band of 16 / NW rows
+	__shared__ unsigned long long s_reach[NW][NW]; // [band][staging wave]: staged entries that can touch the band
 
 	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
 	const int tx = tile % a.gx, ty = tile / a.gx;
@@ -382,19 +442,36 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 		if (base == FR_PRIO_STEP) __builtin_amdgcn_s_setprio(1);
 		else if (base == 2 * FR_PRIO_STEP) __builtin_amdgcn_s_setprio(2);
 		else if (base == 3 * FR_PRIO_STEP) __builtin_amdgcn_s_setprio(3);
-		if (base + tid < n) { s0[tid] = p0; s1[tid] = p1; sl1[tid] = pl1; if (blending) sl2[tid] = pl2; }
+		const bool staged = base + tid < n;
+		if (staged) { s0[tid] = p0; s1[tid] = p1; sl1[tid] = pl1; if (blending) sl2[tid] = pl2; }
+		{
+			// alpha < 1/255 everywhere (forward.cu:563) <=> power < -ln(255 opacity): tighter than -4.5 for faint splats
+			const float op = blending ? fmaxf(pl1.w, pl2.w) : pl1.w;
+			const float thr = fmaxf(-4.5f, -__logf(255.0f * op) - 0.01f);
+#pragma unroll
+			for (int w = 0; w < NW; w++)
+			{
+				const float Y0 = (float)(ty * FR_TILE + w * (16 / NW));
+				const bool reach = staged && splat_reaches(p0.x, p0.y, p0.z, p0.w, p1.x, thr,
+					(float)(tx * FR_TILE), (float)(tx * FR_TILE + 15), Y0, Y0 + (float)(16 / NW - 1));
+				const unsigned long long m = __ballot(reach);
+				if ((tid & 63) == 0) s_reach[w][tid >> 6] = m;
+			}
+		}
 		if (base + NT + tid < n) fetch(base + NT + tid);
 		__syncthreads();
-		const int cnt = min(NT, n - base);
 		v2f pyp[HP];
 #pragma unroll
 		for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
-		for (int j = 0; j < cnt; j++)
+		bool stop = false;
+		for (int sw = 0; sw < NW && !stop; sw++)
+		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; rm &= rm - 1)
 		{
+			const int j = sw * 64 + __builtin_ctzll(rm);
 			float tmax = -1.0f;
 #pragma unroll
 			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(fmaxf(S1[h].T.x, S1[h].T.y), fmaxf(S2[h].T.x, S2[h].T.y)));
-			if (!__any(tmax > 0.0f)) break;
+			if (!__any(tmax > 0.0f)) { stop = true; break; }
 #ifdef FR_TILE_TIMERS
 			tm_proc++;
 #endif
