@@ -48,17 +48,18 @@ template <bool CUTOFF, int PPL>
 __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 {
 	constexpr int NT = 256 / PPL;
-	constexpr int RSTEP = 16 / PPL;
+	constexpr int NW = NT / 64; // waves per tile, each owning a band of 16 / NW rows (see tile_row)
 	__shared__ float4 s0[NT];
 	__shared__ float4 s1[NT];
 	__shared__ float s2[NT];
 	__shared__ int sid[NT];
+	__shared__ unsigned long long s_reach[NW][NW]; // [band][staging wave]: staged entries that can touch the band
 
 	const int tile = (int)a.tile_order[blockIdx.x]; // longest lists first
 	const int tx = tile % a.gx, ty = tile / a.gx;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
-	const int lx = tid & 15, ry = tid >> 4;
+	const int lx = tid & 15;
 	const int px = tx * FR_TILE + lx;
 	const float pxf = (float)px;
 	const uint2 range = a.ranges[tile];
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 #pragma unroll
 	for (int k = 0; k < PPL; k++)
 	{
-		const int py = ty * FR_TILE + ry + k * RSTEP;
+		const int py = ty * FR_TILE + tile_row<PPL>(tid, k);
 		pyf[k] = (float)py;
 		const bool inside = px < a.W && py < a.H;
 		const size_t pid = (size_t)a.W * py + px;
@@ -116,7 +117,23 @@ __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 	{
 		__syncthreads();
 		const int cnt = min(NT, top);
-		if (tid < cnt) { s0[tid] = p0; s1[tid] = p1; s2[tid] = p2; sid[tid] = (int)pid; }
+		const bool staged = tid < cnt;
+		if (staged) { s0[tid] = p0; s1[tid] = p1; s2[tid] = p2; sid[tid] = (int)pid; }
+		{
+			// entries that cannot touch a wave's rows are skipped for that wave: same thresholds as the per-pixel
+			// tests below (power < -4.5, alpha < 1/255 <=> power < -ln(255 opacity)), see splat_reaches()
+			const float thr_a = -__logf(255.0f * p1.y) - 0.01f;
+			const float thr = CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a;
+#pragma unroll
+			for (int w = 0; w < NW; w++)
+			{
+				const float Y0 = (float)(ty * FR_TILE + w * (16 / NW));
+				const bool reach = staged && splat_reaches(p0.x, p0.y, p0.z, p0.w, p1.x, thr,
+					(float)(tx * FR_TILE), (float)(tx * FR_TILE + 15), Y0, Y0 + (float)(16 / NW - 1));
+				const unsigned long long m = __ballot(reach);
+				if (lane == 0) s_reach[w][tid >> 6] = m;
+			}
+		}
 		if (top - NT - tid > 0)
 		{
 			pid = a.point_list[range.x + top - NT - 1 - tid];
@@ -124,8 +141,10 @@ __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 			p0 = r[0]; p1 = r[1]; p2 = r[2].x;
 		}
 		__syncthreads();
-		for (int j = 0; j < cnt; j++)
+		for (int sw = 0; sw < NW; sw++)
+		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; rm &= rm - 1)
 		{
+			const int j = sw * 64 + __builtin_ctzll(rm);
 			const int pos = top - 1 - j; // 0-based position in the tile list
 			if (pos >= wave_last) continue; // wave-uniform
 			const float4 g0 = s0[j];

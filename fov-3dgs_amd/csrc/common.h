@@ -238,6 +238,53 @@ __device__ __forceinline__ bool obb_hits_tile(const Obb &o, int tx, int ty)
 	return true;
 }
 
+// ---- helpers shared by the forward and backward tile kernels ----
+// Can the splat reach the pixel rectangle [X0, X1] x [Y0, Y1] at all? power = -q/2 with the convex quadratic
+// q = A dx^2 + 2 B dx dy + C dy^2, whose minimum over a box not containing the centre lies on one of the four
+// edges (1-D minimiser clamped to the edge). Returns false only if every pixel of the rectangle is certain to be
+// skipped by the blend (power below `thr` by a margin far above float rounding); degenerate conics are kept.
+// This is evaluated ONCE per staged entry and wave band by the lane that stages the entry, so that the waves
+// iterate only over entries that can touch their band: the 3-sigma box of the binning stage also admits tiles
+// that only the box corners reach, and a two-wave tile halves the footprint once more.
+__device__ __forceinline__ bool splat_reaches(float gx, float gy, float A, float B, float C, float thr,
+	float X0, float X1, float Y0, float Y1)
+{
+	const float ax = X0 - gx, bx = X1 - gx, ay = Y0 - gy, by = Y1 - gy;
+	if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f) || !(ax == ax) || !(ay == ay)) return true;
+	if (ax <= 0.0f && bx >= 0.0f && ay <= 0.0f && by >= 0.0f) return true;
+	const float iA = 1.0f / A, iC = 1.0f / C;
+	float qmin = 3.0e38f;
+#pragma unroll
+	for (int e = 0; e < 2; e++)
+	{
+		const float dx = e ? bx : ax;
+		const float dy = fminf(fmaxf(-(B * dx) * iC, ay), by);
+		qmin = fminf(qmin, (A * dx + 2.0f * B * dy) * dx + C * dy * dy);
+		const float ey = e ? by : ay;
+		const float ex = fminf(fmaxf(-(B * ey) * iA, ax), bx);
+		qmin = fminf(qmin, (A * ex + 2.0f * B * ey) * ex + C * ey * ey);
+	}
+	const float mx = fmaxf(fabsf(ax), fabsf(bx)), my = fmaxf(fabsf(ay), fabsf(by));
+	const float mag = A * mx * mx + C * my * my + 2.0f * fabsf(B) * mx * my;
+	return !(-0.5f * qmin < thr - (2e-5f * mag + 1e-3f));
+}
+
+// a wave-uniform 64-bit value moved to scalar registers (loop control on it then runs on the scalar unit)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
+
+// Rows of a tile are dealt to the waves of its workgroup in contiguous bands (16 / waves rows each); inside a
+// band a lane owns rows r, r + 4, ... of its column: a small splat then misses the other band's wave entirely.
+template <int PPL>
+__device__ __forceinline__ int tile_row(int tid, int k)
+{
+	constexpr int NW = 256 / PPL / 64; // waves per tile
+	return (tid >> 6) * (16 / NW) + ((tid >> 4) & 3) + 4 * k;
+}
+
 // SH basis constants (reference auxiliary.h:22-39)
 #define FR_SH_C0 0.28209479177387814f
 #define FR_SH_C1 0.4886025119029199f
