@@ -209,7 +209,10 @@ def main():
     P, Px = args.points, W * H
     alg_bytes = {
         # SURVEY.md 8(d) per-unit figures x units of one launch
-        "preprocess": 20 * P + 224 * V_in + (48 + 24) * st["V"],
+        # B_pre = 20 P + 224 V_in + 48 V (+24 V OBB axes), split over this build's two kernels: projection reads
+        # xyz/scale/rotation and writes radii + axes, binning reads opacity + SH and writes the per-Gaussian record
+        "project": 20 * P + 28 * V_in + 24 * st["V"],
+        "bin": 196 * V_in + 48 * st["V"],
         "render": 32 * st["D_single"] + 52 * st["D_blend"] + 12 * Px,
         # this build's binning moves (depth,id) once per stage instead of a 6-pass radix sort
         "emit": 12 * st["D"] + 44 * st["V"],
@@ -217,13 +220,14 @@ def main():
         "tile_scan": 16 * T,
         "tile_levels": 20 * T,
     }
-    dominant = max(("preprocess", "render", "tile_sort", "emit"), key=lambda k: mean_ms[k])
+    dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: mean_ms[k])
     achieved = alg_bytes[dominant] / (mean_ms[dominant] * 1e-3) / 1e9
     traffic = None
     try:  # HBM bytes per launch of that kernel from the committed PMC pass (profiles/), if it exists
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["kernels"]
-        kname = {"render": "k_render_fov", "preprocess": "k_bin", "tile_sort": "k_tile_sort", "emit": "k_emit"}[dominant]
-        traffic = int((2 * pmc[kname]["FETCH_SIZE_KiB"] + pmc[kname]["WRITE_SIZE_KiB"]) * 1024)
+        knames = {"render": ["k_render_fov"], "project": ["k_project"], "bin": ["k_bin", "k_hist_colscan"],
+                  "tile_sort": ["k_tile_msort"], "emit": ["k_emit"]}[dominant]
+        traffic = int(sum(2 * pmc[k]["FETCH_SIZE_KiB_per_frame"] + pmc[k]["WRITE_SIZE_KiB_per_frame"] for k in knames) * 1024)
     except Exception:
         pass
     roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",

@@ -13,7 +13,7 @@ ABI_VERSION = 1
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
 VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC = 4, 5
-STAGES = ("tile_levels", "preprocess", "tile_scan", "emit", "tile_sort", "render")
+STAGES = ("tile_levels", "project", "bin", "tile_scan", "emit", "tile_sort", "render")
 VARIANT_IDS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3, "pcheck_obb_max": 4,
                "pcheck_obb_loss_weighted_max_count": 5}
 

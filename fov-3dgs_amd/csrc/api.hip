@@ -134,8 +134,10 @@ int fr_forward(fr_forward_args *a)
 	}
 	mark(FR_STAGE_TILE_LEVELS);
 	if (a->variant == FR_VARIANT_FOV_PCHECK_OBB) { rc = launch_tile_levels(c); if (rc) return rc; }
-	mark(FR_STAGE_PREPROCESS);
-	rc = launch_preprocess(c); if (rc) return rc;
+	mark(FR_STAGE_PROJECT);
+	rc = launch_project(c); if (rc) return rc;
+	mark(FR_STAGE_BIN);
+	rc = launch_bin(c); if (rc) return rc;
 	mark(FR_STAGE_TILE_SCAN);
 	rc = launch_tile_scan(c); if (rc) return rc;
 	mark(FR_STAGE_EMIT);

@@ -317,7 +317,8 @@ struct FwdCtx {
 	BinWS bin;
 };
 int launch_tile_levels(FwdCtx &c);
-int launch_preprocess(FwdCtx &c);
+int launch_project(FwdCtx &c);
+int launch_bin(FwdCtx &c);
 int launch_tile_scan(FwdCtx &c);
 int launch_emit(FwdCtx &c);
 int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile);

@@ -546,11 +546,11 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	if (n) flush();
 }
 
-// Persistent workgroups of FR_BIN_THREADS threads; slab s (FR_BIN_THREADS consecutive Gaussians)
-// belongs to workgroup s % gridDim.x -- k_emit uses the same assignment. LDSH: per-tile instance
-// counts are accumulated in an LDS-private histogram (T <= 16 Ki tiles fit the 160 KiB LDS twice
-// over) and written once per workgroup to hist[block][tile]: no global atomics at all. Otherwise
-// (huge tile grids) the counters are bumped with global atomics.
+// Stage 2 (RS rasterizer_impl.cu:70-146, RF :264-383 + :490-530): for every survivor, count the tiles it
+// really lands in (OBB / foveal tests), bump the per-tile instance counters, evaluate its colour(s) and finish
+// its record. Persistent workgroups of FR_BIN_THREADS threads, work handed out per wave (see below).
+// LDSH: the counters are an LDS-private histogram (T <= 16 Ki tiles) written once per workgroup to
+// hist[block][tile] -- no global atomics at all; otherwise (huge tile grids) global atomics on tile_count.
 #define BUMP_TILE(ti) do { if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
 template <int VARIANT, bool LDSH>
 __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
@@ -1162,7 +1162,7 @@ int launch_tile_levels(FwdCtx &c)
 	return check_launch("tile_levels", c.stream, a->debug);
 }
 
-int launch_preprocess(FwdCtx &c)
+static PreArgs make_pre_args(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	PreArgs p;
@@ -1176,6 +1176,14 @@ int launch_preprocess(FwdCtx &c)
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.lv_bbox = c.img.lv_bbox; p.T = c.T;
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
+	return p;
+}
+
+// stage "project": per-Gaussian projection + conservative culling -> vis_list
+int launch_project(FwdCtx &c)
+{
+	const fr_forward_args *a = c.a;
+	PreArgs p = make_pre_args(c);
 	{
 		const int pchunks = (a->P + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS;
 		const dim3 pgrid(pchunks < 2048 ? pchunks : 2048), pblock(FR_PROJ_THREADS); // 8 workgroups per CU
@@ -1185,9 +1193,15 @@ int launch_preprocess(FwdCtx &c)
 		case FR_VARIANT_FOV_PCHECK_OBB: hipLaunchKernelGGL(k_project<FR_VARIANT_FOV_PCHECK_OBB>, pgrid, pblock, 0, c.stream, p); break;
 		default: hipLaunchKernelGGL(k_project<FR_VARIANT_PCHECK_OBB>, pgrid, pblock, 0, c.stream, p); break;
 		}
-		int prc = check_launch("project", c.stream, a->debug);
-		if (prc) return prc;
+		return check_launch("project", c.stream, a->debug);
 	}
+}
+
+// stage "bin": tile counts (LDS histograms), colours, final records; then the column scan of the histograms
+int launch_bin(FwdCtx &c)
+{
+	const fr_forward_args *a = c.a;
+	PreArgs p = make_pre_args(c);
 	const bool ldsh = c.img.hist != nullptr;
 	const int nblk = bin_blocks(a->P);
 	const dim3 grid(nblk), block(FR_BIN_THREADS);

@@ -114,8 +114,8 @@ typedef struct fr_forward_args {
 	                              * its first plane, …_loss_weighted_max_count/cuda_rasterizer/forward.cu:435) */
 } fr_forward_args;
 
-enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PREPROCESS = 1, FR_STAGE_TILE_SCAN = 2, FR_STAGE_EMIT = 3,
-	FR_STAGE_TILE_SORT = 4, FR_STAGE_RENDER = 5, FR_NUM_STAGES = 6 };
+enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
+	FR_STAGE_TILE_SORT = 5, FR_STAGE_RENDER = 6, FR_NUM_STAGES = 7 };
 
 typedef struct fr_backward_args {
 	int32_t variant;             /* ORIGINAL, PCHECK_OBB_SUM, PCHECK_OBB_MAX or PCHECK_OBB_LWMC */
