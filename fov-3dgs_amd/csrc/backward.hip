@@ -127,9 +127,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 #pragma unroll
 			for (int w = 0; w < NW; w++)
 			{
-				const float Y0 = (float)(ty * FR_TILE + w * (16 / NW));
-				const bool reach = staged && splat_reaches(p0.x, p0.y, p0.z, p0.w, p1.x, thr,
-					(float)(tx * FR_TILE), (float)(tx * FR_TILE + 15), Y0, Y0 + (float)(16 / NW - 1));
+				const bool reach = staged && band_reaches<PPL>(w, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr);
 				const unsigned long long m = __ballot(reach);
 				if (lane == 0) s_reach[w][tid >> 6] = m;
 			}

@@ -278,11 +278,20 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
 
 // Rows of a tile are dealt to the waves of its workgroup in contiguous bands (16 / waves rows each); inside a
 // band a lane owns rows r, r + 4, ... of its column: a small splat then misses the other band's wave entirely.
+// (Alternating 4-row strips balance the two waves better but let most splats touch both: measured slower.)
 template <int PPL>
 __device__ __forceinline__ int tile_row(int tid, int k)
 {
 	constexpr int NW = 256 / PPL / 64; // waves per tile
 	return (tid >> 6) * (16 / NW) + ((tid >> 4) & 3) + 4 * k;
+}
+// can the splat touch any pixel that wave w of tile (tx, ty) owns?
+template <int PPL>
+__device__ __forceinline__ bool band_reaches(int w, int tx, int ty, float gx, float gy, float A, float B, float C, float thr)
+{
+	constexpr int NW = 256 / PPL / 64;
+	const float Y0 = (float)(ty * FR_TILE + w * (16 / NW));
+	return splat_reaches(gx, gy, A, B, C, thr, (float)(tx * FR_TILE), (float)(tx * FR_TILE + 15), Y0, Y0 + (float)(16 / NW - 1));
 }
 
 // SH basis constants (reference auxiliary.h:22-39)

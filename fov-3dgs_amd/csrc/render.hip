@@ -18,10 +18,6 @@
 // launches two full grids that early-return on each other's tiles).
 #include "common.h"
 
-#ifndef FR_PRIO_STEP
-#define FR_PRIO_STEP 128 // render: entries blended per wave-priority step (multiple of 64)
-#endif
-
 namespace fr {
 
 __device__ __forceinline__ float fast_exp(float p)
@@ -201,9 +197,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 #pragma unroll
 			for (int w = 0; w < NW; w++)
 			{
-				const float Y0 = (float)(ty * FR_TILE + w * (16 / NW));
-				const bool reach = staged && splat_reaches(p0.x, p0.y, p0.z, p0.w, p1.x, thr,
-					(float)(tx * FR_TILE), (float)(tx * FR_TILE + 15), Y0, Y0 + (float)(16 / NW - 1));
+				const bool reach = staged && band_reaches<PPL>(w, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr);
 				const unsigned long long m = __ballot(reach);
 				if ((tid & 63) == 0) s_reach[w][tid >> 6] = m;
 			}
@@ -368,7 +362,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 	for (int h = 0; h < HP; h++) { S1[h].C0 = S1[h].C1 = S1[h].C2 = (v2f){ 0.f, 0.f }; S2[h].C0 = S2[h].C1 = S2[h].C2 = (v2f){ 0.f, 0.f }; }
 
 #ifdef FR_TILE_TIMERS
-	const uint64_t tm0 = wall_clock64(); uint32_t tm_proc = 0, tm_hit = 0;
+	const uint64_t tm0 = wall_clock64(); uint32_t tm_proc = 0, tm_hit = 0; uint64_t tm_loop = 0, tm_sync = 0;
 #endif
 	// prefetch registers
 	float4 p0 = make_float4(0, 0, 0, 0), pl1 = p0, pl2 = p0;
@@ -389,13 +383,13 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 		float tmax0 = -1.0f;
 #pragma unroll
 		for (int h = 0; h < HP; h++) tmax0 = fmaxf(tmax0, fmaxf(fmaxf(S1[h].T.x, S1[h].T.y), fmaxf(S2[h].T.x, S2[h].T.y)));
+#ifdef FR_TILE_TIMERS
+		const uint64_t tq0 = wall_clock64();
+#endif
 		if (__syncthreads_and(!(tmax0 > 0.0f))) break;
-		// The frame ends when the tile that blends the most entries ends, and a wave alone on its SIMD blends an
-		// entry 3-4x faster than one that shares it with four others: waves that are deep into their list take
-		// precedence in the SIMD's arbiter (tiles that saturate early never get there).
-		if (base == FR_PRIO_STEP) __builtin_amdgcn_s_setprio(1);
-		else if (base == 2 * FR_PRIO_STEP) __builtin_amdgcn_s_setprio(2);
-		else if (base == 3 * FR_PRIO_STEP) __builtin_amdgcn_s_setprio(3);
+#ifdef FR_TILE_TIMERS
+		tm_sync += wall_clock64() - tq0;
+#endif
 		const bool staged = base + tid < n;
 		if (staged) { s0[tid] = p0; s1[tid] = p1; sl1[tid] = pl1; if (blending) sl2[tid] = pl2; }
 		{
@@ -405,9 +399,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 #pragma unroll
 			for (int w = 0; w < NW; w++)
 			{
-				const float Y0 = (float)(ty * FR_TILE + w * (16 / NW));
-				const bool reach = staged && splat_reaches(p0.x, p0.y, p0.z, p0.w, p1.x, thr,
-					(float)(tx * FR_TILE), (float)(tx * FR_TILE + 15), Y0, Y0 + (float)(16 / NW - 1));
+				const bool reach = staged && band_reaches<PPL>(w, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr);
 				const unsigned long long m = __ballot(reach);
 				if ((tid & 63) == 0) s_reach[w][tid >> 6] = m;
 			}
@@ -417,6 +409,9 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 		v2f pyp[HP];
 #pragma unroll
 		for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
+#ifdef FR_TILE_TIMERS
+		const uint64_t tq1 = wall_clock64();
+#endif
 		bool stop = false;
 		for (int sw = 0; sw < NW && !stop; sw++)
 		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; rm &= rm - 1)
@@ -462,6 +457,9 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 				if (blending) blend2(S2[h], inx[h] && l2_ok, iny[h] && l2_ok, e, c2);
 			}
 		}
+#ifdef FR_TILE_TIMERS
+		tm_loop += wall_clock64() - tq1;
+#endif
 	}
 
 #ifdef FR_TILE_TIMERS
@@ -469,6 +467,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 	{
 		a.final_T[tile] = (float)(wall_clock64() - tm0); a.final_T[a.T + tile] = (float)(tm0 & 0xffffff);
 		a.n_contrib[tile] = tm_proc; a.n_contrib[a.T + tile] = tm_hit;
+		a.n_contrib[2 * a.T + tile] = (uint32_t)tm_loop; a.n_contrib[3 * a.T + tile] = (uint32_t)tm_sync;
 	}
 #endif
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];

@@ -21,8 +21,8 @@ img = r[5]; T = ((W + 15) // 16) * ((H + 15) // 16)
 def view(ptr, n, dt):
     off = ptr - img.data_ptr(); return img[off:off + 4 * n].view(dt)
 ft = view(lib.fr_image_final_T(vid, W, H, img.data_ptr()), 2 * T, torch.float32).cpu().numpy()
-nc2 = view(lib.fr_image_n_contrib(vid, W, H, img.data_ptr()), 2 * T, torch.int32).cpu().numpy()
-nc, nh = nc2[:T], nc2[T:]
+nc2 = view(lib.fr_image_n_contrib(vid, W, H, img.data_ptr()), 4 * T, torch.int32).cpu().numpy()
+nc, nh, tloop, tsync = nc2[:T], nc2[T:2 * T], nc2[2 * T:3 * T] * 10.0, nc2[3 * T:] * 10.0
 rg = view(lib.fr_image_ranges(vid, W, H, img.data_ptr()), 2 * T, torch.int32).cpu().numpy().reshape(T, 2)
 n = rg[:, 1] - rg[:, 0]
 cyc = ft[:T] * 10.0  # ns (100 MHz)
@@ -30,7 +30,7 @@ start = ft[T:]
 print("tiles", T, "sum list", n.sum(), "processed", nc.sum(), "with a hit", nh.sum())
 print("wave time ns: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (cyc.mean(), np.percentile(cyc, 50), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max()))
 order = np.argsort(-cyc)[:8]
-for t in order: print("tile", t, "n", n[t], "processed", nc[t], "hit", nh[t], "ns", cyc[t], "ns/entry %.1f" % (cyc[t] / max(nc[t], 1)), "start", start[t])
+for t in order: print("tile", t, "n", n[t], "processed", nc[t], "hit", nh[t], "loop ns", tloop[t], "topsync ns", tsync[t], "ns", cyc[t], "ns/entry %.1f" % (cyc[t] / max(nc[t], 1)), "start", start[t])
 st = (start - start.min()) % (1 << 24)
 print("start spread ns: p50 %.0f p99 %.0f max %.0f" % (np.percentile(st, 50) * 10, np.percentile(st, 99) * 10, st.max() * 10))
 print("sum wave time ms", cyc.sum() / 1e6, " / 4096 slots =", cyc.sum() / 4096 / 1e6)
