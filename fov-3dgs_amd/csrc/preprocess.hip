@@ -229,7 +229,9 @@ struct Proj {
 	uint32_t tnum;
 };
 // sc / q: the Gaussian's raw scales and rotation (unused with cov3D_precomp); hl: RF highest level.
-template <bool FOV>
+// MODE 0: stop after the conservative frame test, r.alive = "may reach the frame"; MODE 1: the full projection
+// of a Gaussian that passed it (k_project runs MODE 0 on everything and MODE 1 on the compacted survivors).
+template <bool FOV, int MODE>
 __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, const float p[3], const float sc[3], float4 q, float hl)
 {
 	Proj r; r.alive = false; r.tnum = 0; r.radius = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0;
@@ -286,8 +288,8 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, cons
 	// diagonal), hence lambda1 <= 2.42 B + 1.05 and the radius by r_ub below; getRect is monotone in the radius,
 	// so an empty rectangle for r_ub means an empty rectangle for the true radius and the reference drops the
 	// splat as well (forward.cu:229-231); RF: the same for the rectangle clipped to the level box, see
-	// walk_rect(). NaN/inf anywhere makes the test pass and the full path decide. (A wave leaves early only
-	// if all its 64 Gaussians fail, but then it skips two thirds of the arithmetic.)
+	// walk_rect(). NaN/inf anywhere makes the test pass and the full path decide.
+	if (MODE == 0)
 	{
 		float tf = 0.0f;
 #pragma unroll
@@ -309,6 +311,8 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, cons
 			}
 			if (x1 <= x0 || y1 <= y0) return r;
 		}
+		r.alive = true;
+		return r;
 	}
 
 	// 3D covariance: forward.cu:118-152
@@ -453,12 +457,14 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 // is needed, so the waves of a CU drift apart and overlap their load and ALU phases.
 #define FR_PROJ_THREADS 256
 #define FR_PROJ_WLIST 512
+#define FR_PROJ_QUEUE 128 // survivors of pass 1 a wave can hold (< 64 left over + up to 64 new)
 template <int VARIANT>
 __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	__shared__ uint32_t s_list[FR_PROJ_THREADS / 64][FR_PROJ_WLIST];
+	__shared__ float s_queue[FR_PROJ_THREADS / 64][12 * FR_PROJ_QUEUE];
 	const int lane = threadIdx.x & 63;
 	uint32_t *list = s_list[threadIdx.x >> 6];
 	uint32_t n = 0; // entries staged by this wave (wave-uniform)
@@ -476,8 +482,10 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		__builtin_amdgcn_wave_barrier();
 		n = 0;
 	};
-	// The inputs of the NEXT chunk are fetched while the current one is projected: the kernel is a chain of
-	// load -> ~700 instructions -> store per chunk, and with ~5 waves per SIMD nothing else hides the loads.
+	// Two passes per wave. Pass 1 (every Gaussian, inputs of the NEXT chunk prefetched into registers): near plane
+	// and the conservative frame test, ~1/4 of the arithmetic. Its survivors are scattered over the wave (the
+	// input order is arbitrary), so they are queued in LDS WITH their inputs and pass 2, the full projection, runs
+	// on 64 queued survivors at a time: no lane idles behind culled neighbours and nothing is fetched twice.
 	struct Raw { float p[3], sc[3]; float4 q; float hl; };
 	const bool have_sr = a.cov3D_precomp == nullptr;
 	auto fetch = [&](const int idx)
@@ -497,17 +505,22 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		}
 		return w;
 	};
-	const int nchunks = (a.P + 63) / 64;
-	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
-	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
-	Raw nxt = fetch(wave_gid < nchunks ? wave_gid * 64 + lane : a.P);
-	for (int chunk = wave_gid; chunk < nchunks; chunk += nwaves)
+#ifdef FR_EXP_COUNT
+	uint32_t dbg_maybe = 0;
+#endif
+	float *qf = s_queue[threadIdx.x >> 6];            // [12][FR_PROJ_QUEUE]: idx, p, sc, q, hl of the queued survivors
+	uint32_t qn = 0;                                  // queued survivors (wave-uniform)
+	auto full = [&](const int slot, const bool active)
 	{
-		const int idx = chunk * 64 + lane;
-		const Raw cur = nxt;
-		nxt = fetch(chunk + nwaves < nchunks ? (chunk + nwaves) * 64 + lane : a.P);
+		const int idx = active ? __float_as_int(qf[slot]) : 0;
+		Raw w;
+#pragma unroll
+		for (int i = 0; i < 3; i++) { w.p[i] = qf[(1 + i) * FR_PROJ_QUEUE + slot]; w.sc[i] = qf[(4 + i) * FR_PROJ_QUEUE + slot]; }
+		w.q = make_float4(qf[7 * FR_PROJ_QUEUE + slot], qf[8 * FR_PROJ_QUEUE + slot], qf[9 * FR_PROJ_QUEUE + slot], qf[10 * FR_PROJ_QUEUE + slot]);
+		w.hl = qf[11 * FR_PROJ_QUEUE + slot];
+		const Raw &cur = w;
 		Proj pr; pr.alive = false; pr.tnum = 0;
-		if (idx < a.P) pr = project_gaussian<FOV>(a, idx, cur.p, cur.sc, cur.q, cur.hl);
+		if (active) pr = project_gaussian<FOV, 1>(a, idx, cur.p, cur.sc, cur.q, cur.hl);
 		if (pr.alive)
 		{
 			float4 ev = make_float4(0, 0, 0, 0);
@@ -537,11 +550,63 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 				if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
 			}
 		}
-		if (idx < a.P) a.radii[idx] = pr.alive ? pr.radius : 0;
+		if (active) a.radii[idx] = pr.alive ? pr.radius : 0;
 		const unsigned long long m = __ballot(pr.alive);
 		if (pr.alive) list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
 		n += (uint32_t)__popcll(m);
 		if (n > FR_PROJ_WLIST - 64) flush();
+	};
+	const int nchunks = (a.P + 63) / 64;
+	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
+	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
+	Raw nxt = fetch(wave_gid < nchunks ? wave_gid * 64 + lane : a.P);
+	for (int chunk = wave_gid; chunk < nchunks; chunk += nwaves)
+	{
+		const int idx = chunk * 64 + lane;
+		const Raw cur = nxt;
+		nxt = fetch(chunk + nwaves < nchunks ? (chunk + nwaves) * 64 + lane : a.P);
+		bool maybe = false;
+		if (idx < a.P)
+		{
+			maybe = project_gaussian<FOV, 0>(a, idx, cur.p, cur.sc, cur.q, cur.hl).alive;
+			if (!maybe) a.radii[idx] = 0;
+		}
+		const unsigned long long m = __ballot(maybe);
+		if (maybe)
+		{
+			const uint32_t slot = qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			qf[slot] = __int_as_float(idx);
+#pragma unroll
+			for (int i = 0; i < 3; i++) { qf[(1 + i) * FR_PROJ_QUEUE + slot] = cur.p[i]; qf[(4 + i) * FR_PROJ_QUEUE + slot] = cur.sc[i]; }
+			qf[7 * FR_PROJ_QUEUE + slot] = cur.q.x; qf[8 * FR_PROJ_QUEUE + slot] = cur.q.y;
+			qf[9 * FR_PROJ_QUEUE + slot] = cur.q.z; qf[10 * FR_PROJ_QUEUE + slot] = cur.q.w;
+			qf[11 * FR_PROJ_QUEUE + slot] = cur.hl;
+		}
+		qn += (uint32_t)__popcll(m);
+#ifdef FR_EXP_COUNT
+		dbg_maybe += (uint32_t)__popcll(m);
+#endif
+		if (qn >= 64)
+		{
+			// the queue was written by other lanes of this wave
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			qn -= 64;
+			full((int)qn + lane, true);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+#ifdef FR_EXP_COUNT
+	if (lane == 0) atomicAdd(a.geom.slab_ctr + 2, dbg_maybe);
+#endif
+	if (qn)
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		full(lane < (int)qn ? lane : 0, lane < (int)qn);
 	}
 	if (n) flush();
 }
@@ -1185,8 +1250,23 @@ int launch_project(FwdCtx &c)
 	const fr_forward_args *a = c.a;
 	PreArgs p = make_pre_args(c);
 	{
+		// persistent waves: exactly as many workgroups as the device keeps resident (a second, partial round of
+		// workgroups would run on a half-empty chip)
+		static int resident[3] = { 0, 0, 0 };
+		const int slot = a->variant == FR_VARIANT_ORIGINAL ? 0 : (a->variant == FR_VARIANT_FOV_PCHECK_OBB ? 1 : 2);
+		if (resident[slot] == 0)
+		{
+			int per_cu = 0, dev = 0;
+			hipDeviceProp_t prop;
+			const void *fn = slot == 0 ? (const void *)k_project<FR_VARIANT_ORIGINAL>
+				: (slot == 1 ? (const void *)k_project<FR_VARIANT_FOV_PCHECK_OBB> : (const void *)k_project<FR_VARIANT_PCHECK_OBB>);
+			if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FR_PROJ_THREADS, 0) != hipSuccess || per_cu < 1)
+			{ per_cu = 4; prop.multiProcessorCount = 256; }
+			resident[slot] = per_cu * prop.multiProcessorCount;
+		}
 		const int pchunks = (a->P + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS;
-		const dim3 pgrid(pchunks < 2048 ? pchunks : 2048), pblock(FR_PROJ_THREADS); // 8 workgroups per CU
+		const dim3 pgrid(pchunks < resident[slot] ? pchunks : resident[slot]), pblock(FR_PROJ_THREADS);
 		switch (a->variant)
 		{
 		case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL(k_project<FR_VARIANT_ORIGINAL>, pgrid, pblock, 0, c.stream, p); break;

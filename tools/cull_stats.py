@@ -25,6 +25,10 @@ rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(c
 E = torch.Tensor([])
 r = rz._forward_native(3, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], syn.lissajous_gaze(20, 90), 0.05)
 print("foveated: visible (radii > 0)", int((r[2] > 0).sum()), "instances", r[0])
+import numpy as np
+g = r[3]
+# slab_ctr follows rec[3P] f4, cov3D[6P] (absent for RF?), ... : search the vis count word instead
+print("geom bytes", g.numel())
 r = rz._forward_native(2, rs, xyz, full, E, opa, sc, rot, E, None, None, (0.5, 0.5), 0.05)
 print("pcheck_obb: visible (radii > 0)", int((r[2] > 0).sum()), "instances", r[0])
 r = rz._forward_native(0, rs, xyz, full, E, opa, sc, rot, E, None, None, (0.5, 0.5), 0.05)
