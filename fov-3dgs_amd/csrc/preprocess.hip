@@ -203,6 +203,9 @@ __device__ __forceinline__ void sh_colour(int deg, int navail, const float *__re
 	for (int ch = 0; ch < 3; ch++) out[ch] = acc[ch] + 0.5f;
 }
 
+// raw per-Gaussian inputs of the projection
+struct RawGaussian { float p[3], sc[3]; float4 q; float hl; };
+
 struct PreArgs {
 	int P, D, M, W, H, gx, gy;
 	float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
@@ -448,23 +451,21 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 	return hi & ~((1ull << a) - 1ull);
 }
 
-// Stage 1: projection, covariance, conic, radius, tile rectangle -- memory-streaming, one thread per
-// Gaussian, persistent waves striding over 64-wide chunks. Survivors are appended to vis_list so that
-// the binning and colour stages below run on dense waves (typically 10-20 % of a scene is on screen).
-// Every WAVE stages its survivors in an LDS list of its own and flushes it with one global atomic per
-// ~450 entries: a single device-scope counter saturates at ~90 atomics/us on MI355X, so one atomic per
-// wave and chunk (94 k per frame at 6 M Gaussians) would cost a millisecond -- and no workgroup barrier
-// is needed, so the waves of a CU drift apart and overlap their load and ALU phases.
+// Stage 1: the part of the reference's preprocess every Gaussian must go through -- near plane, projected
+// centre -- plus a conservative frame test (project_gaussian<.., 0>), streaming over the whole cloud with
+// persistent waves (next chunk's inputs prefetched into registers). Typically 10-30 % of a scene survive; they
+// are appended to vis_list so that everything expensive (covariance chain, eigen axes, tile walk, SH) runs on
+// dense waves in k_bin. Every WAVE stages its survivors in an LDS list of its own and flushes it with one
+// global atomic per ~450 entries: a single device-scope counter saturates at ~90 atomics/us on MI355X, so one
+// atomic per wave and chunk (94 k per frame at 6 M Gaussians) would cost a millisecond -- and no workgroup
+// barrier is needed, so the waves of a CU drift apart and overlap their load and ALU phases.
 #define FR_PROJ_THREADS 256
 #define FR_PROJ_WLIST 512
-#define FR_PROJ_QUEUE 128 // survivors of pass 1 a wave can hold (< 64 left over + up to 64 new)
 template <int VARIANT>
 __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 {
-	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	__shared__ uint32_t s_list[FR_PROJ_THREADS / 64][FR_PROJ_WLIST];
-	__shared__ float s_queue[FR_PROJ_THREADS / 64][12 * FR_PROJ_QUEUE];
 	const int lane = threadIdx.x & 63;
 	uint32_t *list = s_list[threadIdx.x >> 6];
 	uint32_t n = 0; // entries staged by this wave (wave-uniform)
@@ -482,15 +483,10 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		__builtin_amdgcn_wave_barrier();
 		n = 0;
 	};
-	// Two passes per wave. Pass 1 (every Gaussian, inputs of the NEXT chunk prefetched into registers): near plane
-	// and the conservative frame test, ~1/4 of the arithmetic. Its survivors are scattered over the wave (the
-	// input order is arbitrary), so they are queued in LDS WITH their inputs and pass 2, the full projection, runs
-	// on 64 queued survivors at a time: no lane idles behind culled neighbours and nothing is fetched twice.
-	struct Raw { float p[3], sc[3]; float4 q; float hl; };
 	const bool have_sr = a.cov3D_precomp == nullptr;
 	auto fetch = [&](const int idx)
 	{
-		Raw w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0); w.hl = 0.f;
+		RawGaussian w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0); w.hl = 0.f;
 		if (idx < a.P)
 		{
 #pragma unroll
@@ -505,108 +501,25 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		}
 		return w;
 	};
-#ifdef FR_EXP_COUNT
-	uint32_t dbg_maybe = 0;
-#endif
-	float *qf = s_queue[threadIdx.x >> 6];            // [12][FR_PROJ_QUEUE]: idx, p, sc, q, hl of the queued survivors
-	uint32_t qn = 0;                                  // queued survivors (wave-uniform)
-	auto full = [&](const int slot, const bool active)
-	{
-		const int idx = active ? __float_as_int(qf[slot]) : 0;
-		Raw w;
-#pragma unroll
-		for (int i = 0; i < 3; i++) { w.p[i] = qf[(1 + i) * FR_PROJ_QUEUE + slot]; w.sc[i] = qf[(4 + i) * FR_PROJ_QUEUE + slot]; }
-		w.q = make_float4(qf[7 * FR_PROJ_QUEUE + slot], qf[8 * FR_PROJ_QUEUE + slot], qf[9 * FR_PROJ_QUEUE + slot], qf[10 * FR_PROJ_QUEUE + slot]);
-		w.hl = qf[11 * FR_PROJ_QUEUE + slot];
-		const Raw &cur = w;
-		Proj pr; pr.alive = false; pr.tnum = 0;
-		if (active) pr = project_gaussian<FOV, 1>(a, idx, cur.p, cur.sc, cur.q, cur.hl);
-		if (pr.alive)
-		{
-			float4 ev = make_float4(0, 0, 0, 0);
-			float2 el = make_float2(0, 0);
-			if (CULL && pr.tnum > 1)
-			{
-				// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
-				float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
-				const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
-				e1x *= n1; e1y *= n1;
-				const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
-				e2x *= n2; e2y *= n2;
-				ev = make_float4(e1x, e1y, e2x, e2y);
-				el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
-			}
-			// splats whose clipped walk rectangle is empty land in no tile: the reference zeroes their radius
-			// after its rectangle walk (RS rasterizer_impl.cu:141-145), here they never reach k_bin
-			const WalkRect w = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el,
-				cur.hl, a.lv_bbox);
-			pr.alive = w.tnum != 0;
-			if (pr.alive)
-			{
-				float4 *rec = a.geom.rec + 3 * (size_t)idx;
-				rec[0] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
-				rec[1] = make_float4(pr.conic_c, 0.f, 0.f, 0.f);
-				rec[2] = make_float4(0.f, pr.depth, 0.f, 0.f);
-				if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
-			}
-		}
-		if (active) a.radii[idx] = pr.alive ? pr.radius : 0;
-		const unsigned long long m = __ballot(pr.alive);
-		if (pr.alive) list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
-		n += (uint32_t)__popcll(m);
-		if (n > FR_PROJ_WLIST - 64) flush();
-	};
 	const int nchunks = (a.P + 63) / 64;
 	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
 	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
-	Raw nxt = fetch(wave_gid < nchunks ? wave_gid * 64 + lane : a.P);
+	RawGaussian nxt = fetch(wave_gid < nchunks ? wave_gid * 64 + lane : a.P);
 	for (int chunk = wave_gid; chunk < nchunks; chunk += nwaves)
 	{
 		const int idx = chunk * 64 + lane;
-		const Raw cur = nxt;
+		const RawGaussian cur = nxt;
 		nxt = fetch(chunk + nwaves < nchunks ? (chunk + nwaves) * 64 + lane : a.P);
 		bool maybe = false;
 		if (idx < a.P)
 		{
 			maybe = project_gaussian<FOV, 0>(a, idx, cur.p, cur.sc, cur.q, cur.hl).alive;
-			if (!maybe) a.radii[idx] = 0;
+			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
 		}
 		const unsigned long long m = __ballot(maybe);
-		if (maybe)
-		{
-			const uint32_t slot = qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-			qf[slot] = __int_as_float(idx);
-#pragma unroll
-			for (int i = 0; i < 3; i++) { qf[(1 + i) * FR_PROJ_QUEUE + slot] = cur.p[i]; qf[(4 + i) * FR_PROJ_QUEUE + slot] = cur.sc[i]; }
-			qf[7 * FR_PROJ_QUEUE + slot] = cur.q.x; qf[8 * FR_PROJ_QUEUE + slot] = cur.q.y;
-			qf[9 * FR_PROJ_QUEUE + slot] = cur.q.z; qf[10 * FR_PROJ_QUEUE + slot] = cur.q.w;
-			qf[11 * FR_PROJ_QUEUE + slot] = cur.hl;
-		}
-		qn += (uint32_t)__popcll(m);
-#ifdef FR_EXP_COUNT
-		dbg_maybe += (uint32_t)__popcll(m);
-#endif
-		if (qn >= 64)
-		{
-			// the queue was written by other lanes of this wave
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			qn -= 64;
-			full((int)qn + lane, true);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-		}
-	}
-#ifdef FR_EXP_COUNT
-	if (lane == 0) atomicAdd(a.geom.slab_ctr + 2, dbg_maybe);
-#endif
-	if (qn)
-	{
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		full(lane < (int)qn ? lane : 0, lane < (int)qn);
+		if (maybe) list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+		n += (uint32_t)__popcll(m);
+		if (n > FR_PROJ_WLIST - 64) flush();
 	}
 	if (n) flush();
 }
@@ -647,6 +560,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// by ALL waves of the workgroup after the slab loop: left to the wave that met them they were the kernel's
 	// critical path
 	__shared__ int s_gidx[FR_GIANT_MAX];
+	__shared__ float2 s_gcd[FR_GIANT_MAX]; // conic c, depth of the deferred splat
 	__shared__ uint32_t s_gcount[FR_GIANT_MAX], s_gmask[FR_GIANT_MAX];
 	__shared__ uint32_t s_ng;
 	if (threadIdx.x < FR_GIANT_MAX) { s_gcount[threadIdx.x] = 0; s_gmask[threadIdx.x] = 0; }
@@ -821,17 +735,45 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	bool be_blend = false, boxtest = false;
 	if (item < V)
 	{
+		// the candidate's full projection (covariance chain, conic, radius: forward.cu:155-262), its OBB axes and
+		// the rectangle to walk; candidates that turn out to reach no tile get radius 0, like every culled Gaussian
 		idx = (int)a.geom.vis_list[item];
-		const float4 *rec = a.geom.rec + 3 * (size_t)idx;
-		const float4 r0 = rec[0];
-		r1 = rec[1]; r2 = rec[2];
-		pr.pix_x = r0.x; pr.pix_y = r0.y;
-		pr.radius = a.radii[idx];
-		if (CULL) { ev = a.geom.evec[idx]; el = a.geom.elen[idx]; }
+		RawGaussian w; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 3; i++) w.p[i] = a.means3D[3 * (size_t)idx + i];
+		if (a.cov3D_precomp == nullptr)
+		{
+#pragma unroll
+			for (int i = 0; i < 3; i++) w.sc[i] = a.scales[3 * (size_t)idx + i];
+			w.q = ((const float4 *)a.rotations)[idx];
+		}
 		if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
-		const WalkRect w = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, hl, a.lv_bbox);
-		pr.x0 = w.x0; pr.y0 = w.y0; pr.x1 = w.x1; pr.y1 = w.y1; pr.tnum = w.tnum; boxtest = w.boxtest;
-		pr.alive = true;
+		pr = project_gaussian<FOV, 1>(a, idx, w.p, w.sc, w.q, hl);
+		if (pr.alive)
+		{
+			if (CULL && pr.tnum > 1)
+			{
+				// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
+				float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
+				const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
+				e1x *= n1; e1y *= n1;
+				const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
+				e2x *= n2; e2y *= n2;
+				ev = make_float4(e1x, e1y, e2x, e2y);
+				el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
+			}
+			const WalkRect wr = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, hl, a.lv_bbox);
+			pr.x0 = wr.x0; pr.y0 = wr.y0; pr.x1 = wr.x1; pr.y1 = wr.y1; pr.tnum = wr.tnum; boxtest = wr.boxtest;
+			pr.alive = wr.tnum != 0;
+		}
+		a.radii[idx] = pr.alive ? pr.radius : 0;
+		if (pr.alive)
+		{
+			// first third of the record + OBB axes: k_emit and the giant phase below read them back
+			a.geom.rec[3 * (size_t)idx] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
+			if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
+			r1.x = pr.conic_c; r2.y = pr.depth;
+		}
 	}
 
 	// ---- count the tiles this splat really lands in (and bump the per-tile counters) ----
@@ -861,7 +803,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		if (pr.alive && !in_place && pr.tnum >= FR_GIANT_TNUM)
 		{
 			const uint32_t slot = atomicAdd(&s_ng, 1u);
-			if (slot < FR_GIANT_MAX) { s_gidx[slot] = idx; deferred = true; }
+			if (slot < FR_GIANT_MAX) { s_gidx[slot] = idx; s_gcd[slot] = make_float2(r1.x, r2.y); deferred = true; }
 		}
 		const bool big = pr.alive && !in_place && !deferred && pr.tnum >= FR_BIG_TNUM;
 		if (__ballot(big)) __builtin_amdgcn_s_setprio(3);
@@ -970,7 +912,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		float lowest = ghl, highest = 0.0f;
 		bool be_blend = false;
 		if (FOV && gcount != 0) range_from_mask(s_gmask[threadIdx.x], lowest, highest, be_blend);
-		finish(gi, gcount, ghl, lowest, highest, be_blend, a.geom.rec[3 * (size_t)gi + 1].x, a.geom.rec[3 * (size_t)gi + 2].y);
+		finish(gi, gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y);
 	}
 #ifdef FR_BIN_TIMERS
 	if (lane == 0)
