@@ -231,11 +231,76 @@ struct Proj {
 	int radius, x0, y0, x1, y1;
 	uint32_t tnum;
 };
-// sc / q: the Gaussian's raw scales and rotation (unused with cov3D_precomp); hl: RF highest level.
-// MODE 0: stop after the conservative frame test, r.alive = "may reach the frame"; MODE 1: the full projection
-// of a Gaussian that passed it (k_project runs MODE 0 on everything and MODE 1 on the compacted survivors).
-template <bool FOV, int MODE>
-__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, const float p[3], const float sc[3], float4 q, float hl)
+// Upper bound of the squared spectral norm of the view matrix' 3x3 block (1 for a rigid camera): the spectral
+// radius of W^T W is at most its largest absolute row sum.
+__device__ __forceinline__ float view_norm2_bound(const float *vm)
+{
+	const float c0[3] = { vm[0], vm[1], vm[2] }, c1[3] = { vm[4], vm[5], vm[6] }, c2[3] = { vm[8], vm[9], vm[10] };
+	const float g00 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2], g11 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2],
+		g22 = c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
+	const float g01 = fabsf(c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2]), g02 = fabsf(c0[0] * c2[0] + c0[1] * c2[1] + c0[2] * c2[2]),
+		g12 = fabsf(c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2]);
+	return fmaxf(g00 + g01 + g02, fmaxf(g01 + g11 + g12, g02 + g12 + g22)) * 1.001f;
+}
+
+// Conservative visibility test of k_project (more than half of the Gaussians in front of the camera of a
+// room-scale scene cannot reach the frame). Exact part: the near plane (auxiliary.h:139-164, same expression as
+// the full projection). Bound: every entry of the 2D covariance T^T Sigma T (forward.cu:74-113) is at most
+// B = rho(Sigma) |T|_F^2 in magnitude (+0.3 on the diagonal), so lambda1 <= 2.42 B + 1.05 and the radius is at
+// most r_ub; |T|_F <= |W|_2 |J|_F with J's four non-zero entries; getRect is monotone in the radius, so an empty
+// rectangle for r_ub (RF: clipped to the level box, see walk_rect) means the reference drops the splat as well
+// (forward.cu:229-231). Everything here is evaluated approximately (no double, one division) and padded by
+// 1 % + 2 px, far above the rounding of either formulation; NaN/inf anywhere makes the test pass.
+template <bool FOV>
+__device__ __forceinline__ bool frame_test(const PreArgs &a, int idx, const float p[3], const float sc[3], float4 q, float hl, float wn2)
+{
+	const float *vm = a.viewmatrix, *pm = a.projmatrix;
+	const float tz = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
+	if (tz <= 0.2f) return false;
+	const float hx = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
+	const float hy = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
+	const float hw = pm[3] * p[0] + pm[7] * p[1] + pm[11] * p[2] + pm[15];
+	const float t0 = vm[0] * p[0] + vm[4] * p[1] + vm[8] * p[2] + vm[12];
+	const float t1 = vm[1] * p[0] + vm[5] * p[1] + vm[9] * p[2] + vm[13];
+	const float p_w = 1.0f / (hw + 0.0000001f);
+	const float pix_x = ((hx * p_w + 1.0f) * a.W - 1.0f) * 0.5f, pix_y = ((hy * p_w + 1.0f) * a.H - 1.0f) * 0.5f;
+	const float iz = __builtin_amdgcn_rcpf(tz);
+	const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+	const float cx = fminf(limx, fmaxf(-limx, t0 * iz)), cy = fminf(limy, fmaxf(-limy, t1 * iz));
+	const float ja = a.focal_x * iz, jb = a.focal_y * iz;
+	const float jf = (ja * ja) * (1.0f + cx * cx) + (jb * jb) * (1.0f + cy * cy); // |J|_F^2
+	float rho; // upper bound of the spectral norm of the 3D covariance
+	if (a.cov3D_precomp != nullptr)
+	{
+		const float *c = a.cov3D_precomp + 6 * (size_t)idx;
+		rho = fabsf(c[0]) + fabsf(c[3]) + fabsf(c[5]) + 2.0f * (fabsf(c[1]) + fabsf(c[2]) + fabsf(c[4]));
+	}
+	else
+	{
+		// Sigma = M^T M with M = S R, and R = (1 - 2|v|^2) I + 2 v v^T + 2 r [v]x has the singular values 1 and
+		// sqrt((1 - 2|v|^2)^2 + 4 r^2 |v|^2) (= 1 for a unit quaternion; the reference does not normalise here)
+		const float vv = q.y * q.y + q.z * q.z + q.w * q.w;
+		const float smax = a.scale_modifier * fmaxf(fabsf(sc[0]), fmaxf(fabsf(sc[1]), fabsf(sc[2])));
+		rho = smax * smax * fmaxf(1.0f, (1.0f - 2.0f * vv) * (1.0f - 2.0f * vv) + 4.0f * q.x * q.x * vv);
+	}
+	const float lam_ub = 2.42f * (rho * (wn2 * jf)) * 1.01f + 1.05f;
+	const float r_ub = ceilf(3.0f * __builtin_sqrtf(lam_ub)) * 1.01f + 2.0f;
+	if (!(r_ub < 1e9f)) return true;
+	int x0, y0, x1, y1;
+	get_rect_f(pix_x, pix_y, r_ub, a.gx, a.gy, x0, y0, x1, y1);
+	if (FOV)
+	{
+		const int k = (int)fminf(fmaxf(ceilf(hl + 1.0f), 0.0f), 4.0f);
+		const uint4 b = *(const uint4 *)(a.lv_bbox + k * FR_LV_BBOX_STRIDE);
+		x0 = max(x0, a.gx - (int)b.x); y0 = max(y0, a.gy - (int)b.y);
+		x1 = min(x1, (int)b.z); y1 = min(y1, (int)b.w);
+	}
+	return x1 > x0 && y1 > y0;
+}
+
+// The reference's per-Gaussian projection (forward.cu:155-262): near plane, 3D covariance, EWA 2D covariance,
+// conic, radius, tile rectangle. sc / q: raw scales and rotation (unused with cov3D_precomp).
+__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, const float p[3], const float sc[3], float4 q)
 {
 	Proj r; r.alive = false; r.tnum = 0; r.radius = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0;
 	r.pix_x = r.pix_y = r.depth = r.conic_a = r.conic_b = r.conic_c = r.cov0 = r.cov1 = r.lambda1 = r.lambda2 = 0.f;
@@ -253,7 +318,7 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, cons
 	r.depth = t[2];
 	if (r.depth <= 0.2f) return r;
 
-	// Jacobian of the projection and T = W * J (EWA, forward.cu:74-113); needed by the early-out below
+	// Jacobian of the projection and T = W * J (EWA, forward.cu:74-113)
 	const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
 	const float txtz = t[0] / t[2], tytz = t[1] / t[2];
 	const float tx = fminf(limx, fmaxf(-limx, txtz)) * t[2];
@@ -267,56 +332,14 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, cons
 	r.pix_x = (float)((((double)projx + 1.0) * a.W - 1.0) * 0.5);
 	r.pix_y = (float)((((double)projy + 1.0) * a.H - 1.0) * 0.5);
 
-	float s0 = 0, s1 = 0, s2 = 0;
 	float cov3D[6];
-	float rho; // upper bound of the spectral norm of the 3D covariance
 	if (a.cov3D_precomp != nullptr)
 	{
 #pragma unroll
 		for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[6 * (size_t)idx + i];
-		rho = fabsf(cov3D[0]) + fabsf(cov3D[3]) + fabsf(cov3D[5]) + 2.0f * (fabsf(cov3D[1]) + fabsf(cov3D[2]) + fabsf(cov3D[4]));
 	}
-	else
-	{
-		const float mod = a.scale_modifier;
-		s0 = mod * sc[0]; s1 = mod * sc[1]; s2 = mod * sc[2];
-		// Sigma = M^T M with M = S R, and R = (1 - 2|v|^2) I + 2 v v^T + 2 r [v]x has the singular values 1 and
-		// sqrt((1 - 2|v|^2)^2 + 4 r^2 |v|^2) (= 1 for a unit quaternion; the reference does not normalise here)
-		const float vv = q.y * q.y + q.z * q.z + q.w * q.w;
-		const float smax = fmaxf(fabsf(s0), fmaxf(fabsf(s1), fabsf(s2)));
-		rho = smax * smax * fmaxf(1.0f, (1.0f - 2.0f * vv) * (1.0f - 2.0f * vv) + 4.0f * q.x * q.x * vv);
-	}
-	// Conservative visibility test (more than half of the Gaussians in front of the camera of a room-scale scene
-	// cannot reach the frame): every entry of the 2D covariance is bounded by B = rho |T|_F^2 (+0.3 on the
-	// diagonal), hence lambda1 <= 2.42 B + 1.05 and the radius by r_ub below; getRect is monotone in the radius,
-	// so an empty rectangle for r_ub means an empty rectangle for the true radius and the reference drops the
-	// splat as well (forward.cu:229-231); RF: the same for the rectangle clipped to the level box, see
-	// walk_rect(). NaN/inf anywhere makes the test pass and the full path decide.
-	if (MODE == 0)
-	{
-		float tf = 0.0f;
-#pragma unroll
-		for (int i = 0; i < 3; i++)
-#pragma unroll
-			for (int j = 0; j < 3; j++) tf += Tm.c[i][j] * Tm.c[i][j];
-		const float lam_ub = 2.42f * (rho * tf) + 1.05f;
-		const float r_ub = ceilf(3.0f * sqrtf(lam_ub)) * 1.01f + 2.0f;
-		if (r_ub < 1e9f)
-		{
-			int x0, y0, x1, y1;
-			get_rect_f(r.pix_x, r.pix_y, r_ub, a.gx, a.gy, x0, y0, x1, y1);
-			if (FOV)
-			{
-				const int k = (int)fminf(fmaxf(ceilf(hl + 1.0f), 0.0f), 4.0f);
-				const uint4 b = *(const uint4 *)(a.lv_bbox + k * FR_LV_BBOX_STRIDE);
-				x0 = max(x0, a.gx - (int)b.x); y0 = max(y0, a.gy - (int)b.y);
-				x1 = min(x1, (int)b.z); y1 = min(y1, (int)b.w);
-			}
-			if (x1 <= x0 || y1 <= y0) return r;
-		}
-		r.alive = true;
-		return r;
-	}
+	const float mod = a.scale_modifier;
+	const float s0 = mod * sc[0], s1 = mod * sc[1], s2 = mod * sc[2];
 
 	// 3D covariance: forward.cu:118-152
 	if (a.cov3D_precomp == nullptr)
@@ -484,6 +507,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		n = 0;
 	};
 	const bool have_sr = a.cov3D_precomp == nullptr;
+	const float wn2 = view_norm2_bound(a.viewmatrix);
 	auto fetch = [&](const int idx)
 	{
 		RawGaussian w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0); w.hl = 0.f;
@@ -504,16 +528,20 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	const int nchunks = (a.P + 63) / 64;
 	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
 	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
+	// two chunks in flight per wave: at ~20 waves per CU one chunk (2.8 KB per wave) does not cover the memory
+	// latency at full bandwidth
 	RawGaussian nxt = fetch(wave_gid < nchunks ? wave_gid * 64 + lane : a.P);
+	RawGaussian nxt2 = fetch(wave_gid + nwaves < nchunks ? (wave_gid + nwaves) * 64 + lane : a.P);
 	for (int chunk = wave_gid; chunk < nchunks; chunk += nwaves)
 	{
 		const int idx = chunk * 64 + lane;
 		const RawGaussian cur = nxt;
-		nxt = fetch(chunk + nwaves < nchunks ? (chunk + nwaves) * 64 + lane : a.P);
+		nxt = nxt2;
+		nxt2 = fetch(chunk + 2 * nwaves < nchunks ? (chunk + 2 * nwaves) * 64 + lane : a.P);
 		bool maybe = false;
 		if (idx < a.P)
 		{
-			maybe = project_gaussian<FOV, 0>(a, idx, cur.p, cur.sc, cur.q, cur.hl).alive;
+			maybe = frame_test<FOV>(a, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
 			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
 		}
 		const unsigned long long m = __ballot(maybe);
@@ -748,7 +776,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			w.q = ((const float4 *)a.rotations)[idx];
 		}
 		if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
-		pr = project_gaussian<FOV, 1>(a, idx, w.p, w.sc, w.q, hl);
+		pr = project_gaussian(a, idx, w.p, w.sc, w.q);
 		if (pr.alive)
 		{
 			if (CULL && pr.tnum > 1)
