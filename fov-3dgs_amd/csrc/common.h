@@ -10,7 +10,7 @@
 #define FR_FOV_LEVELS 4       // RF auxiliary.h:26 fov_num
 #define FR_SORT_LDS_MAX 8192  // longest per-tile list sorted inside LDS (64 KiB of u64 keys)
 #define FR_BIN_THREADS 512    // workgroup size of the binning kernels (preprocess / emit)
-#define FR_BIN_BLOCKS 768     // persistent workgroups of the binning kernels (3 per CU)
+#define FR_BIN_BLOCKS 512     // persistent workgroups of the binning kernels (2 per CU: k_bin needs ~120 VGPRs and up to 68 KiB LDS)
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop

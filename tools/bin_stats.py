@@ -26,7 +26,7 @@ geom = r[3]
 # cov3D sits right after rec (3P float4, 256-aligned)
 P = xyz.shape[0]
 off = ((P * 48 + 255) // 256) * 256
-dbg = geom[off:off + 768 * 8 * 8 * 4].view(torch.float32).view(768 * 8, 8).cpu().numpy()
+dbg = geom[off:off + 512 * 8 * 8 * 4].view(torch.float32).view(512 * 8, 8).cpu().numpy()
 tot, sched, load, pairs, col, pulled = [dbg[:, i] * (10 if i < 5 else 1) for i in range(6)]
 print("waves", len(tot), "wave total us: mean %.0f max %.0f" % (tot.mean() / 1e3, tot.max() / 1e3))
 print("  slab loop end: mean %.1f p99 %.1f max %.1f us" % (sched.mean() / 1e3, np.percentile(sched, 99) / 1e3, sched.max() / 1e3))
