@@ -28,32 +28,38 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 	if (tid < 34) bucket[tid] = 0;
 	uint32_t vmax = 0;
 	__syncthreads();
-	for (int base = 0; base < T; base += 1024)
+	// one pass: every thread owns a contiguous run of `per` tiles (8 at 1080p), sums it, the 1024 sums are scanned
+	// once (wave scan + 16 wave totals), then the thread walks its run again to write the ranges
+	const int per = (T + 1023) / 1024;
+	const int t0 = tid * per, t1 = min(T, t0 + per);
+	uint32_t mine = 0;
+	for (int i = t0; i < t1; i++)
 	{
-		const int i = base + tid;
-		const uint32_t v = i < T ? tile_count[i] : 0u;
+		const uint32_t v = tile_count[i];
+		mine += v;
 		vmax = max(vmax, v);
-		if (i < T) atomicAdd(&bucket[v ? 32 - __clz((int)v) : 0], 1u); // bucket b: 2^(b-1) <= v < 2^b
-		// inclusive scan inside the wave
-		uint32_t s = v;
-#pragma unroll
-		for (int off = 1; off < 64; off <<= 1)
-		{
-			const uint32_t n = __shfl_up(s, off);
-			if (lane >= off) s += n;
-		}
-		if (lane == 63) wave_sum[wid] = s;
-		__syncthreads();
-		uint32_t wave_off = 0, block_total = 0;
-#pragma unroll
-		for (int w = 0; w < 16; w++) { if (w < wid) wave_off += wave_sum[w]; block_total += wave_sum[w]; }
-		const uint32_t carry = carry_s;
-		const uint32_t excl = carry + wave_off + s - v;
-		if (i < T) ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u); // empty tiles stay (0,0) like the reference's memset
-		__syncthreads();
-		if (tid == 0) carry_s = carry + block_total;
-		__syncthreads();
+		atomicAdd(&bucket[v ? 32 - __clz((int)v) : 0], 1u); // bucket b: 2^(b-1) <= v < 2^b
 	}
+	uint32_t s = mine; // inclusive scan inside the wave
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1)
+	{
+		const uint32_t n = __shfl_up(s, off);
+		if (lane >= off) s += n;
+	}
+	if (lane == 63) wave_sum[wid] = s;
+	__syncthreads();
+	uint32_t wave_off = 0, block_total = 0;
+#pragma unroll
+	for (int w = 0; w < 16; w++) { if (w < wid) wave_off += wave_sum[w]; block_total += wave_sum[w]; }
+	uint32_t run = wave_off + s - mine;
+	for (int i = t0; i < t1; i++)
+	{
+		const uint32_t v = tile_count[i];
+		ranges[i] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u); // empty tiles stay (0,0) like the reference's memset
+		run += v;
+	}
+	if (tid == 0) carry_s = block_total;
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor(vmax, off));
 	if (lane == 0) wave_max[wid] = vmax;

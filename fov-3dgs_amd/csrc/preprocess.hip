@@ -82,22 +82,34 @@ __device__ float tile_level(int tx, int ty, int W, int H, float gaze_x, float ga
 	return level;
 }
 
-// One thread per tile: level of the tile and of its 4 neighbours (recomputed instead of a second
-// kernel + global round trip), finite-difference gradients, conservative tile minimum and the
+// One thread per tile: level of the tile and of its 4 neighbours, finite-difference gradients, conservative tile minimum and the
 // two-level-blend flag. out = float[5][T]: level, tile_min, grad_x, grad_y, blending.
 // lv_bbox[k] (zeroed by the caller): bounding box of the tiles with tile_min < k, see walk_rect().
-__global__ void k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x, float gaze_y, float alpha, float *out,
+// A workgroup owns a 16 x 16 patch of tiles: every level is evaluated once (plus the patch's one-tile halo) and
+// shared through LDS -- the level function (acos, tan, three sqrt) is ~500 instructions.
+__global__ void __launch_bounds__(256) k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x, float gaze_y, float alpha, float *out,
 	uint32_t *lv_bbox)
 {
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool live = idx < T;
-	const int ty = live ? idx / gx : 0, tx = live ? idx % gx : 0;
-	const float lf = tile_level(tx, ty, W, H, gaze_x, gaze_y, alpha);
-	float right = -1, left = -1, up = -1, down = -1;
-	if (tx + 1 < gx) right = tile_level(tx + 1, ty, W, H, gaze_x, gaze_y, alpha);
-	if (tx - 1 >= 0) left = tile_level(tx - 1, ty, W, H, gaze_x, gaze_y, alpha);
-	if (ty + 1 < gy) up = tile_level(tx, ty + 1, W, H, gaze_x, gaze_y, alpha);
-	if (ty - 1 >= 0) down = tile_level(tx, ty - 1, W, H, gaze_x, gaze_y, alpha);
+	__shared__ float s_lv[18][18]; // [y + 1][x + 1]; -1 = outside the grid
+	const int pxn = (gx + 15) / 16;
+	const int bx = (int)blockIdx.x % pxn, by = (int)blockIdx.x / pxn;
+	const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+	const int tx = bx * 16 + lx, ty = by * 16 + ly;
+	const bool live = tx < gx && ty < gy;
+	const int idx = ty * gx + tx;
+	s_lv[ly + 1][lx + 1] = live ? tile_level(tx, ty, W, H, gaze_x, gaze_y, alpha) : -1.0f;
+	if (threadIdx.x < 64)
+	{
+		// halo: side 0 = left column, 1 = right column, 2 = row above, 3 = row below
+		const int side = threadIdx.x >> 4, k = threadIdx.x & 15;
+		const int hx = side == 0 ? -1 : (side == 1 ? 16 : k), hy = side == 2 ? -1 : (side == 3 ? 16 : k);
+		const int gxx = bx * 16 + hx, gyy = by * 16 + hy;
+		const bool in = gxx >= 0 && gxx < gx && gyy >= 0 && gyy < gy;
+		s_lv[hy + 1][hx + 1] = in ? tile_level(gxx, gyy, W, H, gaze_x, gaze_y, alpha) : -1.0f;
+	}
+	__syncthreads();
+	const float lf = s_lv[ly + 1][lx + 1];
+	const float right = s_lv[ly + 1][lx + 2], left = s_lv[ly + 1][lx], up = s_lv[ly + 2][lx + 1], down = s_lv[ly][lx + 1];
 	float gxv = 0, gyv = 0;
 	if (right != -1 && left != -1) gxv = (right - left) / 2.0f;
 	else if (right != -1) gxv = right - lf;
@@ -1192,7 +1204,7 @@ static inline size_t lds_tile_table_bytes(int T) { return (size_t)T * sizeof(flo
 int launch_tile_levels(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
-	hipLaunchKernelGGL(k_tile_levels, dim3((c.T + 255) / 256), dim3(256), 0, c.stream,
+	hipLaunchKernelGGL(k_tile_levels, dim3(((c.gx + 15) / 16) * ((c.gy + 15) / 16)), dim3(256), 0, c.stream,
 		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv, c.img.lv_bbox);
 	return check_launch("tile_levels", c.stream, a->debug);
 }
