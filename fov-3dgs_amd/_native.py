@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfovraster_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
 VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC = 4, 5
@@ -38,6 +38,7 @@ class ForwardArgs(C.Structure):
         ("num_rendered", C.c_int32), ("max_tile_instances", C.c_int32),
         ("stage_events", C.POINTER(C.c_void_p)),
         ("loss_map", _FP),
+        ("shs_rest", _FP),
     ]
 
 
@@ -54,6 +55,8 @@ class BackwardArgs(C.Structure):
         ("dL_dmean2D", _FP), ("dL_dconic", _FP), ("dL_dopacity", _FP), ("dL_dcolor", _FP), ("dL_dmean3D", _FP),
         ("dL_dcov3D", _FP), ("dL_dsh", _FP), ("dL_dscale", _FP), ("dL_drot", _FP),
         ("stage_events", C.POINTER(C.c_void_p)),
+        ("shs_rest", _FP),
+        ("dL_dsh_rest", _FP),
     ]
 
 

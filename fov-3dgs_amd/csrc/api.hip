@@ -48,6 +48,7 @@ static int validate_forward(const fr_forward_args *a)
 	const bool fov = a->variant == FR_VARIANT_FOV_PCHECK_OBB;
 	if (fov)
 	{
+		if (a->shs_rest) { set_error("shs_rest is not used by the foveated variant (its shs already is the rest part)"); return FR_ERR_INVALID; }
 		if (!a->shs || !a->shs_dcs || !a->highest_levels) { set_error("foveated variant needs shs (rest), shs_dcs and highest_levels"); return FR_ERR_INVALID; }
 		if (a->M != 15) { set_error("foveated variant expects M=15 rest coefficients, got %d", a->M); return FR_ERR_INVALID; }
 	}
@@ -55,6 +56,7 @@ static int validate_forward(const fr_forward_args *a)
 	{
 		if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) { set_error("provide exactly one of shs / colors_precomp"); return FR_ERR_INVALID; }
 		if (a->shs && a->M < (a->D + 1) * (a->D + 1)) { set_error("M=%d too small for SH degree %d", a->M, a->D); return FR_ERR_INVALID; }
+		if (a->shs_rest && (!a->shs || a->M < 2)) { set_error("shs_rest needs shs (the DC part) and M >= 2"); return FR_ERR_INVALID; }
 	}
 	if (a->D < 0 || a->D > 3) { set_error("SH degree %d not in 0..3", a->D); return FR_ERR_INVALID; }
 	const bool has_sr = a->scales && a->rotations;
@@ -176,6 +178,7 @@ int fr_backward(const fr_backward_args *a)
 	if (!a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor || !a->dL_dmean3D || !a->dL_dcov3D || !a->dL_dscale || !a->dL_drot)
 	{ set_error("missing gradient output pointer"); return FR_ERR_INVALID; }
 	if (a->shs && !a->dL_dsh) { set_error("dL_dsh is null"); return FR_ERR_INVALID; }
+	if (a->shs_rest && (!a->shs || !a->dL_dsh_rest)) { set_error("shs_rest needs shs and dL_dsh_rest"); return FR_ERR_INVALID; }
 	return launch_backward(a);
 }
 

@@ -246,13 +246,13 @@ __device__ __forceinline__ M3b mb_t(const M3b &a)
 struct BwdPreArgs {
 	int P, D, M, W, H;
 	float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
-	const float *means3D, *scales, *rotations, *shs, *cov3D_precomp, *colors_precomp;
+	const float *means3D, *scales, *rotations, *shs, *shs_rest, *cov3D_precomp, *colors_precomp;
 	const float *viewmatrix, *projmatrix, *campos;
 	const int *radii;
 	const float4 *rec;
 	const float *cov3D_ws;
 	const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
-	float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+	float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscale, *dL_drot;
 	const uint32_t *vis_list;  // forward's compact list of projected Gaussians
 	const uint32_t *vis_count; // its length (device)
 };
@@ -348,8 +348,12 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	// ---- SH backward: backward.cu:20-139 ----
 	if (a.colors_precomp == nullptr && a.shs != nullptr)
 	{
-		const float *sh = a.shs + (size_t)idx * a.M * 3;
-		float *dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+		// coefficient k >= 1 at sh[3k + ch]; with split storage (shs = DC [P,1,3], shs_rest = [P,M-1,3]) the pointers
+		// are biased by one coefficient so that the same indexing works (k = 0 is only ever written, through dsh0)
+		const bool split = a.shs_rest != nullptr;
+		const float *sh = split ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : a.shs + (size_t)idx * a.M * 3;
+		float *dsh = split ? a.dL_dsh_rest + (size_t)idx * (a.M - 1) * 3 - 3 : a.dL_dsh + (size_t)idx * a.M * 3;
+		float *dsh0 = split ? a.dL_dsh + 3 * (size_t)idx : dsh;
 		const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)idx + 2].z);
 		const float dox = m[0] - a.campos[0], doy = m[1] - a.campos[1], doz = m[2] - a.campos[2];
 		const float len = sqrtf(dox * dox + doy * doy + doz * doz);
@@ -361,7 +365,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		const int deg = a.D;
 #define SHV(k, ch) sh[3 * (k) + (ch)]
 #define DSH(k, w) { const float w_ = (w); dsh[3 * (k)] = w_ * dRGB[0]; dsh[3 * (k) + 1] = w_ * dRGB[1]; dsh[3 * (k) + 2] = w_ * dRGB[2]; }
-		DSH(0, FR_SH_C0);
+		dsh0[0] = FR_SH_C0 * dRGB[0]; dsh0[1] = FR_SH_C0 * dRGB[1]; dsh0[2] = FR_SH_C0 * dRGB[2];
 		if (deg > 0)
 		{
 			DSH(1, -FR_SH_C1 * y); DSH(2, FR_SH_C1 * z); DSH(3, -FR_SH_C1 * x);
@@ -524,12 +528,12 @@ int launch_backward(const fr_backward_args *a)
 	p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy;
 	p.focal_y = a->H / (2.0f * a->tanfovy); p.focal_x = a->W / (2.0f * a->tanfovx);
 	p.scale_modifier = a->scale_modifier;
-	p.means3D = a->means3D; p.scales = a->scales; p.rotations = a->rotations; p.shs = a->shs;
+	p.means3D = a->means3D; p.scales = a->scales; p.rotations = a->rotations; p.shs = a->shs; p.shs_rest = a->shs_rest;
 	p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
 	p.radii = a->radii; p.rec = geom.rec; p.cov3D_ws = geom.cov3D;
 	p.dL_dmean2D = a->dL_dmean2D; p.dL_dconic = a->dL_dconic; p.dL_dcolor = a->dL_dcolor;
-	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
+	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dsh_rest = a->dL_dsh_rest; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
 	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1;
 	const int pblocks = (a->P + 255) / 256;
 	hipLaunchKernelGGL(k_preprocess_bwd, dim3(pblocks < 2048 ? pblocks : 2048), dim3(256), 0, stream, p);

@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(256) k_tile_levels(int T, int gx, int gy, int 
 }
 
 // ---- SH colour: forward.cu:20-71 (full) and RF rasterizer_impl.cu:37-84 (rest only) -----------
-// sh points at the navail = 3*M floats of this Gaussian; REST: coefficient k is stored at slot k-1.
+// sh points at the navail = 3*M floats of this Gaussian; REST: coefficient k is stored at slot k-1 and coefficient 0
+// comes from dc[3] if that is given (split storage: features_dc / features_rest), else it is left out (RF).
 // Every lane reads its own Gaussian, i.e. its own cache lines, and a CU's address unit handles such a
 // scattered access lane by lane: 48 dword loads per Gaussian made this the slowest part of k_bin. The
 // coefficients are therefore fetched 16 bytes at a time (dword-aligned: 45 floats per Gaussian in RF) and
@@ -160,7 +161,8 @@ __global__ void __launch_bounds__(256) k_tile_levels(int T, int gx, int gy, int 
 // k = 0..15 left to right), so the result is bit-identical to the scalar formulation.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 template <bool REST>
-__device__ __forceinline__ void sh_colour(int deg, int navail, const float *__restrict__ sh, float dx, float dy, float dz, float out[3])
+__device__ __forceinline__ void sh_colour(int deg, int navail, const float *__restrict__ sh, const float *__restrict__ dc,
+	float dx, float dy, float dz, float out[3])
 {
 	const float len = sqrtf(dx * dx + dy * dy + dz * dz);
 	const float x = dx / len, y = dy / len, z = dz / len;
@@ -176,6 +178,11 @@ __device__ __forceinline__ void sh_colour(int deg, int navail, const float *__re
 	constexpr int SKIP = REST ? 1 : 0;
 	const int nfl = 3 * ((deg + 1) * (deg + 1) - SKIP); // floats in use
 	float acc[3] = { 0.0f, 0.0f, 0.0f };
+	if (REST && dc != nullptr)
+	{
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) acc[ch] = basis[0] * dc[ch]; // == 0 + C0 * sh[0] of the unsplit sum
+	}
 	if (navail >= 48 - 3 * SKIP)
 	{
 		// usual case (M = 16 coefficients allocated): every chunk is fetched unconditionally, so the loads are
@@ -222,6 +229,7 @@ struct PreArgs {
 	int P, D, M, W, H, gx, gy;
 	float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
 	const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
+	const float *shs_rest; // split SH storage: shs = DC [P,1,3], shs_rest = [P,M-1,3]; else null
 	const float *viewmatrix, *projmatrix, *campos;
 	const float *shs_dcs, *highest_levels;
 	const float *tile_lv; // RF float[5][T]
@@ -683,7 +691,10 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			if (a.colors_precomp == nullptr)
 			{
 				float c[3];
-				sh_colour<false>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, c);
+				if (a.shs_rest != nullptr)
+					sh_colour<true>(a.D, (a.M - 1) * 3, a.shs_rest + (size_t)idx * (a.M - 1) * 3, a.shs + 3 * (size_t)idx, dirx, diry, dirz, c);
+				else
+					sh_colour<false>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, c);
 #pragma unroll
 				for (int ch = 0; ch < 3; ch++) { if (c[ch] < 0) clamp_bits |= 1u << ch; rgb[ch] = fmaxf(c[ch], 0.0f); }
 			}
@@ -707,7 +718,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			const float dcs[12] = { dc0.x, dc0.y, dc0.z, dc0.w, dc1.x, dc1.y, dc1.z, dc1.w, dc2.x, dc2.y, dc2.z, dc2.w };
 			const float ops[4] = { opl.x, opl.y, opl.z, opl.w };
 			float rest[3];
-			sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, dirx, diry, dirz, rest);
+			sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, rest);
 			static_assert(FR_FOV_LEVELS == 4, "level data is fetched as float4s");
 #pragma unroll
 			for (int l = 0; l < FR_FOV_LEVELS; l++)
@@ -1218,7 +1229,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 	p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.focal_x = c.focal_x; p.focal_y = c.focal_y;
 	p.scale_modifier = a->scale_modifier;
 	p.means3D = a->means3D; p.scales = a->scales; p.rotations = a->rotations; p.opacities = a->opacities;
-	p.shs = a->shs; p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
+	p.shs = a->shs; p.shs_rest = a->shs_rest; p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.lv_bbox = c.img.lv_bbox; p.T = c.T;
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;

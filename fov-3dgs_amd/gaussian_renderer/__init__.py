@@ -46,7 +46,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     opacity = pc.get_opacity
     scales = pc.get_scaling
     rotations = pc.get_rotation
-    shs = pc.get_features_detach_rest if masking else pc.get_features
+    # models that expose their SH tensors separately (get_features_split, an extension of this package) skip the
+    # concatenation; any other model goes through the reference's get_features
+    if hasattr(pc, "get_features_split"):
+        shs = pc.get_features_split_detach_rest if masking else pc.get_features_split
+    else:
+        shs = pc.get_features_detach_rest if masking else pc.get_features
     if masking:
         scales, means3D, rotations = scales.detach(), means3D.detach(), rotations.detach()
 

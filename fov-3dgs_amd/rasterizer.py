@@ -105,7 +105,8 @@ _stage_events_hook = None
 
 
 def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None):
+                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
+                    sh_rest=None):
     """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions])
     persistent=True: the workspaces are the per-device grow-only set (valid until the next call)."""
     lib = _native.load()
@@ -132,7 +133,8 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         a.variant = variant
         a.P, a.D = P, int(rs.sh_degree)
         sh_c = put("shs", sh)
-        a.M = 0 if sh_c is None else sh_c.size(1)
+        rest_c = put("shs_rest", sh_rest)  # split storage: sh = DC [P,1,3], sh_rest = [P,M-1,3]
+        a.M = 0 if sh_c is None else sh_c.size(1) + (0 if rest_c is None else rest_c.size(1))
         a.W, a.H = W, H
         a.prefiltered, a.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
         a.tanfovx, a.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
@@ -170,8 +172,9 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
 
 
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                     grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer):
-    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)"""
+                     grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations[, dL_dsh_rest])
+    (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3])"""
     lib = _native.load()
     dev = means3D.device
     P = means3D.size(0)
@@ -187,11 +190,14 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
 
     with torch.cuda.device(dev):
         sh_c = put("shs", sh)
-        M = 0 if sh_c is None else sh_c.size(1)
+        rest_c = put("shs_rest", sh_rest)
+        M0 = 0 if sh_c is None else sh_c.size(1)
+        M = M0 + (0 if rest_c is None else rest_c.size(1))
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
         dL_dconic, dL_dopacity, dL_dcov3D = z(P, 2, 2), z(P, 1), z(P, 6)
-        dL_dsh, dL_dscales, dL_drotations = z(P, M, 3), z(P, 3), z(P, 4)
+        dL_dsh, dL_dscales, dL_drotations = z(P, M0, 3), z(P, 3), z(P, 4)
+        dL_dsh_rest = z(P, M - M0, 3) if rest_c is not None else None
         if P != 0:
             a.variant, a.P, a.D, a.M, a.R = variant, P, int(rs.sh_degree), M, int(num_rendered)
             a.W, a.H, a.debug = W, H, int(bool(rs.debug))
@@ -213,11 +219,13 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
             a.dL_dmean2D, a.dL_dconic, a.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr()
             a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D = dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr()
             a.dL_dsh = dL_dsh.data_ptr() if M else None
+            a.dL_dsh_rest = dL_dsh_rest.data_ptr() if dL_dsh_rest is not None else None
             a.dL_dscale, a.dL_drot = dL_dscales.data_ptr(), dL_drotations.data_ptr()
             rc = lib.fr_backward(C.byref(a))
             if rc != 0:
                 raise RuntimeError(f"fovraster backward failed ({rc}): {_native.last_error()}")
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return out + (dL_dsh_rest,) if dL_dsh_rest is not None else out
 
 
 def _mark_visible(positions, rs):
@@ -247,31 +255,37 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    raster_settings, loss_map=None):
+                    raster_settings, loss_map=None, sh_rest=None):
+            # sh_rest (extension): the SH coefficients as the two tensors a model stores, sh = features_dc
+            # [P,1,3], sh_rest = features_rest [P,M-1,3]; saves the torch.cat of get_features and its backward
             args = (variant_id, raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations,
                     cov3Ds_precomp)
+            if sh_rest is not None and sh_rest.numel() == 0:
+                sh_rest = None
             keep_ws = has_backward and any(ctx.needs_input_grad)  # backward re-reads the workspaces
             if takes_loss_map:
                 if loss_map is None or loss_map.numel() < raster_settings.image_height * raster_settings.image_width:
                     raise Exception("loss_map with at least image_height*image_width values is required")
-            ctx.n_inputs = 10 if takes_loss_map else 9
+            ctx.n_inputs = 11
+            ctx.split_sh = sh_rest is not None
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
                 try:
-                    res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map)
+                    res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map)
+                res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest)
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = res[:6]
             if not keep_ws:  # nothing will call backward: do not pin the shared workspaces
                 geomBuffer = binningBuffer = imgBuffer = torch.empty(0, dtype=torch.uint8, device=means3D.device)
             ctx.raster_settings = raster_settings
             ctx.num_rendered = num_rendered
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
-                                  geomBuffer, binningBuffer, imgBuffer)
+                                  geomBuffer, binningBuffer, imgBuffer,
+                                  sh_rest if sh_rest is not None else torch.empty(0, device=means3D.device))
             ctx.mark_non_differentiable(radii)
             if with_counts:
                 ctx.mark_non_differentiable(res[6], res[7])
@@ -285,9 +299,10 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 raise RuntimeError("this rasterizer variant is inference-only (no backward in the reference)")
             rs = ctx.raster_settings
             (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
-             geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+             geomBuffer, binningBuffer, imgBuffer, sh_rest) = ctx.saved_tensors
             args = (variant_id, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    grad_out_color, sh, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer)
+                    grad_out_color, sh, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer,
+                    sh_rest if ctx.split_sh else None)
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
@@ -299,18 +314,15 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             else:
                 res = _backward_native(*args)
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-             grad_scales, grad_rotations) = res
+             grad_scales, grad_rotations) = res[:8]
             grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                      grad_rotations, grad_cov3Ds_precomp, None)
-            return grads + (None,) * (ctx.n_inputs - 9)
+            return grads + (None, res[8] if ctx.split_sh else None)  # loss_map, sh_rest
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                            raster_settings, loss_map=None):
-        if takes_loss_map:
-            return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                             cov3Ds_precomp, raster_settings, loss_map)
+                            raster_settings, loss_map=None, sh_rest=None):
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                         cov3Ds_precomp, raster_settings)
+                                         cov3Ds_precomp, raster_settings, loss_map if takes_loss_map else None, sh_rest)
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):
@@ -330,13 +342,16 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                     ((scales is not None or rotations is not None) and cov3D_precomp is not None):
                 raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
             empty = torch.Tensor([])
+            shs_rest = None
+            if isinstance(shs, (tuple, list)):  # extension: (features_dc [P,1,3], features_rest [P,M-1,3])
+                shs, shs_rest = shs
             shs = empty if shs is None else shs
             colors_precomp = empty if colors_precomp is None else colors_precomp
             scales = empty if scales is None else scales
             rotations = empty if rotations is None else rotations
             cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings, loss_map)
+                                       cov3D_precomp, raster_settings, loss_map, shs_rest)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
 

@@ -50,6 +50,16 @@ class GaussianCloud:
         return self._features_rest
 
     @property
+    def get_features_split(self):
+        """(features_dc [P,1,3], features_rest [P,M-1,3]) as stored: the rasterizer takes them as they are
+        (fr_forward_args.shs_rest), which saves get_features' torch.cat and its backward every step."""
+        return self._features_dc, self._features_rest
+
+    @property
+    def get_features_split_detach_rest(self):
+        return self._features_dc, self._features_rest.detach()
+
+    @property
     def get_features_detach_rest(self):
         return torch.cat((self._features_dc, self._features_rest.detach()), dim=1)
 

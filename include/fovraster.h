@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 1
+#define FR_ABI_VERSION 2
 
 /* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
  * fov3dgs/gaussian_wrapper.py:11-23) */
@@ -112,6 +112,10 @@ typedef struct fr_forward_args {
 	void **stage_events;
 	const float *loss_map;       /* LWMC: [>= H*W] per-pixel weights (the reference passes a [3,H,W] map and reads
 	                              * its first plane, …_loss_weighted_max_count/cuda_rasterizer/forward.cu:435) */
+	/* optional (not RF): the SH coefficients as the two tensors a 3DGS model stores them in, so that the caller
+	 * need not concatenate them every step (GaussianModel.get_features, scene/gaussian_model.py:83-86): when
+	 * set, `shs` is the DC part [P,1,3] and `shs_rest` the others [P,M-1,3]; M stays their total (16). */
+	const float *shs_rest;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
@@ -142,6 +146,8 @@ typedef struct fr_backward_args {
 	float *dL_dscale;            /* [P,3] */
 	float *dL_drot;              /* [P,4] */
 	void **stage_events;         /* optional: 3 event handles around render-backward and preprocess-backward */
+	const float *shs_rest;       /* split SH input, see fr_forward_args.shs_rest ... */
+	float *dL_dsh_rest;          /* ... then dL_dsh is [P,1,3] and dL_dsh_rest [P,M-1,3] */
 } fr_backward_args;
 
 int fr_abi_version(void);

@@ -10,6 +10,7 @@ Tolerances (fp32 path; BASELINE north_star: per-pixel match within 1e-4):
   * gradients: float atomics have no defined order in the reference either; the oracle sums in
     double. |diff| <= 1e-4 * max(1, |ref|) + small-outlier budget for threshold flips.
 """
+import math
 import os
 
 import numpy as np
@@ -270,6 +271,35 @@ def test_autograd_module_end_to_end():
     check_grad(cloud._scaling.grad.cpu().numpy(), og["dL_dscale"] * torch.exp(cpu._scaling.detach()).numpy(), "scaling")
     check_grad(cloud._features_dc.grad.cpu().numpy(), og["dL_dsh"][:, :1], "f_dc")
     check_grad(cloud._features_rest.grad.cpu().numpy(), og["dL_dsh"][:, 1:], "f_rest")
+
+
+def test_split_sh_storage_matches_concatenated():
+    """fr_forward_args.shs_rest: features_dc / features_rest handed over as stored give the same image (bit for bit:
+    same summation order) and the same gradients as the torch.cat'ed [P,16,3] tensor of the reference interface."""
+    _need_gpu()
+    from fov3dgs_amd.diff_gaussian_rasterization_pcheck_obb_sum import GaussianRasterizationSettings, GaussianRasterizer
+    dev = "cuda:0"
+    cam = syn.camera_1k(160, 112).to(dev)
+    rs = GaussianRasterizationSettings(112, 160, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                                       torch.tensor([0.1, 0.0, 0.2], device=dev), 1.0, cam.world_view_transform,
+                                       cam.full_proj_transform, 3, cam.camera_center, False, False)
+    w = None
+    res = []
+    for split in (False, True):
+        cloud = syn.scene_1k(P=900, seed=9).to(dev).requires_grad_(True)
+        shs = cloud.get_features_split if split else cloud.get_features
+        out = GaussianRasterizer(rs)(means3D=cloud.get_xyz, means2D=torch.zeros_like(cloud.get_xyz, requires_grad=True),
+                                     opacities=cloud.get_opacity, shs=shs, scales=cloud.get_scaling,
+                                     rotations=cloud.get_rotation)
+        img = out[0]
+        if w is None:
+            w = torch.randn_like(img)
+        (img * w).sum().backward()
+        res.append((img.detach().cpu().numpy(), cloud._features_dc.grad.cpu().numpy(), cloud._features_rest.grad.cpu().numpy(),
+                    cloud._xyz.grad.cpu().numpy()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    for a, b, name in zip(res[0][1:], res[1][1:], ("f_dc", "f_rest", "xyz")):
+        check_grad(b, a, name)
 
 
 def test_foveated_render_entry_point():
