@@ -348,12 +348,31 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	// ---- SH backward: backward.cu:20-139 ----
 	if (a.colors_precomp == nullptr && a.shs != nullptr)
 	{
-		// coefficient k >= 1 at sh[3k + ch]; with split storage (shs = DC [P,1,3], shs_rest = [P,M-1,3]) the pointers
-		// are biased by one coefficient so that the same indexing works (k = 0 is only ever written, through dsh0)
+		// Coefficients and their gradients are kept in registers in the concatenated order (k, channel) -> 3k + ch
+		// and moved 16 bytes at a time: every lane works on its own Gaussian, i.e. its own cache lines, and 48
+		// dword loads + 48 dword stores per Gaussian kept the address unit busy for most of this kernel.
+		// Split storage (shs = DC [P,1,3], shs_rest = [P,M-1,3]): slots 3.. come from / go to the rest tensors.
 		const bool split = a.shs_rest != nullptr;
-		const float *sh = split ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : a.shs + (size_t)idx * a.M * 3;
-		float *dsh = split ? a.dL_dsh_rest + (size_t)idx * (a.M - 1) * 3 - 3 : a.dL_dsh + (size_t)idx * a.M * 3;
-		float *dsh0 = split ? a.dL_dsh + 3 * (size_t)idx : dsh;
+		const int nrest = split ? (a.M - 1) * 3 : a.M * 3 - 3;     // floats available after the DC triple
+		const float *sh_r = split ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 : a.shs + (size_t)idx * a.M * 3 + 3;
+		float *dsh_r = split ? a.dL_dsh_rest + (size_t)idx * (a.M - 1) * 3 : a.dL_dsh + (size_t)idx * a.M * 3 + 3;
+		float *dsh0 = split ? a.dL_dsh + 3 * (size_t)idx : a.dL_dsh + (size_t)idx * a.M * 3;
+		typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+		float shv[48], g[48];
+#pragma unroll
+		for (int i = 0; i < 48; i++) { shv[i] = 0.0f; g[i] = 0.0f; }
+		const int nuse = 3 * ((a.D + 1) * (a.D + 1)) - 3; // rest floats the active degree reads / writes
+		if (nrest >= 45)
+		{
+#pragma unroll
+			for (int q = 0; q < 11; q++) { const f4u v = *(const f4u *)(sh_r + 4 * q); shv[3 + 4 * q] = v.x; shv[4 + 4 * q] = v.y; shv[5 + 4 * q] = v.z; shv[6 + 4 * q] = v.w; }
+			shv[47] = sh_r[44];
+		}
+		else
+		{
+#pragma unroll
+			for (int i = 0; i < 45; i++) if (i < nuse) shv[3 + i] = sh_r[i];
+		}
 		const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)idx + 2].z);
 		const float dox = m[0] - a.campos[0], doy = m[1] - a.campos[1], doz = m[2] - a.campos[2];
 		const float len = sqrtf(dox * dox + doy * doy + doz * doz);
@@ -363,8 +382,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * (size_t)idx + ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
 		float ddx[3] = { 0, 0, 0 }, ddy[3] = { 0, 0, 0 }, ddz[3] = { 0, 0, 0 };
 		const int deg = a.D;
-#define SHV(k, ch) sh[3 * (k) + (ch)]
-#define DSH(k, w) { const float w_ = (w); dsh[3 * (k)] = w_ * dRGB[0]; dsh[3 * (k) + 1] = w_ * dRGB[1]; dsh[3 * (k) + 2] = w_ * dRGB[2]; }
+#define SHV(k, ch) shv[3 * (k) + (ch)]
+#define DSH(k, w) { const float w_ = (w); g[3 * (k)] = w_ * dRGB[0]; g[3 * (k) + 1] = w_ * dRGB[1]; g[3 * (k) + 2] = w_ * dRGB[2]; }
 		dsh0[0] = FR_SH_C0 * dRGB[0]; dsh0[1] = FR_SH_C0 * dRGB[1]; dsh0[2] = FR_SH_C0 * dRGB[2];
 		if (deg > 0)
 		{
@@ -428,6 +447,17 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		}
 #undef SHV
 #undef DSH
+		// gradients of the rest coefficients of the active degree (the others stay at the caller's zero fill)
+#pragma unroll
+		for (int q = 0; q < 12; q++)
+		{
+			if (4 * q + 4 <= nuse) *(f4u *)(dsh_r + 4 * q) = (f4u){ g[3 + 4 * q], g[4 + 4 * q], g[5 + 4 * q], g[6 + 4 * q] };
+			else
+			{
+#pragma unroll
+				for (int j = 0; j < 4; j++) if (4 * q + j < nuse) dsh_r[4 * q + j] = g[3 + 4 * q + j];
+			}
+		}
 		const float dvx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
 		const float dvy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
 		const float dvz = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
