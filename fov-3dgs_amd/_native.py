@@ -62,7 +62,7 @@ class BackwardArgs(C.Structure):
 
 EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible",
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
-           "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels")
+           "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records")
 
 _lib = None
 
@@ -112,6 +112,8 @@ def load():
         getattr(lib, n).restype = C.c_void_p
     lib.fr_binning_point_list.argtypes = [C.c_int32, C.c_int64, C.c_void_p]
     lib.fr_binning_point_list.restype = C.c_void_p
+    lib.fr_geometry_records.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+    lib.fr_geometry_records.restype = C.c_void_p
     lib.fr_image_tile_levels.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
     lib.fr_image_tile_levels.restype = C.c_void_p
     if lib.fr_abi_version() != ABI_VERSION:

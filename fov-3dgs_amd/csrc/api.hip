@@ -98,6 +98,7 @@ const uint32_t *fr_image_ranges(int32_t variant, int32_t W, int32_t H, const cha
 const uint32_t *fr_binning_point_list(int32_t variant, int64_t n, const char *binning) { (void)variant; return carve_bin(n, (char *)binning).point_list; }
 const float *fr_image_final_T(int32_t variant, int32_t W, int32_t H, const char *image) { return carve_image(variant, W, H, (char *)image).final_T; }
 const uint32_t *fr_image_n_contrib(int32_t variant, int32_t W, int32_t H, const char *image) { return carve_image(variant, W, H, (char *)image).n_contrib; }
+const float *fr_geometry_records(int32_t variant, int32_t P, const char *geometry) { return (const float *)carve_geom(variant, (size_t)P, (char *)geometry).rec; }
 const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image) { return carve_image(FR_VARIANT_FOV_PCHECK_OBB, W, H, (char *)image).tile_lv; }
 
 int fr_forward(fr_forward_args *a)

@@ -175,6 +175,9 @@ const uint32_t *fr_image_ranges(int32_t variant, int32_t W, int32_t H, const cha
 const uint32_t *fr_binning_point_list(int32_t variant, int64_t num_instances, const char *binning);
 const float *fr_image_final_T(int32_t variant, int32_t W, int32_t H, const char *image);
 const uint32_t *fr_image_n_contrib(int32_t variant, int32_t W, int32_t H, const char *image);
+/* per-Gaussian records float[P][12] = (x, y, conic a, conic b | conic c, opacity, r, g | b, depth, clamp bits, -);
+ * valid for Gaussians with radii > 0 (RF: the second third holds (conic c, highest level, -, -)) */
+const float *fr_geometry_records(int32_t variant, int32_t P, const char *geometry);
 /* RF: device pointer to float[5][T] = levels, tile_min, grad_x, grad_y, blending(0/1 as float) */
 const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image);
 
