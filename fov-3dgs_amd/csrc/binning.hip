@@ -12,6 +12,7 @@
 // one 8-byte read and one 4-byte write per instance. The sort key is (depth bits << 32 | id),
 // which reproduces the order a stable sort of the reference's keys emitted in index order gives.
 #include "common.h"
+#include <cstdlib>
 
 namespace fr {
 
@@ -248,22 +249,63 @@ int launch_tile_scan(FwdCtx &c)
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 
+// Helper stream of the calling host thread (per device), created on first use. The size classes of the per-tile
+// sort are independent kernels; the two classes with long lists hold a handful of tiles that each keep one CU busy
+// for 50-80 us, so the (many) short lists are sorted meanwhile on the helper stream (event fork / join).
+struct AuxStream { int device = -1; hipStream_t s, s2; hipEvent_t fork, join, join2; bool ok = false; };
+static AuxStream *aux_stream()
+{
+	static thread_local AuxStream cache[8];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+	AuxStream &a = cache[dev & 7];
+	if (a.device != dev)
+	{
+		a.device = dev;
+		a.ok = hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) == hipSuccess &&
+			hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) == hipSuccess &&
+			hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess &&
+			hipEventCreateWithFlags(&a.join, hipEventDisableTiming) == hipSuccess &&
+			hipEventCreateWithFlags(&a.join2, hipEventDisableTiming) == hipSuccess;
+		(void)hipGetLastError();
+	}
+	return a.ok ? &a : nullptr;
+}
+
 int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
 {
 	(void)num_instances;
 	const dim3 grid(c.T);
 	const uint2 *rg = c.img.ranges;
 	const uint32_t *ord = c.img.tile_order;
+	static const bool serial = getenv("FR_SERIAL_SORT") != nullptr;
+	// long lists exist: short ones go to the helper stream
+	AuxStream *ax = (max_tile > 2048 && !serial && !c.a->debug) ? aux_stream() : nullptr;
+	hipStream_t small = c.stream, mid = c.stream;
+	const bool fork_mid = ax && max_tile > 8192; // two long-list classes: they get a stream each
+	if (ax)
+	{
+		(void)hipEventRecord(ax->fork, c.stream);
+		(void)hipStreamWaitEvent(ax->s, ax->fork, 0);
+		small = ax->s;
+		if (fork_mid) { (void)hipStreamWaitEvent(ax->s2, ax->fork, 0); mid = ax->s2; }
+	}
 	// size classes (tile_order is longest-first, so the big classes start first on the chip)
 	if (max_tile > 16384)
 		hipLaunchKernelGGL(k_tile_sort_global, grid, dim3(256), 0, c.stream, rg, ord, c.bin.entries, c.bin.point_list, 16384);
 	if (max_tile > 8192)
 		hipLaunchKernelGGL((k_tile_msort<1024, 16>), grid, dim3(1024), 16384 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 8192);
 	if (max_tile > 2048)
-		hipLaunchKernelGGL((k_tile_msort<1024, 8>), grid, dim3(1024), 8192 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 2048);
+		hipLaunchKernelGGL((k_tile_msort<1024, 8>), grid, dim3(1024), 8192 * sizeof(uint64_t), mid, rg, ord, c.bin.entries, c.bin.point_list, 2048);
 	if (max_tile > 512)
-		hipLaunchKernelGGL((k_tile_msort<256, 8>), grid, dim3(256), 2048 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 512);
-	hipLaunchKernelGGL((k_tile_msort<64, 8>), grid, dim3(64), 512 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 0);
+		hipLaunchKernelGGL((k_tile_msort<256, 8>), grid, dim3(256), 2048 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list, 512);
+	hipLaunchKernelGGL((k_tile_msort<64, 8>), grid, dim3(64), 512 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list, 0);
+	if (ax)
+	{
+		(void)hipEventRecord(ax->join, ax->s);
+		(void)hipStreamWaitEvent(c.stream, ax->join, 0);
+		if (fork_mid) { (void)hipEventRecord(ax->join2, ax->s2); (void)hipStreamWaitEvent(c.stream, ax->join2, 0); }
+	}
 	return check_launch("tile_sort", c.stream, c.a->debug);
 }
 

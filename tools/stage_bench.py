@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-stage kernel times of one rasterizer variant on the S-6M scene (developer tool).
-usage: python tools/stage_bench.py [variant=fov_pcheck_obb] [frames=20] [points=6000000]"""
+usage: python tools/stage_bench.py [variant=fov_pcheck_obb] [frames=60, the gaze path of bench.py] [points=6000000]"""
 import math
 import os
 import sys
@@ -14,7 +14,7 @@ from fov3dgs_amd import _native, rasterizer as rz, synthetic as syn
 from fov3dgs_amd.profiling import StageTimer
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "fov_pcheck_obb"
-frames = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 6_000_000
 dev = torch.device("cuda", 0)
 cloud = syn.scene_bicycle_scale(P=P, seed=1)
