@@ -18,6 +18,13 @@
 // launches two full grids that early-return on each other's tiles).
 #include "common.h"
 
+#ifndef FR_RENDER_GROUP
+#define FR_RENDER_GROUP 2       // RF: entries whose transmittance-independent part is evaluated together
+#endif
+#ifndef FR_RENDER_GROUP_PLAIN
+#define FR_RENDER_GROUP_PLAIN 2 // plain variants (throughput-bound frames: no gain, no loss)
+#endif
+
 namespace fr {
 
 __device__ __forceinline__ float fast_exp(float p)
@@ -216,32 +223,33 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 #pragma unroll
 		for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
 		bool stop = !blend_batch;
-		for (int sw = 0; sw < NW && !stop; sw++)
-		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; rm &= rm - 1)
+		// Entries can be taken FR_RENDER_GROUP_PLAIN at a time: the part that does not depend on the running transmittance
+		// (record fetch, power, support test, exp) is evaluated for all of them before the first one is blended,
+		// so their dependency chains overlap (see k_render_fov).
+		struct Ent { v2f e[HP]; bool inx[HP], iny[HP]; float4 col; int j; };
+		auto prepare = [&](const int j, const bool valid)
 		{
-			const int j = sw * 64 + __builtin_ctzll(rm);
-			float tmax = -1.0f;
-#pragma unroll
-			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(S[h].T.x, S[h].T.y));
-			if (!__any(tmax > 0.0f)) { stop = true; break; } // wave saturated
+			Ent t;
+			t.j = j;
 			const float4 g0 = s0[j];
 			const float4 g1 = s1[j];
 			const float dx = g0.x - pxf;
 			const float adx2 = (g0.z * dx) * dx;     // A*dx*dx
 			const float bdx = g0.w * dx;             // B*dx
-			v2f pw[HP];
-			bool hx[HP], hy[HP]; // live pixel inside the splat's support
-			bool anyhit = false;
 #pragma unroll
 			for (int h = 0; h < HP; h++)
 			{
-				pw[h] = power2(g0.y - pyp[h], g1.x, adx2, bdx);
-				hx[h] = S[h].T.x > 0.0f && !(pw[h].x > 0.0f) && !(CUTOFF && pw[h].x < -4.5f);
-				hy[h] = S[h].T.y > 0.0f && !(pw[h].y > 0.0f) && !(CUTOFF && pw[h].y < -4.5f);
-				anyhit = anyhit || hx[h] || hy[h];
+				const v2f pw = power2(g0.y - pyp[h], g1.x, adx2, bdx);
+				t.inx[h] = valid && !(pw.x > 0.0f) && !(CUTOFF && pw.x < -4.5f);
+				t.iny[h] = valid && !(pw.y > 0.0f) && !(CUTOFF && pw.y < -4.5f);
+				t.e[h] = exp2_pair(pw);
 			}
-			if (!__any(anyhit)) continue; // splat misses every live pixel of the tile
-			const float4 col = make_float4(g1.z, g1.w, s2[j], g1.y); // r, g, b, opacity
+			t.col = make_float4(g1.z, g1.w, s2[j], g1.y); // r, g, b, opacity
+			return t;
+		};
+		auto blend = [&](const Ent &t)
+		{
+			const int j = t.j;
 			float contrib_sum = 0.0f, contrib_max = 0.0f;
 			bool any_contrib = false;
 			if (PMAX)
@@ -249,14 +257,15 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 				// ..._max forward.cu:381: +1 for every live pixel inside the splat's support (before the alpha test)
 				int c = 0;
 #pragma unroll
-				for (int h = 0; h < HP; h++) c += __popcll(__ballot(hx[h])) + __popcll(__ballot(hy[h]));
-				if ((tid & 63) == 0) atomicAdd(&a.gaussians_count[sid[j]], c);
+				for (int h = 0; h < HP; h++)
+					c += __popcll(__ballot(t.inx[h] && S[h].T.x > 0.0f)) + __popcll(__ballot(t.iny[h] && S[h].T.y > 0.0f));
+				if ((tid & 63) == 0 && c != 0) atomicAdd(&a.gaussians_count[sid[j]], c);
 			}
 #pragma unroll
 			for (int h = 0; h < HP; h++)
 			{
 				v2f w; bool ax, ay;
-				blend2(S[h], hx[h], hy[h], exp2_pair(pw[h]), col, w, ax, ay);
+				blend2(S[h], t.inx[h], t.iny[h], t.e[h], t.col, w, ax, ay);
 				if (AUX)
 				{
 					last[2 * h] = ax ? (uint32_t)(base + j + 1) : last[2 * h];
@@ -290,6 +299,35 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 					if ((tid & 63) == 0) atomicMax((unsigned int *)&a.contributions[sid[j]], __float_as_uint(m));
 				}
 			}
+		};
+		for (int sw = 0; sw < NW && !stop; sw++)
+		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; )
+		{
+			int jj[FR_RENDER_GROUP_PLAIN];
+			bool vv[FR_RENDER_GROUP_PLAIN];
+#pragma unroll
+			for (int g = 0; g < FR_RENDER_GROUP_PLAIN; g++)
+			{
+				vv[g] = rm != 0;
+				jj[g] = vv[g] ? sw * 64 + __builtin_ctzll(rm) : jj[0];
+				rm &= rm - 1; // stays 0 once empty
+			}
+			float tmax = -1.0f;
+#pragma unroll
+			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(S[h].T.x, S[h].T.y));
+			if (!__any(tmax > 0.0f)) { stop = true; break; } // wave saturated
+			Ent t[FR_RENDER_GROUP_PLAIN];
+			bool anyhit = false;
+#pragma unroll
+			for (int g = 0; g < FR_RENDER_GROUP_PLAIN; g++)
+			{
+				t[g] = prepare(jj[g], vv[g]);
+#pragma unroll
+				for (int h = 0; h < HP; h++) anyhit = anyhit || (t[g].inx[h] && S[h].T.x > 0.0f) || (t[g].iny[h] && S[h].T.y > 0.0f);
+			}
+			if (!__any(anyhit)) continue; // the splats miss every live pixel of this wave's rows
+#pragma unroll
+			for (int g = 0; g < FR_RENDER_GROUP_PLAIN; g++) blend(t[g]);
 		}
 	}
 
@@ -413,49 +451,63 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 		const uint64_t tq1 = wall_clock64();
 #endif
 		bool stop = false;
-		for (int sw = 0; sw < NW && !stop; sw++)
-		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; rm &= rm - 1)
+		// Entries are taken two at a time: everything that does not depend on the running transmittance (record
+		// fetch, power, exp, alpha inputs) is evaluated for both before either is blended, so the two dependency
+		// chains overlap -- a wave works through its list serially and the slowest tile's chain is the kernel time.
+		struct Ent { v2f e[HP]; bool inx[HP], iny[HP]; float4 c1, c2; bool l2_ok; };
+		auto prepare = [&](const int j, const bool valid)
 		{
-			const int j = sw * 64 + __builtin_ctzll(rm);
-			float tmax = -1.0f;
-#pragma unroll
-			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(fmaxf(S1[h].T.x, S1[h].T.y), fmaxf(S2[h].T.x, S2[h].T.y)));
-			if (!__any(tmax > 0.0f)) { stop = true; break; }
-#ifdef FR_TILE_TIMERS
-			tm_proc++;
-#endif
+			Ent t;
 			const float4 g0 = s0[j];
 			const float2 g1 = s1[j];
 			const float dx = g0.x - pxf;
 			const float adx2 = (g0.z * dx) * dx;
 			const float bdx = g0.w * dx;
-			v2f pw[HP];
-			bool inx[HP], iny[HP];
-			bool anyhit = false;
 #pragma unroll
 			for (int h = 0; h < HP; h++)
 			{
-				pw[h] = power2(g0.y - pyp[h], g1.x, adx2, bdx);
+				const v2f pw = power2(g0.y - pyp[h], g1.x, adx2, bdx);
 				// in the splat's support: RF forward.cu:556-560 (power > 0 and power < -4.5 are skipped)
-				inx[h] = !(pw[h].x > 0.0f || pw[h].x < -4.5f);
-				iny[h] = !(pw[h].y > 0.0f || pw[h].y < -4.5f);
-				anyhit = anyhit || (inx[h] && (S1[h].T.x > 0.0f || S2[h].T.x > 0.0f)) || (iny[h] && (S1[h].T.y > 0.0f || S2[h].T.y > 0.0f));
+				t.inx[h] = valid && !(pw.x > 0.0f || pw.x < -4.5f);
+				t.iny[h] = valid && !(pw.y > 0.0f || pw.y < -4.5f);
+				t.e[h] = exp2_pair(pw);
 			}
-			if (!__any(anyhit)) continue;
-#ifdef FR_TILE_TIMERS
-			tm_hit++;
-#endif
-			const float4 c1 = sl1[j];
-			const bool l2_ok = !((g1.y + 1.0f) < L2f); // the Gaussian exists at level L2
-			float4 c2 = c1;
-			if (blending) c2 = sl2[j];
+			t.c1 = sl1[j];
+			t.l2_ok = !((g1.y + 1.0f) < L2f); // the Gaussian exists at level L2
+			t.c2 = t.c1;
+			if (blending) t.c2 = sl2[j];
+			return t;
+		};
+		auto blend = [&](const Ent &t)
+		{
 #pragma unroll
 			for (int h = 0; h < HP; h++)
 			{
-				const v2f e = exp2_pair(pw[h]);
-				blend2(S1[h], inx[h], iny[h], e, c1);
-				if (blending) blend2(S2[h], inx[h] && l2_ok, iny[h] && l2_ok, e, c2);
+				blend2(S1[h], t.inx[h], t.iny[h], t.e[h], t.c1);
+				if (blending) blend2(S2[h], t.inx[h] && t.l2_ok, t.iny[h] && t.l2_ok, t.e[h], t.c2);
 			}
+		};
+		for (int sw = 0; sw < NW && !stop; sw++)
+		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; )
+		{
+			int jj[FR_RENDER_GROUP];
+			bool vv[FR_RENDER_GROUP];
+#pragma unroll
+			for (int g = 0; g < FR_RENDER_GROUP; g++)
+			{
+				vv[g] = rm != 0;
+				jj[g] = vv[g] ? sw * 64 + __builtin_ctzll(rm) : jj[0];
+				rm &= rm - 1; // stays 0 once empty
+			}
+			float tmax = -1.0f;
+#pragma unroll
+			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(fmaxf(S1[h].T.x, S1[h].T.y), fmaxf(S2[h].T.x, S2[h].T.y)));
+			if (!__any(tmax > 0.0f)) { stop = true; break; }
+			Ent t[FR_RENDER_GROUP];
+#pragma unroll
+			for (int g = 0; g < FR_RENDER_GROUP; g++) t[g] = prepare(jj[g], vv[g]);
+#pragma unroll
+			for (int g = 0; g < FR_RENDER_GROUP; g++) blend(t[g]);
 		}
 #ifdef FR_TILE_TIMERS
 		tm_loop += wall_clock64() - tq1;
@@ -499,6 +551,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 #ifndef FR_RENDER_PPL
 #define FR_RENDER_PPL 2
 #endif
+
 #ifndef FR_RENDER_FOV_PPL
 #define FR_RENDER_FOV_PPL 2
 #endif
