@@ -18,7 +18,8 @@ namespace fr {
 
 // Single workgroup: exclusive scan of tile_count[T] -> ranges, reset the counters to serve as
 // emission cursors, publish {total, max}.
-__global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals, uint32_t *tile_order)
+__global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals, uint32_t *tile_order,
+	uint32_t *totals_host)
 {
 	__shared__ uint32_t bucket[34];
 	__shared__ uint32_t wave_sum[16];
@@ -73,6 +74,8 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		uint32_t h4 = 0;
 		for (int b = 12; b <= 32; b++) h4 += bucket[b];
 		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11];
+		// the host sizes the binning buffer from these: written straight into its pinned memory (no copy command)
+		if (totals_host) { totals_host[0] = carry_s; totals_host[1] = m; totals_host[2] = h4; totals_host[3] = bucket[10] + bucket[11]; }
 		// bucket start offsets, longest lists first
 		uint32_t run = 0;
 		for (int b = 32; b >= 0; b--) { const uint32_t c = bucket[b]; bucket[b] = run; run += c; }
@@ -245,7 +248,8 @@ __global__ void __launch_bounds__(256) k_tile_sort_global(const uint2 *ranges, c
 
 int launch_tile_scan(FwdCtx &c)
 {
-	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals, c.img.tile_order);
+	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals, c.img.tile_order,
+		c.totals_host_dev);
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 

@@ -320,6 +320,7 @@ struct FwdCtx {
 	hipStream_t stream;
 	int gx, gy, T;
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
+	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4], or null
 	float focal_x, focal_y;
 	GeomWS geom;
 	ImageWS img;
