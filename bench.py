@@ -209,10 +209,11 @@ def main():
     P, Px = args.points, W * H
     alg_bytes = {
         # SURVEY.md 8(d) per-unit figures x units of one launch
-        # B_pre = 20 P + 224 V_in + 48 V (+24 V OBB axes), split over this build's two kernels: projection reads
-        # xyz/scale/rotation and writes radii + axes, binning reads opacity + SH and writes the per-Gaussian record
-        "project": 20 * P + 28 * V_in + 24 * st["V"],
-        "bin": 196 * V_in + 48 * st["V"],
+        # B_pre = 20 P + 224 V_in + 48 V (+24 V OBB axes), split over this build's two kernels: the cull pass streams
+        # xyz/scale/rotation and writes radii; binning projects the survivors, reads opacity + SH and writes the
+        # per-Gaussian record and the OBB axes
+        "project": 20 * P + 28 * V_in,
+        "bin": 196 * V_in + (48 + 24) * st["V"],
         "render": 32 * st["D_single"] + 52 * st["D_blend"] + 12 * Px,
         # this build's binning moves (depth,id) once per stage instead of a 6-pass radix sort
         "emit": 12 * st["D"] + 44 * st["V"],
