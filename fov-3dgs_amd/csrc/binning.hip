@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		uint32_t h4 = 0;
 		for (int b = 12; b <= 32; b++) h4 += bucket[b];
 		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11];
+		totals[4] = 0; // chunk counter of k_split_long
 		// the host sizes the binning buffer from these: written straight into its pinned memory (no copy command)
 		if (totals_host) { totals_host[0] = carry_s; totals_host[1] = m; totals_host[2] = h4; totals_host[3] = bucket[10] + bucket[11]; }
 		// bucket start offsets, longest lists first
@@ -166,17 +167,29 @@ __device__ __forceinline__ void reg_sort(uint64_t (&k)[ITEMS])
 		}
 }
 
-template <int THREADS, int ITEMS>
-__global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, const uint32_t *tile_order, const uint64_t *entries,
-	uint32_t *point_list, int n_lo)
+// CHUNKS = false: one tile list per workgroup (ranges[tile_order[block]]), lists with n_lo < n < n_hi;
+// CHUNKS = true: one chunk of a split long list per workgroup (ranges[block], block < *count), any length: the rare
+// chunk that does not fit (thousands of equal depths) is sorted in place in global memory by the bitonic network.
+template <int THREADS, int ITEMS, bool CHUNKS>
+__global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries,
+	uint32_t *point_list, int n_lo, int n_hi, const uint32_t *count)
 {
 	extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
-	const uint2 rg = ranges[tile_order[blockIdx.x]];
+	if (CHUNKS && blockIdx.x >= *count) return;
+	const uint2 rg = CHUNKS ? ranges[blockIdx.x] : ranges[tile_order[blockIdx.x]];
 	const int n = (int)(rg.y - rg.x);
-	if (n <= n_lo || n > THREADS * ITEMS) return; // another size class sorts this tile
+	if (!CHUNKS && (n <= n_lo || n >= n_hi || n > THREADS * ITEMS)) return; // another path sorts this tile
 	const int tid = threadIdx.x;
-	const uint64_t *src = entries + rg.x;
+	uint64_t *src = entries + rg.x;
 	uint32_t *dst = point_list + rg.x;
+	if (CHUNKS && n > THREADS * ITEMS)
+	{
+		int npow2 = 1;
+		while (npow2 < n) npow2 <<= 1;
+		bitonic_sort<true>(src, n, npow2, tid, THREADS);
+		for (int i = tid; i < n; i += THREADS) dst[i] = (uint32_t)key_ld<true>(src + i);
+		return;
+	}
 	// active capacity: ITEMS * 2^k >= n
 	int runs = 1;
 	while (runs * ITEMS < n) runs <<= 1;
@@ -230,20 +243,87 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 	for (int i = tid; i < n; i += THREADS) dst[i] = (uint32_t)sk[i];
 }
 
-// Lists longer than the largest LDS class: bitonic network in place in global memory (rare).
-__global__ void __launch_bounds__(256) k_tile_sort_global(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries,
-	uint32_t *point_list, int n_lo)
+// Long tile lists (>= FR_SORT_SPLIT_MIN entries) are not sorted as one piece: a handful of them used to occupy one
+// CU each for 50-80 us with sixteen-way merge passes while the rest of the chip had nothing left to do. A counting
+// pass on the depth bits (monotone quantisation into FR_SORT_FINE_BUCKETS buckets between the list's own minimum and
+// maximum) regroups the list into chunks of ~FR_SORT_CHUNK_TARGET entries with disjoint, increasing depth ranges;
+// equal depths share a bucket, so sorting every chunk by (depth, id) sorts the list. The chunks are independent
+// 1024-key sorts that spread over the whole chip. Keys are streamed from global memory three times (min/max,
+// histogram, scatter); LDS holds only the histogram.
+__global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const uint32_t *tile_order, const uint64_t *entries,
+	uint64_t *entries2, uint2 *chunks, uint32_t *chunk_ctr)
 {
+	__shared__ uint32_t s_hist[FR_SORT_FINE_BUCKETS];      // counts -> exclusive offsets -> scatter cursors
+	__shared__ uint32_t s_start[FR_SORT_FINE_BUCKETS + 1]; // compacted chunk starts
+	__shared__ uint32_t s_wave[16], s_wave2[16];
+	__shared__ uint32_t s_lo, s_hi, s_slot;
 	const uint2 rg = ranges[tile_order[blockIdx.x]];
-	const int n = (int)(rg.y - rg.x);
-	if (n <= n_lo) return;
-	const int tid = threadIdx.x;
-	uint64_t *src = entries + rg.x;
-	uint32_t *dst = point_list + rg.x;
-	int npow2 = 1;
-	while (npow2 < n) npow2 <<= 1;
-	bitonic_sort<true>(src, n, npow2, tid, 256);
-	for (int i = tid; i < n; i += 256) dst[i] = (uint32_t)key_ld<true>(src + i);
+	const uint32_t n = rg.y - rg.x;
+	if (n < FR_SORT_SPLIT_MIN) return;
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const uint64_t *src = entries + rg.x;
+	uint64_t *dst = entries2 + rg.x;
+	// 1. range of the depth bits (depths are positive floats: their bit patterns order like the values)
+	uint32_t lo = 0xffffffffu, hi = 0u;
+	for (uint32_t i = tid; i < n; i += 1024) { const uint32_t d = (uint32_t)(src[i] >> 32); lo = min(lo, d); hi = max(hi, d); }
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, off)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, off)); }
+	if (lane == 0) { s_wave[wid] = lo; s_wave2[wid] = hi; }
+	for (int b = tid; b < FR_SORT_FINE_BUCKETS; b += 1024) s_hist[b] = 0;
+	__syncthreads();
+	if (tid == 0)
+	{
+		uint32_t l = s_wave[0], h = s_wave2[0];
+		for (int w = 1; w < 16; w++) { l = min(l, s_wave[w]); h = max(h, s_wave2[w]); }
+		s_lo = l; s_hi = h;
+	}
+	__syncthreads();
+	const uint32_t dmin = s_lo;
+	// bucket = (d - dmin) >> shift with the smallest shift that maps the span into the bucket array
+	int shift = 0;
+	while (((s_hi - dmin) >> shift) >= FR_SORT_FINE_BUCKETS) shift++;
+	// 2. histogram
+	for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[((uint32_t)(src[i] >> 32) - dmin) >> shift], 1u);
+	__syncthreads();
+	// 3. exclusive scan of the 2048 counts (two consecutive buckets per thread)
+	const uint32_t c0 = s_hist[2 * tid], c1 = s_hist[2 * tid + 1];
+	uint32_t sc = c0 + c1;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)sc, off); if (lane >= off) sc += v; }
+	if (lane == 63) s_wave[wid] = sc;
+	__syncthreads();
+	uint32_t wave_off = 0;
+#pragma unroll
+	for (int w = 0; w < 16; w++) if (w < wid) wave_off += s_wave[w];
+	const uint32_t e0 = wave_off + sc - (c0 + c1), e1 = e0 + c0; // exclusive offsets of my two buckets
+	__syncthreads();
+	s_hist[2 * tid] = e0; s_hist[2 * tid + 1] = e1;
+	__syncthreads();
+	// 4. a chunk starts where the running count crosses a multiple of the target (monotone in the bucket index)
+	const uint32_t prev = tid == 0 ? 0u : s_hist[2 * tid - 1];
+	const bool f0 = tid == 0 || (e0 / FR_SORT_CHUNK_TARGET) != (prev / FR_SORT_CHUNK_TARGET);
+	const bool f1 = (e1 / FR_SORT_CHUNK_TARGET) != (e0 / FR_SORT_CHUNK_TARGET);
+	uint32_t fs = (f0 ? 1u : 0u) + (f1 ? 1u : 0u);
+	const uint32_t mine = fs;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)fs, off); if (lane >= off) fs += v; }
+	if (lane == 63) s_wave2[wid] = fs;
+	__syncthreads();
+	uint32_t foff = 0, nchunks = 0;
+#pragma unroll
+	for (int w = 0; w < 16; w++) { if (w < wid) foff += s_wave2[w]; nchunks += s_wave2[w]; }
+	uint32_t pos = foff + fs - mine;
+	if (f0) s_start[pos++] = e0;
+	if (f1) s_start[pos] = e1;
+	if (tid == 0) { s_start[nchunks] = n; s_slot = atomicAdd(chunk_ctr, nchunks); }
+	__syncthreads();
+	for (uint32_t k = tid; k < nchunks; k += 1024) chunks[s_slot + k] = make_uint2(rg.x + s_start[k], rg.x + s_start[k + 1]);
+	// 5. scatter (the offsets become cursors)
+	for (uint32_t i = tid; i < n; i += 1024)
+	{
+		const uint64_t key = src[i];
+		dst[atomicAdd(&s_hist[((uint32_t)(key >> 32) - dmin) >> shift], 1u)] = key;
+	}
 }
 
 int launch_tile_scan(FwdCtx &c)
@@ -278,37 +358,37 @@ static AuxStream *aux_stream()
 
 int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
 {
-	(void)num_instances;
 	const dim3 grid(c.T);
 	const uint2 *rg = c.img.ranges;
 	const uint32_t *ord = c.img.tile_order;
 	static const bool serial = getenv("FR_SERIAL_SORT") != nullptr;
-	// long lists exist: short ones go to the helper stream
-	AuxStream *ax = (max_tile > 2048 && !serial && !c.a->debug) ? aux_stream() : nullptr;
-	hipStream_t small = c.stream, mid = c.stream;
-	const bool fork_mid = ax && max_tile > 8192; // two long-list classes: they get a stream each
+	const int nlong = c.heavy4; // lists with >= FR_SORT_SPLIT_MIN entries: the first entries of tile_order
+	// long lists exist: the short ones are sorted meanwhile on the helper stream
+	AuxStream *ax = (nlong > 0 && !serial && !c.a->debug) ? aux_stream() : nullptr;
+	hipStream_t small = c.stream;
 	if (ax)
 	{
 		(void)hipEventRecord(ax->fork, c.stream);
 		(void)hipStreamWaitEvent(ax->s, ax->fork, 0);
 		small = ax->s;
-		if (fork_mid) { (void)hipStreamWaitEvent(ax->s2, ax->fork, 0); mid = ax->s2; }
 	}
-	// size classes (tile_order is longest-first, so the big classes start first on the chip)
-	if (max_tile > 16384)
-		hipLaunchKernelGGL(k_tile_sort_global, grid, dim3(256), 0, c.stream, rg, ord, c.bin.entries, c.bin.point_list, 16384);
-	if (max_tile > 8192)
-		hipLaunchKernelGGL((k_tile_msort<1024, 16>), grid, dim3(1024), 16384 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.point_list, 8192);
-	if (max_tile > 2048)
-		hipLaunchKernelGGL((k_tile_msort<1024, 8>), grid, dim3(1024), 8192 * sizeof(uint64_t), mid, rg, ord, c.bin.entries, c.bin.point_list, 2048);
+	if (nlong > 0)
+	{
+		uint32_t *chunk_ctr = c.img.totals + 4;
+		hipLaunchKernelGGL(k_split_long, dim3(nlong), dim3(1024), 0, c.stream, rg, ord, c.bin.entries, c.bin.entries2, c.bin.chunks, chunk_ctr);
+		const size_t max_chunks = FR_SORT_MAX_CHUNKS(num_instances);
+		hipLaunchKernelGGL((k_tile_msort<256, 8, true>), dim3((unsigned)max_chunks), dim3(256), 2048 * sizeof(uint64_t), c.stream,
+			c.bin.chunks, (const uint32_t *)nullptr, c.bin.entries2, c.bin.point_list, 0, 0, chunk_ctr);
+	}
 	if (max_tile > 512)
-		hipLaunchKernelGGL((k_tile_msort<256, 8>), grid, dim3(256), 2048 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list, 512);
-	hipLaunchKernelGGL((k_tile_msort<64, 8>), grid, dim3(64), 512 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list, 0);
+		hipLaunchKernelGGL((k_tile_msort<256, 8, false>), grid, dim3(256), 2048 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+			512, FR_SORT_SPLIT_MIN, (const uint32_t *)nullptr);
+	hipLaunchKernelGGL((k_tile_msort<64, 8, false>), grid, dim3(64), 512 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+		0, FR_SORT_SPLIT_MIN, (const uint32_t *)nullptr);
 	if (ax)
 	{
 		(void)hipEventRecord(ax->join, ax->s);
 		(void)hipStreamWaitEvent(c.stream, ax->join, 0);
-		if (fork_mid) { (void)hipEventRecord(ax->join2, ax->s2); (void)hipStreamWaitEvent(c.stream, ax->join2, 0); }
 	}
 	return check_launch("tile_sort", c.stream, c.a->debug);
 }

@@ -15,6 +15,12 @@
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop
 #define FR_GIANT_MAX 64         // giant splats a workgroup can set aside (more: handled like big ones)
+#define FR_SORT_SPLIT_MIN 2048      // tile lists with at least this many entries are split by depth before sorting
+#define FR_SORT_CHUNK_TARGET 960    // ... into chunks of about this many entries (just under the 1024-key sort size)
+#define FR_SORT_FINE_BUCKETS 2048   // depth buckets of the split
+// chunks are cut at multiples of the target in the running count, so a list of n entries yields at most
+// n / target + 1 of them, and there are at most D / FR_SORT_SPLIT_MIN long lists
+#define FR_SORT_MAX_CHUNKS(D) ((size_t)(D) / FR_SORT_CHUNK_TARGET + (size_t)(D) / FR_SORT_SPLIT_MIN + 16)
 #define FR_LV_BBOX_STRIDE 32  // words between the level boxes of ImageWS::lv_bbox (one 128-byte line each)
 #define FR_SLAB_CTR_WORDS 288 // header line + eight 128-byte counter lines
 
@@ -75,7 +81,7 @@ struct ImageWS {
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
 	uint32_t *lv_bbox;    // [5][FR_LV_BBOX_STRIDE] RF: box of the tiles with tile_min < k as {gx - x0, gy - y0, x1, y1} (0 = empty), k = 0..4
-	uint32_t *totals;     // [4]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047}
+	uint32_t *totals;     // [8]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, -...}
 	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
 	uint32_t *hist;       // [FR_BIN_BLOCKS][T] per-workgroup tile histograms (null if T too large for LDS)
@@ -96,7 +102,7 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.ranges = (uint2 *)(base + off); off = align_up(off + T * sizeof(uint2));
 	s.tile_count = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.lv_bbox = (uint32_t *)(base + off); off = align_up(off + 5 * FR_LV_BBOX_STRIDE * sizeof(uint32_t));
-	s.totals = (uint32_t *)(base + off); off = align_up(off + 4 * sizeof(uint32_t));
+	s.totals = (uint32_t *)(base + off); off = align_up(off + 8 * sizeof(uint32_t));
 	s.tile_order = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.tile_lv = nullptr;
 	if (variant == FR_VARIANT_FOV_PCHECK_OBB) { s.tile_lv = (float *)(base + off); off = align_up(off + 5 * T * sizeof(float)); }
@@ -110,6 +116,8 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 struct BinWS {
 	uint64_t *entries;    // [D] (depth bits << 32 | gaussian id), bucketed by tile
 	uint32_t *point_list; // [D] gaussian ids, sorted per tile
+	uint64_t *entries2;   // [D] long lists regrouped into depth-ordered chunks (k_split_long)
+	uint2 *chunks;        // [FR_SORT_MAX_CHUNKS(D)] ranges of those chunks inside entries2 / point_list
 	size_t bytes;
 };
 __host__ __device__ inline BinWS carve_bin(int64_t D, char *base)
@@ -117,6 +125,8 @@ __host__ __device__ inline BinWS carve_bin(int64_t D, char *base)
 	BinWS b; size_t off = 0;
 	b.entries = (uint64_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint64_t));
 	b.point_list = (uint32_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint32_t));
+	b.entries2 = (uint64_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint64_t));
+	b.chunks = (uint2 *)(base + off); off = align_up(off + FR_SORT_MAX_CHUNKS(D) * sizeof(uint2));
 	b.bytes = off + 256;
 	return b;
 }

@@ -87,16 +87,35 @@ class _Workspaces:
 
 
 _persistent_ws = {}
+_pooled_ws = {}  # device -> idle workspace sets of finished training steps
+
+
+class _Lease:
+    """Keeps one workspace set out of the pool while an autograd graph may still read it in backward();
+    the set goes back when the last reference (the autograd context) dies."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __del__(self):
+        try:
+            _pooled_ws.setdefault(self.ws.device, []).append(self.ws)
+        except Exception:  # interpreter shutdown
+            pass
 
 
 def _workspaces_for(device, needs_graph):
-    """Fresh buffers when autograd will keep them for backward, a per-device persistent set otherwise."""
+    """-> (workspaces, lease). A per-device persistent set for calls without an autograd graph; for training a
+    set from a small pool, leased until the graph is gone: allocating GBs of fresh buffers every step made the
+    caching allocator fall back to hipMalloc/hipFree every few steps (30-40 ms stalls)."""
     if needs_graph:
-        return _Workspaces(device)
+        idle = _pooled_ws.get(device)
+        ws = idle.pop() if idle else _Workspaces(device)
+        return ws, _Lease(ws)
     ws = _persistent_ws.get(device)
     if ws is None:
         ws = _persistent_ws[device] = _Workspaces(device)
-    return ws
+    return ws, None
 
 
 # Set by fov3dgs_amd.profiling.StageTimer while a timed region is active: a ctypes array of
@@ -107,8 +126,9 @@ _stage_events_hook = None
 def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                     shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
                     sh_rest=None):
-    """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions])
-    persistent=True: the workspaces are the per-device grow-only set (valid until the next call)."""
+    """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease)
+    persistent=True: the workspaces are the per-device grow-only set (valid until the next call); otherwise they
+    stay reserved for as long as `lease` (the last element) is referenced."""
     lib = _native.load()
     _require_gpu(means3D)
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -128,7 +148,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
     with torch.cuda.device(dev):
         color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-        ws = _workspaces_for(dev, not persistent)
+        ws, lease = _workspaces_for(dev, not persistent)
         counts = contribs = None
         a.variant = variant
         a.P, a.D = P, int(rs.sh_degree)
@@ -168,7 +188,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
     out = (int(a.num_rendered), color, radii, ws.buf[0], ws.buf[1], ws.buf[2])
     if counts is not None:
         out = out + (counts, contribs)
-    return out
+    return out + (lease,)  # last element: keeps the workspace set reserved (None for the persistent set)
 
 
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -283,6 +303,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 geomBuffer = binningBuffer = imgBuffer = torch.empty(0, dtype=torch.uint8, device=means3D.device)
             ctx.raster_settings = raster_settings
             ctx.num_rendered = num_rendered
+            ctx.ws_lease = res[-1] if keep_ws else None
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                                   geomBuffer, binningBuffer, imgBuffer,
                                   sh_rest if sh_rest is not None else torch.empty(0, device=means3D.device))

@@ -43,7 +43,8 @@ def hip_forward(variant, scene, cam, dev="cuda:0", debug=True):
     W, H = rs.image_width, rs.image_height
     T = ((W + 15) // 16) * ((H + 15) // 16)
     out = {"num_rendered": num_rendered, "color": color.cpu().numpy(), "radii": radii.cpu().numpy(),
-           "_tensors": tens, "_rs": rs, "_buffers": (geom, binb, img), "_radii_t": radii}
+           "_tensors": tens, "_rs": rs, "_buffers": (geom, binb, img), "_radii_t": radii,
+           "_lease": res[-1]}  # the workspace set stays reserved while this dict lives
     if img.numel() == 0:  # P == 0: the library returns before touching any workspace
         out["ranges"], out["point_list"] = np.zeros((T, 2), np.uint32), np.zeros(0, np.uint32)
         return out

@@ -12,7 +12,7 @@ bg = torch.zeros(3, device=dev)
 class Pipe: debug = False
 target = torch.rand(3, cam.image_height, cam.image_width, device=dev)
 ts = []
-for it in range(12):
+for it in range(20):
     for p in cloud.parameters(): p.grad = None
     torch.cuda.synchronize(); t0 = time.perf_counter()
     o = render(cam, cloud, Pipe(), bg, cuda_type="pcheck_obb_sum")
@@ -22,4 +22,5 @@ for it in range(12):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     ts.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3))
 ts = np.array(ts[3:])
-print("fwd ms %.3f  bwd ms %.3f  total %.3f" % (ts[:, 0].mean(), ts[:, 1].mean(), ts.sum(1).mean()))
+print("per-iteration total ms:", np.round(ts.sum(1), 2))
+print("fwd ms %.3f  bwd ms %.3f  total %.3f" % (np.median(ts[:, 0]), np.median(ts[:, 1]), np.median(ts.sum(1))))
