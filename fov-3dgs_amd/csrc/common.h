@@ -15,7 +15,8 @@
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop
 #define FR_GIANT_MAX 64         // giant splats a workgroup can set aside (more: handled like big ones)
-#define FR_SORT_SPLIT_MIN 2048      // tile lists with at least this many entries are split by depth before sorting
+#define FR_SORT_SPLIT_LOG2 11       // (4096 / 8192 / 1024 measured slower)
+#define FR_SORT_SPLIT_MIN (1 << FR_SORT_SPLIT_LOG2) // tile lists with at least this many entries are split by depth before sorting
 #define FR_SORT_CHUNK_TARGET 960    // ... into chunks of about this many entries (just under the 1024-key sort size)
 #define FR_SORT_FINE_BUCKETS 2048   // depth buckets of the split
 // chunks are cut at multiples of the target in the running count, so a list of n entries yields at most
