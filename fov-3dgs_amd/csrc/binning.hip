@@ -245,45 +245,33 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 
 // Long tile lists (>= FR_SORT_SPLIT_MIN entries) are not sorted as one piece: a handful of them used to occupy one
 // CU each for 50-80 us with sixteen-way merge passes while the rest of the chip had nothing left to do. A counting
-// pass on the depth bits (monotone quantisation into FR_SORT_FINE_BUCKETS buckets between the list's own minimum and
-// maximum) regroups the list into chunks of ~FR_SORT_CHUNK_TARGET entries with disjoint, increasing depth ranges;
+// pass on the depth bits (a fixed monotone quantisation into FR_SORT_FINE_BUCKETS buckets) regroups the list into chunks of ~FR_SORT_CHUNK_TARGET entries with disjoint, increasing depth ranges;
 // equal depths share a bucket, so sorting every chunk by (depth, id) sorts the list. The chunks are independent
-// 1024-key sorts that spread over the whole chip. Keys are streamed from global memory three times (min/max,
-// histogram, scatter); LDS holds only the histogram.
+// 1024-key sorts that spread over the whole chip. Keys are streamed from global memory twice (histogram,
+// scatter); LDS holds only the histogram.
 __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const uint32_t *tile_order, const uint64_t *entries,
 	uint64_t *entries2, uint2 *chunks, uint32_t *chunk_ctr)
 {
 	__shared__ uint32_t s_hist[FR_SORT_FINE_BUCKETS];      // counts -> exclusive offsets -> scatter cursors
 	__shared__ uint32_t s_start[FR_SORT_FINE_BUCKETS + 1]; // compacted chunk starts
 	__shared__ uint32_t s_wave[16], s_wave2[16];
-	__shared__ uint32_t s_lo, s_hi, s_slot;
+	__shared__ uint32_t s_slot;
 	const uint2 rg = ranges[tile_order[blockIdx.x]];
 	const uint32_t n = rg.y - rg.x;
 	if (n < FR_SORT_SPLIT_MIN) return;
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const uint64_t *src = entries + rg.x;
 	uint64_t *dst = entries2 + rg.x;
-	// 1. range of the depth bits (depths are positive floats: their bit patterns order like the values)
-	uint32_t lo = 0xffffffffu, hi = 0u;
-	for (uint32_t i = tid; i < n; i += 1024) { const uint32_t d = (uint32_t)(src[i] >> 32); lo = min(lo, d); hi = max(hi, d); }
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, off)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, off)); }
-	if (lane == 0) { s_wave[wid] = lo; s_wave2[wid] = hi; }
+	// 1. depth bucket: the bit pattern of a positive float orders like its value, so a fixed monotone map of the
+	// bits needs no pass over the list: 128 buckets per octave from the near plane (0.2) up, 16 octaves, the rest
+	// clamped into the last bucket (uneven buckets are fine, chunks are cut by count)
 	for (int b = tid; b < FR_SORT_FINE_BUCKETS; b += 1024) s_hist[b] = 0;
 	__syncthreads();
-	if (tid == 0)
-	{
-		uint32_t l = s_wave[0], h = s_wave2[0];
-		for (int w = 1; w < 16; w++) { l = min(l, s_wave[w]); h = max(h, s_wave2[w]); }
-		s_lo = l; s_hi = h;
-	}
-	__syncthreads();
-	const uint32_t dmin = s_lo;
-	// bucket = (d - dmin) >> shift with the smallest shift that maps the span into the bucket array
-	int shift = 0;
-	while (((s_hi - dmin) >> shift) >= FR_SORT_FINE_BUCKETS) shift++;
+	constexpr uint32_t dmin = 0x3E4CCCCDu; // 0.2f
+	constexpr int shift = 16;
+#define FR_DEPTH_BUCKET(d) min((uint32_t)(FR_SORT_FINE_BUCKETS - 1), ((d) > dmin ? (d) - dmin : 0u) >> shift)
 	// 2. histogram
-	for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[((uint32_t)(src[i] >> 32) - dmin) >> shift], 1u);
+	for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(src[i] >> 32))], 1u);
 	__syncthreads();
 	// 3. exclusive scan of the 2048 counts (two consecutive buckets per thread)
 	const uint32_t c0 = s_hist[2 * tid], c1 = s_hist[2 * tid + 1];
@@ -322,8 +310,9 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 	for (uint32_t i = tid; i < n; i += 1024)
 	{
 		const uint64_t key = src[i];
-		dst[atomicAdd(&s_hist[((uint32_t)(key >> 32) - dmin) >> shift], 1u)] = key;
+		dst[atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(key >> 32))], 1u)] = key;
 	}
+#undef FR_DEPTH_BUCKET
 }
 
 int launch_tile_scan(FwdCtx &c)
