@@ -349,19 +349,24 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 
 // ---------------- FOV_PCHECK_OBB: single-level and two-level tiles ----------------
 template <int PPL>
-__global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
+__global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
 {
-	constexpr int NT = 256 / PPL;
-	__shared__ float4 s0[NT];   // x, y, A, B
-	__shared__ float2 s1[NT];   // C, highest_level
-	__shared__ float4 sl1[NT];  // level L1: r, g, b, opacity
-	__shared__ float4 sl2[NT];  // level L2 (two-level tiles only)
-	constexpr int NW = NT / 64;  // waves per tile, each owning a band of 16 / NW rows
-	__shared__ unsigned long long s_reach[NW][NW]; // [band][staging wave]: staged entries that can touch the band
+	// The waves of a tile (each owning a band of 16 / NW rows) are INDEPENDENT: every wave walks the whole list in
+	// batches of 64 entries that it fetches, tests against its own band and stages in its own LDS slice. No
+	// workgroup barrier: with shared batches the wave whose band holds less waited for the other one at every
+	// batch (a quarter of the slowest tiles' time); the records are fetched twice, out of L2.
+	// Each wave is a workgroup of its own (grid = tiles x NW): a finished wave frees its slot at once.
+	constexpr int NW = 256 / PPL / 64;
+	__shared__ float4 s0[64];   // x, y, A, B
+	__shared__ float2 s1[64];   // C, highest_level
+	__shared__ float4 sl1[64];  // level L1: r, g, b, opacity
+	__shared__ float4 sl2[64];  // level L2 (two-level tiles only)
 
-	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
+	const int slot = (int)blockIdx.x / NW, wv = (int)blockIdx.x % NW;
+	const int tile = a.tile_order ? (int)a.tile_order[slot] : slot;
 	const int tx = tile % a.gx, ty = tile / a.gx;
-	const int tid = threadIdx.x;
+	const int lane = threadIdx.x;
+	const int tid = wv * 64 + lane; // position inside the tile's 256 / PPL threads (row mapping)
 	const int lx = tid & 15;
 	const int px = tx * FR_TILE + lx;
 	const float pxf = (float)px;
@@ -415,8 +420,8 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 		pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + L1];
 		if (blending) pl2 = a.lvl[(size_t)id * FR_FOV_LEVELS + L2];
 	};
-	if (tid < n) fetch(tid);
-	for (int base = 0; base < n; base += NT)
+	if (lane < n) fetch(lane);
+	for (int base = 0; base < n; base += 64)
 	{
 		float tmax0 = -1.0f;
 #pragma unroll
@@ -424,33 +429,33 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 #ifdef FR_TILE_TIMERS
 		const uint64_t tq0 = wall_clock64();
 #endif
-		if (__syncthreads_and(!(tmax0 > 0.0f))) break;
+		if (!__any(tmax0 > 0.0f)) break;
+		// the previous batch of this wave's LDS slice has been read by all lanes (wave-synchronous, fenced)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 #ifdef FR_TILE_TIMERS
 		tm_sync += wall_clock64() - tq0;
 #endif
-		const bool staged = base + tid < n;
-		if (staged) { s0[tid] = p0; s1[tid] = p1; sl1[tid] = pl1; if (blending) sl2[tid] = pl2; }
+		const bool staged = base + lane < n;
+		if (staged) { s0[lane] = p0; s1[lane] = p1; sl1[lane] = pl1; if (blending) sl2[lane] = pl2; }
+		unsigned long long reach_mask;
 		{
 			// alpha < 1/255 everywhere (forward.cu:563) <=> power < -ln(255 opacity): tighter than -4.5 for faint splats
 			const float op = blending ? fmaxf(pl1.w, pl2.w) : pl1.w;
 			const float thr = fmaxf(-4.5f, -__logf(255.0f * op) - 0.01f);
-#pragma unroll
-			for (int w = 0; w < NW; w++)
-			{
-				const bool reach = staged && band_reaches<PPL>(w, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr);
-				const unsigned long long m = __ballot(reach);
-				if ((tid & 63) == 0) s_reach[w][tid >> 6] = m;
-			}
+			reach_mask = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
 		}
-		if (base + NT + tid < n) fetch(base + NT + tid);
-		__syncthreads();
+		if (base + 64 + lane < n) fetch(base + 64 + lane);
+		// lanes read entries other lanes staged
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		v2f pyp[HP];
 #pragma unroll
 		for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
 #ifdef FR_TILE_TIMERS
 		const uint64_t tq1 = wall_clock64();
 #endif
-		bool stop = false;
 		// Entries are taken two at a time: everything that does not depend on the running transmittance (record
 		// fetch, power, exp, alpha inputs) is evaluated for both before either is blended, so the two dependency
 		// chains overlap -- a wave works through its list serially and the slowest tile's chain is the kernel time.
@@ -487,8 +492,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 				if (blending) blend2(S2[h], t.inx[h] && t.l2_ok, t.iny[h] && t.l2_ok, t.e[h], t.c2);
 			}
 		};
-		for (int sw = 0; sw < NW && !stop; sw++)
-		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; )
+		for (unsigned long long rm = reach_mask; rm; )
 		{
 			int jj[FR_RENDER_GROUP];
 			bool vv[FR_RENDER_GROUP];
@@ -496,13 +500,13 @@ __global__ void __launch_bounds__(256 / PPL) k_render_fov(const RenderArgs a)
 			for (int g = 0; g < FR_RENDER_GROUP; g++)
 			{
 				vv[g] = rm != 0;
-				jj[g] = vv[g] ? sw * 64 + __builtin_ctzll(rm) : jj[0];
+				jj[g] = vv[g] ? __builtin_ctzll(rm) : jj[0];
 				rm &= rm - 1; // stays 0 once empty
 			}
 			float tmax = -1.0f;
 #pragma unroll
 			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(fmaxf(S1[h].T.x, S1[h].T.y), fmaxf(S2[h].T.x, S2[h].T.y)));
-			if (!__any(tmax > 0.0f)) { stop = true; break; }
+			if (!__any(tmax > 0.0f)) break;
 			Ent t[FR_RENDER_GROUP];
 #pragma unroll
 			for (int g = 0; g < FR_RENDER_GROUP; g++) t[g] = prepare(jj[g], vv[g]);
@@ -578,7 +582,7 @@ int launch_render(FwdCtx &c)
 		// The frame ends when the tile that blends the most entries ends, and a wave works through its list
 		// serially: two waves of two rows per lane make that chain ~1.6x shorter than one wave of four rows for
 		// ~30 % more instructions in total (measured 374 -> 286 us on the bench frame).
-		hipLaunchKernelGGL((k_render_fov<FR_RENDER_FOV_PPL>), dim3(c.T), dim3(256 / FR_RENDER_FOV_PPL), 0, c.stream, r);
+		hipLaunchKernelGGL((k_render_fov<FR_RENDER_FOV_PPL>), dim3(c.T * (256 / FR_RENDER_FOV_PPL / 64)), dim3(64), 0, c.stream, r);
 		break;
 	}
 	return check_launch("render", c.stream, a->debug);
