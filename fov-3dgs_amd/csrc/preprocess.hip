@@ -272,9 +272,9 @@ __device__ __forceinline__ float view_norm2_bound(const float *vm)
 // (forward.cu:229-231). Everything here is evaluated approximately (no double, one division) and padded by
 // 1 % + 2 px, far above the rounding of either formulation; NaN/inf anywhere makes the test pass.
 template <bool FOV>
-__device__ __forceinline__ bool frame_test(const PreArgs &a, int idx, const float p[3], const float sc[3], float4 q, float hl, float wn2)
+__device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, const float *pm, int idx, const float p[3], const float sc[3], float4 q,
+	float hl, float wn2)
 {
-	const float *vm = a.viewmatrix, *pm = a.projmatrix;
 	const float tz = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
 	if (tz <= 0.2f) return false;
 	const float hx = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
@@ -504,6 +504,9 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 // barrier is needed, so the waves of a CU drift apart and overlap their load and ALU phases.
 #define FR_PROJ_THREADS 256
 #define FR_PROJ_WLIST 512
+#ifndef FR_PROJ_DEPTH
+#define FR_PROJ_DEPTH 3 // (2: 0.120 ms, 3: 0.110 ms, 4: 0.131 ms on the bench scene)
+#endif
 template <int VARIANT>
 __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 {
@@ -528,46 +531,59 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	};
 	const bool have_sr = a.cov3D_precomp == nullptr;
 	const float wn2 = view_norm2_bound(a.viewmatrix);
-	auto fetch = [&](const int idx)
+	// The camera matrices go to scalar registers once: read through the argument pointers inside the loop they are
+	// re-fetched for every chunk (the stores below may alias them as far as the compiler knows), and waiting for
+	// them also waits for the prefetches issued before.
+	float vm[16], pm[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++)
 	{
-		RawGaussian w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0); w.hl = 0.f;
-		if (idx < a.P)
-		{
+		vm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.viewmatrix[i])));
+		pm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.projmatrix[i])));
+	}
+	// No branch around the prefetch loads (a conditional load is waited for where its branch ends): out-of-range lanes
+	// read the last Gaussian; without scales / rotations the unused values come from the cov3D_precomp array.
+	const float *sc_src = have_sr ? a.scales : a.cov3D_precomp;
+	const float *q_src = have_sr ? a.rotations : a.cov3D_precomp;
+	auto fetch = [&](const int chunk)
+	{
+		const size_t i = (size_t)min(chunk * 64 + lane, a.P - 1);
+		RawGaussian w;
 #pragma unroll
-			for (int i = 0; i < 3; i++) w.p[i] = a.means3D[3 * (size_t)idx + i];
-			if (have_sr)
-			{
-#pragma unroll
-				for (int i = 0; i < 3; i++) w.sc[i] = a.scales[3 * (size_t)idx + i];
-				w.q = ((const float4 *)a.rotations)[idx];
-			}
-			if (FOV) w.hl = a.highest_levels[idx];
-		}
+		for (int k = 0; k < 3; k++) { w.p[k] = a.means3D[3 * i + k]; w.sc[k] = sc_src[3 * i + k]; }
+		w.q = *(const float4 *)(q_src + 4 * i);
+		w.hl = FOV ? a.highest_levels[i] : 0.0f;
 		return w;
 	};
 	const int nchunks = (a.P + 63) / 64;
 	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
 	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
-	// two chunks in flight per wave: at ~20 waves per CU one chunk (2.8 KB per wave) does not cover the memory
-	// latency at full bandwidth
-	RawGaussian nxt = fetch(wave_gid < nchunks ? wave_gid * 64 + lane : a.P);
-	RawGaussian nxt2 = fetch(wave_gid + nwaves < nchunks ? (wave_gid + nwaves) * 64 + lane : a.P);
-	for (int chunk = wave_gid; chunk < nchunks; chunk += nwaves)
+	auto step = [&](const RawGaussian &cur, const int chunk)
 	{
 		const int idx = chunk * 64 + lane;
-		const RawGaussian cur = nxt;
-		nxt = nxt2;
-		nxt2 = fetch(chunk + 2 * nwaves < nchunks ? (chunk + 2 * nwaves) * 64 + lane : a.P);
 		bool maybe = false;
-		if (idx < a.P)
+		if (chunk < nchunks && idx < a.P)
 		{
-			maybe = frame_test<FOV>(a, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
+			maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
 			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
 		}
 		const unsigned long long m = __ballot(maybe);
 		if (maybe) list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
 		n += (uint32_t)__popcll(m);
 		if (n > FR_PROJ_WLIST - 64) flush();
+	};
+	// FR_PROJ_DEPTH chunks in flight per wave, each in its own register set that is refilled in place
+	RawGaussian R[FR_PROJ_DEPTH];
+#pragma unroll
+	for (int d = 0; d < FR_PROJ_DEPTH; d++) R[d] = fetch(min(wave_gid + d * nwaves, nchunks - 1));
+	for (int base = wave_gid; base < nchunks; base += FR_PROJ_DEPTH * nwaves)
+	{
+#pragma unroll
+		for (int d = 0; d < FR_PROJ_DEPTH; d++)
+		{
+			step(R[d], base + d * nwaves);
+			R[d] = fetch(min(base + (d + FR_PROJ_DEPTH) * nwaves, nchunks - 1));
+		}
 	}
 	if (n) flush();
 }
