@@ -320,11 +320,10 @@ __device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, co
 
 // The reference's per-Gaussian projection (forward.cu:155-262): near plane, 3D covariance, EWA 2D covariance,
 // conic, radius, tile rectangle. sc / q: raw scales and rotation (unused with cov3D_precomp).
-__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, int idx, const float p[3], const float sc[3], float4 q)
+__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, const float *vm, const float *pm, int idx, const float p[3], const float sc[3], float4 q)
 {
 	Proj r; r.alive = false; r.tnum = 0; r.radius = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0;
 	r.pix_x = r.pix_y = r.depth = r.conic_a = r.conic_b = r.conic_c = r.cov0 = r.cov1 = r.lambda1 = r.lambda2 = 0.f;
-	const float *vm = a.viewmatrix, *pm = a.projmatrix;
 	// near cull: auxiliary.h:139-164
 	const float hx = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
 	const float hy = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
@@ -642,6 +641,14 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// wave_head): k_emit must replay the same slab -> workgroup assignment because its bucket offsets are
 	// per workgroup.
 	__shared__ int s_own[FR_BIN_THREADS];
+	// camera matrices in scalar registers (see k_project)
+	float cam_vm[16], cam_pm[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+	{
+		cam_vm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.viewmatrix[i])));
+		cam_pm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.projmatrix[i])));
+	}
 	const int V = (int)a.geom.slab_ctr[1]; // entries of vis_list
 	const int nslabs = (V + 63) / 64;
 	const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
@@ -815,7 +822,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			w.q = ((const float4 *)a.rotations)[idx];
 		}
 		if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
-		pr = project_gaussian(a, idx, w.p, w.sc, w.q);
+		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q);
 		if (pr.alive)
 		{
 			if (CULL && pr.tnum > 1)
