@@ -40,6 +40,7 @@ static int validate_forward(const fr_forward_args *a)
 	if (!a) { set_error("null args"); return FR_ERR_INVALID; }
 	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_PCHECK_OBB_LWMC) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
 	if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return FR_ERR_INVALID; }
+	if (a->P > (1 << 30) || a->W > 16 * 65535 || a->H > 16 * 65535) { set_error("too large: P=%d (max 2^30) W=%d H=%d (max 65535 tiles per axis)", a->P, a->W, a->H); return FR_ERR_INVALID; }
 	if (!a->out_color) { set_error("out_color is null"); return FR_ERR_INVALID; }
 	if (a->P == 0) return FR_OK;
 	if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->campos || !a->background || !a->radii)

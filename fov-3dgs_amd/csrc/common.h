@@ -42,8 +42,9 @@ __host__ __device__ inline size_t align_up(size_t x, size_t a = 256) { return (x
 struct GeomWS {
 	float4 *rec;        // [3P]
 	float *cov3D;       // [6P]
-	float4 *evec;       // [P]  OBB axes (e1x,e1y,e2x,e2y)      (not ORIGINAL)
-	float2 *elen;       // [P]  OBB half-lengths                 (not ORIGINAL)
+	float4 *wrec;       // [4P] walk record of vis_list entry i at [4i..4i+3], written by k_bin in list order for k_emit:
+	                    //      (cx, cy, e1x, e1y | e2x, e2y, len1, len2 | id + flags << 30, depth bits, x0 + y0 << 16, width |
+	                    //      tiles, highest level, -, -); flags: 1 = lands in a tile, 2 = the OBB test applies
 	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity)
 	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8
 	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {-, number of entries in vis_list, ...}; k_bin's eight slab pull
@@ -58,11 +59,8 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 	GeomWS g; size_t off = 0;
 	g.rec = (float4 *)(base + off); off = align_up(off + P * 3 * sizeof(float4));
 	g.cov3D = (float *)(base + off); off = align_up(off + P * 6 * sizeof(float));
-	g.evec = nullptr; g.elen = nullptr; g.lvl = nullptr; g.lrange = nullptr;
-	if (variant != FR_VARIANT_ORIGINAL) {
-		g.evec = (float4 *)(base + off); off = align_up(off + P * sizeof(float4));
-		g.elen = (float2 *)(base + off); off = align_up(off + P * sizeof(float2));
-	}
+	g.lvl = nullptr; g.lrange = nullptr;
+	g.wrec = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4));
 	if (variant == FR_VARIANT_FOV_PCHECK_OBB) {
 		g.lvl = (float4 *)(base + off); off = align_up(off + P * FR_FOV_LEVELS * sizeof(float4));
 		g.lrange = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));

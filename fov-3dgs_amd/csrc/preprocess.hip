@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// "giant" splats (FR_GIANT_TNUM+ tiles, up to the whole frame = 128 wave steps) are set aside here and walked
 	// by ALL waves of the workgroup after the slab loop: left to the wave that met them they were the kernel's
 	// critical path
-	__shared__ int s_gidx[FR_GIANT_MAX];
+	__shared__ int s_gidx[FR_GIANT_MAX], s_gitem[FR_GIANT_MAX];
 	__shared__ float2 s_gcd[FR_GIANT_MAX]; // conic c, depth of the deferred splat
 	__shared__ uint32_t s_gcount[FR_GIANT_MAX], s_gmask[FR_GIANT_MAX];
 	__shared__ uint32_t s_ng;
@@ -843,9 +843,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		a.radii[idx] = pr.alive ? pr.radius : 0;
 		if (pr.alive)
 		{
-			// first third of the record + OBB axes: k_emit and the giant phase below read them back
-			a.geom.rec[3 * (size_t)idx] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
-			if (CULL) { a.geom.evec[idx] = ev; a.geom.elen[idx] = el; }
+			a.geom.rec[3 * (size_t)idx] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b); // first third of the record
 			r1.x = pr.conic_c; r2.y = pr.depth;
 		}
 	}
@@ -877,7 +875,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		if (pr.alive && !in_place && pr.tnum >= FR_GIANT_TNUM)
 		{
 			const uint32_t slot = atomicAdd(&s_ng, 1u);
-			if (slot < FR_GIANT_MAX) { s_gidx[slot] = idx; s_gcd[slot] = make_float2(r1.x, r2.y); deferred = true; }
+			if (slot < FR_GIANT_MAX) { s_gidx[slot] = idx; s_gitem[slot] = item; s_gcd[slot] = make_float2(r1.x, r2.y); deferred = true; }
 		}
 		const bool big = pr.alive && !in_place && !deferred && pr.tnum >= FR_BIG_TNUM;
 		if (__ballot(big)) __builtin_amdgcn_s_setprio(3);
@@ -954,6 +952,17 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
 		TM_END(tm_p);
 		if (pr.alive && !deferred) finish(idx, count, hl, lowest, highest, be_blend, r1.x, r2.y);
+		// walk record for k_emit (and for the giant phase below), in list order: coalesced 64-byte rows
+		if (item < V)
+		{
+			const uint32_t flags = ((pr.alive && (deferred || count != 0)) ? 1u : 0u) | (boxtest ? 2u : 0u);
+			float4 *wr = a.geom.wrec + 4 * (size_t)item;
+			wr[0] = make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y);
+			wr[1] = make_float4(ev.z, ev.w, el.x, el.y);
+			wr[2] = make_float4(__uint_as_float((uint32_t)idx | (flags << 30)), pr.depth, __uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)),
+				__uint_as_float((uint32_t)(pr.x1 - pr.x0)));
+			wr[3] = make_float4(__uint_as_float(pr.tnum), hl, 0.0f, 0.0f);
+		}
 	}
 	TM_END(tm_c);
 	} // slab loop
@@ -966,15 +975,13 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	const int ng = min((int)s_ng, FR_GIANT_MAX);
 	for (int g = 0; g < ng; g++)
 	{
-		const int gi = s_gidx[g];
-		const float4 r0 = a.geom.rec[3 * (size_t)gi];
-		float4 gev = make_float4(0, 0, 0, 0); float2 gel = make_float2(0, 0);
-		if (CULL) { gev = a.geom.evec[gi]; gel = a.geom.elen[gi]; }
-		const float ghl = FOV ? a.highest_levels[gi] : 0.0f;
-		const WalkRect w = walk_rect<CULL, FOV>(r0.x, r0.y, a.radii[gi], a.gx, a.gy, gev, gel, ghl, a.lv_bbox);
-		const Obb ob = make_obb(r0.x, r0.y, gev, gel);
+		const float4 *wr = a.geom.wrec + 4 * (size_t)s_gitem[g]; // written above by the wave that set the splat aside
+		const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+		const Obb ob = make_obb(w0.x, w0.y, make_float4(w0.z, w0.w, w1.x, w1.y), make_float2(w1.z, w1.w));
+		const uint32_t xy = __float_as_uint(w2.z);
 		uint32_t cnt = 0, bits = 0;
-		walk_uniform(w.x0, w.y0, w.x1 - w.x0, w.tnum, ob, ghl + 1, (uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_BIN_THREADS, cnt, bits);
+		walk_uniform((int)(xy & 0xffffu), (int)(xy >> 16), (int)__float_as_uint(w2.w), __float_as_uint(w3.x), ob, w3.y + 1,
+			(uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_BIN_THREADS, cnt, bits);
 		if (lane == 0) { atomicAdd(&s_gcount[g], cnt); if (FOV) atomicOr(&s_gmask[g], bits); }
 	}
 	__syncthreads();
@@ -1047,7 +1054,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	}
 	__syncthreads();
 	__shared__ int s_own[FR_BIN_THREADS];
-	__shared__ int s_gidx[FR_GIANT_MAX]; // giant splats, walked by the whole workgroup at the end (see k_bin)
+	__shared__ int s_gidx[FR_GIANT_MAX]; // vis_list positions of the giant splats, walked by the whole workgroup at the end (see k_bin)
 	__shared__ uint32_t s_ng;
 	if (threadIdx.x == 0) s_ng = 0;
 	__syncthreads();
@@ -1079,25 +1086,28 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	auto process = [&](const int slab)
 	{
 	const int item = slab * 64 + lane;
-	int idx = 0, radius = 0;
-	if (item < V) { idx = (int)a.geom.vis_list[item]; radius = a.radii[idx]; }
-	const bool alive = radius > 0;
+	// everything k_emit needs about the entry sits in its walk record (one coalesced 64-byte read per lane instead of
+	// a chain of dependent gathers through the Gaussian index)
+	int idx = 0;
+	bool alive = false, boxtest = false;
 	int x0 = 0, y0 = 0, x1 = 0;
 	uint32_t tnum = 0;
-	bool boxtest = false;
 	float cx = 0.f, cy = 0.f, hl = 0.f;
 	uint32_t depth_bits = 0;
 	float4 ev = make_float4(0, 0, 0, 0);
 	float2 el = make_float2(0, 0);
-	if (alive)
+	if (item < V)
 	{
-		const float4 r0 = a.geom.rec[3 * (size_t)idx];
-		cx = r0.x; cy = r0.y;
-		depth_bits = __float_as_uint(a.geom.rec[3 * (size_t)idx + 2].y);
-		if (CULL) { ev = a.geom.evec[idx]; el = a.geom.elen[idx]; }
-		if (FOV) hl = a.highest_levels[idx];
-		const WalkRect w = walk_rect<CULL, FOV>(cx, cy, radius, a.gx, a.gy, ev, el, hl, a.lv_bbox);
-		x0 = w.x0; y0 = w.y0; x1 = w.x1; tnum = w.tnum; boxtest = w.boxtest;
+		const float4 *wr = a.geom.wrec + 4 * (size_t)item;
+		const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+		const uint32_t idf = __float_as_uint(w2.x), xy = __float_as_uint(w2.z);
+		idx = (int)(idf & 0x3fffffffu);
+		alive = (idf >> 30) & 1u; boxtest = (idf >> 31) & 1u;
+		cx = w0.x; cy = w0.y; ev = make_float4(w0.z, w0.w, w1.x, w1.y); el = make_float2(w1.z, w1.w);
+		depth_bits = __float_as_uint(w2.y);
+		x0 = (int)(xy & 0xffffu); y0 = (int)(xy >> 16); x1 = x0 + (int)__float_as_uint(w2.w);
+		tnum = alive ? __float_as_uint(w3.x) : 0u;
+		hl = w3.y;
 	}
 	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
 	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_bin's level test, no box test (single-tile splat)
@@ -1107,7 +1117,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 		if (alive && !in_place && tnum >= FR_GIANT_TNUM)
 		{
 			const uint32_t slot = atomicAdd(&s_ng, 1u);
-			if (slot < FR_GIANT_MAX) { s_gidx[slot] = idx; deferred = true; }
+			if (slot < FR_GIANT_MAX) { s_gidx[slot] = item; deferred = true; }
 		}
 		// big splats: whole wave, wave-uniform owner (see k_bin)
 		const bool big = alive && !in_place && !deferred && tnum >= FR_BIG_TNUM;
@@ -1180,15 +1190,13 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	const int ng = min((int)s_ng, FR_GIANT_MAX);
 	for (int g = 0; g < ng; g++)
 	{
-		const int gi = s_gidx[g];
-		const float4 r0 = a.geom.rec[3 * (size_t)gi];
-		float4 gev = make_float4(0, 0, 0, 0); float2 gel = make_float2(0, 0);
-		if (CULL) { gev = a.geom.evec[gi]; gel = a.geom.elen[gi]; }
-		const float ghl = FOV ? a.highest_levels[gi] : 0.0f;
-		const WalkRect w = walk_rect<CULL, FOV>(r0.x, r0.y, a.radii[gi], a.gx, a.gy, gev, gel, ghl, a.lv_bbox);
-		const Obb ob = make_obb(r0.x, r0.y, gev, gel);
-		const uint64_t opay = ((uint64_t)__float_as_uint(a.geom.rec[3 * (size_t)gi + 2].y) << 32) | (uint32_t)gi;
-		walk_uniform(w.x0, w.y0, w.x1 - w.x0, w.tnum, ob, ghl + 1, opay, (uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_BIN_THREADS);
+		const float4 *wr = a.geom.wrec + 4 * (size_t)s_gidx[g];
+		const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+		const Obb ob = make_obb(w0.x, w0.y, make_float4(w0.z, w0.w, w1.x, w1.y), make_float2(w1.z, w1.w));
+		const uint32_t xy = __float_as_uint(w2.z);
+		const uint64_t opay = ((uint64_t)__float_as_uint(w2.y) << 32) | (__float_as_uint(w2.x) & 0x3fffffffu);
+		walk_uniform((int)(xy & 0xffffu), (int)(xy >> 16), (int)__float_as_uint(w2.w), __float_as_uint(w3.x), ob, w3.y + 1, opay,
+			(uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_BIN_THREADS);
 	}
 }
 #undef NEXT_SLOT
