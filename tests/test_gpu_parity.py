@@ -395,3 +395,32 @@ def test_full_size_properties(variant):
             r3 = run(_native.VARIANT_IDS["pcheck_obb_sum"])
             torch.cuda.synchronize()
         assert r3[0] == D and torch.equal(r3[1], img1)
+
+
+def test_randomised_sweep():
+    """Seeded random sweep over sizes, image shapes, splat size mixes, gaze positions and variants (edge sizes 1, 2,
+    63..65 included): instance lists bit-exact, images within the tolerance of check_image."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    rng = np.random.default_rng(7)
+    variants = ("original", "pcheck_obb_sum", "pcheck_obb", "fov_pcheck_obb", "pcheck_obb_max")
+    for r in range(15):
+        variant = variants[r % len(variants)]
+        P = int(rng.choice([1, 2, 63, 64, 65, 500, 3000, 9000]))
+        W, H = int(rng.integers(17, 700)), int(rng.integers(17, 500))
+        cloud = small_cloud(P, seed=int(rng.integers(1 << 30)), big_fraction=float(rng.choice([0.0, 0.1, 0.5]))) if P >= 8 \
+            else syn.scene_1k(P=P, seed=r)
+        if rng.random() < 0.4 and P >= 8:
+            cloud._scaling[: max(1, P // 50)] += 3.0  # a few frame-filling splats
+        cam = small_camera(W, H)
+        fov = syn.foveation_layers(cloud, seed=r) if variant == "fov_pcheck_obb" else None
+        scene = scene_dict(cloud, variant, fov)
+        cd = cam_dict(cam, gaze=(float(rng.uniform(-0.3, 1.3)), float(rng.uniform(-0.3, 1.3))), alpha=float(rng.choice([0.05, 0.02, 0.2])))
+        want = orc.forward(variant, scene, cd)
+        got = hip_forward(variant, scene, cd)
+        tag = f"round {r}: {variant} P={P} {W}x{H}"
+        assert got["num_rendered"] == want["num_rendered"], tag
+        np.testing.assert_array_equal(got["radii"], want["radii"], err_msg=tag)
+        np.testing.assert_array_equal(got["ranges"], want["ranges"], err_msg=tag)
+        np.testing.assert_array_equal(got["point_list"], want["point_list"], err_msg=tag)
+        check_image(got["color"], want["color"], frac=2e-3)
