@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 // equal depths share a bucket, so sorting every chunk by (depth, id) sorts the list. The chunks are independent
 // 1024-key sorts that spread over the whole chip. Keys are streamed from global memory twice (histogram,
 // scatter); LDS holds only the histogram.
+#define FR_SPLIT_REGS 16 // keys per thread held in registers by k_split_long (lists up to 16384 entries)
 __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const uint32_t *tile_order, const uint64_t *entries,
 	uint64_t *entries2, uint2 *chunks, uint32_t *chunk_ctr)
 {
@@ -270,8 +271,21 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 	constexpr uint32_t dmin = 0x3E4CCCCDu; // 0.2f
 	constexpr int shift = 16;
 #define FR_DEPTH_BUCKET(d) min((uint32_t)(FR_SORT_FINE_BUCKETS - 1), ((d) > dmin ? (d) - dmin : 0u) >> shift)
-	// 2. histogram
-	for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(src[i] >> 32))], 1u);
+	// 2. histogram. Lists of up to FR_SPLIT_REGS x 1024 keys are read ONCE, all loads in flight together, and kept
+	// in registers for the scatter below (a loop of dependent load -> LDS atomic iterations costs a memory round
+	// trip per 1024 keys, and the longest list is this kernel's critical path)
+	const bool in_regs = n <= FR_SPLIT_REGS * 1024u;
+	uint64_t kreg[FR_SPLIT_REGS];
+	if (in_regs)
+	{
+#pragma unroll
+		for (int k = 0; k < FR_SPLIT_REGS; k++) { const uint32_t i = tid + 1024u * k; kreg[k] = i < n ? src[i] : 0ull; }
+#pragma unroll
+		for (int k = 0; k < FR_SPLIT_REGS; k++)
+			if (tid + 1024u * k < n) atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(kreg[k] >> 32))], 1u);
+	}
+	else
+		for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(src[i] >> 32))], 1u);
 	__syncthreads();
 	// 3. exclusive scan of the 2048 counts (two consecutive buckets per thread)
 	const uint32_t c0 = s_hist[2 * tid], c1 = s_hist[2 * tid + 1];
@@ -307,11 +321,18 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 	__syncthreads();
 	for (uint32_t k = tid; k < nchunks; k += 1024) chunks[s_slot + k] = make_uint2(rg.x + s_start[k], rg.x + s_start[k + 1]);
 	// 5. scatter (the offsets become cursors)
-	for (uint32_t i = tid; i < n; i += 1024)
+	if (in_regs)
 	{
-		const uint64_t key = src[i];
-		dst[atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(key >> 32))], 1u)] = key;
+#pragma unroll
+		for (int k = 0; k < FR_SPLIT_REGS; k++)
+			if (tid + 1024u * k < n) dst[atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(kreg[k] >> 32))], 1u)] = kreg[k];
 	}
+	else
+		for (uint32_t i = tid; i < n; i += 1024)
+		{
+			const uint64_t key = src[i];
+			dst[atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(key >> 32))], 1u)] = key;
+		}
 #undef FR_DEPTH_BUCKET
 }
 
