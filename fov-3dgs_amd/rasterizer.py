@@ -146,8 +146,10 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         return t
 
     with torch.cuda.device(dev):
-        color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        # both outputs are written in full by the kernels (every pixel by the blend, every radius by the cull pass
+        # or the binning kernel; the P == 0 path fills the image itself): no zero-fill kernels at the head of the frame
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
         ws, lease = _workspaces_for(dev, not persistent)
         counts = contribs = None
         a.variant = variant

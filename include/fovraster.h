@@ -92,11 +92,11 @@ typedef struct fr_forward_args {
 	const float *campos;         /* [3] */
 	const float *shs_dcs;        /* RF: [P,4,3] per-level DC coefficient */
 	const float *highest_levels; /* RF: [P,1] float */
-	/* outputs (caller-allocated) */
+	/* outputs (caller-allocated; out_color and radii are written in full, they need no initialisation) */
 	float *out_color;            /* [3,H,W] */
 	int32_t *radii;              /* [P] */
-	int32_t *gaussians_count;    /* RS: [P], else NULL */
-	float *contributions;        /* RS: [P], else NULL */
+	int32_t *gaussians_count;    /* RS: [P], else NULL (zeroed by the call, then accumulated) */
+	float *contributions;        /* RS: [P], else NULL (zeroed by the call, then accumulated) */
 	/* workspaces */
 	fr_resize_fn geometry_resize;
 	fr_resize_fn binning_resize;
