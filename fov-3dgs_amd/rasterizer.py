@@ -178,8 +178,8 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         a.out_color, a.radii = color.data_ptr(), radii.data_ptr()
         put("loss_map", loss_map)
         if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC):
-            counts = torch.zeros((P,), dtype=torch.int32, device=dev)
-            contribs = torch.zeros((P,), dtype=torch.float32, device=dev)
+            counts = torch.empty((P,), dtype=torch.int32, device=dev)      # zeroed by fr_forward itself
+            contribs = torch.empty((P,), dtype=torch.float32, device=dev)
             a.gaussians_count, a.contributions = counts.data_ptr(), contribs.data_ptr()
         a.geometry_resize, a.binning_resize, a.image_resize = ws.cbs[0], ws.cbs[1], ws.cbs[2]
         if _stage_events_hook is not None:
