@@ -164,9 +164,6 @@ int fr_forward(fr_forward_args *a)
 	if (!pinned) FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
 	FR_HIP(hipStreamSynchronize(stream));
 	if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; }
-#ifdef FR_EXP_COUNT
-	{ uint32_t dbg[4]; (void)hipMemcpy(dbg, c.geom.slab_ctr, 16, hipMemcpyDeviceToHost); fprintf(stderr, "[fr] vis_list %u, passed the frame test %u\n", dbg[1], dbg[2]); }
-#endif
 	if (totals[0] > 0x7fffffffu) { set_error("too many instances (%u)", totals[0]); return FR_ERR_INVALID; }
 	a->num_rendered = (int32_t)totals[0];
 	a->max_tile_instances = (int32_t)totals[1];

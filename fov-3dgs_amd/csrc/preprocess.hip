@@ -895,11 +895,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			if (lane == L) { count = cnt; lvmask = bits; }
 		}
 		__builtin_amdgcn_s_setprio(0);
-#ifdef FR_EXP_NOPAIRS
-		const uint32_t my_n = 0u; if (pr.alive && !in_place && !deferred) count = 1;
-#else
 		const uint32_t my_n = (pr.alive && !in_place && !big && !deferred) ? pr.tnum : 0u;
-#endif
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
