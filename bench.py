@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also collect every rank's frame on rank 0 (asynchronous RCCL gather overlapped with the next "
+                         "frame). Off by default: the views are independent and the path has no exchange step.")
     args = ap.parse_args()
 
     rank, world, local_rank = multiview.init_distributed()
@@ -159,7 +162,7 @@ def main():
     with torch.no_grad():
         for i in range(Wm):
             out = step(i)
-            if world > 1:
+            if world > 1 and args.gather:
                 multiview.gather_images(out["render"], dst=0)
         barrier_sync(world)
         timer = StageTimer(K)
@@ -167,7 +170,7 @@ def main():
         with timer:
             for i in range(K):
                 out = step(Wm + i)
-                if world > 1:
+                if world > 1 and args.gather:
                     if pending is not None:
                         pending[0].wait()
                     pending = multiview.gather_images(out["render"], dst=0, async_op=True) + (out["render"],)
@@ -279,7 +282,7 @@ def main():
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "S-6M bicycle-scale cloud, 4-layer foveated render (fov_pcheck_obb), moving gaze, "
-                               "one camera per GPU, frames gathered on rank 0",
+                               "one camera per GPU" + (", frames gathered on rank 0" if (world > 1 and args.gather) else ""),
                    "gaussians": P, "width": W, "height": H, "alpha": 0.05, "sh_degree": 3,
                    "visible": int(st["V"]), "in_front": V_in, "instances": int(st["D"]),
                    "instances_blend_tiles": int(st["D_blend"]), "max_tile_list": int(st["max_list"]),
