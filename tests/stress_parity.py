@@ -1,5 +1,5 @@
-"""Randomised HIP-vs-oracle parity sweep (developer tool; the committed tests cover fixed cases).
-usage: python tools/stress_parity.py [rounds=24] [seed=0]"""
+"""Randomised HIP-vs-oracle parity sweep (not collected by pytest; test_randomised_sweep is its fixed-seed sibling).
+usage: python tests/stress_parity.py [rounds=24] [seed=0]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
