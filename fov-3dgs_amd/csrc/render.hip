@@ -126,17 +126,25 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	constexpr bool FETCHCNT = SUM || LWMC;                       // gaussians_count per fetched entry (256-batches)
 	constexpr bool NEEDID = SUM || PMAX || LWMC;
 	constexpr bool AUX = VARIANT != FR_VARIANT_PCHECK_OBB; // final_T / n_contrib kept for backward
+	// INDEP: the waves of a tile are independent workgroups of 64 threads (own batches of 64 entries, own reach mask,
+	// no barrier), as in k_render_fov. The flavours that count fetched entries need the tile-wide "finished" decision
+	// at every 256th entry and keep the shared-batch form (one workgroup of NT threads per tile).
+	constexpr bool INDEP = !FETCHCNT;
+	constexpr int NB = INDEP ? 64 : NT; // threads per workgroup == entries per batch
 
-	__shared__ float4 s0[NT];
-	__shared__ float4 s1[NT];
-	__shared__ float s2[NT];
-	__shared__ int sid[NEEDID ? NT : 1];
+	__shared__ float4 s0[NB];
+	__shared__ float4 s1[NB];
+	__shared__ float s2[NB];
+	__shared__ int sid[NEEDID ? NB : 1];
 	constexpr int NW = NT / 64;  // waves per tile, each owning a band of 16 / NW rows
-	__shared__ unsigned long long s_reach[NW][NW]; // [band][staging wave]: staged entries that can touch the band
+	__shared__ unsigned long long s_reach[NW][NW]; // shared batches: [band][staging wave] = staged entries that can touch the band
 
-	const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
+	const int slot = INDEP ? (int)blockIdx.x / NW : (int)blockIdx.x; // position in tile_order
+	const int tile = a.tile_order ? (int)a.tile_order[slot] : slot;
 	const int tx = tile % a.gx, ty = tile / a.gx;
-	const int tid = threadIdx.x;
+	const int st = threadIdx.x;                                          // staging slot of this thread
+	const int wv = INDEP ? (int)blockIdx.x % NW : (int)(threadIdx.x >> 6); // band of this wave
+	const int tid = INDEP ? wv * 64 + st : st;                          // position among the tile's NT threads (row mapping)
 	const int lx = tid & 15;
 	const int px = tx * FR_TILE + lx;
 	const float pxf = (float)px;
@@ -170,52 +178,70 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	uint32_t pid = 0;
 	float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
 	float p2 = 0.f;
-	if (tid < n)
+	if (st < n)
 	{
-		pid = a.point_list[range.x + tid];
+		pid = a.point_list[range.x + st];
 		const float4 *r = a.rec + 3 * (size_t)pid;
 		p0 = r[0]; p1 = r[1]; p2 = r[2].x;
 	}
 	bool finished = false; // SUM: every pixel saturated, only counting until the next 256 boundary
-	for (int base = 0; base < n; base += NT)
+	for (int base = 0; base < n; base += NB)
 	{
 		float tmax0 = -1.0f;
 #pragma unroll
 		for (int h = 0; h < HP; h++) tmax0 = fmaxf(tmax0, fmaxf(S[h].T.x, S[h].T.y));
-		const bool wg_done = __syncthreads_and(!(tmax0 > 0.0f)) != 0; // also fences the LDS reuse
+		bool wg_done;
+		if (INDEP)
+		{
+			wg_done = !__any(tmax0 > 0.0f);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous batch has been read by all lanes
+			__builtin_amdgcn_wave_barrier();
+		}
+		else wg_done = __syncthreads_and(!(tmax0 > 0.0f)) != 0; // also fences the LDS reuse
 		if (FETCHCNT)
 		{
 			if ((base & 255) == 0) { if (wg_done) break; }
 			finished = wg_done;
 		}
 		else if (wg_done) break;
-		const bool staged = base + tid < n;
+		const bool staged = base + st < n;
 		if (staged)
 		{
-			s0[tid] = p0; s1[tid] = p1; s2[tid] = p2;
-			if (NEEDID) sid[tid] = (int)pid;
+			s0[st] = p0; s1[st] = p1; s2[st] = p2;
+			if (NEEDID) sid[st] = (int)pid;
 			if (FETCHCNT) atomicAdd(&a.gaussians_count[pid], 1);
 		}
+		unsigned long long reach_own = 0;
 		{
 			// which bands can this entry touch at all (see splat_reaches)? alpha < 1/255 (forward.cu:336) <=> power <
 			// -ln(255 opacity); the _max flavour counts pixels BEFORE the alpha test, so only the support cutoff applies
 			const float thr_a = -__logf(255.0f * p1.y) - 0.01f;
 			const float thr = PMAX ? -4.5f : (CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a);
-#pragma unroll
-			for (int w = 0; w < NW; w++)
+			if (INDEP) reach_own = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
+			else
 			{
-				const bool reach = staged && band_reaches<PPL>(w, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr);
-				const unsigned long long m = __ballot(reach);
-				if ((tid & 63) == 0) s_reach[w][tid >> 6] = m;
+#pragma unroll
+				for (int w = 0; w < NW; w++)
+				{
+					const bool reach = staged && band_reaches<PPL>(w, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr);
+					const unsigned long long m = __ballot(reach);
+					if ((st & 63) == 0) s_reach[w][st >> 6] = m;
+				}
 			}
 		}
-		if (base + NT + tid < n)
+		if (base + NB + st < n)
 		{
-			pid = a.point_list[range.x + base + NT + tid];
+			pid = a.point_list[range.x + base + NB + st];
 			const float4 *r = a.rec + 3 * (size_t)pid;
 			p0 = r[0]; p1 = r[1]; p2 = r[2].x;
 		}
-		__syncthreads();
+		if (INDEP)
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // lanes read entries other lanes staged
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+		else __syncthreads();
 		// SUM && finished: nothing left to blend, the loop only keeps counting (no `continue` here: this
 		// loop carries barriers, see the note in k_bin)
 		const bool blend_batch = !(FETCHCNT && finished);
@@ -300,8 +326,8 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 				}
 			}
 		};
-		for (int sw = 0; sw < NW && !stop; sw++)
-		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; )
+		for (int sw = 0; sw < (INDEP ? 1 : NW) && !stop; sw++)
+		for (unsigned long long rm = INDEP ? reach_own : uniform_u64(s_reach[wv][sw]); rm; )
 		{
 			int jj[FR_RENDER_GROUP_PLAIN];
 			bool vv[FR_RENDER_GROUP_PLAIN];
@@ -570,13 +596,14 @@ int launch_render(FwdCtx &c)
 	r.final_T = c.img.final_T; r.n_contrib = c.img.n_contrib;
 	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions; r.loss_map = a->loss_map;
 	constexpr int PPL = FR_RENDER_PPL;
-	const dim3 grid(c.T), block(256 / PPL);
+	const dim3 grid(c.T), block(256 / PPL);                    // shared batches: one workgroup per tile
+	const dim3 grid_iw(c.T * (256 / PPL / 64)), block_iw(64); // independent waves: one workgroup per wave
 	switch (a->variant)
 	{
-	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL((k_render<FR_VARIANT_ORIGINAL, PPL>), grid, block, 0, c.stream, r); break;
+	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL((k_render<FR_VARIANT_ORIGINAL, PPL>), grid_iw, block_iw, 0, c.stream, r); break;
 	case FR_VARIANT_PCHECK_OBB_SUM: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_SUM, PPL>), grid, block, 0, c.stream, r); break;
-	case FR_VARIANT_PCHECK_OBB: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB, PPL>), grid, block, 0, c.stream, r); break;
-	case FR_VARIANT_PCHECK_OBB_MAX: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_MAX, PPL>), grid, block, 0, c.stream, r); break;
+	case FR_VARIANT_PCHECK_OBB: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB, PPL>), grid_iw, block_iw, 0, c.stream, r); break;
+	case FR_VARIANT_PCHECK_OBB_MAX: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_MAX, PPL>), grid_iw, block_iw, 0, c.stream, r); break;
 	case FR_VARIANT_PCHECK_OBB_LWMC: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_LWMC, PPL>), grid, block, 0, c.stream, r); break;
 	default:
 		// The frame ends when the tile that blends the most entries ends, and a wave works through its list
