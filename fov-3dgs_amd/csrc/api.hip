@@ -152,18 +152,40 @@ int fr_forward(fr_forward_args *a)
 		pinned_tried = true;
 		void *h = nullptr, *d = nullptr;
 		if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess)
-		{ pinned = (uint32_t *)h; pinned_dev = (uint32_t *)d; }
+		{ pinned = (uint32_t *)h; pinned_dev = (uint32_t *)d; for (int i = 0; i < 16; i++) pinned[i] = 0; }
 		(void)hipGetLastError();
 	}
+	static thread_local uint32_t frame_seq = 0;
+	if (++frame_seq == 0) frame_seq = 1;
 	c.totals_host_dev = pinned_dev;
+	c.totals_seq = frame_seq;
 	mark(FR_STAGE_TILE_SCAN);
 	rc = launch_tile_scan(c); if (rc) return rc;
 	mark(FR_STAGE_EMIT);
 
 	uint32_t totals[4] = { 0, 0, 0, 0 };
 	if (!pinned) FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
-	FR_HIP(hipStreamSynchronize(stream));
-	if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; }
+	if (pinned && !a->debug)
+	{
+		// poll the sequence word instead of sleeping on the stream: the numbers arrive a few microseconds before
+		// the kernel retires, and the wake-up latency of a stream wait is saved. The stream is queried now and then
+		// so that a failed launch cannot hang the caller.
+		const volatile uint32_t *v = pinned;
+		for (uint32_t spins = 1; __atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != frame_seq; spins++)
+			if ((spins & 0xffff) == 0)
+			{
+				const hipError_t q = hipStreamQuery(stream);
+				if (q == hipErrorNotReady) continue;
+				if (q != hipSuccess) { set_error("hip: %s", hipGetErrorString(q)); return FR_ERR_HIP; }
+				if (__atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != frame_seq) { set_error("tile scan did not publish its totals"); return FR_ERR_HIP; }
+			}
+		for (int i = 0; i < 4; i++) totals[i] = v[i];
+	}
+	else
+	{
+		FR_HIP(hipStreamSynchronize(stream));
+		if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; }
+	}
 	if (totals[0] > 0x7fffffffu) { set_error("too many instances (%u)", totals[0]); return FR_ERR_INVALID; }
 	a->num_rendered = (int32_t)totals[0];
 	a->max_tile_instances = (int32_t)totals[1];

@@ -19,7 +19,7 @@ namespace fr {
 // Single workgroup: exclusive scan of tile_count[T] -> ranges, reset the counters to serve as
 // emission cursors, publish {total, max}.
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals, uint32_t *tile_order,
-	uint32_t *totals_host)
+	uint32_t *totals_host, uint32_t seq)
 {
 	__shared__ uint32_t bucket[34];
 	__shared__ uint32_t wave_sum[16];
@@ -76,7 +76,14 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11];
 		totals[4] = 0; // chunk counter of k_split_long
 		// the host sizes the binning buffer from these: written straight into its pinned memory (no copy command)
-		if (totals_host) { totals_host[0] = carry_s; totals_host[1] = m; totals_host[2] = h4; totals_host[3] = bucket[10] + bucket[11]; }
+		// and followed by this frame's sequence number, which the host polls for (it then prepares the next launches
+		// while this kernel finishes)
+		if (totals_host)
+		{
+			totals_host[0] = carry_s; totals_host[1] = m; totals_host[2] = h4; totals_host[3] = bucket[10] + bucket[11];
+			__threadfence_system();
+			__hip_atomic_store(&totals_host[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 		// bucket start offsets, longest lists first
 		uint32_t run = 0;
 		for (int b = 32; b >= 0; b--) { const uint32_t c = bucket[b]; bucket[b] = run; run += c; }
@@ -339,7 +346,7 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 int launch_tile_scan(FwdCtx &c)
 {
 	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals, c.img.tile_order,
-		c.totals_host_dev);
+		c.totals_host_dev, c.totals_seq);
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 

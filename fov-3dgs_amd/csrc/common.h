@@ -329,7 +329,8 @@ struct FwdCtx {
 	hipStream_t stream;
 	int gx, gy, T;
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
-	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4], or null
+	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4] (+ sequence word), or null
+	uint32_t totals_seq;       // this frame's sequence number for that word
 	float focal_x, focal_y;
 	GeomWS geom;
 	ImageWS img;
