@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfovraster_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
 VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC = 4, 5
@@ -39,6 +39,7 @@ class ForwardArgs(C.Structure):
         ("stage_events", C.POINTER(C.c_void_p)),
         ("loss_map", _FP),
         ("shs_rest", _FP),
+        ("packed_geom", _FP), ("packed_colour", _FP),
     ]
 
 
@@ -60,7 +61,7 @@ class BackwardArgs(C.Structure):
     ]
 
 
-EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible",
+EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible", "fr_pack_geom", "fr_pack_colour",
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
            "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records")
 
@@ -100,6 +101,10 @@ def load():
     lib.fr_backward.restype = C.c_int
     lib.fr_mark_visible.argtypes = [C.c_int32, _FP, _FP, _FP, _FP, C.c_void_p]
     lib.fr_mark_visible.restype = C.c_int
+    lib.fr_pack_geom.argtypes = [C.c_int32, _FP, _FP, _FP, _FP, C.c_int32, _FP, _FP, C.c_void_p]
+    lib.fr_pack_geom.restype = C.c_int
+    lib.fr_pack_colour.argtypes = [C.c_int32, _FP, _FP, _FP, _FP, C.c_void_p]
+    lib.fr_pack_colour.restype = C.c_int
     for n in ("fr_geometry_bytes",):
         getattr(lib, n).argtypes = [C.c_int32, C.c_int32]
         getattr(lib, n).restype = C.c_size_t

@@ -62,6 +62,9 @@ static int validate_forward(const fr_forward_args *a)
 	if (a->D < 0 || a->D > 3) { set_error("SH degree %d not in 0..3", a->D); return FR_ERR_INVALID; }
 	const bool has_sr = a->scales && a->rotations;
 	if (has_sr == (a->cov3D_precomp != nullptr)) { set_error("provide exactly one of scales+rotations / cov3D_precomp"); return FR_ERR_INVALID; }
+	if ((a->packed_geom != nullptr) != (a->packed_colour != nullptr)) { set_error("packed_geom and packed_colour go together"); return FR_ERR_INVALID; }
+	if (a->packed_geom && (!has_sr || !a->shs || a->colors_precomp || a->M != (fov ? 15 : 16)))
+	{ set_error("the packed model needs scales + rotations and shs with all 16 coefficients (M=%d)", a->M); return FR_ERR_INVALID; }
 	if (has_stats(a->variant) && (!a->gaussians_count || !a->contributions)) { set_error("this variant needs gaussians_count and contributions"); return FR_ERR_INVALID; }
 	if (a->variant == FR_VARIANT_PCHECK_OBB_LWMC && !a->loss_map) { set_error("pcheck_obb_loss_weighted_max_count needs loss_map"); return FR_ERR_INVALID; }
 	return FR_OK;
@@ -201,6 +204,22 @@ int fr_forward(fr_forward_args *a)
 	rc = launch_render(c);
 	mark(FR_NUM_STAGES);
 	return rc;
+}
+
+int fr_pack_geom(int32_t P, const float *means3D, const float *scales, const float *rotations, const float *opacities,
+	int32_t levels, const float *highest_levels, float *packed_geom, void *stream)
+{
+	if (P < 0 || levels < 1 || levels > 4 || (P > 0 && (!means3D || !scales || !rotations || !opacities || !packed_geom)))
+	{ set_error("bad pack_geom arguments"); return FR_ERR_INVALID; }
+	if (P == 0) return FR_OK;
+	return launch_pack_geom(P, means3D, scales, rotations, opacities, levels, highest_levels, packed_geom, (hipStream_t)stream);
+}
+
+int fr_pack_colour(int32_t P, const float *shs, const float *shs_rest, const float *shs_dcs, float *packed_colour, void *stream)
+{
+	if (P < 0 || (P > 0 && (!shs || !packed_colour)) || (shs_rest && shs_dcs)) { set_error("bad pack_colour arguments"); return FR_ERR_INVALID; }
+	if (P == 0) return FR_OK;
+	return launch_pack_colour(P, shs, shs_rest, shs_dcs, packed_colour, (hipStream_t)stream);
 }
 
 int fr_backward(const fr_backward_args *a)

@@ -232,6 +232,7 @@ struct PreArgs {
 	const float *shs_rest; // split SH storage: shs = DC [P,1,3], shs_rest = [P,M-1,3]; else null
 	const float *viewmatrix, *projmatrix, *campos;
 	const float *shs_dcs, *highest_levels;
+	const float *packed_geom, *packed_colour; // optional packed copies of the model (fovraster.h), else null
 	const float *tile_lv; // RF float[5][T]
 	const uint32_t *lv_bbox; // RF [5][FR_LV_BBOX_STRIDE], see walk_rect()
 	int lds_tiles;           // RF: tile_min and the blend flags are staged in LDS (see k_bin)
@@ -514,7 +515,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	const int lane = threadIdx.x & 63;
 	uint32_t *list = s_list[threadIdx.x >> 6];
 	uint32_t n = 0; // entries staged by this wave (wave-uniform)
-	auto flush = [&]()
+	auto flush = [&]() __attribute__((always_inline))
 	{
 		uint32_t base = 0;
 		if (lane == 0) base = atomicAdd(a.geom.slab_ctr + 1, n);
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	// read the last Gaussian; without scales / rotations the unused values come from the cov3D_precomp array.
 	const float *sc_src = have_sr ? a.scales : a.cov3D_precomp;
 	const float *q_src = have_sr ? a.rotations : a.cov3D_precomp;
-	auto fetch = [&](const int chunk)
+	auto fetch = [&](const int chunk) __attribute__((always_inline))
 	{
 		const size_t i = (size_t)min(chunk * 64 + lane, a.P - 1);
 		RawGaussian w;
@@ -557,7 +558,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	const int nchunks = (a.P + 63) / 64;
 	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
 	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
-	auto step = [&](const RawGaussian &cur, const int chunk)
+	auto step = [&](const RawGaussian &cur, const int chunk) __attribute__((always_inline))
 	{
 		const int idx = chunk * 64 + lane;
 		bool maybe = false;
@@ -593,7 +594,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 // LDSH: the counters are an LDS-private histogram (T <= 16 Ki tiles) written once per workgroup to
 // hist[block][tile] -- no global atomics at all; otherwise (huge tile grids) global atomics on tile_count.
 #define BUMP_TILE(ti) do { if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
-template <int VARIANT, bool LDSH>
+template <int VARIANT, bool LDSH, bool PACKED = false>
 __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
@@ -660,7 +661,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// Wave-uniform walk of ONE splat's rectangle: lanes take tiles k0 + lane, k0 + lane + kstep, ... of the on
 	// tiles; returns the number of tiles kept and (RF) their level bits. No owner search, no shuffles.
 	auto walk_uniform = [&](const int ox0, const int oy0, const int ow, const uint32_t on, const Obb &ob, const float olim,
-		const uint32_t k0, const uint32_t kstep, uint32_t &cnt, uint32_t &bits)
+		const uint32_t k0, const uint32_t kstep, uint32_t &cnt, uint32_t &bits) __attribute__((always_inline))
 	{
 		const float rw = 1.0f / (float)ow;
 		for (uint32_t k = k0; k < on; k += kstep)
@@ -693,7 +694,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	};
 	// int(lowest) / int(highest) of RF rasterizer_impl.cu:374-381 from the per-level bits: truncation is
 	// monotone, so int(min(levels)) == min(int(level)); lowest starts at the Gaussian's own level
-	auto range_from_mask = [&](const uint32_t lvmask, float &lowest, float &highest, bool &be_blend)
+	auto range_from_mask = [&](const uint32_t lvmask, float &lowest, float &highest, bool &be_blend) __attribute__((always_inline))
 	{
 		const int lo_bit = __ffs((int)(lvmask & 15u)) - 1, hi_bit = 31 - __clz((int)(lvmask & 15u));
 		lowest = fminf(lowest, (float)lo_bit);
@@ -702,19 +703,22 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	};
 	// Per-Gaussian epilogue once its tile count is known: radius of culled-everywhere splats, colour(s), final record.
 	auto finish = [&](const int idx, const uint32_t count, const float hl, const float lowest, const float highest,
-		const bool be_blend, const float conic_c, const float depth)
+		const bool be_blend, const float conic_c, const float depth) __attribute__((always_inline))
 	{
 		if (count == 0) { a.radii[idx] = 0; return; } // culled everywhere (RS rasterizer_impl.cu:141-145)
 		float rgb[3] = { 0, 0, 0 };
 		uint32_t clamp_bits = 0;
-		const float dirx = a.means3D[3 * (size_t)idx] - a.campos[0], diry = a.means3D[3 * (size_t)idx + 1] - a.campos[1],
-			dirz = a.means3D[3 * (size_t)idx + 2] - a.campos[2];
+		const float *mp = PACKED ? a.packed_geom + 16 * (size_t)idx : a.means3D + 3 * (size_t)idx;
+		const float dirx = mp[0] - a.campos[0], diry = mp[1] - a.campos[1], dirz = mp[2] - a.campos[2];
+		const float *pcol = PACKED ? a.packed_colour + 64 * (size_t)idx : nullptr;
 		if (!FOV)
 		{
 			if (a.colors_precomp == nullptr)
 			{
 				float c[3];
-				if (a.shs_rest != nullptr)
+				if (PACKED)
+					sh_colour<true>(a.D, 45, pcol, pcol + 45, dirx, diry, dirz, c);
+				else if (a.shs_rest != nullptr)
 					sh_colour<true>(a.D, (a.M - 1) * 3, a.shs_rest + (size_t)idx * (a.M - 1) * 3, a.shs + 3 * (size_t)idx, dirx, diry, dirz, c);
 				else
 					sh_colour<false>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, c);
@@ -735,13 +739,14 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
 			a.geom.lrange[idx] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
 			// all four levels' DC colours (12 floats) and opacities are fetched with the SH coefficients: one round trip
-			const f4u *dcp = (const f4u *)(a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
+			const f4u *dcp = (const f4u *)(PACKED ? pcol + 48 : a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
 			const f4u dc0 = dcp[0], dc1 = dcp[1], dc2 = dcp[2];
-			const f4u opl = *(const f4u *)(a.opacities + (size_t)idx * FR_FOV_LEVELS);
+			const f4u opl = *(const f4u *)(PACKED ? a.packed_geom + 16 * (size_t)idx + 12 : a.opacities + (size_t)idx * FR_FOV_LEVELS);
 			const float dcs[12] = { dc0.x, dc0.y, dc0.z, dc0.w, dc1.x, dc1.y, dc1.z, dc1.w, dc2.x, dc2.y, dc2.z, dc2.w };
 			const float ops[4] = { opl.x, opl.y, opl.z, opl.w };
 			float rest[3];
-			sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, rest);
+			if (PACKED) sh_colour<true>(a.D, 45, pcol, nullptr, dirx, diry, dirz, rest);
+			else sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, rest);
 			static_assert(FR_FOV_LEVELS == 4, "level data is fetched as float4s");
 #pragma unroll
 			for (int l = 0; l < FR_FOV_LEVELS; l++)
@@ -759,7 +764,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		float4 *rec = a.geom.rec + 3 * (size_t)idx;
 		if (FOV) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
-		else rec[1] = make_float4(conic_c, a.opacities[idx], rgb[0], rgb[1]);
+		else rec[1] = make_float4(conic_c, PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx], rgb[0], rgb[1]);
 		rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), 0.0f);
 	};
 #ifdef FR_BIN_TIMERS
@@ -813,15 +818,28 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		// the rectangle to walk; candidates that turn out to reach no tile get radius 0, like every culled Gaussian
 		idx = (int)a.geom.vis_list[item];
 		RawGaussian w; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0);
-#pragma unroll
-		for (int i = 0; i < 3; i++) w.p[i] = a.means3D[3 * (size_t)idx + i];
-		if (a.cov3D_precomp == nullptr)
+		if (PACKED)
+		{
+			// one 64-byte row instead of four or five mostly-unused cache lines
+			const float4 *pg = (const float4 *)a.packed_geom + 4 * (size_t)idx;
+			const float4 g0 = pg[0], g1 = pg[1], g2 = pg[2];
+			w.p[0] = g0.x; w.p[1] = g0.y; w.p[2] = g0.z;
+			w.sc[0] = g0.w; w.sc[1] = g1.x; w.sc[2] = g1.y;
+			w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
+			if (FOV) { hl = g2.z; lowest = hl; }
+		}
+		else
 		{
 #pragma unroll
-			for (int i = 0; i < 3; i++) w.sc[i] = a.scales[3 * (size_t)idx + i];
-			w.q = ((const float4 *)a.rotations)[idx];
+			for (int i = 0; i < 3; i++) w.p[i] = a.means3D[3 * (size_t)idx + i];
+			if (a.cov3D_precomp == nullptr)
+			{
+#pragma unroll
+				for (int i = 0; i < 3; i++) w.sc[i] = a.scales[3 * (size_t)idx + i];
+				w.q = ((const float4 *)a.rotations)[idx];
+			}
+			if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
 		}
-		if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
 		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q);
 		if (pr.alive)
 		{
@@ -985,7 +1003,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	{
 		const int gi = s_gidx[threadIdx.x];
 		const uint32_t gcount = s_gcount[threadIdx.x];
-		const float ghl = FOV ? a.highest_levels[gi] : 0.0f;
+		const float ghl = FOV ? (PACKED ? a.packed_geom[16 * (size_t)gi + 10] : a.highest_levels[gi]) : 0.0f;
 		float lowest = ghl, highest = 0.0f;
 		bool be_blend = false;
 		if (FOV && gcount != 0) range_from_mask(s_gmask[threadIdx.x], lowest, highest, be_blend);
@@ -1056,7 +1074,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	__syncthreads();
 	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
 	auto walk_uniform = [&](const int ox0, const int oy0, const int ow, const uint32_t on, const Obb &ob, const float olim,
-		const uint64_t opay, const uint32_t k0, const uint32_t kstep)
+		const uint64_t opay, const uint32_t k0, const uint32_t kstep) __attribute__((always_inline))
 	{
 		const float rw = 1.0f / (float)ow;
 		for (uint32_t k = k0; k < on; k += kstep)
@@ -1079,7 +1097,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	};
 	const int V = (int)a.geom.slab_ctr[1];
 	const int nslabs = (V + 63) / 64; // wave-sized slabs, as in k_bin
-	auto process = [&](const int slab)
+	auto process = [&](const int slab) __attribute__((always_inline))
 	{
 	const int item = slab * 64 + lane;
 	// everything k_emit needs about the entry sits in its walk record (one coalesced 64-byte read per lane instead of
@@ -1239,6 +1257,58 @@ __global__ void k_mark_visible(int P, const float *means3D, const float *vm, uin
 	present[idx] = !(z <= 0.2f);
 }
 
+// Packed copies of a static model (fovraster.h: fr_forward_args.packed_geom / packed_colour). One thread per output
+// float4: the writes are perfectly coalesced, the reads are small strided gathers that run once per model.
+__global__ void k_pack_geom(int P, const float *means3D, const float *scales, const float *rotations, const float *opacities,
+	int levels, const float *highest_levels, float4 *out)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)P * 4) return;
+	const size_t g = i >> 2;
+	const int part = (int)(i & 3);
+	float4 v;
+	if (part == 0) v = make_float4(means3D[3 * g], means3D[3 * g + 1], means3D[3 * g + 2], scales[3 * g]);
+	else if (part == 1) v = make_float4(scales[3 * g + 1], scales[3 * g + 2], rotations[4 * g], rotations[4 * g + 1]);
+	else if (part == 2) v = make_float4(rotations[4 * g + 2], rotations[4 * g + 3], highest_levels ? highest_levels[g] : 0.0f, 0.0f);
+	else
+	{
+		const float *o = opacities + g * (size_t)levels;
+		v = make_float4(o[0], levels > 1 ? o[1] : 0.0f, levels > 2 ? o[2] : 0.0f, levels > 3 ? o[3] : 0.0f);
+	}
+	out[i] = v;
+}
+__global__ void k_pack_colour(int P, const float *shs, const float *shs_rest, const float *shs_dcs, float *out)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)P * 64) return;
+	const size_t g = i >> 6;
+	const int k = (int)(i & 63);
+	float v = 0.0f;
+	if (shs_dcs != nullptr)
+	{
+		// RF: shs = coefficients 1..15
+		if (k < 45) v = shs[g * 45 + k];
+		else if (k >= 48 && k < 60) v = shs_dcs[g * 12 + (k - 48)];
+	}
+	else if (shs_rest != nullptr) { if (k < 45) v = shs_rest[g * 45 + k]; else if (k < 48) v = shs[g * 3 + (k - 45)]; }
+	else { if (k < 45) v = shs[g * 48 + 3 + k]; else if (k < 48) v = shs[g * 48 + (k - 45)]; }
+	out[i] = v;
+}
+int launch_pack_geom(int P, const float *means3D, const float *scales, const float *rotations, const float *opacities, int levels,
+	const float *highest_levels, float *out, hipStream_t stream)
+{
+	const size_t n = (size_t)P * 4;
+	hipLaunchKernelGGL(k_pack_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P, means3D, scales, rotations, opacities, levels,
+		highest_levels, (float4 *)out);
+	return check_launch("pack_geom", stream, 0);
+}
+int launch_pack_colour(int P, const float *shs, const float *shs_rest, const float *shs_dcs, float *out, hipStream_t stream)
+{
+	const size_t n = (size_t)P * 64;
+	hipLaunchKernelGGL(k_pack_colour, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P, shs, shs_rest, shs_dcs, out);
+	return check_launch("pack_colour", stream, 0);
+}
+
 // ---- launchers -------------------------------------------------------------------------------
 // bytes of the RF tile table in LDS: tile_min floats + one blend bit per tile
 static inline size_t lds_tile_table_bytes(int T) { return (size_t)T * sizeof(float) + (size_t)((T + 31) / 32) * sizeof(uint32_t); }
@@ -1263,6 +1333,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 	p.means3D = a->means3D; p.scales = a->scales; p.rotations = a->rotations; p.opacities = a->opacities;
 	p.shs = a->shs; p.shs_rest = a->shs_rest; p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
+	p.packed_geom = a->packed_geom; p.packed_colour = a->packed_colour;
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.lv_bbox = c.img.lv_bbox; p.T = c.T;
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
@@ -1319,7 +1390,17 @@ int launch_bin(FwdCtx &c)
 			hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
 	}
-#define LAUNCH_PRE(V) do { if (ldsh) hipLaunchKernelGGL((k_bin<V, true>), grid, block, lds, c.stream, p); \
+	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the
+	// ordinary path 5 %); it needs both packed tensors and the LDS histogram path
+	const bool packed = ldsh && a->packed_geom && a->packed_colour;
+	if (lds > 64u * 1024u && packed)
+	{
+		static const hipError_t once = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_FOV_PCHECK_OBB, true, true>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
+	}
+#define LAUNCH_PRE(V) do { if (packed) hipLaunchKernelGGL((k_bin<V, true, true>), grid, block, lds, c.stream, p); \
+	else if (ldsh) hipLaunchKernelGGL((k_bin<V, true>), grid, block, lds, c.stream, p); \
 	else hipLaunchKernelGGL((k_bin<V, false>), grid, block, 0, c.stream, p); } while (0)
 	switch (a->variant)
 	{

@@ -13,8 +13,9 @@ from ..rasterizer import GaussianRasterizationSettings
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, masking=False,
-           starter=None, ender=None, cuda_type="", loss_map=None):
-    """Render the scene. Background tensor (bg_color) must be on the GPU."""
+           starter=None, ender=None, cuda_type="", loss_map=None, packed=None):
+    """Render the scene. Background tensor (bg_color) must be on the GPU.
+    packed (extension): a rasterizer.PackedModel of this (static) model made by pack_model(); same image, faster binning."""
     xyz = pc.get_xyz
     # zero tensor that makes autograd return the gradient of the 2D (screen-space) means
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
@@ -57,12 +58,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     if starter is not None:
         starter.record()
+    extra = {} if packed is None else {"packed": packed}
     if cuda_type == "pcheck_obb_loss_weighted_max_count":
         out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,
-                         scales=scales, rotations=rotations, cov3D_precomp=None, loss_map=loss_map)
+                         scales=scales, rotations=rotations, cov3D_precomp=None, loss_map=loss_map, **extra)
     else:
         out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,
-                         scales=scales, rotations=rotations, cov3D_precomp=None)
+                         scales=scales, rotations=rotations, cov3D_precomp=None, **extra)
     if ender is not None:
         ender.record()
 

@@ -7,8 +7,9 @@ from ..diff_gaussian_rasterization_fov_pcheck_obb import GaussianRasterizationSe
 
 
 def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, alpha=None, gazeArray=None,
-           blending=None, starter=None, ender=None, highest_levels=None, shs_dcs=None, opacities=None):
-    """Render the scene for one gaze. Background tensor (bg_color) must be on the GPU."""
+           blending=None, starter=None, ender=None, highest_levels=None, shs_dcs=None, opacities=None, packed=None):
+    """Render the scene for one gaze. Background tensor (bg_color) must be on the GPU.
+    packed (extension): a rasterizer.PackedModel of this (static) model made by pack_model(); same image, faster binning."""
     xyz = pc.get_xyz
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
@@ -46,7 +47,7 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, a
     rendered_image, radii = rasterizer(
         means3D=means3D, means2D=means2D, shs_rest=shs_rest, colors_precomp=None, opacities=opacity, scales=scales,
         rotations=rotations, cov3D_precomp=None, shs_dcs=shs_dcs, highest_levels=highest_levels,
-        gazeArray=gazeArray, alpha=alpha, blending=blending)
+        gazeArray=gazeArray, alpha=alpha, blending=blending, packed=packed)
     if ender is not None:
         ender.record()
 

@@ -118,6 +118,52 @@ def _workspaces_for(device, needs_graph):
     return ws, None
 
 
+class PackedModel:
+    """Packed copies of a STATIC model's rasterizer inputs (include/fovraster.h: packed_geom [P,16] /
+    packed_colour [P,64]): made once per model with pack_model(), passed to GaussianRasterizer(..., packed=...) next
+    to the ordinary tensors, which must hold the same values. Forward-only (ignored by the backward pass); the
+    image is bit-identical with and without."""
+
+    def __init__(self, geom, colour):
+        self.geom, self.colour = geom, colour
+
+    def check(self, P, dev):
+        for t, w in ((self.geom, 16), (self.colour, 64)):
+            if t is not None and (t.device != dev or t.dtype != torch.float32 or tuple(t.shape) != (P, w) or not t.is_contiguous()):
+                raise RuntimeError(f"packed model does not match: expected float32 [{P}, {w}] on {dev}")
+
+
+def pack_model(means3D, scales, rotations, opacities, shs=None, shs_rest=None, shs_dcs=None, highest_levels=None):
+    """-> PackedModel. opacities [P,1] (or [P,4] per level for the foveated rasterizer, with shs_dcs [P,4,3],
+    highest_levels [P,1] and shs = the 15 rest coefficients); shs [P,16,3], or shs [P,1,3] + shs_rest [P,15,3].
+    """
+    lib = _native.load()
+    _require_gpu(means3D)
+    dev = means3D.device
+    P = means3D.size(0)
+    f = lambda t: None if t is None else _f32(t.detach(), dev)
+    m, sc, ro, op, sh, rest, dcs, hl = (f(t) for t in (means3D, scales, rotations, opacities, shs, shs_rest, shs_dcs, highest_levels))
+    levels = op.numel() // max(P, 1) if P else 1
+    geom = torch.empty((P, 16), dtype=torch.float32, device=dev)
+    if sh is None:
+        raise RuntimeError("pack_model needs the SH coefficients (the packed layout has no colors_precomp form)")
+    colour = None
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.fr_pack_geom(P, _ptr(m), _ptr(sc), _ptr(ro), _ptr(op), int(levels), _ptr(hl), _ptr(geom), stream)
+        if rc != 0:
+            raise RuntimeError(f"fovraster pack_geom failed ({rc}): {_native.last_error()}")
+        if sh is not None:
+            ncoef = sh.size(1) + (rest.size(1) if rest is not None else 0)
+            if ncoef != (15 if dcs is not None else 16):
+                raise RuntimeError(f"pack_model needs all 16 SH coefficients, got {ncoef}")
+            colour = torch.empty((P, 64), dtype=torch.float32, device=dev)
+            rc = lib.fr_pack_colour(P, _ptr(sh), _ptr(rest), _ptr(dcs), _ptr(colour), stream)
+            if rc != 0:
+                raise RuntimeError(f"fovraster pack_colour failed ({rc}): {_native.last_error()}")
+    return PackedModel(geom, colour)
+
+
 # Set by fov3dgs_amd.profiling.StageTimer while a timed region is active: a ctypes array of
 # FR_NUM_STAGES + 1 event handles that the next forward call records on its stream.
 _stage_events_hook = None
@@ -125,7 +171,7 @@ _stage_events_hook = None
 
 def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                     shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
-                    sh_rest=None):
+                    sh_rest=None, packed=None):
     """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease)
     persistent=True: the workspaces are the per-device grow-only set (valid until the next call); otherwise they
     stay reserved for as long as `lease` (the last element) is referenced."""
@@ -177,6 +223,10 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         put("highest_levels", highest_levels)
         a.out_color, a.radii = color.data_ptr(), radii.data_ptr()
         put("loss_map", loss_map)
+        if packed is not None:
+            packed.check(P, dev)
+            a.packed_geom = _ptr(packed.geom)
+            a.packed_colour = _ptr(packed.colour)
         if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC):
             counts = torch.empty((P,), dtype=torch.int32, device=dev)      # zeroed by fr_forward itself
             contribs = torch.empty((P,), dtype=torch.float32, device=dev)
@@ -277,7 +327,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    raster_settings, loss_map=None, sh_rest=None):
+                    raster_settings, loss_map=None, sh_rest=None, packed=None):
             # sh_rest (extension): the SH coefficients as the two tensors a model stores, sh = features_dc
             # [P,1,3], sh_rest = features_rest [P,M-1,3]; saves the torch.cat of get_features and its backward
             args = (variant_id, raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations,
@@ -293,13 +343,13 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
                 try:
-                    res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest)
+                    res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest)
+                res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed)
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = res[:6]
             if not keep_ws:  # nothing will call backward: do not pin the shared workspaces
                 geomBuffer = binningBuffer = imgBuffer = torch.empty(0, dtype=torch.uint8, device=means3D.device)
@@ -340,12 +390,12 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
              grad_scales, grad_rotations) = res[:8]
             grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                      grad_rotations, grad_cov3Ds_precomp, None)
-            return grads + (None, res[8] if ctx.split_sh else None)  # loss_map, sh_rest
+            return grads + (None, res[8] if ctx.split_sh else None, None)  # loss_map, sh_rest, packed
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                            raster_settings, loss_map=None, sh_rest=None):
+                            raster_settings, loss_map=None, sh_rest=None, packed=None):
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                         cov3Ds_precomp, raster_settings, loss_map if takes_loss_map else None, sh_rest)
+                                         cov3Ds_precomp, raster_settings, loss_map if takes_loss_map else None, sh_rest, packed)
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):
@@ -357,7 +407,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 return _mark_visible(positions, self.raster_settings)
 
         def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                    cov3D_precomp=None, loss_map=None):
+                    cov3D_precomp=None, loss_map=None, packed=None):
             raster_settings = self.raster_settings
             if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
                 raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -374,7 +424,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             rotations = empty if rotations is None else rotations
             cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings, loss_map, shs_rest)
+                                       cov3D_precomp, raster_settings, loss_map, shs_rest, packed)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
 
@@ -396,19 +446,19 @@ def _make_fov():
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    raster_settings, shs_dcs, highest_levels, gazeArray, alpha, blending):
+                    raster_settings, shs_dcs, highest_levels, gazeArray, alpha, blending, packed=None):
             args = (variant_id, raster_settings, means3D, shs_rest, colors_precomp, opacities, scales, rotations,
                     cov3Ds_precomp, shs_dcs, highest_levels, _gaze_pair(gazeArray), float(alpha))
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    res = _forward_native(*args, persistent=True)
+                    res = _forward_native(*args, persistent=True, packed=packed)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                res = _forward_native(*args, persistent=True)
+                res = _forward_native(*args, persistent=True, packed=packed)
             num_rendered, color, radii = res[:3]
             ctx.num_rendered = num_rendered
             ctx.mark_non_differentiable(radii)
@@ -418,13 +468,14 @@ def _make_fov():
         def backward(ctx, grad_out_color, _):
             # RF/diff_gaussian_rasterization_fov_pcheck_obb/__init__.py:128-187: the foveated extension is
             # inference-only and hands back None for every input
-            return (None,) * 14
+            return (None,) * 15
 
     def rasterize_gaussians(means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations,
-                            cov3Ds_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha, blending):
+                            cov3Ds_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha, blending,
+                            packed=None):
         return _RasterizeGaussians.apply(means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations,
                                          cov3Ds_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha,
-                                         blending)
+                                         blending, packed)
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):
@@ -437,7 +488,7 @@ def _make_fov():
 
         def forward(self, means3D, means2D, opacities, shs_rest=None, colors_precomp=None, scales=None,
                     rotations=None, cov3D_precomp=None, shs_dcs=None, highest_levels=None, gazeArray=None,
-                    alpha=None, blending=None):
+                    alpha=None, blending=None, packed=None):
             raster_settings = self.raster_settings
             if (shs_rest is None and colors_precomp is None) or (shs_rest is not None and colors_precomp is not None):
                 raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -452,6 +503,6 @@ def _make_fov():
             cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
             return rasterize_gaussians(means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations,
                                        cov3D_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha,
-                                       blending)
+                                       blending, packed)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer

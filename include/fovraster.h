@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 2
+#define FR_ABI_VERSION 3
 
 /* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
  * fov3dgs/gaussian_wrapper.py:11-23) */
@@ -116,6 +116,18 @@ typedef struct fr_forward_args {
 	 * need not concatenate them every step (GaussianModel.get_features, scene/gaussian_model.py:83-86): when
 	 * set, `shs` is the DC part [P,1,3] and `shs_rest` the others [P,M-1,3]; M stays their total (16). */
 	const float *shs_rest;
+	/* optional: the per-Gaussian inputs of a STATIC model in the layout the binning kernel reads fastest (made once,
+	 * e.g. when the model is loaded; the reference has no counterpart -- its inputs are the separate tensors above,
+	 * which stay mandatory and must hold the same values). The binning kernel reads a candidate's parameters from
+	 * five different tensors, i.e. five mostly-unused cache lines per Gaussian, and 180-byte SH rows that straddle
+	 * lines; with these it reads one 64-byte row and one aligned 256-byte row instead. Results are bit-identical.
+	 *   packed_geom   [P][16]: x y z | sx sy sz | q0 q1 q2 q3 | highest_level (RF, else 0) | 0 | opacity[4]
+	 *                          (RF: the four levels; else opacity, 0, 0, 0)         needs scales + rotations
+	 *   packed_colour [P][64]: SH coefficients 1..15 [45] | SH coefficient 0 [3] (not RF) | shs_dcs [4][3] (RF) | 0[4]
+	 *                                                                             needs shs with M = 16 (RF: 15)
+	 * Both or neither. fr_pack_geom / fr_pack_colour fill them on the device. */
+	const float *packed_geom;
+	const float *packed_colour;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
@@ -159,6 +171,12 @@ void fr_event_destroy(void *event);
 int fr_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 
 int fr_forward(fr_forward_args *args);
+/* Fill fr_forward_args.packed_geom / packed_colour (device buffers of P*16 / P*64 floats) from the tensors of the
+ * same names; opacities is [P,levels] with levels = 1 or 4, highest_levels / shs_dcs may be NULL (not RF);
+ * shs_rest NULL: shs is [P,16,3] (RF: [P,15,3] = coefficients 1..15 and shs_dcs given), else shs = [P,1,3]. */
+int fr_pack_geom(int32_t P, const float *means3D, const float *scales, const float *rotations, const float *opacities,
+	int32_t levels, const float *highest_levels, float *packed_geom, void *stream);
+int fr_pack_colour(int32_t P, const float *shs, const float *shs_rest, const float *shs_dcs, float *packed_colour, void *stream);
 int fr_backward(const fr_backward_args *args);
 int fr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
 	uint8_t *present /* [P] bool */, void *stream);

@@ -302,6 +302,66 @@ def test_split_sh_storage_matches_concatenated():
         check_grad(b, a, name)
 
 
+def test_packed_model_gives_identical_images():
+    """fr_forward_args.packed_geom / packed_colour (the static-model layout of include/fovraster.h): the pack kernels
+    lay the rows out as documented, and every variant renders bit-identical images, radii and statistics with them."""
+    _need_gpu()
+    from fov3dgs_amd.rasterizer import pack_model
+    from fov3dgs_amd.gaussian_renderer import render
+    from fov3dgs_amd.gaussian_renderer_fov import render as render_fov
+    dev = "cuda:0"
+    cloud = syn.scene_1k(P=1500, seed=12).to(dev)
+    cam = syn.camera_1k(208, 144).to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.0], device=dev)
+
+    class Pipe:
+        debug = False
+    with torch.no_grad():
+        # plain variants: concatenated and split SH inputs pack to the same rows
+        pk = pack_model(cloud.get_xyz, cloud.get_scaling, cloud.get_rotation, cloud.get_opacity, shs=cloud.get_features)
+        dc, rest = cloud.get_features_split
+        pk2 = pack_model(cloud.get_xyz, cloud.get_scaling, cloud.get_rotation, cloud.get_opacity, shs=dc, shs_rest=rest)
+        assert torch.equal(pk.geom, pk2.geom) and torch.equal(pk.colour, pk2.colour)
+        g = pk.geom.cpu().numpy()
+        np.testing.assert_array_equal(g[:, 0:3], cloud.get_xyz.cpu().numpy())
+        np.testing.assert_array_equal(g[:, 3:6], cloud.get_scaling.cpu().numpy())
+        np.testing.assert_array_equal(g[:, 6:10], cloud.get_rotation.cpu().numpy())
+        np.testing.assert_array_equal(g[:, 12], cloud.get_opacity.cpu().numpy()[:, 0])
+        assert not g[:, 10:12].any() and not g[:, 13:].any()
+        c = pk.colour.cpu().numpy()
+        f = cloud.get_features.cpu().numpy().reshape(-1, 48)
+        np.testing.assert_array_equal(c[:, :45], f[:, 3:])
+        np.testing.assert_array_equal(c[:, 45:48], f[:, :3])
+        assert not c[:, 48:].any()
+        for cuda_type in ("original", "pcheck_obb", "pcheck_obb_sum"):
+            a = render(cam, cloud, Pipe(), bg, cuda_type=cuda_type)
+            b = render(cam, cloud, Pipe(), bg, cuda_type=cuda_type, packed=pk)
+            for k in a:
+                if k == "contribs":  # float atomics: the summation order differs from run to run
+                    np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), rtol=1e-4, atol=1e-6)
+                else:
+                    assert torch.equal(a[k], b[k]), (cuda_type, k)
+        # foveated
+        highest, shs_dcs, opac = syn.foveation_layers(cloud, seed=3)
+        pf = pack_model(cloud.get_xyz, cloud.get_scaling, cloud.get_rotation, opac, shs=cloud.get_rest_features,
+                        shs_dcs=shs_dcs, highest_levels=highest)
+        gf = pf.geom.cpu().numpy()
+        np.testing.assert_array_equal(gf[:, 10], highest.cpu().numpy().reshape(-1))
+        np.testing.assert_array_equal(gf[:, 12:16], opac.cpu().numpy())
+        cf = pf.colour.cpu().numpy()
+        np.testing.assert_array_equal(cf[:, :45], cloud.get_rest_features.cpu().numpy().reshape(-1, 45))
+        np.testing.assert_array_equal(cf[:, 48:60], shs_dcs.cpu().numpy().reshape(-1, 12))
+        for gaze in ((0.5, 0.5), (0.2, 0.8)):
+            kw = dict(alpha=0.05, gazeArray=torch.tensor(gaze), blending=True, highest_levels=highest, shs_dcs=shs_dcs,
+                      opacities=opac)
+            a = render_fov(cam, cloud, bg, **kw)
+            b = render_fov(cam, cloud, bg, packed=pf, **kw)
+            assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
+        # a packed model of the wrong size is refused
+        with pytest.raises(RuntimeError):
+            render(cam, syn.scene_1k(P=10, seed=1).to(dev), Pipe(), bg, cuda_type="pcheck_obb", packed=pk)
+
+
 def test_foveated_render_entry_point():
     _need_gpu()
     from fov3dgs_amd.gaussian_renderer_fov import render

@@ -29,12 +29,19 @@ rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(c
                                       1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
 vid = _native.VARIANT_IDS[variant]
 E = torch.Tensor([])
+packed = None
+if os.environ.get("FR_PACKED"):  # the static-model layout (include/fovraster.h packed_geom / packed_colour)
+    with torch.no_grad():
+        if variant == "fov_pcheck_obb":
+            packed = rz.pack_model(xyz, sc, rot, fov[2], shs=rest, shs_dcs=fov[1], highest_levels=fov[0])
+        else:
+            packed = rz.pack_model(xyz, sc, rot, op, shs=feats)
 
 
 def frame(i):
     if variant == "fov_pcheck_obb":
-        return rz._forward_native(vid, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], syn.lissajous_gaze(i, 90), 0.05, persistent=True)
-    return rz._forward_native(vid, rs, xyz, feats, E, op, sc, rot, E, persistent=True)
+        return rz._forward_native(vid, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], syn.lissajous_gaze(i, 90), 0.05, persistent=True, packed=packed)
+    return rz._forward_native(vid, rs, xyz, feats, E, op, sc, rot, E, persistent=True, packed=packed)
 
 
 for i in range(5):

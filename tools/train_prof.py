@@ -12,7 +12,8 @@ bg = torch.zeros(3, device=dev)
 class Pipe: debug = False
 target = torch.rand(3, cam.image_height, cam.image_width, device=dev)
 ts = []
-for it in range(20):
+NIT = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for it in range(NIT):
     for p in cloud.parameters(): p.grad = None
     torch.cuda.synchronize(); t0 = time.perf_counter()
     o = render(cam, cloud, Pipe(), bg, cuda_type="pcheck_obb_sum")
@@ -21,6 +22,6 @@ for it in range(20):
     loss.backward()
     torch.cuda.synchronize(); t2 = time.perf_counter()
     ts.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3))
-ts = np.array(ts[3:])
+ts = np.array(ts[min(3, NIT - 1):])
 print("per-iteration total ms:", np.round(ts.sum(1), 2))
 print("fwd ms %.3f  bwd ms %.3f  total %.3f" % (np.median(ts[:, 0]), np.median(ts[:, 1]), np.median(ts.sum(1))))
