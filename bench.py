@@ -252,6 +252,18 @@ def main():
                 render_plain(cam, pc, Pipe(), bg, cuda_type="pcheck_obb")
             torch.cuda.synchronize()
             extra["nonfov_forward_fps"] = round(n / (time.perf_counter() - t1), 2)
+            # the same foveated frames without the packed copy of the static model that render() makes and caches by
+            # itself (gaussian_renderer_fov._auto_packed; include/fovraster.h packed_geom / packed_colour)
+            for i in range(Wm):
+                render_fov(cam, pc, bg, alpha=0.05, gazeArray=syn.lissajous_gaze(i, 90), blending=True,
+                           highest_levels=highest, shs_dcs=shs_dcs, opacities=opac, packed=None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(K):
+                render_fov(cam, pc, bg, alpha=0.05, gazeArray=syn.lissajous_gaze(Wm + i, 90), blending=True,
+                           highest_levels=highest, shs_dcs=shs_dcs, opacities=opac, packed=None)
+            torch.cuda.synchronize()
+            extra["unpacked_model_fps"] = round(K / (time.perf_counter() - t1), 2)
         tr = cloud.requires_grad_(True)
         target = torch.rand(3, H, W, device=dev)
         ts = []
@@ -286,6 +298,8 @@ def main():
                    "gaussians": P, "width": W, "height": H, "alpha": 0.05, "sh_degree": 3,
                    "visible": int(st["V"]), "in_front": V_in, "instances": int(st["D"]),
                    "instances_blend_tiles": int(st["D_blend"]), "max_tile_list": int(st["max_list"]),
+                   "model_layout": "static model: render() packs it once during warm-up (packed_geom/packed_colour, "
+                                   "bit-identical image); extra.unpacked_model_fps = same frames without",
                    "parallelism": f"views{world}"},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -1,15 +1,53 @@
 """render() for the foveated rasterizer (reference: fov3dgs/gaussian_renderer_fov/__init__.py:19-105)."""
 import math
+import weakref
 
 import torch
 
 from ..diff_gaussian_rasterization_fov_pcheck_obb import GaussianRasterizationSettings, GaussianRasterizer
+from ..rasterizer import PackedModel, pack_model
+
+
+class _PackState:
+    __slots__ = ("refs", "versions", "packed")
+
+    def __init__(self, tensors):
+        self.refs = [weakref.ref(t) for t in tensors]
+        self.versions = [t._version for t in tensors]
+        self.packed = None
+
+    def matches(self, tensors):
+        return len(self.refs) == len(tensors) and all(
+            r() is t and v == t._version for r, v, t in zip(self.refs, self.versions, tensors))
+
+
+def _auto_packed(pc, means3D, scales, rotations, opacity, shs_rest, shs_dcs, highest_levels):
+    """The packed layout of a static model (rasterizer.pack_model), made once and kept on the model object.
+    A model counts as static when a call hands over the very same tensor objects, unmodified (autograd version
+    counters), as the call before it: the second such call packs, later ones reuse. Models whose getters build new
+    tensors on every call (activations evaluated per call) never match and render from the ordinary tensors."""
+    tensors = (means3D, scales, rotations, opacity, shs_rest, shs_dcs, highest_levels)
+    if any(t is None or not t.is_cuda for t in tensors) or (torch.is_grad_enabled() and any(t.requires_grad for t in tensors)):
+        return None
+    st = getattr(pc, "_fovraster_pack_state", None)
+    if st is not None and st.matches(tensors):
+        if st.packed is None:
+            st.packed = pack_model(means3D, scales, rotations, opacity, shs=shs_rest, shs_dcs=shs_dcs,
+                                   highest_levels=highest_levels)
+        return st.packed
+    try:
+        pc._fovraster_pack_state = _PackState(tensors)
+    except AttributeError:
+        pass
+    return None
 
 
 def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, alpha=None, gazeArray=None,
-           blending=None, starter=None, ender=None, highest_levels=None, shs_dcs=None, opacities=None, packed=None):
+           blending=None, starter=None, ender=None, highest_levels=None, shs_dcs=None, opacities=None, packed="auto"):
     """Render the scene for one gaze. Background tensor (bg_color) must be on the GPU.
-    packed (extension): a rasterizer.PackedModel of this (static) model made by pack_model(); same image, faster binning."""
+    packed (extension; the image is bit-identical either way): a rasterizer.PackedModel of this model made by
+    pack_model(); "auto" (default) = made and cached here once the model is seen to be static (_auto_packed);
+    None = render from the ordinary tensors only."""
     xyz = pc.get_xyz
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
@@ -42,6 +80,8 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, a
     rotations = pc.get_rotation
     shs_rest = pc.get_rest_features
 
+    if isinstance(packed, str):
+        packed = _auto_packed(pc, means3D, scales, rotations, opacity, shs_rest, shs_dcs, highest_levels)
     if starter is not None:
         starter.record()
     rendered_image, radii = rasterizer(

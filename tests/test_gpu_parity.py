@@ -357,6 +357,29 @@ def test_packed_model_gives_identical_images():
             a = render_fov(cam, cloud, bg, **kw)
             b = render_fov(cam, cloud, bg, packed=pf, **kw)
             assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
+        # render() packs a static model by itself: the second call with the same, unmodified tensor objects
+        class Frozen:
+            pass
+        fz = Frozen()
+        fz.get_xyz, fz.get_scaling, fz.get_rotation = cloud.get_xyz, cloud.get_scaling, cloud.get_rotation
+        fz.get_rest_features, fz.active_sh_degree = cloud.get_rest_features, cloud.active_sh_degree
+        kw = dict(alpha=0.05, gazeArray=torch.tensor((0.4, 0.6)), blending=True, highest_levels=highest, shs_dcs=shs_dcs,
+                  opacities=opac)
+        ref_img = render_fov(cam, fz, bg, packed=None, **kw)["render"]
+        assert not hasattr(fz, "_fovraster_pack_state")
+        imgs = [render_fov(cam, fz, bg, **kw)["render"] for _ in range(3)]
+        assert fz._fovraster_pack_state.packed is not None
+        for im in imgs:
+            assert torch.equal(im, ref_img)
+        fz.get_scaling.mul_(1.5)  # an in-place change is noticed (version counter): no stale packed copy
+        ref2 = render_fov(cam, fz, bg, packed=None, **kw)["render"]
+        assert not torch.equal(ref2, ref_img)
+        assert torch.equal(render_fov(cam, fz, bg, **kw)["render"], ref2) and fz._fovraster_pack_state.packed is None
+        assert torch.equal(render_fov(cam, fz, bg, **kw)["render"], ref2) and fz._fovraster_pack_state.packed is not None
+        # a model whose getters build new tensors per call is never packed
+        for _ in range(3):
+            render_fov(cam, cloud, bg, **kw)
+        assert cloud._fovraster_pack_state.packed is None
         # a packed model of the wrong size is refused
         with pytest.raises(RuntimeError):
             render(cam, syn.scene_1k(P=10, seed=1).to(dev), Pipe(), bg, cuda_type="pcheck_obb", packed=pk)
