@@ -62,7 +62,8 @@ static int validate_forward(const fr_forward_args *a)
 	if (a->D < 0 || a->D > 3) { set_error("SH degree %d not in 0..3", a->D); return FR_ERR_INVALID; }
 	const bool has_sr = a->scales && a->rotations;
 	if (has_sr == (a->cov3D_precomp != nullptr)) { set_error("provide exactly one of scales+rotations / cov3D_precomp"); return FR_ERR_INVALID; }
-	if ((a->packed_geom != nullptr) != (a->packed_colour != nullptr)) { set_error("packed_geom and packed_colour go together"); return FR_ERR_INVALID; }
+	if ((a->packed_geom != nullptr) != (a->packed_colour != nullptr) || (a->packed_geom != nullptr) != (a->packed_cull != nullptr))
+	{ set_error("packed_geom, packed_colour and packed_cull go together"); return FR_ERR_INVALID; }
 	if (a->packed_geom && (!has_sr || !a->shs || a->colors_precomp || a->M != (fov ? 15 : 16)))
 	{ set_error("the packed model needs scales + rotations and shs with all 16 coefficients (M=%d)", a->M); return FR_ERR_INVALID; }
 	if (has_stats(a->variant) && (!a->gaussians_count || !a->contributions)) { set_error("this variant needs gaussians_count and contributions"); return FR_ERR_INVALID; }
@@ -213,6 +214,13 @@ int fr_pack_geom(int32_t P, const float *means3D, const float *scales, const flo
 	{ set_error("bad pack_geom arguments"); return FR_ERR_INVALID; }
 	if (P == 0) return FR_OK;
 	return launch_pack_geom(P, means3D, scales, rotations, opacities, levels, highest_levels, packed_geom, (hipStream_t)stream);
+}
+
+int fr_pack_cull(int32_t P, const float *means3D, const float *scales, const float *rotations, float *packed_cull, void *stream)
+{
+	if (P < 0 || (P > 0 && (!means3D || !scales || !rotations || !packed_cull))) { set_error("bad pack_cull arguments"); return FR_ERR_INVALID; }
+	if (P == 0) return FR_OK;
+	return launch_pack_cull(P, means3D, scales, rotations, packed_cull, (hipStream_t)stream);
 }
 
 int fr_pack_colour(int32_t P, const float *shs, const float *shs_rest, const float *shs_dcs, float *packed_colour, void *stream)

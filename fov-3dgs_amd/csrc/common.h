@@ -339,6 +339,7 @@ struct FwdCtx {
 int launch_tile_levels(FwdCtx &c);
 int launch_pack_geom(int P, const float *means3D, const float *scales, const float *rotations, const float *opacities, int levels,
 	const float *highest_levels, float *out, hipStream_t stream);
+int launch_pack_cull(int P, const float *means3D, const float *scales, const float *rotations, float *out, hipStream_t stream);
 int launch_pack_colour(int P, const float *shs, const float *shs_rest, const float *shs_dcs, float *out, hipStream_t stream);
 int launch_project(FwdCtx &c);
 int launch_bin(FwdCtx &c);

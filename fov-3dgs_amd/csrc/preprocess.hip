@@ -232,7 +232,7 @@ struct PreArgs {
 	const float *shs_rest; // split SH storage: shs = DC [P,1,3], shs_rest = [P,M-1,3]; else null
 	const float *viewmatrix, *projmatrix, *campos;
 	const float *shs_dcs, *highest_levels;
-	const float *packed_geom, *packed_colour; // optional packed copies of the model (fovraster.h), else null
+	const float *packed_geom, *packed_colour, *packed_cull; // optional packed copies of the model (fovraster.h), else null
 	const float *tile_lv; // RF float[5][T]
 	const uint32_t *lv_bbox; // RF [5][FR_LV_BBOX_STRIDE], see walk_rect()
 	int lds_tiles;           // RF: tile_min and the blend flags are staged in LDS (see k_bin)
@@ -272,9 +272,9 @@ __device__ __forceinline__ float view_norm2_bound(const float *vm)
 // rectangle for r_ub (RF: clipped to the level box, see walk_rect) means the reference drops the splat as well
 // (forward.cu:229-231). Everything here is evaluated approximately (no double, one division) and padded by
 // 1 % + 2 px, far above the rounding of either formulation; NaN/inf anywhere makes the test pass.
+// rho: upper bound of the spectral norm of the 3D covariance
 template <bool FOV>
-__device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, const float *pm, int idx, const float p[3], const float sc[3], float4 q,
-	float hl, float wn2)
+__device__ __forceinline__ bool frame_test_rho(const PreArgs &a, const float *vm, const float *pm, const float p[3], const float rho, float hl, float wn2)
 {
 	const float tz = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
 	if (tz <= 0.2f) return false;
@@ -290,20 +290,6 @@ __device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, co
 	const float cx = fminf(limx, fmaxf(-limx, t0 * iz)), cy = fminf(limy, fmaxf(-limy, t1 * iz));
 	const float ja = a.focal_x * iz, jb = a.focal_y * iz;
 	const float jf = (ja * ja) * (1.0f + cx * cx) + (jb * jb) * (1.0f + cy * cy); // |J|_F^2
-	float rho; // upper bound of the spectral norm of the 3D covariance
-	if (a.cov3D_precomp != nullptr)
-	{
-		const float *c = a.cov3D_precomp + 6 * (size_t)idx;
-		rho = fabsf(c[0]) + fabsf(c[3]) + fabsf(c[5]) + 2.0f * (fabsf(c[1]) + fabsf(c[2]) + fabsf(c[4]));
-	}
-	else
-	{
-		// Sigma = M^T M with M = S R, and R = (1 - 2|v|^2) I + 2 v v^T + 2 r [v]x has the singular values 1 and
-		// sqrt((1 - 2|v|^2)^2 + 4 r^2 |v|^2) (= 1 for a unit quaternion; the reference does not normalise here)
-		const float vv = q.y * q.y + q.z * q.z + q.w * q.w;
-		const float smax = a.scale_modifier * fmaxf(fabsf(sc[0]), fmaxf(fabsf(sc[1]), fabsf(sc[2])));
-		rho = smax * smax * fmaxf(1.0f, (1.0f - 2.0f * vv) * (1.0f - 2.0f * vv) + 4.0f * q.x * q.x * vv);
-	}
 	const float lam_ub = 2.42f * (rho * (wn2 * jf)) * 1.01f + 1.05f;
 	const float r_ub = ceilf(3.0f * __builtin_sqrtf(lam_ub)) * 1.01f + 2.0f;
 	if (!(r_ub < 1e9f)) return true;
@@ -317,6 +303,31 @@ __device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, co
 		x1 = min(x1, (int)b.z); y1 = min(y1, (int)b.w);
 	}
 	return x1 > x0 && y1 > y0;
+}
+// Sigma = M^T M with M = S R, and R = (1 - 2|v|^2) I + 2 v v^T + 2 r [v]x has the singular values 1 and
+// sqrt((1 - 2|v|^2)^2 + 4 r^2 |v|^2) (= 1 for a unit quaternion; the reference does not normalise here):
+// rho(Sigma) <= (scale_modifier * smax)^2 * this factor. Without the modifier it is the fourth float of a
+// packed_cull row (fovraster.h).
+__device__ __forceinline__ float rho_unit(const float sc[3], const float4 q)
+{
+	const float vv = q.y * q.y + q.z * q.z + q.w * q.w;
+	const float smax = fmaxf(fabsf(sc[0]), fmaxf(fabsf(sc[1]), fabsf(sc[2])));
+	return smax * smax * fmaxf(1.0f, (1.0f - 2.0f * vv) * (1.0f - 2.0f * vv) + 4.0f * q.x * q.x * vv);
+}
+template <bool FOV>
+__device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, const float *pm, int idx, const float p[3], const float sc[3], float4 q,
+	float hl, float wn2)
+{
+	const float tz = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
+	if (tz <= 0.2f) return false;
+	float rho;
+	if (a.cov3D_precomp != nullptr)
+	{
+		const float *c = a.cov3D_precomp + 6 * (size_t)idx;
+		rho = fabsf(c[0]) + fabsf(c[3]) + fabsf(c[5]) + 2.0f * (fabsf(c[1]) + fabsf(c[2]) + fabsf(c[4]));
+	}
+	else rho = (a.scale_modifier * a.scale_modifier) * rho_unit(sc, q);
+	return frame_test_rho<FOV>(a, vm, pm, p, rho, hl, wn2);
 }
 
 // The reference's per-Gaussian projection (forward.cu:155-262): near plane, 3D covariance, EWA 2D covariance,
@@ -502,14 +513,22 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 // global atomic per ~450 entries: a single device-scope counter saturates at ~90 atomics/us on MI355X, so one
 // atomic per wave and chunk (94 k per frame at 6 M Gaussians) would cost a millisecond -- and no workgroup
 // barrier is needed, so the waves of a CU drift apart and overlap their load and ALU phases.
-#define FR_PROJ_THREADS 256
+#ifndef FR_PROJ_THREADS
+#define FR_PROJ_THREADS 1024
+#endif
 #define FR_PROJ_WLIST 512
 #ifndef FR_PROJ_DEPTH
 #define FR_PROJ_DEPTH 3 // (2: 0.120 ms, 3: 0.110 ms, 4: 0.131 ms on the bench scene)
 #endif
-template <int VARIANT>
+// PACKED: position and covariance bound come as one float4 per Gaussian (packed_cull) instead of 3 + 3 + 4 floats
+// from three tensors; with 5 instead of 11 registers per chunk the ring can be deeper.
+#ifndef FR_PROJ_DEPTH_PACKED
+#define FR_PROJ_DEPTH_PACKED 4
+#endif
+template <int VARIANT, bool PACKED = false>
 __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 {
+	constexpr int DEPTH = PACKED ? FR_PROJ_DEPTH_PACKED : FR_PROJ_DEPTH;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	__shared__ uint32_t s_list[FR_PROJ_THREADS / 64][FR_PROJ_WLIST];
 	const int lane = threadIdx.x & 63;
@@ -549,9 +568,17 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	{
 		const size_t i = (size_t)min(chunk * 64 + lane, a.P - 1);
 		RawGaussian w;
+		if (PACKED)
+		{
+			const float4 c = ((const float4 *)a.packed_cull)[i];
+			w.p[0] = c.x; w.p[1] = c.y; w.p[2] = c.z; w.sc[0] = c.w; w.sc[1] = w.sc[2] = 0.0f; w.q = make_float4(0, 0, 0, 0);
+		}
+		else
+		{
 #pragma unroll
-		for (int k = 0; k < 3; k++) { w.p[k] = a.means3D[3 * i + k]; w.sc[k] = sc_src[3 * i + k]; }
-		w.q = *(const float4 *)(q_src + 4 * i);
+			for (int k = 0; k < 3; k++) { w.p[k] = a.means3D[3 * i + k]; w.sc[k] = sc_src[3 * i + k]; }
+			w.q = *(const float4 *)(q_src + 4 * i);
+		}
 		w.hl = FOV ? a.highest_levels[i] : 0.0f;
 		return w;
 	};
@@ -564,7 +591,8 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		bool maybe = false;
 		if (chunk < nchunks && idx < a.P)
 		{
-			maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
+			if (PACKED) maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * cur.sc[0], cur.hl, wn2);
+			else maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
 			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
 		}
 		const unsigned long long m = __ballot(maybe);
@@ -573,19 +601,33 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		if (n > FR_PROJ_WLIST - 64) flush();
 	};
 	// FR_PROJ_DEPTH chunks in flight per wave, each in its own register set that is refilled in place
-	RawGaussian R[FR_PROJ_DEPTH];
+	RawGaussian R[DEPTH];
 #pragma unroll
-	for (int d = 0; d < FR_PROJ_DEPTH; d++) R[d] = fetch(min(wave_gid + d * nwaves, nchunks - 1));
-	for (int base = wave_gid; base < nchunks; base += FR_PROJ_DEPTH * nwaves)
+	for (int d = 0; d < DEPTH; d++) R[d] = fetch(min(wave_gid + d * nwaves, nchunks - 1));
+	for (int base = wave_gid; base < nchunks; base += DEPTH * nwaves)
 	{
 #pragma unroll
-		for (int d = 0; d < FR_PROJ_DEPTH; d++)
+		for (int d = 0; d < DEPTH; d++)
 		{
 			step(R[d], base + d * nwaves);
-			R[d] = fetch(min(base + (d + FR_PROJ_DEPTH) * nwaves, nchunks - 1));
+			R[d] = fetch(min(base + (d + DEPTH) * nwaves, nchunks - 1));
 		}
 	}
-	if (n) flush();
+	// The leftovers go out with ONE atomic per workgroup: all waves finish at about the same time, and one atomic per
+	// wave (4096 - 8192 of them on the same counter, ~11 ns each) was a 45 - 90 us queue at the end of the kernel.
+	__shared__ uint32_t s_left[FR_PROJ_THREADS / 64], s_left_base;
+	if (lane == 0) s_left[threadIdx.x >> 6] = n;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t total = 0;
+		for (int w = 0; w < FR_PROJ_THREADS / 64; w++) total += s_left[w];
+		s_left_base = total ? atomicAdd(a.geom.slab_ctr + 1, total) : 0u;
+	}
+	__syncthreads();
+	uint32_t out = s_left_base;
+	for (int w = 0; w < (int)(threadIdx.x >> 6); w++) out += s_left[w];
+	for (uint32_t i = lane; i < n; i += 64) a.geom.vis_list[out + i] = list[i];
 }
 
 // Stage 2 (RS rasterizer_impl.cu:70-146, RF :264-383 + :490-530): for every survivor, count the tiles it
@@ -1277,6 +1319,13 @@ __global__ void k_pack_geom(int P, const float *means3D, const float *scales, co
 	}
 	out[i] = v;
 }
+__global__ void k_pack_cull(int P, const float *means3D, const float *scales, const float *rotations, float4 *out)
+{
+	const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= (size_t)P) return;
+	const float sc[3] = { scales[3 * g], scales[3 * g + 1], scales[3 * g + 2] };
+	out[g] = make_float4(means3D[3 * g], means3D[3 * g + 1], means3D[3 * g + 2], rho_unit(sc, ((const float4 *)rotations)[g]));
+}
 __global__ void k_pack_colour(int P, const float *shs, const float *shs_rest, const float *shs_dcs, float *out)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1301,6 +1350,11 @@ int launch_pack_geom(int P, const float *means3D, const float *scales, const flo
 	hipLaunchKernelGGL(k_pack_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P, means3D, scales, rotations, opacities, levels,
 		highest_levels, (float4 *)out);
 	return check_launch("pack_geom", stream, 0);
+}
+int launch_pack_cull(int P, const float *means3D, const float *scales, const float *rotations, float *out, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_pack_cull, dim3((unsigned)(((size_t)P + 255) / 256)), dim3(256), 0, stream, P, means3D, scales, rotations, (float4 *)out);
+	return check_launch("pack_cull", stream, 0);
 }
 int launch_pack_colour(int P, const float *shs, const float *shs_rest, const float *shs_dcs, float *out, hipStream_t stream)
 {
@@ -1333,7 +1387,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 	p.means3D = a->means3D; p.scales = a->scales; p.rotations = a->rotations; p.opacities = a->opacities;
 	p.shs = a->shs; p.shs_rest = a->shs_rest; p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
-	p.packed_geom = a->packed_geom; p.packed_colour = a->packed_colour;
+	p.packed_geom = a->packed_geom; p.packed_colour = a->packed_colour; p.packed_cull = a->packed_cull;
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.lv_bbox = c.img.lv_bbox; p.T = c.T;
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
@@ -1348,14 +1402,18 @@ int launch_project(FwdCtx &c)
 	{
 		// persistent waves: exactly as many workgroups as the device keeps resident (a second, partial round of
 		// workgroups would run on a half-empty chip)
-		static int resident[3] = { 0, 0, 0 };
-		const int slot = a->variant == FR_VARIANT_ORIGINAL ? 0 : (a->variant == FR_VARIANT_FOV_PCHECK_OBB ? 1 : 2);
+		static int resident[6] = { 0, 0, 0, 0, 0, 0 };
+		const bool packed = a->packed_cull != nullptr;
+		const int vslot = a->variant == FR_VARIANT_ORIGINAL ? 0 : (a->variant == FR_VARIANT_FOV_PCHECK_OBB ? 1 : 2);
+		const int slot = vslot + (packed ? 3 : 0);
 		if (resident[slot] == 0)
 		{
 			int per_cu = 0, dev = 0;
 			hipDeviceProp_t prop;
-			const void *fn = slot == 0 ? (const void *)k_project<FR_VARIANT_ORIGINAL>
-				: (slot == 1 ? (const void *)k_project<FR_VARIANT_FOV_PCHECK_OBB> : (const void *)k_project<FR_VARIANT_PCHECK_OBB>);
+			const void *fns[6] = { (const void *)k_project<FR_VARIANT_ORIGINAL>, (const void *)k_project<FR_VARIANT_FOV_PCHECK_OBB>,
+				(const void *)k_project<FR_VARIANT_PCHECK_OBB>, (const void *)k_project<FR_VARIANT_ORIGINAL, true>,
+				(const void *)k_project<FR_VARIANT_FOV_PCHECK_OBB, true>, (const void *)k_project<FR_VARIANT_PCHECK_OBB, true> };
+			const void *fn = fns[slot];
 			if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
 				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FR_PROJ_THREADS, 0) != hipSuccess || per_cu < 1)
 			{ per_cu = 4; prop.multiProcessorCount = 256; }
@@ -1363,12 +1421,15 @@ int launch_project(FwdCtx &c)
 		}
 		const int pchunks = (a->P + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS;
 		const dim3 pgrid(pchunks < resident[slot] ? pchunks : resident[slot]), pblock(FR_PROJ_THREADS);
-		switch (a->variant)
+#define LAUNCH_PROJ(V) do { if (packed) hipLaunchKernelGGL((k_project<V, true>), pgrid, pblock, 0, c.stream, p); \
+	else hipLaunchKernelGGL((k_project<V>), pgrid, pblock, 0, c.stream, p); } while (0)
+		switch (vslot)
 		{
-		case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL(k_project<FR_VARIANT_ORIGINAL>, pgrid, pblock, 0, c.stream, p); break;
-		case FR_VARIANT_FOV_PCHECK_OBB: hipLaunchKernelGGL(k_project<FR_VARIANT_FOV_PCHECK_OBB>, pgrid, pblock, 0, c.stream, p); break;
-		default: hipLaunchKernelGGL(k_project<FR_VARIANT_PCHECK_OBB>, pgrid, pblock, 0, c.stream, p); break;
+		case 0: LAUNCH_PROJ(FR_VARIANT_ORIGINAL); break;
+		case 1: LAUNCH_PROJ(FR_VARIANT_FOV_PCHECK_OBB); break;
+		default: LAUNCH_PROJ(FR_VARIANT_PCHECK_OBB); break;
 		}
+#undef LAUNCH_PROJ
 		return check_launch("project", c.stream, a->debug);
 	}
 }

@@ -120,15 +120,15 @@ def _workspaces_for(device, needs_graph):
 
 class PackedModel:
     """Packed copies of a STATIC model's rasterizer inputs (include/fovraster.h: packed_geom [P,16] /
-    packed_colour [P,64]): made once per model with pack_model(), passed to GaussianRasterizer(..., packed=...) next
+    packed_colour [P,64] / packed_cull [P,4]): made once per model with pack_model(), passed to GaussianRasterizer(..., packed=...) next
     to the ordinary tensors, which must hold the same values. Forward-only (ignored by the backward pass); the
     image is bit-identical with and without."""
 
-    def __init__(self, geom, colour):
-        self.geom, self.colour = geom, colour
+    def __init__(self, geom, colour, cull):
+        self.geom, self.colour, self.cull = geom, colour, cull
 
     def check(self, P, dev):
-        for t, w in ((self.geom, 16), (self.colour, 64)):
+        for t, w in ((self.geom, 16), (self.colour, 64), (self.cull, 4)):
             if t is not None and (t.device != dev or t.dtype != torch.float32 or tuple(t.shape) != (P, w) or not t.is_contiguous()):
                 raise RuntimeError(f"packed model does not match: expected float32 [{P}, {w}] on {dev}")
 
@@ -145,14 +145,17 @@ def pack_model(means3D, scales, rotations, opacities, shs=None, shs_rest=None, s
     m, sc, ro, op, sh, rest, dcs, hl = (f(t) for t in (means3D, scales, rotations, opacities, shs, shs_rest, shs_dcs, highest_levels))
     levels = op.numel() // max(P, 1) if P else 1
     geom = torch.empty((P, 16), dtype=torch.float32, device=dev)
+    cull = torch.empty((P, 4), dtype=torch.float32, device=dev)
     if sh is None:
         raise RuntimeError("pack_model needs the SH coefficients (the packed layout has no colors_precomp form)")
     colour = None
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = lib.fr_pack_geom(P, _ptr(m), _ptr(sc), _ptr(ro), _ptr(op), int(levels), _ptr(hl), _ptr(geom), stream)
+        if rc == 0:
+            rc = lib.fr_pack_cull(P, _ptr(m), _ptr(sc), _ptr(ro), _ptr(cull), stream)
         if rc != 0:
-            raise RuntimeError(f"fovraster pack_geom failed ({rc}): {_native.last_error()}")
+            raise RuntimeError(f"fovraster pack_geom / pack_cull failed ({rc}): {_native.last_error()}")
         if sh is not None:
             ncoef = sh.size(1) + (rest.size(1) if rest is not None else 0)
             if ncoef != (15 if dcs is not None else 16):
@@ -161,7 +164,7 @@ def pack_model(means3D, scales, rotations, opacities, shs=None, shs_rest=None, s
             rc = lib.fr_pack_colour(P, _ptr(sh), _ptr(rest), _ptr(dcs), _ptr(colour), stream)
             if rc != 0:
                 raise RuntimeError(f"fovraster pack_colour failed ({rc}): {_native.last_error()}")
-    return PackedModel(geom, colour)
+    return PackedModel(geom, colour, cull)
 
 
 # Set by fov3dgs_amd.profiling.StageTimer while a timed region is active: a ctypes array of
@@ -227,6 +230,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
             packed.check(P, dev)
             a.packed_geom = _ptr(packed.geom)
             a.packed_colour = _ptr(packed.colour)
+            a.packed_cull = _ptr(packed.cull)
         if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC):
             counts = torch.empty((P,), dtype=torch.int32, device=dev)      # zeroed by fr_forward itself
             contribs = torch.empty((P,), dtype=torch.float32, device=dev)

@@ -125,9 +125,12 @@ typedef struct fr_forward_args {
 	 *                          (RF: the four levels; else opacity, 0, 0, 0)         needs scales + rotations
 	 *   packed_colour [P][64]: SH coefficients 1..15 [45] | SH coefficient 0 [3] (not RF) | shs_dcs [4][3] (RF) | 0[4]
 	 *                                                                             needs shs with M = 16 (RF: 15)
-	 * Both or neither. fr_pack_geom / fr_pack_colour fill them on the device. */
+	 *   packed_cull   [P][4] : x y z | bound of the covariance's spectral norm at scale_modifier 1 (max scale^2, times
+	 *                          the factor a non-unit quaternion adds): all the conservative cull pass reads
+	 * All three or none. fr_pack_geom / fr_pack_colour / fr_pack_cull fill them on the device. */
 	const float *packed_geom;
 	const float *packed_colour;
+	const float *packed_cull;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
@@ -171,11 +174,12 @@ void fr_event_destroy(void *event);
 int fr_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 
 int fr_forward(fr_forward_args *args);
-/* Fill fr_forward_args.packed_geom / packed_colour (device buffers of P*16 / P*64 floats) from the tensors of the
+/* Fill fr_forward_args.packed_geom / packed_colour / packed_cull (device buffers of P*16 / P*64 / P*4 floats) from the tensors of the
  * same names; opacities is [P,levels] with levels = 1 or 4, highest_levels / shs_dcs may be NULL (not RF);
  * shs_rest NULL: shs is [P,16,3] (RF: [P,15,3] = coefficients 1..15 and shs_dcs given), else shs = [P,1,3]. */
 int fr_pack_geom(int32_t P, const float *means3D, const float *scales, const float *rotations, const float *opacities,
 	int32_t levels, const float *highest_levels, float *packed_geom, void *stream);
+int fr_pack_cull(int32_t P, const float *means3D, const float *scales, const float *rotations, float *packed_cull, void *stream);
 int fr_pack_colour(int32_t P, const float *shs, const float *shs_rest, const float *shs_dcs, float *packed_colour, void *stream);
 int fr_backward(const fr_backward_args *args);
 int fr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

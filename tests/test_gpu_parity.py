@@ -328,6 +328,9 @@ def test_packed_model_gives_identical_images():
         np.testing.assert_array_equal(g[:, 6:10], cloud.get_rotation.cpu().numpy())
         np.testing.assert_array_equal(g[:, 12], cloud.get_opacity.cpu().numpy()[:, 0])
         assert not g[:, 10:12].any() and not g[:, 13:].any()
+        cu = pk.cull.cpu().numpy()
+        np.testing.assert_array_equal(cu[:, :3], g[:, 0:3])
+        np.testing.assert_allclose(cu[:, 3], (g[:, 3:6].max(axis=1)) ** 2, rtol=1e-5)  # unit quaternions: factor 1
         c = pk.colour.cpu().numpy()
         f = cloud.get_features.cpu().numpy().reshape(-1, 48)
         np.testing.assert_array_equal(c[:, :45], f[:, 3:])
