@@ -9,7 +9,7 @@ import math
 import torch
 
 from ..gaussian_wrapper import get_gs_rasterizer
-from ..rasterizer import GaussianRasterizationSettings
+from ..rasterizer import GaussianRasterizationSettings, zero_points_like
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, masking=False,
@@ -18,11 +18,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     packed (extension): a rasterizer.PackedModel of this (static) model made by pack_model(); same image, faster binning."""
     xyz = pc.get_xyz
     # zero tensor that makes autograd return the gradient of the 2D (screen-space) means
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    else:
+        screenspace_points = zero_points_like(xyz)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

@@ -5,7 +5,7 @@ import weakref
 import torch
 
 from ..diff_gaussian_rasterization_fov_pcheck_obb import GaussianRasterizationSettings, GaussianRasterizer
-from ..rasterizer import PackedModel, pack_model
+from ..rasterizer import PackedModel, pack_model, zero_points_like
 
 
 class _PackState:
@@ -49,11 +49,14 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, a
     pack_model(); "auto" (default) = made and cached here once the model is seen to be static (_auto_packed);
     None = render from the ordinary tensors only."""
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    else:
+        screenspace_points = zero_points_like(xyz)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

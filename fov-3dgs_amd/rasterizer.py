@@ -118,6 +118,20 @@ def _workspaces_for(device, needs_graph):
     return ws, None
 
 
+_zero_rows = {}
+
+
+def zero_points_like(xyz):
+    """All-zero [P,3] tensor for render()'s `viewspace_points` when autograd is off: a stride-0 view of one cached zero
+    row instead of the reference's zeros_like(xyz) + 0 (a 72 MB fill and a 144 MB add per frame at 6 M Gaussians that
+    only exist to carry a gradient). Same shape, dtype and values; read-only by convention."""
+    key = (xyz.device, xyz.dtype)
+    row = _zero_rows.get(key)
+    if row is None:
+        row = _zero_rows[key] = torch.zeros((1, xyz.shape[-1]), dtype=xyz.dtype, device=xyz.device)
+    return row.expand(xyz.shape)
+
+
 class PackedModel:
     """Packed copies of a STATIC model's rasterizer inputs (include/fovraster.h: packed_geom [P,16] /
     packed_colour [P,64] / packed_cull [P,4]): made once per model with pack_model(), passed to GaussianRasterizer(..., packed=...) next
