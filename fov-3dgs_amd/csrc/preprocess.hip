@@ -1088,9 +1088,13 @@ struct EmitArgs {
 };
 // LDSH: the workgroup's write cursor of every tile lives in LDS, initialised to
 // tile start + (instances of the same tile owned by lower-numbered workgroups).
+#ifndef FR_EMIT_SHARE
+#define FR_EMIT_SHARE 2
+#endif
+#define FR_EMIT_THREADS (FR_BIN_THREADS * FR_EMIT_SHARE)
 #define NEXT_SLOT(ti) (LDSH ? atomicAdd(&lds_cur[(ti)], 1u) : a.ranges[(ti)].x + atomicAdd(&a.cursor[(ti)], 1u))
 template <int VARIANT, bool LDSH>
-__global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
+__global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
@@ -1101,15 +1105,15 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	if (ldst)
 	{
 		const float *gmin = a.tile_lv + a.T;
-		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_tmin[t] = gmin[t];
+		for (int t = threadIdx.x; t < a.T; t += FR_EMIT_THREADS) lds_tmin[t] = gmin[t];
 	}
 	if (LDSH)
 	{
 		const uint32_t *pre = a.hist + (size_t)blockIdx.x * a.T;
-		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_cur[t] = a.ranges[t].x + pre[t];
+		for (int t = threadIdx.x; t < a.T; t += FR_EMIT_THREADS) lds_cur[t] = a.ranges[t].x + pre[t];
 	}
 	__syncthreads();
-	__shared__ int s_own[FR_BIN_THREADS];
+	__shared__ int s_own[FR_EMIT_THREADS];
 	__shared__ int s_gidx[FR_GIANT_MAX]; // vis_list positions of the giant splats, walked by the whole workgroup at the end (see k_bin)
 	__shared__ uint32_t s_ng;
 	if (threadIdx.x == 0) s_ng = 0;
@@ -1228,18 +1232,22 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 	{
 		// replay k_bin's slab -> wave assignment (the bucket offsets are per workgroup) by walking the
 		// chain that wave left behind
-		int slab = a.geom.wave_head[(int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6)];
-		while (slab >= 0)
+		// FR_EMIT_SHARE waves share the chain one of k_bin's waves left (they take every FR_EMIT_SHARE-th slab of it): the
+		// kernel waits on memory 70 % of the time (a slab's scattered stores and the next slab's loads sit behind
+		// one in-order counter), more waves per SIMD is what hides that
+		const int w = (int)(threadIdx.x >> 6);
+		int slab = a.geom.wave_head[(int)blockIdx.x * (FR_BIN_THREADS / 64) + (w % (FR_BIN_THREADS / 64))];
+		for (int pos = 0; slab >= 0; pos++)
 		{
 			const int next = a.geom.slab_next[slab];
-			process(slab);
+			if (pos % FR_EMIT_SHARE == w / (FR_BIN_THREADS / 64)) process(slab);
 			slab = next;
 		}
 	}
 	else
 	{
-		const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
-		const int nwaves = (int)gridDim.x * (FR_BIN_THREADS / 64);
+		const int wave_gid = (int)blockIdx.x * (FR_EMIT_THREADS / 64) + (int)(threadIdx.x >> 6);
+		const int nwaves = (int)gridDim.x * (FR_EMIT_THREADS / 64);
 		for (int slab = wave_gid; slab < nslabs; slab += nwaves) process(slab);
 	}
 	__syncthreads();
@@ -1252,7 +1260,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_emit(const EmitArgs a)
 		const uint32_t xy = __float_as_uint(w2.z);
 		const uint64_t opay = ((uint64_t)__float_as_uint(w2.y) << 32) | (__float_as_uint(w2.x) & 0x3fffffffu);
 		walk_uniform((int)(xy & 0xffffu), (int)(xy >> 16), (int)__float_as_uint(w2.w), __float_as_uint(w3.x), ob, w3.y + 1, opay,
-			(uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_BIN_THREADS);
+			(uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_EMIT_THREADS);
 	}
 }
 #undef NEXT_SLOT
@@ -1484,7 +1492,7 @@ int launch_emit(FwdCtx &c)
 	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.lv_bbox = c.img.lv_bbox; e.ranges = c.img.ranges;
 	e.cursor = c.img.tile_count; e.entries = c.bin.entries; e.hist = c.img.hist;
 	const bool ldsh = c.img.hist != nullptr;
-	const dim3 grid(bin_blocks(a->P)), block(FR_BIN_THREADS);
+	const dim3 grid(bin_blocks(a->P)), block(FR_EMIT_THREADS);
 	e.lds_tiles = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
 	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (e.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
 	if (lds > 64u * 1024u)
