@@ -27,17 +27,23 @@ def _view(buf, ptr, count, dtype):
     return buf[off:off + nbytes].view(dtype)
 
 
-def hip_forward(variant, scene, cam, dev="cuda:0", debug=True):
-    """-> dict shaped like oracle.forward()'s (the subset the HIP library keeps)."""
+def hip_forward(variant, scene, cam, dev="cuda:0", debug=True, packed=False):
+    """-> dict shaped like oracle.forward()'s (the subset the HIP library keeps).
+    packed: also hand the model over in the packed static-model layout (needs scales + rotations + 16 SH coefficients)."""
     lib = _native.load()
     vid = VARIANT_IDS[variant]
     rs = settings_from(cam, dev, debug)
     tens = {k: _t(scene.get(k), dev) for k in ("means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
                                                 "cov3D_precomp", "shs_dcs", "highest_levels")}
+    pk = None
+    if packed:
+        from fov3dgs_amd.rasterizer import pack_model
+        pk = pack_model(tens["means3D"], tens["scales"], tens["rotations"], tens["opacities"], shs=tens["shs"],
+                        shs_dcs=tens["shs_dcs"], highest_levels=tens["highest_levels"])
     res = _forward_native(vid, rs, tens["means3D"], tens["shs"], tens["colors_precomp"], tens["opacities"],
                           tens["scales"], tens["rotations"], tens["cov3D_precomp"], tens["shs_dcs"],
                           tens["highest_levels"], cam.get("gaze", (0.5, 0.5)), cam.get("alpha", 0.05),
-                          loss_map=_t(scene.get("loss_map"), dev))
+                          loss_map=_t(scene.get("loss_map"), dev), packed=pk)
     torch.cuda.synchronize()
     num_rendered, color, radii, geom, binb, img = res[:6]
     W, H = rs.image_width, rs.image_height

@@ -29,6 +29,9 @@ for r in range(rounds):
         np.array_equal(got["ranges"], want["ranges"]) and np.array_equal(got["point_list"], want["point_list"])
     d = np.abs(got["color"] - want["color"])
     ok = ok and np.isfinite(got["color"]).all() and d.max() <= 2e-2 and np.mean(d > 1e-4) <= 2e-3
+    if ok and scene.get("scales") is not None and scene.get("shs") is not None:  # packed layout: bit-identical
+        pk = hip_forward(variant, scene, cd, packed=True)
+        ok = pk["num_rendered"] == got["num_rendered"] and all(np.array_equal(pk[k], got[k]) for k in ("radii", "ranges", "point_list", "color"))
     print(f"{r:3d} {variant:16s} P={P:6d} {W}x{H} big={big} D={want['num_rendered']:8d} max list {int((want['ranges'][:,1]-want['ranges'][:,0]).max()):6d} "
           f"img max diff {d.max():.2e} -> {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1

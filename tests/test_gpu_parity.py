@@ -510,3 +510,9 @@ def test_randomised_sweep():
         np.testing.assert_array_equal(got["ranges"], want["ranges"], err_msg=tag)
         np.testing.assert_array_equal(got["point_list"], want["point_list"], err_msg=tag)
         check_image(got["color"], want["color"], frac=2e-3)
+        if P >= 1 and scene.get("scales") is not None and scene.get("shs") is not None:
+            # the packed static-model layout: bit-identical to the ordinary tensors
+            pk = hip_forward(variant, scene, cd, packed=True)
+            assert pk["num_rendered"] == got["num_rendered"], tag
+            for k in ("radii", "ranges", "point_list", "color"):
+                np.testing.assert_array_equal(pk[k], got[k], err_msg=tag + " packed " + k)
