@@ -9,8 +9,13 @@
 #define FR_TILE_PIX 256
 #define FR_FOV_LEVELS 4       // RF auxiliary.h:26 fov_num
 #define FR_SORT_LDS_MAX 8192  // longest per-tile list sorted inside LDS (64 KiB of u64 keys)
-#define FR_BIN_THREADS 512    // workgroup size of the binning kernels (preprocess / emit)
-#define FR_BIN_BLOCKS 512     // persistent workgroups of the binning kernels (2 per CU: k_bin needs ~120 VGPRs and up to 68 KiB LDS)
+#ifndef FR_BIN_THREADS
+#define FR_BIN_THREADS 512    // workgroup size of k_bin (k_emit: FR_EMIT_SHARE times as many)
+#endif
+// persistent workgroups of the binning kernels: 2 per CU by LDS (up to 76 KiB each); k_bin's ~145 VGPRs let only one of
+// them run at a time (2 waves/SIMD), the other finds the slab counters empty -- 384-thread workgroups (3 waves/SIMD)
+// measured no faster (0.253 vs 0.247 ms): the kernel follows its heaviest slabs, not its occupancy
+#define FR_BIN_BLOCKS 512
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop
