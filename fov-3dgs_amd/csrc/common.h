@@ -333,6 +333,7 @@ struct FwdCtx {
 	fr_forward_args *a;
 	hipStream_t stream;
 	int gx, gy, T;
+	int bin_wgs;        // workgroups k_bin ran with (k_emit replays the same number)
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
 	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4] (+ sequence word), or null
 	uint32_t totals_seq;       // this frame's sequence number for that word

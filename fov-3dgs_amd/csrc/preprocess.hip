@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	{
 		float *d = a.geom.cov3D + (size_t)wave_gid * 8;
 		d[0] = (float)(wall_clock64() - tm0); d[1] = (float)(tm_loop_end - tm0); d[2] = (float)tm_l; d[3] = (float)tm_p; d[4] = (float)tm_c;
-		d[5] = (float)tm_n; d[6] = (float)tm_sh; d[7] = (float)tm_steps;
+		d[5] = (float)tm_n; d[6] = (float)(tm0 & 0xffffffull); d[7] = (float)tm_steps;
 	}
 #endif
 	if (LDSH)
@@ -1448,8 +1448,8 @@ int launch_bin(FwdCtx &c)
 	const fr_forward_args *a = c.a;
 	PreArgs p = make_pre_args(c);
 	const bool ldsh = c.img.hist != nullptr;
-	const int nblk = bin_blocks(a->P);
-	const dim3 grid(nblk), block(FR_BIN_THREADS);
+	int nblk = bin_blocks(a->P);
+	const dim3 block(FR_BIN_THREADS);
 	// LDS per workgroup: tile histogram (+ RF: tile_min and blend bits when two workgroups still fit a CU)
 	p.lds_tiles = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
 	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
@@ -1468,9 +1468,30 @@ int launch_bin(FwdCtx &c)
 			hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
 	}
-#define LAUNCH_PRE(V) do { if (packed) hipLaunchKernelGGL((k_bin<V, true, true>), grid, block, lds, c.stream, p); \
-	else if (ldsh) hipLaunchKernelGGL((k_bin<V, true>), grid, block, lds, c.stream, p); \
-	else hipLaunchKernelGGL((k_bin<V, false>), grid, block, 0, c.stream, p); } while (0)
+	// Never more workgroups than the device keeps resident: the slabs are handed out dynamically, so workgroups of a
+	// second round start when the first ones are done, find the counters empty and only cost their LDS set-up, an
+	// all-zero histogram row and the tail of the kernel (measured: 256 of 512 workgroups, 175 -> 211 us).
+	auto launch = [&](const void *fn, void (*kern)(const PreArgs), size_t dyn) {
+		static thread_local struct { const void *fn; size_t dyn; int wgs; } cache[12];
+		static thread_local int ncache = 0;
+		int wgs = 0;
+		for (int i = 0; i < ncache; i++) if (cache[i].fn == fn && cache[i].dyn == dyn) wgs = cache[i].wgs;
+		if (wgs == 0)
+		{
+			int per_cu = 0, dev = 0;
+			hipDeviceProp_t prop;
+			if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FR_BIN_THREADS, dyn) != hipSuccess || per_cu < 1)
+			{ per_cu = 1; prop.multiProcessorCount = 256; (void)hipGetLastError(); }
+			wgs = per_cu * prop.multiProcessorCount;
+			if (ncache < 12) { cache[ncache].fn = fn; cache[ncache].dyn = dyn; cache[ncache].wgs = wgs; ncache++; }
+		}
+		nblk = nblk < wgs ? nblk : wgs;
+		hipLaunchKernelGGL(kern, dim3(nblk), block, dyn, c.stream, p);
+	};
+#define LAUNCH_PRE(V) do { if (packed) launch((const void *)k_bin<V, true, true>, k_bin<V, true, true>, lds); \
+	else if (ldsh) launch((const void *)k_bin<V, true>, k_bin<V, true>, lds); \
+	else launch((const void *)k_bin<V, false>, k_bin<V, false>, 0); } while (0)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
@@ -1478,6 +1499,7 @@ int launch_bin(FwdCtx &c)
 	default: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
 	}
 #undef LAUNCH_PRE
+	c.bin_wgs = nblk;
 	int rc = check_launch("preprocess", c.stream, a->debug);
 	if (rc || !ldsh) return rc;
 	hipLaunchKernelGGL(k_hist_colscan, dim3((c.T + FR_CS_TILES - 1) / FR_CS_TILES), dim3(256), 0, c.stream, c.T, nblk, c.img.hist, c.img.tile_count);
@@ -1492,7 +1514,7 @@ int launch_emit(FwdCtx &c)
 	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.lv_bbox = c.img.lv_bbox; e.ranges = c.img.ranges;
 	e.cursor = c.img.tile_count; e.entries = c.bin.entries; e.hist = c.img.hist;
 	const bool ldsh = c.img.hist != nullptr;
-	const dim3 grid(bin_blocks(a->P)), block(FR_EMIT_THREADS);
+	const dim3 grid(c.bin_wgs), block(FR_EMIT_THREADS);
 	e.lds_tiles = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
 	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (e.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
 	if (lds > 64u * 1024u)
