@@ -134,7 +134,8 @@ int fr_forward(fr_forward_args *a)
 	c.img = carve_image(a->variant, a->W, a->H, iptr);
 
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
-	FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
+	if (a->variant != FR_VARIANT_FOV_PCHECK_OBB) // RF: k_tile_levels clears them
+		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
 	if (has_stats(a->variant))
 	{
 		FR_HIP(hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, stream));

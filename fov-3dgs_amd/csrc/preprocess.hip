@@ -88,8 +88,11 @@ __device__ float tile_level(int tx, int ty, int W, int H, float gaze_x, float ga
 // A workgroup owns a 16 x 16 patch of tiles: every level is evaluated once (plus the patch's one-tile halo) and
 // shared through LDS -- the level function (acos, tan, three sqrt) is ~500 instructions.
 __global__ void __launch_bounds__(256) k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x, float gaze_y, float alpha, float *out,
-	uint32_t *lv_bbox)
+	uint32_t *lv_bbox, uint32_t *slab_ctr)
 {
+	// the counters of the two kernels that follow are cleared here (one fill command less at the head of the frame)
+	if (blockIdx.x == 0)
+		for (int i = threadIdx.x; i < FR_SLAB_CTR_WORDS; i += 256) slab_ctr[i] = 0;
 	__shared__ float s_lv[18][18]; // [y + 1][x + 1]; -1 = outside the grid
 	const int pxn = (gx + 15) / 16;
 	const int bx = (int)blockIdx.x % pxn, by = (int)blockIdx.x / pxn;
@@ -1380,7 +1383,7 @@ int launch_tile_levels(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	hipLaunchKernelGGL(k_tile_levels, dim3(((c.gx + 15) / 16) * ((c.gy + 15) / 16)), dim3(256), 0, c.stream,
-		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv, c.img.lv_bbox);
+		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv, c.img.lv_bbox, c.geom.slab_ctr);
 	return check_launch("tile_levels", c.stream, a->debug);
 }
 
