@@ -237,6 +237,10 @@ def test_huge_tile_grid_uses_global_counter_path(variant):
     np.testing.assert_array_equal(got["ranges"], want["ranges"])
     np.testing.assert_array_equal(got["point_list"], want["point_list"])
     check_image(got["color"], want["color"])
+    # a packed model on this path: the cull pass reads it, the binning kernel falls back to the ordinary tensors
+    pk = hip_forward(variant, scene, cd, packed=True)
+    for k in ("radii", "ranges", "point_list", "color"):
+        np.testing.assert_array_equal(pk[k], got[k], err_msg="packed " + k)
 
 
 def test_autograd_module_end_to_end():
