@@ -231,6 +231,25 @@ int fr_pack_colour(int32_t P, const float *shs, const float *shs_rest, const flo
 	return launch_pack_colour(P, shs, shs_rest, shs_dcs, packed_colour, (hipStream_t)stream);
 }
 
+int64_t fr_l1_ssim_blocks(int32_t C, int32_t H, int32_t W)
+{
+	if (C <= 0 || H <= 0 || W <= 0) return 0;
+	return (int64_t)C * ((H + 15) / 16) * ((W + 15) / 16);
+}
+
+int fr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float *img, const float *target, float *dmaps, float *partials, void *stream)
+{
+	if (C <= 0 || H <= 0 || W <= 0 || C > 65535 || !img || !target || !partials) { set_error("bad l1_ssim_forward arguments"); return FR_ERR_INVALID; }
+	return launch_l1_ssim_forward(C, H, W, img, target, dmaps, partials, (hipStream_t)stream);
+}
+
+int fr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float *img, const float *target, const float *dmaps, float w_l1, float w_ssim,
+	float *dL_dimg, void *stream)
+{
+	if (C <= 0 || H <= 0 || W <= 0 || C > 65535 || !img || !target || !dmaps || !dL_dimg) { set_error("bad l1_ssim_backward arguments"); return FR_ERR_INVALID; }
+	return launch_l1_ssim_backward(C, H, W, img, target, dmaps, w_l1, w_ssim, dL_dimg, (hipStream_t)stream);
+}
+
 int fr_backward(const fr_backward_args *a)
 {
 	if (!a) { set_error("null args"); return FR_ERR_INVALID; }

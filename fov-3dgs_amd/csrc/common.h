@@ -347,6 +347,9 @@ int launch_pack_geom(int P, const float *means3D, const float *scales, const flo
 	const float *highest_levels, float *out, hipStream_t stream);
 int launch_pack_cull(int P, const float *means3D, const float *scales, const float *rotations, float *out, hipStream_t stream);
 int launch_pack_colour(int P, const float *shs, const float *shs_rest, const float *shs_dcs, float *out, hipStream_t stream);
+int launch_l1_ssim_forward(int C, int H, int W, const float *x, const float *y, float *dmaps, float *partials, hipStream_t stream);
+int launch_l1_ssim_backward(int C, int H, int W, const float *x, const float *y, const float *dmaps, float w_l1, float w_ssim,
+	float *dL_dx, hipStream_t stream);
 int launch_project(FwdCtx &c);
 int launch_bin(FwdCtx &c);
 int launch_tile_scan(FwdCtx &c);

@@ -1,0 +1,97 @@
+"""Image losses of a training iteration (reference: fov3dgs/utils/loss_utils.py).
+
+`l1_loss`, `ssim` keep the reference's signatures; `l1_ssim_loss(image, gt, lambda_dssim)` is the combination
+eff_finetune.py:124-125 uses, (1 - l) * l1_loss + l * (1 - ssim), as ONE forward and ONE backward HIP kernel
+(csrc/loss.hip) instead of five grouped 121-tap convolutions, ~15 elementwise kernels and their autograd graph.
+GPU tensors only: there is no CPU fallback (NativeLibraryError / RuntimeError otherwise).
+"""
+import torch
+
+from . import _native
+
+
+def l1_loss(network_output, gt):
+    """loss_utils.py:17-18"""
+    return torch.abs((network_output - gt)).mean()
+
+
+def l2_loss(network_output, gt):
+    """loss_utils.py:23-24"""
+    return ((network_output - gt) ** 2).mean()
+
+
+def _chw(t, name):
+    if t.dim() == 4 and t.size(0) == 1:
+        t = t[0]
+    if t.dim() != 3:
+        raise RuntimeError(f"{name} must be [C,H,W] (or [1,C,H,W]), got {tuple(t.shape)}")
+    if not t.is_cuda:
+        raise RuntimeError("fovraster losses need GPU tensors: there is no CPU fallback")
+    return t.contiguous().float()
+
+
+def _forward(img, gt, want_maps):
+    lib = _native.load()
+    C, H, W = img.shape
+    nb = lib.fr_l1_ssim_blocks(C, H, W)
+    partials = torch.empty((nb, 2), dtype=torch.float32, device=img.device)
+    dmaps = torch.empty((3, C, H, W), dtype=torch.float32, device=img.device) if want_maps else None
+    with torch.cuda.device(img.device):
+        rc = lib.fr_l1_ssim_forward(C, H, W, img.data_ptr(), gt.data_ptr(), dmaps.data_ptr() if want_maps else None,
+                                    partials.data_ptr(), torch.cuda.current_stream(img.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"fovraster l1_ssim_forward failed ({rc}): {_native.last_error()}")
+    sums = partials.sum(0, dtype=torch.float64)  # deterministic: per-tile sums, no float atomics
+    n = float(C * H * W)
+    return (sums[0] / n).float(), (sums[1] / n).float(), dmaps
+
+
+def _backward(img, gt, dmaps, w_l1, w_ssim):
+    lib = _native.load()
+    C, H, W = img.shape
+    grad = torch.empty_like(img)
+    with torch.cuda.device(img.device):
+        rc = lib.fr_l1_ssim_backward(C, H, W, img.data_ptr(), gt.data_ptr(), dmaps.data_ptr(), float(w_l1), float(w_ssim),
+                                     grad.data_ptr(), torch.cuda.current_stream(img.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"fovraster l1_ssim_backward failed ({rc}): {_native.last_error()}")
+    return grad
+
+
+class _L1SSIM(torch.autograd.Function):
+    """loss = (1 - lam) * mean|x - y| + lam * (1 - mean ssim_map); lam = None: returns mean ssim_map itself."""
+
+    @staticmethod
+    def forward(ctx, img, gt, lam):
+        shape = img.shape
+        x, y = _chw(img, "image"), _chw(gt, "gt")
+        if x.shape != y.shape:
+            raise RuntimeError(f"image {tuple(x.shape)} and gt {tuple(y.shape)} differ")
+        need = img.requires_grad
+        l1, ss, dmaps = _forward(x, y, need)
+        ctx.lam, ctx.shape = lam, shape
+        if need:
+            ctx.save_for_backward(x, y, dmaps)
+        return ss if lam is None else (1.0 - lam) * l1 + lam * (1.0 - ss)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, dmaps = ctx.saved_tensors
+        n = float(x.numel())
+        if ctx.lam is None:
+            grad = _backward(x, y, dmaps, 0.0, 1.0 / n)
+        else:
+            grad = _backward(x, y, dmaps, (1.0 - ctx.lam) / n, -ctx.lam / n)
+        return (grad * g).reshape(ctx.shape), None, None
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """loss_utils.py:37-46 (+ _ssim :57-76): mean SSIM with the 11x11 Gaussian window, differentiable in img1."""
+    if window_size != 11 or not size_average:
+        raise RuntimeError("fovraster ssim implements the reference's default call: window_size=11, size_average=True")
+    return _L1SSIM.apply(img1, img2, None)
+
+
+def l1_ssim_loss(image, gt, lambda_dssim=0.2):
+    """(1 - lambda) * l1_loss(image, gt) + lambda * (1 - ssim(image, gt)), eff_finetune.py:124-125, fused."""
+    return _L1SSIM.apply(image, gt, float(lambda_dssim))

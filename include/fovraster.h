@@ -185,6 +185,18 @@ int fr_backward(const fr_backward_args *args);
 int fr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
 	uint8_t *present /* [P] bool */, void *stream);
 
+/* Image loss of a training iteration, fused (replaces fov3dgs/utils/loss_utils.py:17-18 l1_loss and
+ * :37-76 ssim as eff_finetune.py:124-125 combines them). img / target: [C,H,W] fp32 device tensors.
+ *   forward:  partials[b] = (sum |img - target|, sum ssim_map) over the 16x16 tile b of one channel,
+ *             b < fr_l1_ssim_blocks(C,H,W); the caller adds them up (l1 = sum0 / (C H W), ssim = sum1 / (C H W)).
+ *             dmaps [3,C,H,W] (optional, NULL = value only) keeps what the backward needs.
+ *   backward: dL_dimg = w_l1 * sign(img - target) + w_ssim * d(sum ssim_map)/d img, written in full.
+ *             For loss = (1-l) L1 + l (1 - SSIM) with upstream gradient g: w_l1 = g (1-l) / (C H W), w_ssim = -g l / (C H W). */
+int64_t fr_l1_ssim_blocks(int32_t C, int32_t H, int32_t W);
+int fr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float *img, const float *target, float *dmaps, float *partials, void *stream);
+int fr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float *img, const float *target, const float *dmaps, float w_l1, float w_ssim,
+	float *dL_dimg, void *stream);
+
 /* Bytes fr_forward will request for the geometry / image workspaces (P, W, H dependent) and for the
  * binning workspace given a number of instances; lets a caller pre-size persistent buffers. */
 size_t fr_geometry_bytes(int32_t variant, int32_t P);
