@@ -279,6 +279,42 @@ def main():
             ts.append((time.perf_counter() - t1) * 1e3)
         extra["train_fwd_bwd_ms"] = round(float(np.median(ts[2:])), 3)
         extra["train_loss"] = "L1 (rasterizer fwd+bwd incl. torch activations)"
+        # the eff_finetune.py step with its real loss, 0.8 L1 + 0.2 (1 - SSIM): the fused HIP loss (csrc/loss.hip) next
+        # to the reference's formulation (five grouped conv2d's + elementwise ops + autograd) in torch on the same GPU
+        from fov3dgs_amd.loss_utils import l1_ssim_loss
+        import torch.nn.functional as F
+        g1 = torch.tensor([math.exp(-(i - 5) ** 2 / 4.5) for i in range(11)], device=dev)
+        g1 = g1 / g1.sum()
+        win = (g1[:, None] @ g1[None, :])[None, None].expand(3, 1, 11, 11).contiguous()
+
+        def torch_loss(img, gt):
+            a, b = img[None], gt[None]
+            mu1, mu2 = F.conv2d(a, win, padding=5, groups=3), F.conv2d(b, win, padding=5, groups=3)
+            s1 = F.conv2d(a * a, win, padding=5, groups=3) - mu1 * mu1
+            s2 = F.conv2d(b * b, win, padding=5, groups=3) - mu2 * mu2
+            s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
+            m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+            return 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - m.mean())
+
+        for name, fn in (("fused", lambda i, t: l1_ssim_loss(i, t, 0.2)), ("torch", torch_loss)):
+            ts, tl = [], []
+            for it in range(10):
+                for p in tr.parameters():
+                    p.grad = None
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
+                fn(o["render"], target).backward()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) * 1e3)
+                img = o["render"].detach().requires_grad_(True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn(img, target).backward()
+                torch.cuda.synchronize()
+                tl.append((time.perf_counter() - t1) * 1e3)
+            extra[f"train_step_l1_ssim_{name}_ms"] = round(float(np.median(ts[2:])), 3)
+            extra[f"loss_fwd_bwd_{name}_ms"] = round(float(np.median(tl[2:])), 3)
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
