@@ -61,7 +61,7 @@ class BackwardArgs(C.Structure):
     ]
 
 
-EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible", "fr_pack_geom", "fr_pack_colour", "fr_pack_cull", "fr_l1_ssim_blocks", "fr_l1_ssim_forward", "fr_l1_ssim_backward",
+EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible", "fr_pack_geom", "fr_pack_colour", "fr_pack_cull", "fr_activate_forward", "fr_activate_backward", "fr_l1_ssim_blocks", "fr_l1_ssim_forward", "fr_l1_ssim_backward",
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
            "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records")
 
@@ -107,6 +107,10 @@ def load():
     lib.fr_pack_colour.restype = C.c_int
     lib.fr_pack_cull.argtypes = [C.c_int32, _FP, _FP, _FP, _FP, C.c_void_p]
     lib.fr_pack_cull.restype = C.c_int
+    lib.fr_activate_forward.argtypes = [C.c_int32] + [_FP] * 6 + [C.c_void_p]
+    lib.fr_activate_forward.restype = C.c_int
+    lib.fr_activate_backward.argtypes = [C.c_int32] + [_FP] * 9 + [C.c_void_p]
+    lib.fr_activate_backward.restype = C.c_int
     lib.fr_l1_ssim_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.fr_l1_ssim_blocks.restype = C.c_int64
     lib.fr_l1_ssim_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, C.c_void_p]

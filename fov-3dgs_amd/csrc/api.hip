@@ -231,6 +231,24 @@ int fr_pack_colour(int32_t P, const float *shs, const float *shs_rest, const flo
 	return launch_pack_colour(P, shs, shs_rest, shs_dcs, packed_colour, (hipStream_t)stream);
 }
 
+int fr_activate_forward(int32_t P, const float *raw_scaling, const float *raw_rotation, const float *raw_opacity, float *scaling, float *rotation,
+	float *opacity, void *stream)
+{
+	if (P < 0 || (P > 0 && (!raw_scaling || !raw_rotation || !raw_opacity || !scaling || !rotation || !opacity))) { set_error("bad activate_forward arguments"); return FR_ERR_INVALID; }
+	if (P == 0) return FR_OK;
+	return launch_activate_forward(P, raw_scaling, raw_rotation, raw_opacity, scaling, rotation, opacity, (hipStream_t)stream);
+}
+
+int fr_activate_backward(int32_t P, const float *raw_scaling, const float *raw_rotation, const float *raw_opacity, const float *dL_dscaling,
+	const float *dL_drotation, const float *dL_dopacity, float *dL_draw_scaling, float *dL_draw_rotation, float *dL_draw_opacity, void *stream)
+{
+	if (P < 0 || (P > 0 && (!raw_scaling || !raw_rotation || !raw_opacity || !dL_draw_scaling || !dL_draw_rotation || !dL_draw_opacity)))
+	{ set_error("bad activate_backward arguments"); return FR_ERR_INVALID; }
+	if (P == 0) return FR_OK;
+	return launch_activate_backward(P, raw_scaling, raw_rotation, raw_opacity, dL_dscaling, dL_drotation, dL_dopacity, dL_draw_scaling, dL_draw_rotation,
+		dL_draw_opacity, (hipStream_t)stream);
+}
+
 int64_t fr_l1_ssim_blocks(int32_t C, int32_t H, int32_t W)
 {
 	if (C <= 0 || H <= 0 || W <= 0) return 0;

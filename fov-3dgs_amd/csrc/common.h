@@ -350,6 +350,9 @@ int launch_pack_colour(int P, const float *shs, const float *shs_rest, const flo
 int launch_l1_ssim_forward(int C, int H, int W, const float *x, const float *y, float *dmaps, float *partials, hipStream_t stream);
 int launch_l1_ssim_backward(int C, int H, int W, const float *x, const float *y, const float *dmaps, float w_l1, float w_ssim,
 	float *dL_dx, hipStream_t stream);
+int launch_activate_forward(int P, const float *rs, const float *rq, const float *ro, float *s, float *q, float *o, hipStream_t stream);
+int launch_activate_backward(int P, const float *rs, const float *rq, const float *ro, const float *gs, const float *gq, const float *go,
+	float *ds, float *dq, float *dop, hipStream_t stream);
 int launch_project(FwdCtx &c);
 int launch_bin(FwdCtx &c);
 int launch_tile_scan(FwdCtx &c);

@@ -47,9 +47,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     means3D = xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
-    scales = pc.get_scaling
-    rotations = pc.get_rotation
+    if hasattr(pc, "get_activated"):  # extension: the three activations as one fused pass (activations.py)
+        scales, rotations, opacity = pc.get_activated
+    else:
+        opacity = pc.get_opacity
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
     # models that expose their SH tensors separately (get_features_split, an extension of this package) skip the
     # concatenation; any other model goes through the reference's get_features
     if hasattr(pc, "get_features_split"):

@@ -42,6 +42,15 @@ class GaussianCloud:
         return torch.sigmoid(self._opacity)
 
     @property
+    def get_activated(self):
+        """(scaling, rotation, opacity) in one fused pass each way on the GPU (activations.py; extension, picked up by
+        gaussian_renderer.render()); the three getters above on the CPU."""
+        if self._scaling.is_cuda:
+            from .activations import activate
+            return activate(self._scaling, self._rotation, self._opacity)
+        return self.get_scaling, self.get_rotation, self.get_opacity
+
+    @property
     def get_features(self):
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 

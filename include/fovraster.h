@@ -185,6 +185,15 @@ int fr_backward(const fr_backward_args *args);
 int fr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
 	uint8_t *present /* [P] bool */, void *stream);
 
+/* The parameter activations in front of the rasterizer in a training iteration, one pass each way (SURVEY.md 8f rank 3;
+ * replaces GaussianModel.get_scaling / get_rotation / get_opacity, fov3dgs/scene/gaussian_model.py:200-240, i.e.
+ * exp [P,3], x / max(|x|, 1e-12) [P,4], sigmoid [P,1], and their autograd). Backward: dL_d* are the gradients w.r.t. the
+ * activated values (NULL = zero), dL_draw_* the results, written in full. */
+int fr_activate_forward(int32_t P, const float *raw_scaling, const float *raw_rotation, const float *raw_opacity, float *scaling, float *rotation,
+	float *opacity, void *stream);
+int fr_activate_backward(int32_t P, const float *raw_scaling, const float *raw_rotation, const float *raw_opacity, const float *dL_dscaling,
+	const float *dL_drotation, const float *dL_dopacity, float *dL_draw_scaling, float *dL_draw_rotation, float *dL_draw_opacity, void *stream);
+
 /* Image loss of a training iteration, fused (replaces fov3dgs/utils/loss_utils.py:17-18 l1_loss and
  * :37-76 ssim as eff_finetune.py:124-125 combines them). img / target: [C,H,W] fp32 device tensors.
  *   forward:  partials[b] = (sum |img - target|, sum ssim_map) over the 16x16 tile b of one channel,

@@ -322,15 +322,17 @@ def test_packed_model_gives_identical_images():
         debug = False
     with torch.no_grad():
         # plain variants: concatenated and split SH inputs pack to the same rows
-        pk = pack_model(cloud.get_xyz, cloud.get_scaling, cloud.get_rotation, cloud.get_opacity, shs=cloud.get_features)
+        # render() takes the activations from cloud.get_activated (the fused pass): the packed copy must hold the same values
+        act_s, act_q, act_o = cloud.get_activated
+        pk = pack_model(cloud.get_xyz, act_s, act_q, act_o, shs=cloud.get_features)
         dc, rest = cloud.get_features_split
-        pk2 = pack_model(cloud.get_xyz, cloud.get_scaling, cloud.get_rotation, cloud.get_opacity, shs=dc, shs_rest=rest)
+        pk2 = pack_model(cloud.get_xyz, act_s, act_q, act_o, shs=dc, shs_rest=rest)
         assert torch.equal(pk.geom, pk2.geom) and torch.equal(pk.colour, pk2.colour)
         g = pk.geom.cpu().numpy()
         np.testing.assert_array_equal(g[:, 0:3], cloud.get_xyz.cpu().numpy())
-        np.testing.assert_array_equal(g[:, 3:6], cloud.get_scaling.cpu().numpy())
-        np.testing.assert_array_equal(g[:, 6:10], cloud.get_rotation.cpu().numpy())
-        np.testing.assert_array_equal(g[:, 12], cloud.get_opacity.cpu().numpy()[:, 0])
+        np.testing.assert_array_equal(g[:, 3:6], act_s.cpu().numpy())
+        np.testing.assert_array_equal(g[:, 6:10], act_q.cpu().numpy())
+        np.testing.assert_array_equal(g[:, 12], act_o.cpu().numpy()[:, 0])
         assert not g[:, 10:12].any() and not g[:, 13:].any()
         cu = pk.cull.cpu().numpy()
         np.testing.assert_array_equal(cu[:, :3], g[:, 0:3])

@@ -99,3 +99,36 @@ def test_hip_losses_full_size_properties():
     assert abs(lu.l1_ssim_loss(a, b, 0.2).item() - want) < 3e-6
     with pytest.raises(RuntimeError):
         lu.ssim(a.cpu(), b.cpu())
+
+
+@pytest.mark.gpu
+def test_fused_activations_match_torch():
+    """exp / normalize / sigmoid of the model parameters as one kernel each way: values within
+    2 ulp-ish (1e-6 relative) of the torch expressions the reference's getters use, gradients 1e-5 relative."""
+    _need_gpu()
+    from fov3dgs_amd.activations import activate
+    g = torch.Generator().manual_seed(3)
+    P = 10007
+    rs = (torch.randn((P, 3), generator=g) * 2 - 3).cuda().requires_grad_(True)
+    rq = torch.randn((P, 4), generator=g).cuda()
+    rq[:5] = 0.0                      # the clamped-denominator branch
+    rq[5:10] *= 1e-14
+    rq = rq.requires_grad_(True)
+    ro = (torch.randn((P, 1), generator=g) * 3).cuda().requires_grad_(True)
+    s, q, o = activate(rs, rq, ro)
+    ws, wq, wo = torch.randn_like(s), torch.randn_like(q), torch.randn_like(o)
+    (s * ws).sum().add((q * wq).sum()).add((o * wo).sum()).backward()
+    got = [t.detach().cpu() for t in (s, q, o, rs.grad, rq.grad, ro.grad)]
+    rs2, rq2, ro2 = (t.detach().clone().requires_grad_(True) for t in (rs, rq, ro))
+    s2, q2, o2 = torch.exp(rs2), torch.nn.functional.normalize(rq2), torch.sigmoid(ro2)
+    (s2 * ws).sum().add((q2 * wq).sum()).add((o2 * wo).sum()).backward()
+    want = [t.detach().cpu() for t in (s2, q2, o2, rs2.grad, rq2.grad, ro2.grad)]
+    for name, a, b, rtol in zip(("s", "q", "o", "ds", "dq", "do"), got, want, (1e-6, 1e-6, 1e-6, 1e-5, 1e-5, 1e-5)):
+        sel = slice(10, None) if name == "dq" else slice(None)  # degenerate quaternions: value checked, gradient convention not pinned
+        np.testing.assert_allclose(a[sel].numpy(), b[sel].numpy(), rtol=rtol, atol=1e-7 * float(b.abs().max()), err_msg=name)
+    # missing upstream gradients count as zeros
+    s3, q3, o3 = activate(rs, rq, ro)
+    rs.grad = rq.grad = ro.grad = None
+    s3.sum().backward()
+    assert float(rq.grad.abs().max()) == 0.0 and float(ro.grad.abs().max()) == 0.0
+    np.testing.assert_allclose(rs.grad.cpu().numpy(), s3.detach().cpu().numpy(), rtol=1e-6)
