@@ -332,7 +332,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
 		dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
 #pragma unroll
-		for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+		for (int i = 0; i < 6; i++) if (a.dL_dcov3D != nullptr) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
 	}
 	// ---- projection backward: backward.cu:370-387 ----
 	{

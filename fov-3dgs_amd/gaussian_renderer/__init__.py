@@ -47,8 +47,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     means3D = xyz
     means2D = screenspace_points
-    if hasattr(pc, "get_activated"):  # extension: the three activations as one fused pass (activations.py)
-        scales, rotations, opacity = pc.get_activated
+    act = getattr(pc, "get_activated", None)  # extension: the three activations as one fused pass (activations.py)
+    if act is not None:
+        scales, rotations, opacity = act
     else:
         opacity = pc.get_opacity
         scales = pc.get_scaling

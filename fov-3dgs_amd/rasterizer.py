@@ -262,9 +262,10 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
 
 
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                     grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None):
+                     grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None,
+                     want_cov3D_grad=False):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations[, dL_dsh_rest])
-    (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3])"""
+    (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3]; dL_dcov3D is None unless cov3Ds_precomp is given or want_cov3D_grad)"""
     lib = _native.load()
     dev = means3D.device
     P = means3D.size(0)
@@ -285,7 +286,10 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
         M = M0 + (0 if rest_c is None else rest_c.size(1))
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
-        dL_dconic, dL_dopacity, dL_dcov3D = z(P, 2, 2), z(P, 1), z(P, 6)
+        dL_dconic, dL_dopacity = z(P, 2, 2), z(P, 1)
+        # only an output when the 3D covariances are an input; otherwise an intermediate nobody reads (144 MB at 6 M)
+        has_cov = want_cov3D_grad or (cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0)
+        dL_dcov3D = z(P, 6) if has_cov else None
         dL_dsh, dL_dscales, dL_drotations = z(P, M0, 3), z(P, 3), z(P, 4)
         dL_dsh_rest = z(P, M - M0, 3) if rest_c is not None else None
         if P != 0:
@@ -307,7 +311,8 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
             a.radii = radii.data_ptr()
             a.geometry, a.binning, a.image = geomBuffer.data_ptr(), _ptr(binningBuffer if binningBuffer.numel() else None), imgBuffer.data_ptr()
             a.dL_dmean2D, a.dL_dconic, a.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr()
-            a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D = dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr()
+            a.dL_dcolor, a.dL_dmean3D = dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr()
+            a.dL_dcov3D = dL_dcov3D.data_ptr() if dL_dcov3D is not None else None
             a.dL_dsh = dL_dsh.data_ptr() if M else None
             a.dL_dsh_rest = dL_dsh_rest.data_ptr() if dL_dsh_rest is not None else None
             a.dL_dscale, a.dL_drot = dL_dscales.data_ptr(), dL_drotations.data_ptr()

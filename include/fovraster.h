@@ -156,7 +156,7 @@ typedef struct fr_backward_args {
 	float *dL_dopacity;          /* [P,1] */
 	float *dL_dcolor;            /* [P,3] */
 	float *dL_dmean3D;           /* [P,3] */
-	float *dL_dcov3D;            /* [P,6] */
+	float *dL_dcov3D;            /* [P,6]; may be NULL when cov3D_precomp is NULL (then it is an intermediate nobody reads) */
 	float *dL_dsh;               /* [P,M,3] */
 	float *dL_dscale;            /* [P,3] */
 	float *dL_drot;              /* [P,4] */
