@@ -257,11 +257,16 @@ struct BwdPreArgs {
 	const uint32_t *vis_count; // its length (device)
 };
 
-__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx)
+// row: the 64-byte row the forward pass left for this vis_list entry (xyz | raw scale | rotation | 3D covariance), or
+// null when the covariances were an input: one coalesced row instead of gathers from four tensors.
+__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx, const float4 *row)
 {
 	const float *vm = a.viewmatrix, *proj = a.projmatrix;
-	const float m[3] = { a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2] };
-	const float *cov3D = a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : a.cov3D_ws + 6 * (size_t)idx;
+	float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+	if (row != nullptr) { r0 = row[0]; r1 = row[1]; r2 = row[2]; r3 = row[3]; }
+	const float m[3] = { row ? r0.x : a.means3D[3 * idx], row ? r0.y : a.means3D[3 * idx + 1], row ? r0.z : a.means3D[3 * idx + 2] };
+	const float cov_row[6] = { r2.z, r2.w, r3.x, r3.y, r3.z, r3.w };
+	const float *cov3D = row ? cov_row : a.cov3D_precomp + 6 * (size_t)idx;
 	const float fx = a.focal_x, fy = a.focal_y;
 	float dmean[3];
 	float dcov[6];
@@ -474,13 +479,14 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	// ---- 3D covariance backward: backward.cu:278-341 ----
 	if (a.cov3D_precomp == nullptr && a.scales != nullptr)
 	{
-		const float4 q = ((const float4 *)a.rotations)[idx];
+		const float4 q = row ? make_float4(r1.z, r1.w, r2.x, r2.y) : ((const float4 *)a.rotations)[idx];
 		const float r = q.x, x = q.y, y = q.z, z = q.w;
 		const M3b R = mb_cols(
 			1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
 			2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
 			2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
-		const float s[3] = { a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1], a.scale_modifier * a.scales[3 * idx + 2] };
+		const float s[3] = { a.scale_modifier * (row ? r0.w : a.scales[3 * idx]), a.scale_modifier * (row ? r1.x : a.scales[3 * idx + 1]),
+			a.scale_modifier * (row ? r1.y : a.scales[3 * idx + 2]) };
 		const M3b S = mb_cols(s[0], 0, 0, 0, s[1], 0, 0, 0, s[2]);
 		M3b Mm = mb_mul(S, R);
 		const M3b dSigma = mb_cols(
@@ -521,7 +527,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x)
 	{
 		const int idx = (int)a.vis_list[i];
-		if (a.radii[idx] > 0) preprocess_bwd_one(a, idx);
+		if (a.radii[idx] > 0) preprocess_bwd_one(a, idx, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i);
 	}
 }
 

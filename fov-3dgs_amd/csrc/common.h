@@ -46,7 +46,8 @@ __host__ __device__ inline size_t align_up(size_t x, size_t a = 256) { return (x
 //   [2] = (b, depth, clamp bits, unused)
 struct GeomWS {
 	float4 *rec;        // [3P]
-	float *cov3D;       // [6P]
+	float *cov3D;       // training variants: [16P] one 64-byte row per vis_list entry, in list order, written by k_bin for the
+	                    // backward pass: (xyz | raw scale | rotation | 3D covariance) -- one coalesced row instead of four gathers
 	float4 *wrec;       // [4P] walk record of vis_list entry i at [4i..4i+3], written by k_bin in list order for k_emit:
 	                    //      (cx, cy, e1x, e1y | e2x, e2y, len1, len2 | id + flags << 30, depth bits, x0 + y0 << 16, width |
 	                    //      tiles, highest level, -, -); flags: 1 = lands in a tile, 2 = the OBB test applies
@@ -63,7 +64,10 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 {
 	GeomWS g; size_t off = 0;
 	g.rec = (float4 *)(base + off); off = align_up(off + P * 3 * sizeof(float4));
-	g.cov3D = (float *)(base + off); off = align_up(off + P * 6 * sizeof(float));
+	// variants with a backward pass keep a 64-byte row per vis_list entry for it (see GeomWS::cov3D); the others only
+	// need room for the developer timers
+	const bool keeps = variant != FR_VARIANT_PCHECK_OBB && variant != FR_VARIANT_FOV_PCHECK_OBB;
+	g.cov3D = (float *)(base + off); off = align_up(off + P * (keeps ? 16 : 6) * sizeof(float));
 	g.lvl = nullptr; g.lrange = nullptr;
 	g.wrec = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4));
 	if (variant == FR_VARIANT_FOV_PCHECK_OBB) {

@@ -335,7 +335,9 @@ __device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, co
 
 // The reference's per-Gaussian projection (forward.cu:155-262): near plane, 3D covariance, EWA 2D covariance,
 // conic, radius, tile rectangle. sc / q: raw scales and rotation (unused with cov3D_precomp).
-__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, const float *vm, const float *pm, int idx, const float p[3], const float sc[3], float4 q)
+// stash: where to leave (xyz | raw scale | rotation | 3D covariance) for the backward pass, or null.
+__device__ __forceinline__ Proj project_gaussian(const PreArgs &a, const float *vm, const float *pm, int idx, const float p[3], const float sc[3], float4 q,
+	float4 *stash)
 {
 	Proj r; r.alive = false; r.tnum = 0; r.radius = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0;
 	r.pix_x = r.pix_y = r.depth = r.conic_a = r.conic_b = r.conic_c = r.cov0 = r.cov1 = r.lambda1 = r.lambda2 = 0.f;
@@ -388,10 +390,12 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, const float *
 		const M3 Sg = m3_mul(m3_t(Mm), Mm);
 		cov3D[0] = Sg.c[0][0]; cov3D[1] = Sg.c[0][1]; cov3D[2] = Sg.c[0][2];
 		cov3D[3] = Sg.c[1][1]; cov3D[4] = Sg.c[1][2]; cov3D[5] = Sg.c[2][2];
-		if (a.write_cov3D)
+		if (stash != nullptr)
 		{
-#pragma unroll
-			for (int i = 0; i < 6; i++) a.geom.cov3D[6 * (size_t)idx + i] = cov3D[i];
+			stash[0] = make_float4(p[0], p[1], p[2], sc[0]);
+			stash[1] = make_float4(sc[1], sc[2], q.x, q.y);
+			stash[2] = make_float4(q.z, q.w, cov3D[0], cov3D[1]);
+			stash[3] = make_float4(cov3D[2], cov3D[3], cov3D[4], cov3D[5]);
 		}
 	}
 
@@ -885,7 +889,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			}
 			if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
 		}
-		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q);
+		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q, a.write_cov3D ? (float4 *)a.geom.cov3D + 4 * (size_t)item : nullptr);
 		if (pr.alive)
 		{
 			if (CULL && pr.tnum > 1)
