@@ -150,16 +150,22 @@ int fr_forward(fr_forward_args *a)
 	// the one host synchronisation of a frame: how many instances must the binning buffer hold. k_tile_scan writes
 	// the four numbers into pinned, device-mapped host memory of this thread (a copy command after the kernel
 	// costs ~10 us more of an idle GPU); pageable-copy fallback if that memory cannot be had.
-	static thread_local uint32_t *pinned = nullptr, *pinned_dev = nullptr;
-	static thread_local bool pinned_tried = false;
-	if (!pinned_tried)
+	// (one such block per host thread and device: the device address of mapped host memory belongs to the device
+	// that was current when it was asked for)
+	struct Pinned { uint32_t *host = nullptr, *dev = nullptr; bool tried = false; };
+	static thread_local Pinned pinned_of[16];
+	int cur_dev = 0;
+	(void)hipGetDevice(&cur_dev);
+	Pinned &pn = pinned_of[cur_dev & 15];
+	if (!pn.tried)
 	{
-		pinned_tried = true;
+		pn.tried = true;
 		void *h = nullptr, *d = nullptr;
-		if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess)
-		{ pinned = (uint32_t *)h; pinned_dev = (uint32_t *)d; for (int i = 0; i < 16; i++) pinned[i] = 0; }
+		if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess)
+		{ pn.host = (uint32_t *)h; pn.dev = (uint32_t *)d; for (int i = 0; i < 16; i++) pn.host[i] = 0; }
 		(void)hipGetLastError();
 	}
+	uint32_t *const pinned = pn.host, *const pinned_dev = pn.dev;
 	static thread_local uint32_t frame_seq = 0;
 	if (++frame_seq == 0) frame_seq = 1;
 	c.totals_host_dev = pinned_dev;
