@@ -201,7 +201,11 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 	int runs = 1;
 	while (runs * ITEMS < n) runs <<= 1;
 	const int nact = runs * ITEMS;
-	for (int i = tid; i < nact; i += THREADS) sk[i] = i < n ? src[i] : ~0ull;
+	// LDS layout: one spare slot after every 8 keys (SK). A thread owns ITEMS = 8 consecutive keys, i.e. lanes are 64
+	// bytes apart: unpadded, the 64 lanes of an access fall on 4 of the 32 eight-byte bank pairs (16-way conflict);
+	// with the spare slot the lane stride is 72 bytes and all bank pairs are used.
+#define SK(i) sk[(i) + ((i) >> 3)]
+	for (int i = tid; i < nact; i += THREADS) SK(i) = i < n ? src[i] : ~0ull;
 	__syncthreads();
 	const bool act = tid < runs;
 	uint64_t k[ITEMS];
@@ -209,10 +213,10 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 	if (act)
 	{
 #pragma unroll
-		for (int i = 0; i < ITEMS; i++) k[i] = sk[o + i];
+		for (int i = 0; i < ITEMS; i++) k[i] = SK(o + i);
 		reg_sort<ITEMS>(k);
 #pragma unroll
-		for (int i = 0; i < ITEMS; i++) sk[o + i] = k[i];
+		for (int i = 0; i < ITEMS; i++) SK(o + i) = k[i];
 	}
 	__syncthreads();
 	for (int L = ITEMS; L < nact; L <<= 1)
@@ -221,33 +225,38 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 		{
 			const int base = o & ~(2 * L - 1);
 			const int d = o - base;                      // outputs before mine inside this pair of runs
-			const uint64_t *A = sk + base, *B = sk + base + L;
+			const int a0 = base, b0 = base + L;
+#define A(x) SK(a0 + (x))
+#define B(x) SK(b0 + (x))
 			int lo = max(0, d - L), hi = min(d, L);
 			while (lo < hi)
 			{
 				const int mid = (lo + hi) >> 1;
-				if (A[mid] < B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+				if (A(mid) < B(d - 1 - mid)) lo = mid + 1; else hi = mid;
 			}
 			int i = lo, j = d - lo;
-			uint64_t av = i < L ? A[i] : ~0ull, bv = j < L ? B[j] : ~0ull;
+			uint64_t av = i < L ? A(i) : ~0ull, bv = j < L ? B(j) : ~0ull;
 #pragma unroll
 			for (int t = 0; t < ITEMS; t++)
 			{
 				const bool ta = av <= bv;
 				k[t] = ta ? av : bv;
-				if (ta) { i++; av = i < L ? A[i] : ~0ull; }
-				else { j++; bv = j < L ? B[j] : ~0ull; }
+				if (ta) { i++; av = i < L ? A(i) : ~0ull; }
+				else { j++; bv = j < L ? B(j) : ~0ull; }
 			}
 		}
 		__syncthreads();
 		if (act)
 		{
 #pragma unroll
-			for (int t = 0; t < ITEMS; t++) sk[o + t] = k[t];
+			for (int t = 0; t < ITEMS; t++) SK(o + t) = k[t];
 		}
 		__syncthreads();
 	}
-	for (int i = tid; i < n; i += THREADS) dst[i] = (uint32_t)sk[i];
+	for (int i = tid; i < n; i += THREADS) dst[i] = (uint32_t)SK(i);
+#undef A
+#undef B
+#undef SK
 }
 
 // Long tile lists (>= FR_SORT_SPLIT_MIN entries) are not sorted as one piece: a handful of them used to occupy one
@@ -394,13 +403,13 @@ int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
 		uint32_t *chunk_ctr = c.img.totals + 4;
 		hipLaunchKernelGGL(k_split_long, dim3(nlong), dim3(1024), 0, c.stream, rg, ord, c.bin.entries, c.bin.entries2, c.bin.chunks, chunk_ctr);
 		const size_t max_chunks = FR_SORT_MAX_CHUNKS(num_instances);
-		hipLaunchKernelGGL((k_tile_msort<256, 8, true>), dim3((unsigned)max_chunks), dim3(256), 2048 * sizeof(uint64_t), c.stream,
+		hipLaunchKernelGGL((k_tile_msort<256, 8, true>), dim3((unsigned)max_chunks), dim3(256), 2304 * sizeof(uint64_t), c.stream,
 			c.bin.chunks, (const uint32_t *)nullptr, c.bin.entries2, c.bin.point_list, 0, 0, chunk_ctr);
 	}
 	if (max_tile > 512)
-		hipLaunchKernelGGL((k_tile_msort<256, 8, false>), grid, dim3(256), 2048 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+		hipLaunchKernelGGL((k_tile_msort<256, 8, false>), grid, dim3(256), 2304 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
 			512, FR_SORT_SPLIT_MIN, (const uint32_t *)nullptr);
-	hipLaunchKernelGGL((k_tile_msort<64, 8, false>), grid, dim3(64), 512 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+	hipLaunchKernelGGL((k_tile_msort<64, 8, false>), grid, dim3(64), 576 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
 		0, FR_SORT_SPLIT_MIN, (const uint32_t *)nullptr);
 	if (ax)
 	{
