@@ -78,9 +78,15 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, a
 
     means3D = xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity if opacities is None else opacities
-    scales = pc.get_scaling
-    rotations = pc.get_rotation
+    act = getattr(pc, "get_activated", None)  # extension: the three activations as one fused pass (activations.py)
+    if act is not None:
+        scales, rotations, opacity = act
+        if opacities is not None:
+            opacity = opacities
+    else:
+        opacity = pc.get_opacity if opacities is None else opacities
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
     shs_rest = pc.get_rest_features
 
     if isinstance(packed, str):

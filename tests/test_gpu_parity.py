@@ -352,7 +352,7 @@ def test_packed_model_gives_identical_images():
                     assert torch.equal(a[k], b[k]), (cuda_type, k)
         # foveated
         highest, shs_dcs, opac = syn.foveation_layers(cloud, seed=3)
-        pf = pack_model(cloud.get_xyz, cloud.get_scaling, cloud.get_rotation, opac, shs=cloud.get_rest_features,
+        pf = pack_model(cloud.get_xyz, act_s, act_q, opac, shs=cloud.get_rest_features,
                         shs_dcs=shs_dcs, highest_levels=highest)
         gf = pf.geom.cpu().numpy()
         np.testing.assert_array_equal(gf[:, 10], highest.cpu().numpy().reshape(-1))
