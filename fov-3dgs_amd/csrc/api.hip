@@ -258,7 +258,7 @@ int fr_activate_backward(int32_t P, const float *raw_scaling, const float *raw_r
 int64_t fr_l1_ssim_blocks(int32_t C, int32_t H, int32_t W)
 {
 	if (C <= 0 || H <= 0 || W <= 0) return 0;
-	return (int64_t)C * ((H + 15) / 16) * ((W + 15) / 16);
+	return (int64_t)C * ((H + 31) / 32) * ((W + 15) / 16); // one (sum |x - y|, sum ssim) pair per 16 x 32 tile, see loss.hip
 }
 
 int fr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float *img, const float *target, float *dmaps, float *partials, void *stream)

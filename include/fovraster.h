@@ -196,7 +196,7 @@ int fr_activate_backward(int32_t P, const float *raw_scaling, const float *raw_r
 
 /* Image loss of a training iteration, fused (replaces fov3dgs/utils/loss_utils.py:17-18 l1_loss and
  * :37-76 ssim as eff_finetune.py:124-125 combines them). img / target: [C,H,W] fp32 device tensors.
- *   forward:  partials[b] = (sum |img - target|, sum ssim_map) over the 16x16 tile b of one channel,
+ *   forward:  partials[b] = (sum |img - target|, sum ssim_map) over tile b (16 x 32 pixels) of one channel,
  *             b < fr_l1_ssim_blocks(C,H,W); the caller adds them up (l1 = sum0 / (C H W), ssim = sum1 / (C H W)).
  *             dmaps [3,C,H,W] (optional, NULL = value only) keeps what the backward needs.
  *   backward: dL_dimg = w_l1 * sign(img - target) + w_ssim * d(sum ssim_map)/d img, written in full.
