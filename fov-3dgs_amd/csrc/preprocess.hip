@@ -1381,7 +1381,8 @@ int launch_pack_colour(int P, const float *shs, const float *shs_rest, const flo
 // ---- launchers -------------------------------------------------------------------------------
 // bytes of the RF tile table in LDS: tile_min floats + one blend bit per tile
 static inline size_t lds_tile_table_bytes(int T) { return (size_t)T * sizeof(float) + (size_t)((T + 31) / 32) * sizeof(uint32_t); }
-#define FR_LDS_TILE_TABLE_BUDGET (76u * 1024u) // two workgroups per CU (160 KiB) with their static LDS
+#define FR_LDS_TILE_TABLE_BUDGET (140u * 1024u) // one workgroup of k_bin / k_emit per CU (160 KiB) with its static LDS: every
+                                                 // tile grid that gets LDS histograms (<= 16384 tiles) also gets the LDS tile table
 
 int launch_tile_levels(FwdCtx &c)
 {
@@ -1463,7 +1464,7 @@ int launch_bin(FwdCtx &c)
 	if (lds > 64u * 1024u)
 	{
 		static const hipError_t once = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_FOV_PCHECK_OBB, true>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
 		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
 	}
 	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the
@@ -1472,7 +1473,7 @@ int launch_bin(FwdCtx &c)
 	if (lds > 64u * 1024u && packed)
 	{
 		static const hipError_t once = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_FOV_PCHECK_OBB, true, true>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
 		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
 	}
 	// Never more workgroups than the device keeps resident: the slabs are handed out dynamically, so workgroups of a
@@ -1527,7 +1528,7 @@ int launch_emit(FwdCtx &c)
 	if (lds > 64u * 1024u)
 	{
 		static const hipError_t once = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, true>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
 		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_emit): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
 	}
 #define LAUNCH_EMIT(V) do { if (ldsh) hipLaunchKernelGGL((k_emit<V, true>), grid, block, lds, c.stream, e); \

@@ -220,6 +220,26 @@ def test_tile_sort_size_classes(P):
     check_image(got["color"], want["color"])
 
 
+def test_1440p_tile_grid_keeps_tables_in_lds():
+    """2560x1440 -> 14400 tiles: the largest class of tile grids whose per-workgroup histogram (56 KiB) and RF tile
+    table (58 KiB) still live in LDS (one binning workgroup per CU)."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    cloud = syn.scene_1k(P=1200, seed=21)
+    cloud._scaling += 0.4
+    cam = syn.camera_1k(2560, 1440, 70.0)
+    fov = syn.foveation_layers(cloud, seed=22)
+    scene, cd = scene_dict(cloud, "fov_pcheck_obb", fov), cam_dict(cam, gaze=(0.35, 0.55))
+    want = orc.forward("fov_pcheck_obb", scene, cd)
+    for packed in (False, True):
+        got = hip_forward("fov_pcheck_obb", scene, cd, packed=packed)
+        assert got["num_rendered"] == want["num_rendered"]
+        np.testing.assert_array_equal(got["radii"], want["radii"])
+        np.testing.assert_array_equal(got["ranges"], want["ranges"])
+        np.testing.assert_array_equal(got["point_list"], want["point_list"])
+        check_image(got["color"], want["color"])
+
+
 @pytest.mark.parametrize("variant", ("pcheck_obb", "fov_pcheck_obb"))
 def test_huge_tile_grid_uses_global_counter_path(variant):
     """More than 16384 tiles (4096x2160 -> 34560): the per-workgroup LDS histograms do not fit and the
