@@ -133,6 +133,11 @@ int fr_forward(fr_forward_args *a)
 	c.geom = carve_geom(a->variant, (size_t)a->P, gptr);
 	c.img = carve_image(a->variant, a->W, a->H, iptr);
 
+	static const bool no_split = getenv("FR_NO_FOV_SPLIT") != nullptr;
+	c.fov_split = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && !no_split) ? 1 : 0;
+	// the two waves of a two-level tile ADD their halves to the image (clearing only those tiles inside k_tile_levels
+	// tripled that kernel: 11 -> 32 us; the fill command is 6 us)
+	if (c.fov_split) FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, stream));
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
 	if (a->variant != FR_VARIANT_FOV_PCHECK_OBB) // RF: k_tile_levels clears them
 		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));

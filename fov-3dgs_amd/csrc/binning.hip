@@ -362,8 +362,7 @@ int launch_tile_scan(FwdCtx &c)
 // Helper stream of the calling host thread (per device), created on first use. The size classes of the per-tile
 // sort are independent kernels; the two classes with long lists hold a handful of tiles that each keep one CU busy
 // for 50-80 us, so the (many) short lists are sorted meanwhile on the helper stream (event fork / join).
-struct AuxStream { int device = -1; hipStream_t s, s2; hipEvent_t fork, join, join2; bool ok = false; };
-static AuxStream *aux_stream()
+AuxStream *aux_stream()
 {
 	static thread_local AuxStream cache[8];
 	int dev = 0;

@@ -337,6 +337,7 @@ struct FwdCtx {
 	fr_forward_args *a;
 	hipStream_t stream;
 	int gx, gy, T;
+	int fov_split;      // RF: the two level states of a two-level tile go to different waves (out_color was zero-filled)
 	int bin_wgs;        // workgroups k_bin ran with (k_emit replays the same number)
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
 	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4] (+ sequence word), or null
@@ -346,6 +347,8 @@ struct FwdCtx {
 	ImageWS img;
 	BinWS bin;
 };
+struct AuxStream { int device = -1; hipStream_t s, s2; hipEvent_t fork, join, join2; bool ok = false; };
+AuxStream *aux_stream(); // helper streams of the calling host thread (binning.hip)
 int launch_tile_levels(FwdCtx &c);
 int launch_pack_geom(int P, const float *means3D, const float *scales, const float *rotations, const float *opacities, int levels,
 	const float *highest_levels, float *out, hipStream_t stream);

@@ -374,7 +374,12 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 }
 
 // ---------------- FOV_PCHECK_OBB: single-level and two-level tiles ----------------
-template <int PPL>
+// SPLIT: the two level states of a two-level tile are blended by DIFFERENT waves (grid = tiles x NW x 2): every wave
+// then carries one state (63 instead of 86 registers: 8 waves per SIMD) and half the instructions per entry -- the
+// frame ends with its slowest two-level tile, whose wave walks ~900 entries at ~200 ns each. The two partial results
+// o * w1 and q * (1 - w1) are the two rounded products the reference adds (forward.cu:466-470); they meet by float
+// atomicAdd on a zero-filled pixel, and x + y == y + x bit for bit, so the image does not depend on who comes first.
+template <int PPL, bool SPLIT = false>
 __global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
 {
 	// The waves of a tile (each owning a band of 16 / NW rows) are INDEPENDENT: every wave walks the whole list in
@@ -388,7 +393,9 @@ __global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
 	__shared__ float4 sl1[64];  // level L1: r, g, b, opacity
 	__shared__ float4 sl2[64];  // level L2 (two-level tiles only)
 
-	const int slot = (int)blockIdx.x / NW, wv = (int)blockIdx.x % NW;
+	const int wblk = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
+	const int lev = SPLIT ? (int)blockIdx.x & 1 : 0; // SPLIT: which of the two level states this wave blends
+	const int slot = wblk / NW, wv = wblk % NW;
 	const int tile = a.tile_order ? (int)a.tile_order[slot] : slot;
 	const int tx = tile % a.gx, ty = tile / a.gx;
 	const int lane = threadIdx.x;
@@ -399,7 +406,10 @@ __global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
 	const uint2 range = a.ranges[tile];
 	const int n = (int)(range.y - range.x);
 	const float tlf = a.tile_lv[a.T + tile];                    // tile_min
-	const bool blending = a.tile_lv[4 * (size_t)a.T + tile] != 0.0f;
+	const bool two_level = a.tile_lv[4 * (size_t)a.T + tile] != 0.0f;
+	if (SPLIT && !two_level && lev == 1) return;
+	const bool blending = SPLIT ? false : two_level;   // two states in this wave
+	const bool upper = SPLIT && two_level && lev == 1; // SPLIT: this wave carries the state of level L2 (in S1)
 	const int L1 = f2i(tlf);
 	const int L2 = L1 + 1;
 	const float L2f = tlf + 1.0f;
@@ -422,7 +432,7 @@ __global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
 		inside[k] = px < a.W && py < a.H;
 		est[k] = tlf + ((float)lx * tgx + (float)ly * tgy) / (float)FR_TILE;
 		// RF forward.cu:262-476: level L1 stops contributing beyond est > L2; single-level tiles have no second state
-		const bool done1 = blending ? (!inside[k] || (est[k] > (float)L2)) : !inside[k];
+		const bool done1 = (blending || (SPLIT && two_level && !upper)) ? (!inside[k] || (est[k] > (float)L2)) : !inside[k];
 		const bool done2 = blending ? !inside[k] : true;
 		S1[k >> 1].T[k & 1] = done1 ? -1.0f : 1.0f;
 		S2[k >> 1].T[k & 1] = done2 ? -1.0f : 1.0f;
@@ -443,7 +453,7 @@ __global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
 		p0 = r[0];
 		const float4 r1 = r[1];
 		p1 = make_float2(r1.x, r1.y);
-		pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + L1];
+		pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + (upper ? L2 : L1)];
 		if (blending) pl2 = a.lvl[(size_t)id * FR_FOV_LEVELS + L2];
 	};
 	if (lane < n) fetch(lane);
@@ -505,6 +515,11 @@ __global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
 			}
 			t.c1 = sl1[j];
 			t.l2_ok = !((g1.y + 1.0f) < L2f); // the Gaussian exists at level L2
+			if (upper)
+			{
+#pragma unroll
+				for (int h = 0; h < HP; h++) { t.inx[h] = t.inx[h] && t.l2_ok; t.iny[h] = t.iny[h] && t.l2_ok; }
+			}
 			t.c2 = t.c1;
 			if (blending) t.c2 = sl2[j];
 			return t;
@@ -572,6 +587,18 @@ __global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
 			o1 = o1 * w1 + q1 * (1.f - w1);
 			o2 = o2 * w1 + q2 * (1.f - w1);
 		}
+		if (SPLIT && two_level)
+		{
+			float x = fabsf(est[k] - ((float)L1 + 0.5f)) / 0.5f;
+			x = fmaxf(0.0f, fminf(1.0f, x));
+			const float bT = 3 * x * x - 2 * x * x * x;
+			const float w1 = 1 - bT;
+			const float w = upper ? (1.f - w1) : w1;
+			atomicAdd(&a.out_color[pid], o0 * w);
+			atomicAdd(&a.out_color[plane + pid], o1 * w);
+			atomicAdd(&a.out_color[2 * plane + pid], o2 * w);
+			continue;
+		}
 		a.out_color[pid] = o0;
 		a.out_color[plane + pid] = o1;
 		a.out_color[2 * plane + pid] = o2;
@@ -609,7 +636,8 @@ int launch_render(FwdCtx &c)
 		// The frame ends when the tile that blends the most entries ends, and a wave works through its list
 		// serially: two waves of two rows per lane make that chain ~1.6x shorter than one wave of four rows for
 		// ~30 % more instructions in total (measured 374 -> 286 us on the bench frame).
-		hipLaunchKernelGGL((k_render_fov<FR_RENDER_FOV_PPL>), dim3(c.T * (256 / FR_RENDER_FOV_PPL / 64)), dim3(64), 0, c.stream, r);
+		if (c.fov_split) hipLaunchKernelGGL((k_render_fov<FR_RENDER_FOV_PPL, true>), dim3(2 * c.T * (256 / FR_RENDER_FOV_PPL / 64)), dim3(64), 0, c.stream, r);
+		else hipLaunchKernelGGL((k_render_fov<FR_RENDER_FOV_PPL>), dim3(c.T * (256 / FR_RENDER_FOV_PPL / 64)), dim3(64), 0, c.stream, r);
 		break;
 	}
 	return check_launch("render", c.stream, a->debug);

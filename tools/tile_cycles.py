@@ -38,3 +38,10 @@ end = st * 10 + cyc
 print("end ns: p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(end, [50, 90, 99, 100])))
 late = np.argsort(-end)[:8]
 for t in late: print("late tile", t, "n", n[t], "processed", nc[t], "hit", nh[t], "start", st[t] * 10, "dur", cyc[t])
+
+lv = view(lib.fr_image_tile_levels(W, H, img.data_ptr()), 5 * T, torch.float32).cpu().numpy().reshape(5, T)
+bl = lv[4] != 0
+print("blend tiles", int(bl.sum()), "of", T, " wave time ns mean: blend %.0f single %.0f; ns/processed entry: blend %.1f single %.1f" % (
+    cyc[bl].mean(), cyc[~bl].mean(), cyc[bl].sum() / max(nc[bl].sum(), 1), cyc[~bl].sum() / max(nc[~bl].sum(), 1)))
+print("slowest 20 tiles: blend among them", int(bl[np.argsort(-cyc)[:20]].sum()), " longest list among blend", n[bl].max(), "single", n[~bl].max())
+print("sum wave time: blend %.2f ms single %.2f ms" % (cyc[bl].sum() / 1e6, cyc[~bl].sum() / 1e6))
