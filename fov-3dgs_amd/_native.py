@@ -63,7 +63,9 @@ class BackwardArgs(C.Structure):
 
 EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible", "fr_pack_geom", "fr_pack_colour", "fr_pack_cull", "fr_activate_forward", "fr_activate_backward", "fr_l1_ssim_blocks", "fr_l1_ssim_forward", "fr_l1_ssim_backward",
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
-           "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records")
+           "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records",
+           "fr_geometry_vis_list", "fr_geometry_vis_count", "fr_geometry_walk_records", "fr_geometry_level_colours",
+           "fr_geometry_level_ranges")
 
 _lib = None
 
@@ -131,6 +133,12 @@ def load():
     lib.fr_binning_point_list.restype = C.c_void_p
     lib.fr_geometry_records.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
     lib.fr_geometry_records.restype = C.c_void_p
+    for n in ("fr_geometry_vis_list", "fr_geometry_vis_count", "fr_geometry_walk_records"):
+        getattr(lib, n).argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+        getattr(lib, n).restype = C.c_void_p
+    for n in ("fr_geometry_level_colours", "fr_geometry_level_ranges"):
+        getattr(lib, n).argtypes = [C.c_int32, C.c_void_p]
+        getattr(lib, n).restype = C.c_void_p
     lib.fr_image_tile_levels.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
     lib.fr_image_tile_levels.restype = C.c_void_p
     if lib.fr_abi_version() != ABI_VERSION:

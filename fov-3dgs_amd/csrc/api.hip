@@ -104,6 +104,11 @@ const uint32_t *fr_binning_point_list(int32_t variant, int64_t n, const char *bi
 const float *fr_image_final_T(int32_t variant, int32_t W, int32_t H, const char *image) { return carve_image(variant, W, H, (char *)image).final_T; }
 const uint32_t *fr_image_n_contrib(int32_t variant, int32_t W, int32_t H, const char *image) { return carve_image(variant, W, H, (char *)image).n_contrib; }
 const float *fr_geometry_records(int32_t variant, int32_t P, const char *geometry) { return (const float *)carve_geom(variant, (size_t)P, (char *)geometry).rec; }
+const uint32_t *fr_geometry_vis_list(int32_t variant, int32_t P, const char *geometry) { return carve_geom(variant, (size_t)P, (char *)geometry).vis_list; }
+const uint32_t *fr_geometry_vis_count(int32_t variant, int32_t P, const char *geometry) { return carve_geom(variant, (size_t)P, (char *)geometry).slab_ctr + 1; }
+const float *fr_geometry_walk_records(int32_t variant, int32_t P, const char *geometry) { return (const float *)carve_geom(variant, (size_t)P, (char *)geometry).wrec; }
+const float *fr_geometry_level_colours(int32_t P, const char *geometry) { return (const float *)carve_geom(FR_VARIANT_FOV_PCHECK_OBB, (size_t)P, (char *)geometry).lvl; }
+const uint32_t *fr_geometry_level_ranges(int32_t P, const char *geometry) { return carve_geom(FR_VARIANT_FOV_PCHECK_OBB, (size_t)P, (char *)geometry).lrange; }
 const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image) { return carve_image(FR_VARIANT_FOV_PCHECK_OBB, W, H, (char *)image).tile_lv; }
 
 int fr_forward(fr_forward_args *a)

@@ -223,6 +223,18 @@ const uint32_t *fr_image_n_contrib(int32_t variant, int32_t W, int32_t H, const 
 const float *fr_geometry_records(int32_t variant, int32_t P, const char *geometry);
 /* RF: device pointer to float[5][T] = levels, tile_min, grad_x, grad_y, blending(0/1 as float) */
 const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image);
+/* the Gaussians that survived projection, in the (unordered) order the binning kernels list them: uint32 [count], with
+ * count = *fr_geometry_vis_count (a device word) */
+const uint32_t *fr_geometry_vis_list(int32_t variant, int32_t P, const char *geometry);
+const uint32_t *fr_geometry_vis_count(int32_t variant, int32_t P, const char *geometry);
+/* walk record of vis_list entry i: float[16] = (centre x, y, OBB axis 1 x, y | axis 2 x, y, half length 1, 2 |
+ * id + flags << 30, depth bits, clipped rectangle x0 + y0 << 16, its width | tiles, highest level, -, -)
+ * -- what the reference keeps as eigen_vecs / eigen_lengths (RS forward.cu:244-265) */
+const float *fr_geometry_walk_records(int32_t variant, int32_t P, const char *geometry);
+/* RF: per-Gaussian per-level (r, g, b, opacity) float[P][4][4] (compute_fov_colors, RF rasterizer_impl.cu:490-530; only
+ * the levels of the Gaussian's level range are written) and the packed level ranges uint32 [P] = lo | hi << 8 */
+const float *fr_geometry_level_colours(int32_t P, const char *geometry);
+const uint32_t *fr_geometry_level_ranges(int32_t P, const char *geometry);
 
 #ifdef __cplusplus
 }

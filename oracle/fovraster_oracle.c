@@ -1,7 +1,7 @@
 /*
  * fovraster_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
  *
- * A plain-C, single-threaded restatement of the rasterizer hot path of
+ * A plain-C restatement of the rasterizer hot path of
  * horizon-research/Fov-3DGS (the tile-based 3D-Gaussian-splatting rasterizer
  * behind GaussianRasterizer / gaussian_renderer_fov.render()).  It exists so
  * that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can
@@ -36,6 +36,23 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* Threads: every loop over Gaussians / tiles below is independent per iteration, so the build with -fopenmp may
+ * spread them over host cores (orc_set_threads; default 1 = the plain serial program). Integer / index outputs and
+ * images are identical for any thread count (each iteration owns its outputs; the instance order is a total order);
+ * only the per-Gaussian sums that cross tiles (RS contributions, backward gradients) are accumulated by atomic adds
+ * in DOUBLE, whose order may move the rounded float by an ulp. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return g_threads; }
+#ifdef _OPENMP
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_PARALLEL_FOR(...) ORC_PRAGMA(omp parallel for schedule(__VA_ARGS__) num_threads(g_threads))
+#define ORC_ATOMIC ORC_PRAGMA(omp atomic)
+#else
+#define ORC_PARALLEL_FOR(...)
+#define ORC_ATOMIC
+#endif
 
 #ifdef ORC_DOUBLE
 typedef double real;
@@ -343,6 +360,8 @@ static int preprocess(const orc_in *in, orc_out *o)
 	const real focal_x = W / ((real)2.0 * in->tanfovx);
 	const int with_eigen = in->variant != ORC_R0;
 	const int with_sh = in->variant != ORC_RF;
+	int trapped = 0;
+	ORC_PARALLEL_FOR(static)
 	for (int idx = 0; idx < P; idx++)
 	{
 		o->radii[idx] = 0;
@@ -357,7 +376,7 @@ static int preprocess(const orc_in *in, orc_out *o)
 		transformPoint4x3(p_orig, in->viewmatrix, p_view);
 		if (p_view[2] <= (real)0.2f)
 		{
-			if (in->prefiltered) return -1;
+			if (in->prefiltered) trapped = 1; /* benign race: every writer stores 1 */
 			continue;
 		}
 		const real *cov3D;
@@ -424,7 +443,7 @@ static int preprocess(const orc_in *in, orc_out *o)
 		o->tiles_rect[idx] = tnum;
 		o->tiles_touched[idx] = tnum;
 	}
-	return 0;
+	return trapped ? -1 : 0;
 }
 
 /* ---------------- RF tile level map ----------------
@@ -508,6 +527,106 @@ static int inst_cmp(const void *a, const void *b)
 	if (x->seq != y->seq) return x->seq < y->seq ? -1 : 1;
 	return 0;
 }
+/* One Gaussian's walk over its tile rectangle with the cull tests of its variant. emit == NULL: the counting pass
+ * (tiles_touched, the radii reset, RF level_ranges -- the per-Gaussian outputs of OBB_test / filter); emit != NULL:
+ * the duplicateWithKeys pass, instances inside the tile window are written to emit[0..] with sequence numbers seq0..
+ * Returns the number of in-window instances. */
+static int64_t walk_one(const orc_in *in, orc_out *o, int idx, int gx, int gy, int twn, int cull, int fov, inst_t *emit, int64_t seq0)
+{
+	if (!(o->radii[idx] > 0)) return 0;
+	int64_t n = 0;
+#define ORC_EMIT(X, Y) do { if (in_window(in, (X), (Y))) { if (emit) { emit[n].tile = (uint32_t)((Y) * gx + (X)); emit[n].depth = o->depths[idx]; \
+	emit[n].id = (uint32_t)idx; emit[n].seq = (uint64_t)(seq0 + n); } n++; } } while (0)
+	int rmin[2], rmax[2];
+	real px = o->means2D[2 * idx], py = o->means2D[2 * idx + 1];
+	getRect(px, py, o->radii[idx], rmin, rmax, gx, gy);
+	uint32_t tnum = (uint32_t)(rmax[1] - rmin[1]) * (uint32_t)(rmax[0] - rmin[0]);
+	uint32_t count = 0;
+	real hl = fov ? in->highest_levels[idx] : 0;
+	real lowest = hl, highest = 0;
+	int be_blend = 0;
+	if (!cull)
+	{
+		for (int y = rmin[1]; y < rmax[1]; y++)
+			for (int x = rmin[0]; x < rmax[0]; x++)
+			{
+				ORC_EMIT(x, y);
+				count++;
+			}
+	}
+	else if (tnum == 1)
+	{
+		int keep = 1;
+		if (fov)
+		{
+			uint32_t ti = (uint32_t)(rmin[1] * twn + rmin[0]);
+			real level = o->tile_min[ti];
+			keep = level < (hl + 1);
+			if (keep) { lowest = level; highest = level; be_blend = o->tile_blend[ti] || be_blend; }
+		}
+		if (keep)
+		{
+			ORC_EMIT(rmin[0], rmin[1]);
+			count = 1;
+		}
+	}
+	else
+	{
+		const real *ev = o->eigen_vec + 4 * idx;
+		real e1[2] = { ev[0], ev[1] }, e2[2] = { ev[2], ev[3] };
+		real len1 = o->eigen_len[2 * idx], len2 = o->eigen_len[2 * idx + 1];
+		real c[2] = { px, py };
+		real d1x = len1 * e1[0], d1y = len1 * e1[1], d2x = len2 * e2[0], d2y = len2 * e2[1];
+		real vtx[4][2] = {
+			{ c[0] + d1x + d2x, c[1] + d1y + d2y },
+			{ c[0] - d1x + d2x, c[1] - d1y + d2y },
+			{ c[0] - d1x - d2x, c[1] - d1y - d2y },
+			{ c[0] + d1x - d2x, c[1] + d1y - d2y } };
+		for (int y = rmin[1]; y < rmax[1]; y++)
+			for (int x = rmin[0]; x < rmax[0]; x++)
+			{
+				int inside = 1;
+				real level = 0; int blending = 0;
+				if (fov)
+				{
+					uint32_t ti = (uint32_t)(y * twn + x);
+					blending = o->tile_blend[ti];
+					level = o->tile_min[ti];
+					inside = level < (hl + 1);
+				}
+				if (inside)
+				{
+					real tpx = (real)x * (real)BLOCK_X + (real)BLOCK_X / (real)2.0f;
+					real tpy = (real)y * (real)BLOCK_Y + (real)BLOCK_Y / (real)2.0f;
+					inside = OBB_check(tpx, tpy, vtx, c, e1, e2, len1, len2);
+					if (inside)
+					{
+						count++;
+						if (fov)
+						{
+							lowest = r_fmin(lowest, level); highest = r_fmax(highest, level);
+							be_blend = blending || be_blend;
+						}
+						ORC_EMIT(x, y);
+					}
+				}
+			}
+	}
+#undef ORC_EMIT
+	if (emit) return n;
+	o->tiles_touched[idx] = count;
+	if (cull && count == 0) o->radii[idx] = 0;
+	else if (fov)
+	{
+		/* RF rasterizer_impl.cu:374-381 */
+		o->level_ranges[2 * idx] = f2i(lowest);
+		int hi = f2i(highest);
+		if (be_blend) hi = imin(hi + 1, FOV_NUM - 1);
+		o->level_ranges[2 * idx + 1] = hi;
+	}
+	return n;
+}
+
 static int64_t bin_and_sort(const orc_in *in, orc_out *o)
 {
 	const int P = in->P, W = in->W, H = in->H;
@@ -517,99 +636,38 @@ static int64_t bin_and_sort(const orc_in *in, orc_out *o)
 	int64_t d0 = 0;
 	for (int i = 0; i < P; i++) d0 += o->tiles_rect[i];
 	o->num_rect = d0;
-	inst_t *inst = (inst_t *)malloc(sizeof(inst_t) * (size_t)(d0 > 0 ? d0 : 1));
-	int64_t n = 0;
-	for (int idx = 0; idx < P; idx++)
-	{
-		if (!(o->radii[idx] > 0)) continue;
-		int rmin[2], rmax[2];
-		real px = o->means2D[2 * idx], py = o->means2D[2 * idx + 1];
-		getRect(px, py, o->radii[idx], rmin, rmax, gx, gy);
-		uint32_t tnum = (uint32_t)(rmax[1] - rmin[1]) * (uint32_t)(rmax[0] - rmin[0]);
-		uint32_t count = 0;
-		real hl = fov ? in->highest_levels[idx] : 0;
-		real lowest = hl, highest = 0;
-		int be_blend = 0;
-		if (!cull)
-		{
-			for (int y = rmin[1]; y < rmax[1]; y++)
-				for (int x = rmin[0]; x < rmax[0]; x++)
-				{
-					if (in_window(in, x, y)) { inst[n].tile = (uint32_t)(y * gx + x); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++; }
-					count++;
-				}
-		}
-		else if (tnum == 1)
-		{
-			int keep = 1;
-			if (fov)
-			{
-				uint32_t ti = (uint32_t)(rmin[1] * twn + rmin[0]);
-				real level = o->tile_min[ti];
-				keep = level < (hl + 1);
-				if (keep) { lowest = level; highest = level; be_blend = o->tile_blend[ti] || be_blend; }
-			}
-			if (keep)
-			{
-				if (in_window(in, rmin[0], rmin[1])) { inst[n].tile = (uint32_t)(rmin[1] * gx + rmin[0]); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++; }
-				count = 1;
-			}
-		}
-		else
-		{
-			const real *ev = o->eigen_vec + 4 * idx;
-			real e1[2] = { ev[0], ev[1] }, e2[2] = { ev[2], ev[3] };
-			real len1 = o->eigen_len[2 * idx], len2 = o->eigen_len[2 * idx + 1];
-			real c[2] = { px, py };
-			real d1x = len1 * e1[0], d1y = len1 * e1[1], d2x = len2 * e2[0], d2y = len2 * e2[1];
-			real vtx[4][2] = {
-				{ c[0] + d1x + d2x, c[1] + d1y + d2y },
-				{ c[0] - d1x + d2x, c[1] - d1y + d2y },
-				{ c[0] - d1x - d2x, c[1] - d1y - d2y },
-				{ c[0] + d1x - d2x, c[1] + d1y - d2y } };
-			for (int y = rmin[1]; y < rmax[1]; y++)
-				for (int x = rmin[0]; x < rmax[0]; x++)
-				{
-					int inside = 1;
-					real level = 0; int blending = 0;
-					if (fov)
-					{
-						uint32_t ti = (uint32_t)(y * twn + x);
-						blending = o->tile_blend[ti];
-						level = o->tile_min[ti];
-						inside = level < (hl + 1);
-					}
-					if (inside)
-					{
-						real tpx = (real)x * (real)BLOCK_X + (real)BLOCK_X / (real)2.0f;
-						real tpy = (real)y * (real)BLOCK_Y + (real)BLOCK_Y / (real)2.0f;
-						inside = OBB_check(tpx, tpy, vtx, c, e1, e2, len1, len2);
-						if (inside)
-						{
-							count++;
-							if (fov)
-							{
-								lowest = r_fmin(lowest, level); highest = r_fmax(highest, level);
-								be_blend = blending || be_blend;
-							}
-							if (in_window(in, x, y)) { inst[n].tile = (uint32_t)(y * gx + x); inst[n].depth = o->depths[idx]; inst[n].id = idx; inst[n].seq = n; n++; }
-						}
-					}
-				}
-		}
-		o->tiles_touched[idx] = count;
-		if (cull && count == 0) o->radii[idx] = 0;
-		else if (fov)
-		{
-			/* RF rasterizer_impl.cu:374-381 */
-			o->level_ranges[2 * idx] = f2i(lowest);
-			int hi = f2i(highest);
-			if (be_blend) hi = imin(hi + 1, FOV_NUM - 1);
-			o->level_ranges[2 * idx + 1] = hi;
-		}
-	}
+	/* pass 1: per-Gaussian counts (the reference's OBB_test / filter kernel + InclusiveSum) */
+	int64_t *offs = (int64_t *)malloc(sizeof(int64_t) * ((size_t)P + 1));
+	ORC_PARALLEL_FOR(dynamic, 1024)
+	for (int idx = 0; idx < P; idx++) offs[idx + 1] = walk_one(in, o, idx, gx, gy, twn, cull, fov, NULL, 0);
+	offs[0] = 0;
+	for (int i = 0; i < P; i++) offs[i + 1] += offs[i];
+	const int64_t n = offs[P];
 	o->num_rendered = n;
-	qsort(inst, (size_t)n, sizeof(inst_t), inst_cmp);
+	/* pass 2: duplicateWithKeys; the sequence number is the position the serial reference loop would emit at */
+	inst_t *inst = (inst_t *)malloc(sizeof(inst_t) * (size_t)(n > 0 ? n : 1));
+	ORC_PARALLEL_FOR(dynamic, 1024)
+	for (int idx = 0; idx < P; idx++)
+		if (offs[idx + 1] > offs[idx]) walk_one(in, o, idx, gx, gy, twn, cull, fov, inst + offs[idx], offs[idx]);
+	free(offs);
+	/* stable sort by (tile, depth): buckets by tile (counting sort, keeps emission order), then every bucket by
+	 * (depth, sequence) -- the same total order as one sort over (tile, depth, sequence) */
+	int64_t *tstart = (int64_t *)calloc((size_t)T + 1, sizeof(int64_t));
+	for (int64_t i = 0; i < n; i++) tstart[inst[i].tile + 1]++;
+	for (int t = 0; t < T; t++) tstart[t + 1] += tstart[t];
+	inst_t *sorted = (inst_t *)malloc(sizeof(inst_t) * (size_t)(n > 0 ? n : 1));
+	{
+		int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * ((size_t)T + 1));
+		memcpy(cur, tstart, sizeof(int64_t) * ((size_t)T + 1));
+		for (int64_t i = 0; i < n; i++) sorted[cur[inst[i].tile]++] = inst[i];
+		free(cur);
+	}
+	free(inst);
+	inst = sorted;
+	ORC_PARALLEL_FOR(dynamic, 8)
+	for (int t = 0; t < T; t++)
+		if (tstart[t + 1] - tstart[t] > 1) qsort(inst + tstart[t], (size_t)(tstart[t + 1] - tstart[t]), sizeof(inst_t), inst_cmp);
+	free(tstart);
 	/* identifyTileRanges: R0 rasterizer_impl.cu:116-138 (+ memset :310) */
 	memset(o->ranges, 0, sizeof(uint32_t) * 2 * (size_t)T);
 	for (int64_t i = 0; i < n; i++)
@@ -644,6 +702,7 @@ static int64_t bin_and_sort(const orc_in *in, orc_out *o)
 /* RF rasterizer_impl.cu:490-530 */
 static void compute_fov_colors(const orc_in *in, orc_out *o)
 {
+	ORC_PARALLEL_FOR(static)
 	for (int idx = 0; idx < in->P; idx++)
 	{
 		if (!(o->radii[idx] > 0)) continue;
@@ -678,9 +737,15 @@ static void render_plain(const orc_in *in, orc_out *o)
 		contrib = (double *)calloc((size_t)in->P, sizeof(double));
 		memset(o->gaussians_count, 0, sizeof(int32_t) * (size_t)in->P);
 	}
-	for (int ty = 0; ty < gy; ty++)
-		for (int tx = 0; tx < gx; tx++)
+	/* the running-maximum statistics of RMAX / LWMC are not associative under atomics: those two stay serial */
+	const int nthreads = (variant == ORC_RMAX || variant == ORC_LWMC) ? 1 : g_threads;
+	(void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+	for (int tile = 0; tile < gx * gy; tile++)
 		{
+			const int ty = tile / gx, tx = tile % gx;
 			if (!in_window(in, tx, ty)) continue;
 			const uint32_t r0 = o->ranges[2 * (ty * gx + tx)], r1 = o->ranges[2 * (ty * gx + tx) + 1];
 			const int n = (int)(r1 - r0);
@@ -717,7 +782,7 @@ static void render_plain(const orc_in *in, orc_out *o)
 						}
 						else
 							for (int ch = 0; ch < 3; ch++) C[ch] += o->rgb[3 * g + ch] * alpha * T;
-						if (variant == ORC_RS) contrib[g] += (double)(alpha * T);
+						if (variant == ORC_RS) { ORC_ATOMIC contrib[g] += (double)(alpha * T); }
 						else if (variant == ORC_RMAX) { if ((double)(alpha * T) > contrib[g]) contrib[g] = (double)(alpha * T); } /* atomicMaxFloat, …_max forward.cu:400 */
 						else if (variant == ORC_LWMC) { const real cv = alpha * T; if (cv > max_point_contrib) { max_point_contrib = cv; max_point_idx = (int)g; } }
 						T = test_T;
@@ -740,7 +805,7 @@ static void render_plain(const orc_in *in, orc_out *o)
 				int rounds = (n + BLOCK_SIZE - 1) / BLOCK_SIZE;
 				int executed = never_done ? rounds : imin(rounds, (all_done_pos + BLOCK_SIZE - 1) / BLOCK_SIZE);
 				int fetched = imin(n, executed * BLOCK_SIZE);
-				for (int j = 0; j < fetched; j++) o->gaussians_count[o->point_list[r0 + j]] += 1;
+				for (int j = 0; j < fetched; j++) { ORC_ATOMIC o->gaussians_count[o->point_list[r0 + j]] += 1; }
 			}
 		}
 	if (contrib)
@@ -758,9 +823,10 @@ static void render_fov(const orc_in *in, orc_out *o)
 	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 	const int twn = (W + 15) / BLOCK_X;
 	const real start_blend = (real)0.5f, blend_width = (real)0.5f;
-	for (int ty = 0; ty < gy; ty++)
-		for (int tx = 0; tx < gx; tx++)
+	ORC_PARALLEL_FOR(dynamic, 4)
+	for (int tile = 0; tile < gx * gy; tile++)
 		{
+			const int ty = tile / gx, tx = tile % gx;
 			if (!in_window(in, tx, ty)) continue;
 			const uint32_t r0 = o->ranges[2 * (ty * gx + tx)], r1 = o->ranges[2 * (ty * gx + tx) + 1];
 			const int n = (int)(r1 - r0);
@@ -885,6 +951,7 @@ void orc_sh_colors(const orc_in *in, int rest, real *out)
 /* R0 rasterizer_impl.cu:54-66 (checkFrustum / mark_visible) */
 void orc_mark_visible(const orc_in *in, uint8_t *present)
 {
+	ORC_PARALLEL_FOR(static)
 	for (int i = 0; i < in->P; i++)
 	{
 		real pv[3];
@@ -904,9 +971,10 @@ static void backward_render(const orc_in *in, const orc_out *o, const real *dL_d
 	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 	const int cutoff = in->variant != ORC_R0;
 	const real ddelx_dx = (real)(0.5 * W), ddely_dy = (real)(0.5 * H);
-	for (int ty = 0; ty < gy; ty++)
-		for (int tx = 0; tx < gx; tx++)
+	ORC_PARALLEL_FOR(dynamic, 4)
+	for (int tile = 0; tile < gx * gy; tile++)
 		{
+			const int ty = tile / gx, tx = tile % gx;
 			const uint32_t r0 = o->ranges[2 * (ty * gx + tx)], r1 = o->ranges[2 * (ty * gx + tx) + 1];
 			const int n = (int)(r1 - r0);
 			for (int ly = 0; ly < BLOCK_Y; ly++)
@@ -946,7 +1014,7 @@ static void backward_render(const orc_in *in, const orc_out *o, const real *dL_d
 							last_color[ch] = c;
 							const real dL_dchannel = dL_dpixel[ch];
 							dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-							d_color[3 * g + ch] += (double)(dchannel_dcolor * dL_dchannel);
+							{ ORC_ATOMIC d_color[3 * g + ch] += (double)(dchannel_dcolor * dL_dchannel); }
 						}
 						dL_dalpha *= T;
 						last_alpha = alpha;
@@ -957,12 +1025,12 @@ static void backward_render(const orc_in *in, const orc_out *o, const real *dL_d
 						const real gdx = G * dx, gdy = G * dy;
 						const real dG_ddelx = -gdx * ca - gdy * cb;
 						const real dG_ddely = -gdy * cc - gdx * cb;
-						d_mean2D[2 * g] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-						d_mean2D[2 * g + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
-						d_conic[3 * g] += (double)((real)-0.5f * gdx * dx * dL_dG);
-						d_conic[3 * g + 1] += (double)((real)-0.5f * gdx * dy * dL_dG);
-						d_conic[3 * g + 2] += (double)((real)-0.5f * gdy * dy * dL_dG);
-						d_opacity[g] += (double)(G * dL_dalpha);
+						{ ORC_ATOMIC d_mean2D[2 * g] += (double)(dL_dG * dG_ddelx * ddelx_dx); }
+						{ ORC_ATOMIC d_mean2D[2 * g + 1] += (double)(dL_dG * dG_ddely * ddely_dy); }
+						{ ORC_ATOMIC d_conic[3 * g] += (double)((real)-0.5f * gdx * dx * dL_dG); }
+						{ ORC_ATOMIC d_conic[3 * g + 1] += (double)((real)-0.5f * gdx * dy * dL_dG); }
+						{ ORC_ATOMIC d_conic[3 * g + 2] += (double)((real)-0.5f * gdy * dy * dL_dG); }
+						{ ORC_ATOMIC d_opacity[g] += (double)(G * dL_dalpha); }
 					}
 				}
 		}
@@ -1175,6 +1243,7 @@ int orc_backward(const orc_in *in, const orc_out *o, orc_grads *g)
 	double *dop = (double *)calloc((size_t)P, sizeof(double));
 	double *dcl = (double *)calloc((size_t)P * 3, sizeof(double));
 	backward_render(in, o, g->dL_dpix, dm2, dcn, dop, dcl);
+	ORC_PARALLEL_FOR(static)
 	for (int i = 0; i < P; i++)
 	{
 		g->dL_dmean2D[3 * i] = (real)dm2[2 * i]; g->dL_dmean2D[3 * i + 1] = (real)dm2[2 * i + 1];
@@ -1185,6 +1254,7 @@ int orc_backward(const orc_in *in, const orc_out *o, orc_grads *g)
 	free(dm2); free(dcn); free(dop); free(dcl);
 	const real focal_y = in->H / ((real)2.0 * in->tanfovy), focal_x = in->W / ((real)2.0 * in->tanfovx);
 	const real *proj = in->projmatrix;
+	ORC_PARALLEL_FOR(dynamic, 1024)
 	for (int idx = 0; idx < P; idx++)
 	{
 		if (!(o->radii[idx] > 0)) continue;

@@ -32,12 +32,22 @@ def build(force=False):
         outs.append(out)
         if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(SRC):
             continue
-        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", *flags, "-o", out, SRC, "-lm"]
+        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-Wall", *flags, "-o", out, SRC, "-lm"]
         subprocess.check_call(cmd)
     return outs
 
 
 _LIBS = {}
+_THREADS = 1
+
+
+def set_threads(n):
+    """Host threads the oracle's per-Gaussian / per-tile loops are spread over (default 1). Index outputs and images
+    do not depend on it; per-Gaussian sums across tiles are accumulated in double by atomic adds."""
+    global _THREADS
+    _THREADS = max(1, int(n))
+    for lib in _LIBS.values():
+        lib.orc_set_threads(_THREADS)
 
 
 def _lib(dtype):
@@ -49,6 +59,7 @@ def _lib(dtype):
         lib.orc_backward.restype = C.c_int
         lib.orc_sizeof_real.restype = C.c_int
         assert lib.orc_sizeof_real() == key
+        lib.orc_set_threads(_THREADS)
         _LIBS[key] = lib
     return _LIBS[key]
 
@@ -157,7 +168,7 @@ def forward(variant, scene, cam, dtype=np.float32):
     keep = []
     inp, OrcOut, _, P, M, vi = _prep_inputs(variant, scene, cam, dtype, keep)
     W, H = inp.W, inp.H
-    capacity = 0
+    capacity = int(cam.get("capacity_hint", 0))  # saves the second pass when the caller knows a bound on the instances
     for _ in range(2):
         out, o = _alloc_outputs(OrcOut, P, W, H, dtype, capacity)
         n = lib.orc_forward(C.byref(inp), C.byref(out))
