@@ -155,7 +155,7 @@ def main():
     def step(i):
         gaze = syn.lissajous_gaze(i, 90)
         out = render_fov(cam, pc, bg, alpha=0.05, gazeArray=gaze, blending=True, highest_levels=highest,
-                         shs_dcs=shs_dcs, opacities=opac)
+                         shs_dcs=shs_dcs, opacities=opac, packed="auto")
         return out
 
     pending = None

@@ -41,6 +41,7 @@ static int validate_forward(const fr_forward_args *a)
 	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_PCHECK_OBB_LWMC) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
 	if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return FR_ERR_INVALID; }
 	if (a->P > (1 << 30) || a->W > 16 * 65535 || a->H > 16 * 65535) { set_error("too large: P=%d (max 2^30) W=%d H=%d (max 65535 tiles per axis)", a->P, a->W, a->H); return FR_ERR_INVALID; }
+	if ((int64_t)((a->W + FR_TILE - 1) / FR_TILE) * ((a->H + FR_TILE - 1) / FR_TILE) >= (1 << 29)) { set_error("too many tiles (W=%d H=%d)", a->W, a->H); return FR_ERR_INVALID; }
 	if (!a->out_color) { set_error("out_color is null"); return FR_ERR_INVALID; }
 	if (a->P == 0) return FR_OK;
 	if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->campos || !a->background || !a->radii)
@@ -138,10 +139,9 @@ int fr_forward(fr_forward_args *a)
 	c.geom = carve_geom(a->variant, (size_t)a->P, gptr);
 	c.img = carve_image(a->variant, a->W, a->H, iptr);
 
-	static const bool no_split = getenv("FR_NO_FOV_SPLIT") != nullptr;
-	c.fov_split = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && !no_split) ? 1 : 0;
-	// the two waves of a two-level tile ADD their halves to the image (clearing only those tiles inside k_tile_levels
-	// tripled that kernel: 11 -> 32 us; the fill command is 6 us)
+	// RF: the two level states of a two-level tile are blended by different waves, which ADD their halves to the image
+	// (clearing only those tiles inside k_tile_levels tripled that kernel: 11 -> 32 us; the fill command is 6 us)
+	c.fov_split = a->variant == FR_VARIANT_FOV_PCHECK_OBB ? 1 : 0;
 	if (c.fov_split) FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, stream));
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
 	if (a->variant != FR_VARIANT_FOV_PCHECK_OBB) // RF: k_tile_levels clears them
@@ -184,7 +184,7 @@ int fr_forward(fr_forward_args *a)
 	rc = launch_tile_scan(c); if (rc) return rc;
 	mark(FR_STAGE_EMIT);
 
-	uint32_t totals[4] = { 0, 0, 0, 0 };
+	uint32_t totals[6] = { 0, 0, 0, 0, 0, 0 };
 	if (!pinned) FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
 	if (pinned && !a->debug)
 	{
@@ -201,16 +201,18 @@ int fr_forward(fr_forward_args *a)
 				if (__atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != frame_seq) { set_error("tile scan did not publish its totals"); return FR_ERR_HIP; }
 			}
 		for (int i = 0; i < 4; i++) totals[i] = v[i];
+		totals[5] = v[5];
 	}
 	else
 	{
 		FR_HIP(hipStreamSynchronize(stream));
-		if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; }
+		if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; totals[5] = v[5]; }
 	}
 	if (totals[0] > 0x7fffffffu) { set_error("too many instances (%u)", totals[0]); return FR_ERR_INVALID; }
 	a->num_rendered = (int32_t)totals[0];
 	a->max_tile_instances = (int32_t)totals[1];
 	c.heavy4 = (int)totals[2]; c.heavy2 = (int)totals[3];
+	c.n_items = (int)totals[5];
 
 	char *bptr = a->binning_resize(a->resize_user[1], carve_bin(totals[0], nullptr).bytes);
 	if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }

@@ -18,16 +18,21 @@ namespace fr {
 
 // Single workgroup: exclusive scan of tile_count[T] -> ranges, reset the counters to serve as
 // emission cursors, publish {total, max}.
+// Also lays out the blend kernel's work items (render_items): one per wave that has something to do -- two bands per
+// tile, and for the RF two-level tiles (blend flag in tile_blend, null otherwise) one such pair per level state --
+// in the same longest-list-first order, so that the persistent blend waves pull the costliest items first and no
+// workgroup is launched just to find out that its tile has a single level.
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals, uint32_t *tile_order,
-	uint32_t *totals_host, uint32_t seq)
+	uint32_t *totals_host, uint32_t seq, const float *tile_blend, uint32_t *render_items)
 {
 	__shared__ uint32_t bucket[34];
+	__shared__ uint32_t ibucket[34];
 	__shared__ uint32_t wave_sum[16];
 	__shared__ uint32_t carry_s;
 	__shared__ uint32_t wave_max[16];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	if (tid == 0) carry_s = 0;
-	if (tid < 34) bucket[tid] = 0;
+	if (tid < 34) { bucket[tid] = 0; ibucket[tid] = 0; }
 	uint32_t vmax = 0;
 	__syncthreads();
 	// one pass: every thread owns a contiguous run of `per` tiles (8 at 1080p), sums it, the 1024 sums are scanned
@@ -41,6 +46,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		mine += v;
 		vmax = max(vmax, v);
 		atomicAdd(&bucket[v ? 32 - __clz((int)v) : 0], 1u); // bucket b: 2^(b-1) <= v < 2^b
+		atomicAdd(&ibucket[v ? 32 - __clz((int)v) : 0], (tile_blend && tile_blend[i] != 0.0f) ? 4u : 2u);
 	}
 	uint32_t s = mine; // inclusive scan inside the wave
 #pragma unroll
@@ -75,12 +81,16 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		for (int b = 12; b <= 32; b++) h4 += bucket[b];
 		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11];
 		totals[4] = 0; // chunk counter of k_split_long
+		uint32_t nitems = 0;
+		for (int b = 32; b >= 0; b--) { const uint32_t c = ibucket[b]; ibucket[b] = nitems; nitems += c; }
+		totals[5] = nitems;
 		// the host sizes the binning buffer from these: written straight into its pinned memory (no copy command)
 		// and followed by this frame's sequence number, which the host polls for (it then prepares the next launches
 		// while this kernel finishes)
 		if (totals_host)
 		{
 			totals_host[0] = carry_s; totals_host[1] = m; totals_host[2] = h4; totals_host[3] = bucket[10] + bucket[11];
+			totals_host[5] = nitems;
 			__threadfence_system();
 			__hip_atomic_store(&totals_host[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
@@ -97,6 +107,10 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		const uint32_t v = tile_count[i];
 		tile_order[atomicAdd(&bucket[v ? 32 - __clz((int)v) : 0], 1u)] = (uint32_t)i;
 		tile_count[i] = 0;
+		const uint32_t two = (tile_blend && tile_blend[i] != 0.0f) ? 1u : 0u;
+		uint32_t *it = render_items + atomicAdd(&ibucket[v ? 32 - __clz((int)v) : 0], two ? 4u : 2u);
+		it[0] = (uint32_t)i << 3 | two << 2; it[1] = (uint32_t)i << 3 | two << 2 | 1u;
+		if (two) { it[2] = (uint32_t)i << 3 | 4u | 2u; it[3] = (uint32_t)i << 3 | 4u | 2u | 1u; }
 	}
 }
 
@@ -355,7 +369,7 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 int launch_tile_scan(FwdCtx &c)
 {
 	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals, c.img.tile_order,
-		c.totals_host_dev, c.totals_seq);
+		c.totals_host_dev, c.totals_seq, c.img.tile_lv ? c.img.tile_lv + 4 * (size_t)c.T : (const float *)nullptr, c.img.render_items);
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 

@@ -89,7 +89,8 @@ struct ImageWS {
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
 	uint32_t *lv_bbox;    // [5][FR_LV_BBOX_STRIDE] RF: box of the tiles with tile_min < k as {gx - x0, gy - y0, x1, y1} (0 = empty), k = 0..4
-	uint32_t *totals;     // [8]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, -...}
+	uint32_t *totals;     // [8]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, #blend items, -...}
+	uint32_t *render_items; // [4T] blend work items, longest lists first: tile << 3 | band | level state << 1 | two-level << 2 (k_tile_scan)
 	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
 	uint32_t *hist;       // [FR_BIN_BLOCKS][T] per-workgroup tile histograms (null if T too large for LDS)
@@ -111,6 +112,7 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.tile_count = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.lv_bbox = (uint32_t *)(base + off); off = align_up(off + 5 * FR_LV_BBOX_STRIDE * sizeof(uint32_t));
 	s.totals = (uint32_t *)(base + off); off = align_up(off + 8 * sizeof(uint32_t));
+	s.render_items = (uint32_t *)(base + off); off = align_up(off + 4 * T * sizeof(uint32_t));
 	s.tile_order = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.tile_lv = nullptr;
 	if (variant == FR_VARIANT_FOV_PCHECK_OBB) { s.tile_lv = (float *)(base + off); off = align_up(off + 5 * T * sizeof(float)); }
@@ -340,6 +342,7 @@ struct FwdCtx {
 	int fov_split;      // RF: the two level states of a two-level tile go to different waves (out_color was zero-filled)
 	int bin_wgs;        // workgroups k_bin ran with (k_emit replays the same number)
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
+	int n_items;        // entries of ImageWS::render_items
 	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4] (+ sequence word), or null
 	uint32_t totals_seq;       // this frame's sequence number for that word
 	float focal_x, focal_y;

@@ -17,6 +17,7 @@
 // The foveated renderer handles single-level and two-level tiles in one launch (the reference
 // launches two full grids that early-return on each other's tiles).
 #include "common.h"
+#include <cstdlib>
 
 #ifndef FR_RENDER_GROUP
 #define FR_RENDER_GROUP 2       // RF: entries whose transmittance-independent part is evaluated together
@@ -106,6 +107,8 @@ struct RenderArgs {
 	int *gaussians_count;   // RS / MAX / LWMC
 	float *contributions;   // RS / MAX / LWMC
 	const float *loss_map;  // LWMC
+	const uint32_t *render_items; // work items, longest list first (k_tile_scan): tile << 3 | band | level state << 1 | two-level << 2 ...
+	uint32_t n_items;             // ... and their number
 };
 
 // ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB ----------------
@@ -139,11 +142,16 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	constexpr int NW = NT / 64;  // waves per tile, each owning a band of 16 / NW rows
 	__shared__ unsigned long long s_reach[NW][NW]; // shared batches: [band][staging wave] = staged entries that can touch the band
 
-	const int slot = INDEP ? (int)blockIdx.x / NW : (int)blockIdx.x; // position in tile_order
-	const int tile = a.tile_order ? (int)a.tile_order[slot] : slot;
-	const int tx = tile % a.gx, ty = tile / a.gx;
+	// One workgroup per work item, longest lists first: INDEP: one band of a tile = an entry of render_items; shared
+	// batches: one tile = an entry of tile_order (both laid out by k_tile_scan).
+	static_assert(PPL == 2, "work items encode two bands per tile");
 	const int st = threadIdx.x;                                          // staging slot of this thread
-	const int wv = INDEP ? (int)blockIdx.x % NW : (int)(threadIdx.x >> 6); // band of this wave
+	const uint32_t idx = blockIdx.x;
+	if (INDEP && idx >= a.n_items) return;
+	const uint32_t item = INDEP ? a.render_items[idx] : a.tile_order[idx] << 3;
+	const int tile = (int)(item >> 3);
+	const int tx = tile % a.gx, ty = tile / a.gx;
+	const int wv = INDEP ? (int)(item & 1u) : (int)(threadIdx.x >> 6); // band of this wave
 	const int tid = INDEP ? wv * 64 + st : st;                          // position among the tile's NT threads (row mapping)
 	const int lx = tid & 15;
 	const int px = tx * FR_TILE + lx;
@@ -374,244 +382,214 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 }
 
 // ---------------- FOV_PCHECK_OBB: single-level and two-level tiles ----------------
-// SPLIT: the two level states of a two-level tile are blended by DIFFERENT waves (grid = tiles x NW x 2): every wave
-// then carries one state (63 instead of 86 registers: 8 waves per SIMD) and half the instructions per entry -- the
-// frame ends with its slowest two-level tile, whose wave walks ~900 entries at ~200 ns each. The two partial results
-// o * w1 and q * (1 - w1) are the two rounded products the reference adds (forward.cu:466-470); they meet by float
-// atomicAdd on a zero-filled pixel, and x + y == y + x bit for bit, so the image does not depend on who comes first.
-template <int PPL, bool SPLIT = false>
-__global__ void __launch_bounds__(64) k_render_fov(const RenderArgs a)
+// Work item = one wave's share of a tile: a band of eight rows, and for a two-level tile one of its two level states
+// (every wave then carries one state: 63 registers, 8 waves per SIMD, half the instructions per entry -- the longest
+// waves of a frame are those of two-level tiles). The two partial results o * w1 and q * (1 - w1) are the two rounded
+// products the reference adds (forward.cu:466-470); they meet by float atomicAdd on a zero-filled pixel, and
+// x + y == y + x bit for bit, so the image does not depend on who comes first.
+//
+// One single-wave workgroup per item, items laid out longest list first by k_tile_scan. What was measured on the way
+// here (S-6M bench frames, kernel time): one workgroup per (tile, band, level state) with the upper-level workgroups of
+// single-level tiles returning at once -- 43 % of the grid, interleaved with the real work -- 226 us, the wave slots
+// never more than ~40 % full (per-wave timers); the compact item list below, same dispatch, 148 us; persistent waves
+// pulling the items from 64 queues 182 us (a wave cannot migrate: at the tail some SIMDs still hold eight busy waves
+// while others are empty; handing the slot back after every item: 152 us, i.e. the hardware's placement of fresh
+// workgroups IS the load balancer); s_setprio by round or by remaining list length: nothing.
+template <int PPL>
+__global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 {
-	// The waves of a tile (each owning a band of 16 / NW rows) are INDEPENDENT: every wave walks the whole list in
-	// batches of 64 entries that it fetches, tests against its own band and stages in its own LDS slice. No
-	// workgroup barrier: with shared batches the wave whose band holds less waited for the other one at every
-	// batch (a quarter of the slowest tiles' time); the records are fetched twice, out of L2.
-	// Each wave is a workgroup of its own (grid = tiles x NW): a finished wave frees its slot at once.
-	constexpr int NW = 256 / PPL / 64;
+	static_assert(PPL == 2, "work items encode two bands per tile");
+	constexpr int HP = PPL / 2;
 	__shared__ float4 s0[64];   // x, y, A, B
 	__shared__ float2 s1[64];   // C, highest_level
-	__shared__ float4 sl1[64];  // level L1: r, g, b, opacity
-	__shared__ float4 sl2[64];  // level L2 (two-level tiles only)
+	__shared__ float4 sl1[64];  // this wave's level: r, g, b, opacity
 
-	const int wblk = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
-	const int lev = SPLIT ? (int)blockIdx.x & 1 : 0; // SPLIT: which of the two level states this wave blends
-	const int slot = wblk / NW, wv = wblk % NW;
-	const int tile = a.tile_order ? (int)a.tile_order[slot] : slot;
-	const int tx = tile % a.gx, ty = tile / a.gx;
 	const int lane = threadIdx.x;
-	const int tid = wv * 64 + lane; // position inside the tile's 256 / PPL threads (row mapping)
-	const int lx = tid & 15;
-	const int px = tx * FR_TILE + lx;
-	const float pxf = (float)px;
-	const uint2 range = a.ranges[tile];
-	const int n = (int)(range.y - range.x);
-	const float tlf = a.tile_lv[a.T + tile];                    // tile_min
-	const bool two_level = a.tile_lv[4 * (size_t)a.T + tile] != 0.0f;
-	if (SPLIT && !two_level && lev == 1) return;
-	const bool blending = SPLIT ? false : two_level;   // two states in this wave
-	const bool upper = SPLIT && two_level && lev == 1; // SPLIT: this wave carries the state of level L2 (in S1)
-	const int L1 = f2i(tlf);
-	const int L2 = L1 + 1;
-	const float L2f = tlf + 1.0f;
-	const float tgx = a.tile_lv[2 * (size_t)a.T + tile], tgy = a.tile_lv[3 * (size_t)a.T + tile];
-
-	// Per-lane state of the four pixels (rows ry, ry+4, ry+8, ry+12), kept as two packed pairs so that the blend
-	// runs on v_pk_mul/v_pk_fma. A finished pixel carries its transmittance NEGATED: "still blending" is T > 0,
-	// no separate flag registers, and |T| is the value the reference keeps.
-	static_assert(PPL == 4 || PPL == 2, "the packed blend handles pairs of rows");
-	constexpr int HP = PPL / 2;
-	Px2 S1[HP], S2[HP];
-	float pyf[PPL], est[PPL];
-	bool inside[PPL];
-#pragma unroll
-	for (int k = 0; k < PPL; k++)
-	{
-		const int ly = tile_row<PPL>(tid, k);
-		const int py = ty * FR_TILE + ly;
-		pyf[k] = (float)py;
-		inside[k] = px < a.W && py < a.H;
-		est[k] = tlf + ((float)lx * tgx + (float)ly * tgy) / (float)FR_TILE;
-		// RF forward.cu:262-476: level L1 stops contributing beyond est > L2; single-level tiles have no second state
-		const bool done1 = (blending || (SPLIT && two_level && !upper)) ? (!inside[k] || (est[k] > (float)L2)) : !inside[k];
-		const bool done2 = blending ? !inside[k] : true;
-		S1[k >> 1].T[k & 1] = done1 ? -1.0f : 1.0f;
-		S2[k >> 1].T[k & 1] = done2 ? -1.0f : 1.0f;
-	}
-#pragma unroll
-	for (int h = 0; h < HP; h++) { S1[h].C0 = S1[h].C1 = S1[h].C2 = (v2f){ 0.f, 0.f }; S2[h].C0 = S2[h].C1 = S2[h].C2 = (v2f){ 0.f, 0.f }; }
-
-#ifdef FR_TILE_TIMERS
-	const uint64_t tm0 = wall_clock64(); uint32_t tm_proc = 0, tm_hit = 0; uint64_t tm_loop = 0, tm_sync = 0;
-#endif
-	// prefetch registers
-	float4 p0 = make_float4(0, 0, 0, 0), pl1 = p0, pl2 = p0;
-	float2 p1 = make_float2(0, 0);
-	auto fetch = [&](int e)
-	{
-		const uint32_t id = a.point_list[range.x + e];
-		const float4 *r = a.rec + 3 * (size_t)id;
-		p0 = r[0];
-		const float4 r1 = r[1];
-		p1 = make_float2(r1.x, r1.y);
-		pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + (upper ? L2 : L1)];
-		if (blending) pl2 = a.lvl[(size_t)id * FR_FOV_LEVELS + L2];
-	};
-	if (lane < n) fetch(lane);
-	for (int base = 0; base < n; base += 64)
-	{
-		float tmax0 = -1.0f;
-#pragma unroll
-		for (int h = 0; h < HP; h++) tmax0 = fmaxf(tmax0, fmaxf(fmaxf(S1[h].T.x, S1[h].T.y), fmaxf(S2[h].T.x, S2[h].T.y)));
-#ifdef FR_TILE_TIMERS
-		const uint64_t tq0 = wall_clock64();
-#endif
-		if (!__any(tmax0 > 0.0f)) break;
-		// the previous batch of this wave's LDS slice has been read by all lanes (wave-synchronous, fenced)
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-#ifdef FR_TILE_TIMERS
-		tm_sync += wall_clock64() - tq0;
-#endif
-		const bool staged = base + lane < n;
-		if (staged) { s0[lane] = p0; s1[lane] = p1; sl1[lane] = pl1; if (blending) sl2[lane] = pl2; }
-		unsigned long long reach_mask;
-		{
-			// alpha < 1/255 everywhere (forward.cu:563) <=> power < -ln(255 opacity): tighter than -4.5 for faint splats
-			const float op = blending ? fmaxf(pl1.w, pl2.w) : pl1.w;
-			const float thr = fmaxf(-4.5f, -__logf(255.0f * op) - 0.01f);
-			reach_mask = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
-		}
-		if (base + 64 + lane < n) fetch(base + 64 + lane);
-		// lanes read entries other lanes staged
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		v2f pyp[HP];
-#pragma unroll
-		for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
-#ifdef FR_TILE_TIMERS
-		const uint64_t tq1 = wall_clock64();
-#endif
-		// Entries are taken two at a time: everything that does not depend on the running transmittance (record
-		// fetch, power, exp, alpha inputs) is evaluated for both before either is blended, so the two dependency
-		// chains overlap -- a wave works through its list serially and the slowest tile's chain is the kernel time.
-		struct Ent { v2f e[HP]; bool inx[HP], iny[HP]; float4 c1, c2; bool l2_ok; };
-		auto prepare = [&](const int j, const bool valid)
-		{
-			Ent t;
-			const float4 g0 = s0[j];
-			const float2 g1 = s1[j];
-			const float dx = g0.x - pxf;
-			const float adx2 = (g0.z * dx) * dx;
-			const float bdx = g0.w * dx;
-#pragma unroll
-			for (int h = 0; h < HP; h++)
-			{
-				const v2f pw = power2(g0.y - pyp[h], g1.x, adx2, bdx);
-				// in the splat's support: RF forward.cu:556-560 (power > 0 and power < -4.5 are skipped)
-				t.inx[h] = valid && !(pw.x > 0.0f || pw.x < -4.5f);
-				t.iny[h] = valid && !(pw.y > 0.0f || pw.y < -4.5f);
-				t.e[h] = exp2_pair(pw);
-			}
-			t.c1 = sl1[j];
-			t.l2_ok = !((g1.y + 1.0f) < L2f); // the Gaussian exists at level L2
-			if (upper)
-			{
-#pragma unroll
-				for (int h = 0; h < HP; h++) { t.inx[h] = t.inx[h] && t.l2_ok; t.iny[h] = t.iny[h] && t.l2_ok; }
-			}
-			t.c2 = t.c1;
-			if (blending) t.c2 = sl2[j];
-			return t;
-		};
-		auto blend = [&](const Ent &t)
-		{
-#pragma unroll
-			for (int h = 0; h < HP; h++)
-			{
-				blend2(S1[h], t.inx[h], t.iny[h], t.e[h], t.c1);
-				if (blending) blend2(S2[h], t.inx[h] && t.l2_ok, t.iny[h] && t.l2_ok, t.e[h], t.c2);
-			}
-		};
-		for (unsigned long long rm = reach_mask; rm; )
-		{
-			int jj[FR_RENDER_GROUP];
-			bool vv[FR_RENDER_GROUP];
-#pragma unroll
-			for (int g = 0; g < FR_RENDER_GROUP; g++)
-			{
-				vv[g] = rm != 0;
-				jj[g] = vv[g] ? __builtin_ctzll(rm) : jj[0];
-				rm &= rm - 1; // stays 0 once empty
-			}
-			float tmax = -1.0f;
-#pragma unroll
-			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(fmaxf(S1[h].T.x, S1[h].T.y), fmaxf(S2[h].T.x, S2[h].T.y)));
-			if (!__any(tmax > 0.0f)) break;
-			Ent t[FR_RENDER_GROUP];
-#pragma unroll
-			for (int g = 0; g < FR_RENDER_GROUP; g++) t[g] = prepare(jj[g], vv[g]);
-#pragma unroll
-			for (int g = 0; g < FR_RENDER_GROUP; g++) blend(t[g]);
-		}
-#ifdef FR_TILE_TIMERS
-		tm_loop += wall_clock64() - tq1;
-#endif
-	}
-
-#ifdef FR_TILE_TIMERS
-	if (tid == 0)
-	{
-		a.final_T[tile] = (float)(wall_clock64() - tm0); a.final_T[a.T + tile] = (float)(tm0 & 0xffffff);
-		a.n_contrib[tile] = tm_proc; a.n_contrib[a.T + tile] = tm_hit;
-		a.n_contrib[2 * a.T + tile] = (uint32_t)tm_loop; a.n_contrib[3 * a.T + tile] = (uint32_t)tm_sync;
-	}
-#endif
+	const uint32_t idx = blockIdx.x;
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 	const size_t plane = (size_t)a.W * a.H;
-#pragma unroll
-	for (int k = 0; k < PPL; k++)
 	{
-		if (!inside[k]) continue;
-		const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
-		const float t1 = fabsf(S1[k >> 1].T[k & 1]), t2 = fabsf(S2[k >> 1].T[k & 1]);
-		float o0 = fmaf(bg0, t1, S1[k >> 1].C0[k & 1]), o1 = fmaf(bg1, t1, S1[k >> 1].C1[k & 1]), o2 = fmaf(bg2, t1, S1[k >> 1].C2[k & 1]);
-		if (blending)
+		const uint32_t item = a.render_items[idx];
+		const int tile = (int)(item >> 3), wv = (int)(item & 1u);
+		const bool two_level = (item & 4u) != 0;
+		const bool upper = (item & 2u) != 0; // this wave carries the state of level L2
+		const int tx = tile % a.gx, ty = tile / a.gx;
+		const int tid = wv * 64 + lane; // position inside the tile's 256 / PPL threads (row mapping)
+		const int lx = tid & 15;
+		const int px = tx * FR_TILE + lx;
+		const float pxf = (float)px;
+		const uint2 range = a.ranges[tile];
+		const int n = (int)(range.y - range.x);
+		const float tlf = a.tile_lv[a.T + tile];                    // tile_min
+		const int L1 = f2i(tlf);
+		const int L2 = L1 + 1;
+		const float L2f = tlf + 1.0f;
+		const float tgx = a.tile_lv[2 * (size_t)a.T + tile], tgy = a.tile_lv[3 * (size_t)a.T + tile];
+
+		// Per-lane state of the lane's pixels (rows ry, ry + 4), kept as a packed pair so that the blend runs on
+		// v_pk_mul / v_pk_fma. A finished pixel carries its transmittance NEGATED: "still blending" is T > 0, no
+		// separate flag registers, and |T| is the value the reference keeps.
+		Px2 S1[HP];
+		float pyf[PPL], est[PPL];
+		bool inside[PPL];
+#pragma unroll
+		for (int k = 0; k < PPL; k++)
 		{
-			const float q0 = fmaf(bg0, t2, S2[k >> 1].C0[k & 1]), q1 = fmaf(bg1, t2, S2[k >> 1].C1[k & 1]), q2 = fmaf(bg2, t2, S2[k >> 1].C2[k & 1]);
-			float x = fabsf(est[k] - ((float)L1 + 0.5f)) / 0.5f;
-			x = fmaxf(0.0f, fminf(1.0f, x));
-			const float bT = 3 * x * x - 2 * x * x * x;
-			const float w1 = 1 - bT;
-			o0 = o0 * w1 + q0 * (1.f - w1);
-			o1 = o1 * w1 + q1 * (1.f - w1);
-			o2 = o2 * w1 + q2 * (1.f - w1);
+			const int ly = tile_row<PPL>(tid, k);
+			const int py = ty * FR_TILE + ly;
+			pyf[k] = (float)py;
+			inside[k] = px < a.W && py < a.H;
+			est[k] = tlf + ((float)lx * tgx + (float)ly * tgy) / (float)FR_TILE;
+			// RF forward.cu:262-476: level L1 stops contributing beyond est > L2; single-level tiles have no second state
+			const bool done1 = (two_level && !upper) ? (!inside[k] || (est[k] > (float)L2)) : !inside[k];
+			S1[k >> 1].T[k & 1] = done1 ? -1.0f : 1.0f;
 		}
-		if (SPLIT && two_level)
+#pragma unroll
+		for (int h = 0; h < HP; h++) S1[h].C0 = S1[h].C1 = S1[h].C2 = (v2f){ 0.f, 0.f };
+
+#ifdef FR_TILE_TIMERS
+		const uint64_t tm0 = wall_clock64(); uint32_t tm_proc = 0, tm_batches = 0; uint64_t tm_loop = 0, tm_sync = 0;
+#endif
+		// prefetch registers
+		float4 p0 = make_float4(0, 0, 0, 0), pl1 = p0;
+		float2 p1 = make_float2(0, 0);
+		auto fetch = [&](int e)
 		{
-			float x = fabsf(est[k] - ((float)L1 + 0.5f)) / 0.5f;
-			x = fmaxf(0.0f, fminf(1.0f, x));
-			const float bT = 3 * x * x - 2 * x * x * x;
-			const float w1 = 1 - bT;
-			const float w = upper ? (1.f - w1) : w1;
-			atomicAdd(&a.out_color[pid], o0 * w);
-			atomicAdd(&a.out_color[plane + pid], o1 * w);
-			atomicAdd(&a.out_color[2 * plane + pid], o2 * w);
-			continue;
+			const uint32_t id = a.point_list[range.x + e];
+			const float4 *r = a.rec + 3 * (size_t)id;
+			p0 = r[0];
+			const float4 r1 = r[1];
+			p1 = make_float2(r1.x, r1.y);
+			pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + (upper ? L2 : L1)];
+		};
+		if (lane < n) fetch(lane);
+		for (int base = 0; base < n; base += 64)
+		{
+			float tmax0 = -1.0f;
+#pragma unroll
+			for (int h = 0; h < HP; h++) tmax0 = fmaxf(tmax0, fmaxf(S1[h].T.x, S1[h].T.y));
+#ifdef FR_TILE_TIMERS
+			const uint64_t tq0 = wall_clock64();
+#endif
+			if (!__any(tmax0 > 0.0f)) break;
+			// the previous batch has been read by all lanes (wave-synchronous, fenced)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#ifdef FR_TILE_TIMERS
+			tm_sync += wall_clock64() - tq0;
+#endif
+			const bool staged = base + lane < n;
+			if (staged) { s0[lane] = p0; s1[lane] = p1; sl1[lane] = pl1; }
+			unsigned long long reach_mask;
+			{
+				// alpha < 1/255 everywhere (forward.cu:563) <=> power < -ln(255 opacity): tighter than -4.5 for faint splats
+				const float thr = fmaxf(-4.5f, -__logf(255.0f * pl1.w) - 0.01f);
+				// a wave that carries the level-L2 state skips the Gaussians that do not exist at L2 (RF forward.cu:399: about
+				// half the list in a 0/1 tile) here, at one lane's cost, instead of walking them as no-ops
+				const bool exists = !upper || !((p1.y + 1.0f) < L2f);
+				reach_mask = __ballot(staged && exists && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
+			}
+			if (base + 64 + lane < n) fetch(base + 64 + lane);
+			// lanes read entries other lanes staged
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			v2f pyp[HP];
+#pragma unroll
+			for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
+#ifdef FR_TILE_TIMERS
+			const uint64_t tq1 = wall_clock64();
+			tm_proc += (uint32_t)__popcll(reach_mask); tm_batches++;
+#endif
+			// Entries are taken two at a time: everything that does not depend on the running transmittance (record
+			// fetch, power, exp, alpha inputs) is evaluated for both before either is blended, so the two dependency
+			// chains overlap.
+			struct Ent { v2f e[HP]; bool inx[HP], iny[HP]; float4 c1; };
+			auto prepare = [&](const int j, const bool valid)
+			{
+				Ent t;
+				const float4 g0 = s0[j];
+				const float2 g1 = s1[j];
+				const float dx = g0.x - pxf;
+				const float adx2 = (g0.z * dx) * dx;
+				const float bdx = g0.w * dx;
+#pragma unroll
+				for (int h = 0; h < HP; h++)
+				{
+					const v2f pw = power2(g0.y - pyp[h], g1.x, adx2, bdx);
+					// in the splat's support: RF forward.cu:556-560 (power > 0 and power < -4.5 are skipped)
+					t.inx[h] = valid && !(pw.x > 0.0f || pw.x < -4.5f);
+					t.iny[h] = valid && !(pw.y > 0.0f || pw.y < -4.5f);
+					t.e[h] = exp2_pair(pw);
+				}
+				t.c1 = sl1[j];
+				return t;
+			};
+			for (unsigned long long rm = reach_mask; rm; )
+			{
+				int jj[FR_RENDER_GROUP];
+				bool vv[FR_RENDER_GROUP];
+#pragma unroll
+				for (int g = 0; g < FR_RENDER_GROUP; g++)
+				{
+					vv[g] = rm != 0;
+					jj[g] = vv[g] ? __builtin_ctzll(rm) : jj[0];
+					rm &= rm - 1; // stays 0 once empty
+				}
+				float tmax = -1.0f;
+#pragma unroll
+				for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(S1[h].T.x, S1[h].T.y));
+				if (!__any(tmax > 0.0f)) break;
+				Ent t[FR_RENDER_GROUP];
+#pragma unroll
+				for (int g = 0; g < FR_RENDER_GROUP; g++) t[g] = prepare(jj[g], vv[g]);
+#pragma unroll
+				for (int g = 0; g < FR_RENDER_GROUP; g++)
+#pragma unroll
+					for (int h = 0; h < HP; h++) blend2(S1[h], t[g].inx[h], t[g].iny[h], t[g].e[h], t[g].c1);
+			}
+#ifdef FR_TILE_TIMERS
+			tm_loop += wall_clock64() - tq1;
+#endif
 		}
-		a.out_color[pid] = o0;
-		a.out_color[plane + pid] = o1;
-		a.out_color[2 * plane + pid] = o2;
+
+#ifdef FR_TILE_TIMERS
+		if (lane == 0)
+		{
+			// developer build only (tools/tile_cycles.py): per-ITEM records in the otherwise unused final_T / n_contrib arrays
+			const uint32_t G = 4u * (uint32_t)a.T, b = idx;
+			a.final_T[b] = (float)(wall_clock64() - tm0); a.final_T[G + b] = (float)(tm0 & 0xffffff);
+			a.n_contrib[b] = tm_proc; a.n_contrib[G + b] = tm_batches; a.n_contrib[2 * G + b] = (uint32_t)n;
+			a.n_contrib[3 * G + b] = (uint32_t)tile | ((uint32_t)wv << 16) | ((uint32_t)upper << 20) | ((uint32_t)two_level << 21);
+			a.n_contrib[4 * G + b] = (uint32_t)tm_loop; a.n_contrib[5 * G + b] = (uint32_t)tm_sync;
+		}
+#endif
+#pragma unroll
+		for (int k = 0; k < PPL; k++)
+		{
+			if (!inside[k]) continue;
+			const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
+			const float t1 = fabsf(S1[k >> 1].T[k & 1]);
+			const float o0 = fmaf(bg0, t1, S1[k >> 1].C0[k & 1]), o1 = fmaf(bg1, t1, S1[k >> 1].C1[k & 1]), o2 = fmaf(bg2, t1, S1[k >> 1].C2[k & 1]);
+			if (two_level)
+			{
+				// RF forward.cu:455-470: C1 * w1 + C2 * (1 - w1), w1 = 1 - smoothstep
+				float x = fabsf(est[k] - ((float)L1 + 0.5f)) / 0.5f;
+				x = fmaxf(0.0f, fminf(1.0f, x));
+				const float bT = 3 * x * x - 2 * x * x * x;
+				const float w1 = 1 - bT;
+				const float w = upper ? (1.f - w1) : w1;
+				atomicAdd(&a.out_color[pid], o0 * w);
+				atomicAdd(&a.out_color[plane + pid], o1 * w);
+				atomicAdd(&a.out_color[2 * plane + pid], o2 * w);
+				continue;
+			}
+			a.out_color[pid] = o0;
+			a.out_color[plane + pid] = o1;
+			a.out_color[2 * plane + pid] = o2;
+		}
 	}
 }
-
-#ifndef FR_RENDER_PPL
-#define FR_RENDER_PPL 2
-#endif
-
-#ifndef FR_RENDER_FOV_PPL
-#define FR_RENDER_FOV_PPL 2
-#endif
 
 int launch_render(FwdCtx &c)
 {
@@ -622,24 +600,24 @@ int launch_render(FwdCtx &c)
 	r.tile_lv = c.img.tile_lv; r.tile_order = c.img.tile_order; r.T = c.T; r.bg = a->background; r.out_color = a->out_color;
 	r.final_T = c.img.final_T; r.n_contrib = c.img.n_contrib;
 	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions; r.loss_map = a->loss_map;
-	constexpr int PPL = FR_RENDER_PPL;
-	const dim3 grid(c.T), block(256 / PPL);                    // shared batches: one workgroup per tile
-	const dim3 grid_iw(c.T * (256 / PPL / 64)), block_iw(64); // independent waves: one workgroup per wave
+	r.render_items = c.img.render_items; r.n_items = (uint32_t)c.n_items;
+	constexpr int PPL = 2;
+	// INDEP_: the two bands of a tile are separate single-wave workgroups (work items); else one 128-thread workgroup per tile
+#define FR_LAUNCH_RENDER(V, INDEP_) do { \
+		if (INDEP_) hipLaunchKernelGGL((k_render<V, PPL>), dim3(r.n_items), dim3(64), 0, c.stream, r); \
+		else hipLaunchKernelGGL((k_render<V, PPL>), dim3(c.T), dim3(256 / PPL), 0, c.stream, r); } while (0)
 	switch (a->variant)
 	{
-	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL((k_render<FR_VARIANT_ORIGINAL, PPL>), grid_iw, block_iw, 0, c.stream, r); break;
-	case FR_VARIANT_PCHECK_OBB_SUM: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_SUM, PPL>), grid, block, 0, c.stream, r); break;
-	case FR_VARIANT_PCHECK_OBB: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB, PPL>), grid_iw, block_iw, 0, c.stream, r); break;
-	case FR_VARIANT_PCHECK_OBB_MAX: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_MAX, PPL>), grid_iw, block_iw, 0, c.stream, r); break;
-	case FR_VARIANT_PCHECK_OBB_LWMC: hipLaunchKernelGGL((k_render<FR_VARIANT_PCHECK_OBB_LWMC, PPL>), grid, block, 0, c.stream, r); break;
+	case FR_VARIANT_ORIGINAL: FR_LAUNCH_RENDER(FR_VARIANT_ORIGINAL, true); break;
+	case FR_VARIANT_PCHECK_OBB_SUM: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_SUM, false); break;
+	case FR_VARIANT_PCHECK_OBB: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB, true); break;
+	case FR_VARIANT_PCHECK_OBB_MAX: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_MAX, true); break;
+	case FR_VARIANT_PCHECK_OBB_LWMC: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_LWMC, false); break;
 	default:
-		// The frame ends when the tile that blends the most entries ends, and a wave works through its list
-		// serially: two waves of two rows per lane make that chain ~1.6x shorter than one wave of four rows for
-		// ~30 % more instructions in total (measured 374 -> 286 us on the bench frame).
-		if (c.fov_split) hipLaunchKernelGGL((k_render_fov<FR_RENDER_FOV_PPL, true>), dim3(2 * c.T * (256 / FR_RENDER_FOV_PPL / 64)), dim3(64), 0, c.stream, r);
-		else hipLaunchKernelGGL((k_render_fov<FR_RENDER_FOV_PPL>), dim3(c.T * (256 / FR_RENDER_FOV_PPL / 64)), dim3(64), 0, c.stream, r);
+		hipLaunchKernelGGL((k_render_fov<2>), dim3(r.n_items), dim3(64), 0, c.stream, r);
 		break;
 	}
+#undef FR_LAUNCH_RENDER
 	return check_launch("render", c.stream, a->debug);
 }
 

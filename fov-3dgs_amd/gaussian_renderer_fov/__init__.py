@@ -9,16 +9,24 @@ from ..rasterizer import PackedModel, pack_model, zero_points_like
 
 
 class _PackState:
-    __slots__ = ("refs", "versions", "packed")
+    __slots__ = ("refs", "versions", "ptrs", "packed")
 
     def __init__(self, tensors):
         self.refs = [weakref.ref(t) for t in tensors]
         self.versions = [t._version for t in tensors]
+        self.ptrs = [t.data_ptr() for t in tensors]  # `t.data = other` keeps the object and the version, not the storage
         self.packed = None
 
     def matches(self, tensors):
         return len(self.refs) == len(tensors) and all(
-            r() is t and v == t._version for r, v, t in zip(self.refs, self.versions, tensors))
+            r() is t and v == t._version and p == t.data_ptr() for r, v, p, t in zip(self.refs, self.versions, self.ptrs, tensors))
+
+
+def invalidate_packed(pc):
+    """Drop the packed copy render(packed="auto") cached on the model `pc` (after a write the autograd version
+    counters cannot see: `.data` writes, raw-pointer kernels, DLPack aliases)."""
+    if getattr(pc, "_fovraster_pack_state", None) is not None:
+        pc._fovraster_pack_state = None
 
 
 def _auto_packed(pc, means3D, scales, rotations, opacity, shs_rest, shs_dcs, highest_levels):
@@ -43,11 +51,14 @@ def _auto_packed(pc, means3D, scales, rotations, opacity, shs_rest, shs_dcs, hig
 
 
 def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, alpha=None, gazeArray=None,
-           blending=None, starter=None, ender=None, highest_levels=None, shs_dcs=None, opacities=None, packed="auto"):
+           blending=None, starter=None, ender=None, highest_levels=None, shs_dcs=None, opacities=None, packed=None):
     """Render the scene for one gaze. Background tensor (bg_color) must be on the GPU.
-    packed (extension; the image is bit-identical either way): a rasterizer.PackedModel of this model made by
-    pack_model(); "auto" (default) = made and cached here once the model is seen to be static (_auto_packed);
-    None = render from the ordinary tensors only."""
+    packed (extension, opt-in; the image is bit-identical either way): None (default) = render from the ordinary tensors,
+    exactly the reference's interface; a rasterizer.PackedModel of this model made by pack_model(); or "auto" = made and
+    cached here once the model is seen to be static (_auto_packed: same tensor objects, same storage address, same
+    autograd version on two consecutive calls). "auto" costs 336 B per Gaussian (2 GB at 6 M) and cannot see writes that
+    bypass the version counter (`t.data.copy_()`, raw-pointer kernels, DLPack aliases): call invalidate_packed(pc) after
+    such a write."""
     xyz = pc.get_xyz
     if torch.is_grad_enabled():
         screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0

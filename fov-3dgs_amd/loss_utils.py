@@ -63,30 +63,34 @@ class _L1SSIM(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img, gt, lam):
-        shape = img.shape
         x, y = _chw(img, "image"), _chw(gt, "gt")
         if x.shape != y.shape:
             raise RuntimeError(f"image {tuple(x.shape)} and gt {tuple(y.shape)} differ")
-        need = img.requires_grad
-        l1, ss, dmaps = _forward(x, y, need)
-        ctx.lam, ctx.shape = lam, shape
-        if need:
-            ctx.save_for_backward(x, y, dmaps)
+        need_x, need_y = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        l1, ss, dmaps = _forward(x, y, need_x)
+        ctx.lam, ctx.shapes, ctx.dtypes = lam, (img.shape, gt.shape), (img.dtype, gt.dtype)
+        # both losses are symmetric in their arguments (as the reference's l1_loss / ssim are differentiable in both):
+        # the gradient w.r.t. gt is the same kernel with the roles swapped, from a second set of derivative maps
+        dmaps_y = _forward(y, x, True)[2] if need_y else None
+        empty = x.new_empty(0)
+        ctx.save_for_backward(x, y, dmaps if need_x else empty, dmaps_y if need_y else empty)
         return ss if lam is None else (1.0 - lam) * l1 + lam * (1.0 - ss)
 
     @staticmethod
     def backward(ctx, g):
-        x, y, dmaps = ctx.saved_tensors
+        x, y, dmaps, dmaps_y = ctx.saved_tensors
         n = float(x.numel())
-        if ctx.lam is None:
-            grad = _backward(x, y, dmaps, 0.0, 1.0 / n)
-        else:
-            grad = _backward(x, y, dmaps, (1.0 - ctx.lam) / n, -ctx.lam / n)
-        return (grad * g).reshape(ctx.shape), None, None
+        w_l1, w_ssim = (0.0, 1.0 / n) if ctx.lam is None else ((1.0 - ctx.lam) / n, -ctx.lam / n)
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = (_backward(x, y, dmaps, w_l1, w_ssim) * g).reshape(ctx.shapes[0]).to(ctx.dtypes[0])
+        if ctx.needs_input_grad[1]:
+            gy = (_backward(y, x, dmaps_y, w_l1, w_ssim) * g).reshape(ctx.shapes[1]).to(ctx.dtypes[1])
+        return gx, gy, None
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
-    """loss_utils.py:37-46 (+ _ssim :57-76): mean SSIM with the 11x11 Gaussian window, differentiable in img1."""
+    """loss_utils.py:37-46 (+ _ssim :57-76): mean SSIM with the 11x11 Gaussian window, differentiable in both images."""
     if window_size != 11 or not size_average:
         raise RuntimeError("fovraster ssim implements the reference's default call: window_size=11, size_average=True")
     return _L1SSIM.apply(img1, img2, None)

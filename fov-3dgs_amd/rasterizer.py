@@ -339,10 +339,6 @@ def _mark_visible(positions, rs):
     return present
 
 
-def _opacities_for_backward(opacities):
-    return opacities
-
-
 def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
     """Autograd function + module for the non-foveated variants. takes_loss_map: the
     …_loss_weighted_max_count extension has one extra input (`loss_map`, a [3,H,W] or [H,W] tensor)."""
@@ -350,18 +346,20 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    raster_settings, loss_map=None, sh_rest=None, packed=None):
+                    raster_settings, loss_map=None, sh_rest=None, packed=None, grad_mode=True):
             # sh_rest (extension): the SH coefficients as the two tensors a model stores, sh = features_dc
             # [P,1,3], sh_rest = features_rest [P,M-1,3]; saves the torch.cat of get_features and its backward
             args = (variant_id, raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations,
                     cov3Ds_precomp)
             if sh_rest is not None and sh_rest.numel() == 0:
                 sh_rest = None
-            keep_ws = has_backward and any(ctx.needs_input_grad)  # backward re-reads the workspaces
+            # backward re-reads the workspaces; needs_input_grad reflects requires_grad even under torch.no_grad(), where
+            # no graph is built: evaluation renders of a model with Parameters use the persistent inference set
+            # (grad_mode = torch.is_grad_enabled() at the call site: inside forward() it is always off)
+            keep_ws = has_backward and grad_mode and any(ctx.needs_input_grad)
             if takes_loss_map:
                 if loss_map is None or loss_map.numel() < raster_settings.image_height * raster_settings.image_width:
                     raise Exception("loss_map with at least image_height*image_width values is required")
-            ctx.n_inputs = 11
             ctx.split_sh = sh_rest is not None
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
@@ -413,12 +411,13 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
              grad_scales, grad_rotations) = res[:8]
             grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                      grad_rotations, grad_cov3Ds_precomp, None)
-            return grads + (None, res[8] if ctx.split_sh else None, None)  # loss_map, sh_rest, packed
+            return grads + (None, res[8] if ctx.split_sh else None, None, None)  # loss_map, sh_rest, packed, grad_mode
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                             raster_settings, loss_map=None, sh_rest=None, packed=None):
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                         cov3Ds_precomp, raster_settings, loss_map if takes_loss_map else None, sh_rest, packed)
+                                         cov3Ds_precomp, raster_settings, loss_map if takes_loss_map else None, sh_rest, packed,
+                                         torch.is_grad_enabled())
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):

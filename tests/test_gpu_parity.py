@@ -378,20 +378,32 @@ def test_packed_model_gives_identical_images():
         fz.get_rest_features, fz.active_sh_degree = cloud.get_rest_features, cloud.active_sh_degree
         kw = dict(alpha=0.05, gazeArray=torch.tensor((0.4, 0.6)), blending=True, highest_levels=highest, shs_dcs=shs_dcs,
                   opacities=opac)
-        ref_img = render_fov(cam, fz, bg, packed=None, **kw)["render"]
+        from fov3dgs_amd.gaussian_renderer_fov import invalidate_packed
+        ref_img = render_fov(cam, fz, bg, **kw)["render"]  # default: the reference's interface, nothing is cached
         assert not hasattr(fz, "_fovraster_pack_state")
-        imgs = [render_fov(cam, fz, bg, **kw)["render"] for _ in range(3)]
+        imgs = [render_fov(cam, fz, bg, packed="auto", **kw)["render"] for _ in range(3)]
         assert fz._fovraster_pack_state.packed is not None
         for im in imgs:
             assert torch.equal(im, ref_img)
         fz.get_scaling.mul_(1.5)  # an in-place change is noticed (version counter): no stale packed copy
-        ref2 = render_fov(cam, fz, bg, packed=None, **kw)["render"]
+        ref2 = render_fov(cam, fz, bg, **kw)["render"]
         assert not torch.equal(ref2, ref_img)
-        assert torch.equal(render_fov(cam, fz, bg, **kw)["render"], ref2) and fz._fovraster_pack_state.packed is None
-        assert torch.equal(render_fov(cam, fz, bg, **kw)["render"], ref2) and fz._fovraster_pack_state.packed is not None
+        assert torch.equal(render_fov(cam, fz, bg, packed="auto", **kw)["render"], ref2) and fz._fovraster_pack_state.packed is None
+        assert torch.equal(render_fov(cam, fz, bg, packed="auto", **kw)["render"], ref2) and fz._fovraster_pack_state.packed is not None
+        # `t.data = new tensor` keeps object and version but not the storage address: noticed too
+        fz.get_scaling.data = fz.get_scaling.data * 0.5
+        ref3 = render_fov(cam, fz, bg, **kw)["render"]
+        assert torch.equal(render_fov(cam, fz, bg, packed="auto", **kw)["render"], ref3) and fz._fovraster_pack_state.packed is None
+        assert torch.equal(render_fov(cam, fz, bg, packed="auto", **kw)["render"], ref3) and fz._fovraster_pack_state.packed is not None
+        # a write through .data is invisible to the version counter: the documented remedy is invalidate_packed()
+        fz.get_scaling.data.mul_(1.25)
+        invalidate_packed(fz)
+        ref4 = render_fov(cam, fz, bg, **kw)["render"]
+        assert not torch.equal(ref4, ref3)
+        assert torch.equal(render_fov(cam, fz, bg, packed="auto", **kw)["render"], ref4)
         # a model whose getters build new tensors per call is never packed
         for _ in range(3):
-            render_fov(cam, cloud, bg, **kw)
+            render_fov(cam, cloud, bg, packed="auto", **kw)
         assert cloud._fovraster_pack_state.packed is None
         # a packed model of the wrong size is refused
         with pytest.raises(RuntimeError):
@@ -526,3 +538,79 @@ def test_randomised_sweep():
             assert pk["num_rendered"] == got["num_rendered"], tag
             for k in ("radii", "ranges", "point_list", "color"):
                 np.testing.assert_array_equal(pk[k], got[k], err_msg=tag + " packed " + k)
+
+
+def test_mark_visible_matches_oracle():
+    """fr_mark_visible / GaussianRasterizer.markVisible (R0 rasterizer_impl.cu:54-66, rasterize_points.cu:198-217)
+    against the oracle, including points exactly on the near threshold p_view.z == 0.2 (culled: the test is <=)."""
+    _need_gpu()
+    from fov3dgs_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = "cuda:0"
+    cloud = small_cloud(5000, seed=31)
+    cam = syn.camera_1k(128, 128)  # identity world-to-camera: p_view.z == z bit for bit
+    xyz = cloud.get_xyz.detach().numpy().copy()
+    z02 = np.float32(0.2)
+    xyz[:300, 2] = z02                                    # exactly on the threshold
+    xyz[300:600, 2] = np.nextafter(z02, np.float32(1))    # one ulp in front of it
+    xyz[600:900, 2] = np.nextafter(z02, np.float32(0))    # one ulp behind it
+    xyz[900:1000, 2] = np.float32("nan")
+    cd = cam_dict(cam)
+    want = orc.mark_visible(dict(means3D=xyz, opacities=np.zeros((len(xyz), 1), np.float32)), cd)
+    assert not want[:300].any() and want[300:600].all() and not want[600:900].any()
+    cam.to(dev)
+    rs = GaussianRasterizationSettings(128, 128, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev), 1.0,
+                                       cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
+    got = GaussianRasterizer(rs).markVisible(torch.as_tensor(xyz).to(dev))
+    assert got.dtype == torch.bool and got.shape == (len(xyz),)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # a tilted camera (general view matrix) and the empty cloud
+    cam2 = small_camera(160, 96)
+    cd2 = cam_dict(cam2)
+    want2 = orc.mark_visible(dict(means3D=xyz[1000:], opacities=np.zeros((len(xyz) - 1000, 1), np.float32)), cd2)
+    cam2.to(dev)
+    rs2 = rs._replace(viewmatrix=cam2.world_view_transform, projmatrix=cam2.full_proj_transform)
+    got2 = GaussianRasterizer(rs2).markVisible(torch.as_tensor(xyz[1000:]).to(dev))
+    np.testing.assert_array_equal(got2.cpu().numpy(), want2)
+    assert 0 < want2.sum() < len(want2)
+    assert GaussianRasterizer(rs).markVisible(torch.zeros((0, 3), device=dev)).shape == (0,)
+
+
+@pytest.mark.parametrize("gaze", ((0.5, 0.5), (0.15, 0.8)))
+def test_fov_level_colours_match_oracle(gaze):
+    """compute_fov_colors (RF rasterizer_impl.cu:490-530) directly: the per-level (r, g, b, opacity) rows and the
+    level ranges the binning kernel leaves for every visible Gaussian against the oracle's fov_colors /
+    level_ranges, for exactly the slots in a Gaussian's level range (the others are unwritten in the reference too)."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    from fov3dgs_amd import _native
+    lib = _native.load()
+    scene, cam = small_case("fov_pcheck_obb", P=6000, seed=17, gaze=gaze, width=640, height=400)
+    want = orc.forward("fov_pcheck_obb", scene, cam)
+    for packed in (False, True):
+        got = hip_forward("fov_pcheck_obb", scene, cam, packed=packed)
+        geom = got["_buffers"][0]
+        P = scene["means3D"].shape[0]
+
+        def view(ptr, count, dtype):
+            off = ptr - geom.data_ptr()
+            return geom[off:off + 4 * count].view(dtype)
+        lvl = view(lib.fr_geometry_level_colours(P, geom.data_ptr()), 16 * P, torch.float32).view(P, 4, 4).cpu().numpy()
+        lr = view(lib.fr_geometry_level_ranges(P, geom.data_ptr()), P, torch.int32).cpu().numpy()
+        vis = want["radii"] > 0
+        assert vis.sum() > 1000
+        np.testing.assert_array_equal((lr & 0xff)[vis], want["level_ranges"][vis, 0])
+        np.testing.assert_array_equal(((lr >> 8) & 0xff)[vis], want["level_ranges"][vis, 1])
+        lo, hi = want["level_ranges"][:, 0], want["level_ranges"][:, 1]
+        seen_levels = set()
+        for l in range(4):
+            m = vis & (lo <= l) & (l <= hi)
+            if not m.any():
+                continue
+            seen_levels.add(l)
+            np.testing.assert_array_equal(lvl[m, l, 3], scene["opacities"][m, l])
+            np.testing.assert_allclose(lvl[m, l, :3], want["fov_colors"][m, l], rtol=0, atol=1e-6)
+            from tests import parity_report
+            parity_report.record("colour", f"fov level colours level {l} gaze={gaze} packed={packed}", n=int(m.sum()),
+                                 max_abs=float(np.abs(lvl[m, l, :3] - want["fov_colors"][m, l]).max()),
+                                 bitwise_equal=float(np.mean(lvl[m, l, :3].view(np.uint32) == want["fov_colors"][m, l].view(np.uint32))))
+        assert len(seen_levels) == 4

@@ -74,6 +74,18 @@ def test_hip_losses_match_oracle(shape):
         out.backward()
         assert abs(out.item() - want_loss) < 3e-6, (shape, lam)
         np.testing.assert_allclose(x.grad.cpu().numpy(), want_grad.numpy(), atol=2e-7 + 1e-5 / a.numel(), rtol=2e-4, err_msg=str((shape, lam)))
+    # the losses are differentiable in both arguments (as the reference's): gt alone, and both at once
+    want_gy = lo.l1_ssim(b, a, 0.2)[3]  # symmetric loss: d/d(gt) is d/d(first argument) with the roles swapped
+    y = b.cuda().requires_grad_(True)
+    lu.l1_ssim_loss(a.cuda(), y, 0.2).backward()
+    np.testing.assert_allclose(y.grad.cpu().numpy(), want_gy.numpy(), atol=2e-7 + 1e-5 / a.numel(), rtol=2e-4)
+    x, y = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    lu.l1_ssim_loss(x, y, 0.2).backward()
+    np.testing.assert_allclose(y.grad.cpu().numpy(), want_gy.numpy(), atol=2e-7 + 1e-5 / a.numel(), rtol=2e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), lo.l1_ssim(a, b, 0.2)[3].numpy(), atol=2e-7 + 1e-5 / a.numel(), rtol=2e-4)
+    xh = a.cuda().half().requires_grad_(True)   # the gradient comes back in the input's dtype
+    lu.l1_ssim_loss(xh, b.cuda(), 0.2).backward()
+    assert xh.grad.dtype == torch.float16
     # [1,C,H,W] input, no gradient requested, two runs bit-identical (no float atomics)
     v1 = lu.l1_ssim_loss(a.cuda()[None], b.cuda()[None], 0.2)
     v2 = lu.l1_ssim_loss(a.cuda()[None], b.cuda()[None], 0.2)

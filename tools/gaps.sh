@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/gaps.sh  -> per-frame timeline (start offset, duration, gap before) of the foveated frame's kernels
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is unset)}"
 rm -rf /tmp/gp1
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/gp1 -o g -- python3 tools/stage_bench.py fov_pcheck_obb 12 > /dev/null 2>&1
 python3 - <<PY

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/kstats_any.sh <script.py> [args]  -> per-kernel totals of one profiled run (top 25 by time)
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is unset)}"
 rm -rf /tmp/ks2
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks2 -o k -- python3 "$@" > /tmp/ks2.log 2>&1
 tail -2 /tmp/ks2.log

@@ -4,7 +4,7 @@
 # 1) kernel trace + stats of the default bench run (foveated frames + extras, no CPU baseline)
 # 2) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short foveated-only run, per-launch averages
 TAG=${1:-r01}
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is unset)}"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles; mkdir -p $OUT
 rm -rf /tmp/prof_a /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_a -o b -- python3 bench.py --no-cpu-baseline > /tmp/prof_a.log 2>&1

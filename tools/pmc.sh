@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools_pmc.sh "<counters>"  -> per-kernel average counter values for fr:: kernels
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is unset)}"
 rm -rf /tmp/pmc1
 rocprofv3 --kernel-trace --pmc $1 --output-format csv -d /tmp/pmc1 -o p1 -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1
 python3 - <<PY

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_any.sh "<counters>" <script.py> [args] -> per-kernel average counter values for fr:: kernels
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is unset)}"
 C="$1"; shift
 rm -rf /tmp/pmc2
 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc2 -o p -- python3 "$@" > /dev/null 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_stage.sh "<counters>" [stage_bench args]  -> per-kernel average counter values (fr:: kernels)
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is unset)}"
 rm -rf /tmp/pmc1
 C="$1"; shift
 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc1 -o p1 -- python3 tools/stage_bench.py "$@" > /dev/null 2>&1

@@ -1,3 +1,5 @@
+"""Per-wave timing of the foveated blend kernel (developer build: make -C fov-3dgs_amd/csrc EXTRA=-DFR_TILE_TIMERS).
+Prints the distribution of wave durations, the slowest waves and how many waves are in flight over the kernel's span."""
 import math, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,34 +16,45 @@ with torch.no_grad():
 rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev),
                                       1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
 E = torch.Tensor([]); vid = 3; lib = _native.load()
-for i in range(3):
-    r = rz._forward_native(vid, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], syn.lissajous_gaze(20, 90), 0.05)
-torch.cuda.synchronize()
-img = r[5]; T = ((W + 15) // 16) * ((H + 15) // 16)
-def view(ptr, n, dt):
-    off = ptr - img.data_ptr(); return img[off:off + 4 * n].view(dt)
-ft = view(lib.fr_image_final_T(vid, W, H, img.data_ptr()), 2 * T, torch.float32).cpu().numpy()
-nc2 = view(lib.fr_image_n_contrib(vid, W, H, img.data_ptr()), 4 * T, torch.int32).cpu().numpy()
-nc, nh, tloop, tsync = nc2[:T], nc2[T:2 * T], nc2[2 * T:3 * T] * 10.0, nc2[3 * T:] * 10.0
-rg = view(lib.fr_image_ranges(vid, W, H, img.data_ptr()), 2 * T, torch.int32).cpu().numpy().reshape(T, 2)
-n = rg[:, 1] - rg[:, 0]
-cyc = ft[:T] * 10.0  # ns (100 MHz)
-start = ft[T:]
-print("tiles", T, "sum list", n.sum(), "processed", nc.sum(), "with a hit", nh.sum())
-print("wave time ns: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (cyc.mean(), np.percentile(cyc, 50), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max()))
-order = np.argsort(-cyc)[:8]
-for t in order: print("tile", t, "n", n[t], "processed", nc[t], "hit", nh[t], "loop ns", tloop[t], "topsync ns", tsync[t], "ns", cyc[t], "ns/entry %.1f" % (cyc[t] / max(nc[t], 1)), "start", start[t])
-st = (start - start.min()) % (1 << 24)
-print("start spread ns: p50 %.0f p99 %.0f max %.0f" % (np.percentile(st, 50) * 10, np.percentile(st, 99) * 10, st.max() * 10))
-print("sum wave time ms", cyc.sum() / 1e6, " / 4096 slots =", cyc.sum() / 4096 / 1e6)
-end = st * 10 + cyc
-print("end ns: p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(end, [50, 90, 99, 100])))
-late = np.argsort(-end)[:8]
-for t in late: print("late tile", t, "n", n[t], "processed", nc[t], "hit", nh[t], "start", st[t] * 10, "dur", cyc[t])
-
-lv = view(lib.fr_image_tile_levels(W, H, img.data_ptr()), 5 * T, torch.float32).cpu().numpy().reshape(5, T)
-bl = lv[4] != 0
-print("blend tiles", int(bl.sum()), "of", T, " wave time ns mean: blend %.0f single %.0f; ns/processed entry: blend %.1f single %.1f" % (
-    cyc[bl].mean(), cyc[~bl].mean(), cyc[bl].sum() / max(nc[bl].sum(), 1), cyc[~bl].sum() / max(nc[~bl].sum(), 1)))
-print("slowest 20 tiles: blend among them", int(bl[np.argsort(-cyc)[:20]].sum()), " longest list among blend", n[bl].max(), "single", n[~bl].max())
-print("sum wave time: blend %.2f ms single %.2f ms" % (cyc[bl].sum() / 1e6, cyc[~bl].sum() / 1e6))
+frames = [int(x) for x in sys.argv[1:]] or [20]
+for fr in frames:
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    for i in range(3):
+        r = rz._forward_native(vid, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], syn.lissajous_gaze(fr, 90), 0.05, persistent=True)
+        torch.cuda.synchronize()
+        if i < 2:  # clear the timer records (final_T / n_contrib are not used by this variant) before the run that is read
+            img = r[5]
+            for ptr in (lib.fr_image_final_T(vid, W, H, img.data_ptr()), lib.fr_image_n_contrib(vid, W, H, img.data_ptr())):
+                off = ptr - img.data_ptr(); img[off:off + 4 * W * H].zero_()
+            torch.cuda.synchronize()
+    img = r[5]
+    G = 4 * T
+    def view(ptr, n, dt):
+        off = ptr - img.data_ptr(); return img[off:off + 4 * n].view(dt)
+    ft = view(lib.fr_image_final_T(vid, W, H, img.data_ptr()), 2 * G, torch.float32).cpu().numpy()
+    nc = view(lib.fr_image_n_contrib(vid, W, H, img.data_ptr()), 6 * G, torch.int32).cpu().numpy().reshape(6, G)
+    dur, start = ft[:G] * 10.0, ft[G:]
+    proc, batches, n, info, tloop, tsync = nc[0], nc[1], nc[2], nc[3], nc[4] * 10.0, nc[5] * 10.0
+    live = (dur > 0) & (batches > 0)
+    ref = start[np.nonzero(live)[0][0]]  # the first dispatched wave that ran
+    st = np.where(live, ((start - ref + 1000) % (1 << 24) - 1000) * 10.0, 0.0)
+    st -= st[live].min()
+    end = np.where(live, st + dur, 0.0)
+    dur = np.where(live, dur, 0.0)
+    two = (info >> 21) & 1
+    print(f"frame {fr}: waves {G}, that ran the loop {int((batches > 0).sum())}; entries in lists x waves {int(n.sum())}, staged batches {int(batches.sum())} (= {int(batches.sum()) * 64} entries), blended wave-entries {int(proc.sum())}")
+    print("wave ns: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; kernel span %.0f ns; sum of wave time / 8192 slots = %.0f ns" % (
+        dur[live].mean(), *np.percentile(dur[live], [50, 90, 99, 100]), end[live].max(), dur.sum() / 8192))
+    for t in np.arange(0, end[live].max(), 10000.0):
+        m = (st <= t) & (end > t) & live
+        print("  t=%6.0f ns: waves in flight %5d (two-level %5d) started so far %5d" % (t, int(m.sum()), int((m & (two == 1)).sum()), int(((st <= t) & live).sum())))
+    for b in np.argsort(-end)[:12]:
+        print("  late wave %5d tile %4d band %d lev %d two_level %d: list %4d batches %3d blended %4d start %6.0f dur %6.0f ns/blended %.0f loop %.0f topsync %.0f" % (
+            b, info[b] & 0xffff, (info[b] >> 16) & 15, (info[b] >> 20) & 1, two[b], n[b], batches[b], proc[b], st[b], dur[b], dur[b] / max(proc[b], 1), tloop[b], tsync[b]))
+    slow = np.argsort(-dur)[:200]
+    print("  slowest 200 waves: two-level %d, list length p10 %d p50 %d max %d; rank of their tiles in the list-length order: p50 %d max %d" % (
+        int(two[slow].sum()), *np.percentile(n[slow], [10, 50, 100]).astype(int),
+        *np.percentile(np.searchsorted(np.sort(-n[live]), -n[slow]), [50, 100]).astype(int)))
+    print("  corr(list length, dur) %.2f corr(blended, dur) %.2f" % (np.corrcoef(n[live], dur[live])[0, 1], np.corrcoef(proc[live], dur[live])[0, 1]))
+    print("  blended per wave: p50 %d p90 %d p99 %d max %d; two-level waves: %d, their share of wave time %.2f" % (
+        *np.percentile(proc[live], [50, 90, 99, 100]).astype(int), int((two[live] == 1).sum()), dur[two == 1].sum() / dur.sum()))
