@@ -1,70 +1,311 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the foveated 1080p render on a synthetic bicycle-scale cloud.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run,
-one rank per GPU). A step = one foveated frame through gaussian_renderer_fov.render() (4 layers,
-alpha 0.05, Lissajous-moving gaze) of the seeded S-6M cloud at 1920x1080; with N ranks
-each rank renders its own camera of an N-camera ring (weak scaling) and the frames are gathered on
-rank 0 over RCCL, overlapped with the next frame. Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`; rank 0 prints ONE JSON line.
+  N = 1: runs in this process.
+  N > 1 with the torchrun environment (RANK / WORLD_SIZE set): this process is one rank (one GPU).
+  N > 1 without it: this process only LAUNCHES -- before anything here touches a GPU it starts
+          `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`
+          as a child, relays rank 0's JSON line and exits with the child's code.
 
-Besides the headline value the line carries
-  roofline      the dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
-  cpu_baseline  the CPU oracle (a scalar C port of the reference algorithm) on a bounded sample
+A step = one foveated frame through gaussian_renderer_fov.render() (4 layers, alpha 0.05) of the seeded S-6M cloud
+ at 1920x1080 with the model handed over as the reference's tensors. Gaze of timed step i = GAZES[i % 9],
+the reference's fixed set (fov3dgs/render_compose_gazes_fps.py:26: centre + 8 off-centre), so the workload does not
+depend on --steps / --warmup. With N ranks each rank renders its own camera of an 8-camera ring (weak scaling; the views
+are independent: no data-path collective unless --gather).
+
+Besides `value` the line carries
+  value_packed  the same frames with render(packed="auto") (static-model layout, bit-identical image; fovraster.h)
+  roofline      dominant kernel: algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak; `blend` =
+                the same for the blend kernel (+ VALU / occupancy figures of the committed SQ-counter pass);
+                `frame` = all stages' bytes / ms_per_step; `traffic` = PMC bytes of the committed profile if it was made
+                with this very library build (traffic_source says which)
+  cpu_baseline  the CPU oracle (C port of the reference algorithm, OpenMP over Gaussians / tiles) on all host cores
   stages_ms     mean per-stage kernel time of the timed frames
-  extra         non-foveated forward fps and training fwd+bwd ms on the same cloud (N = 1 only)
+  extra         reference-protocol fps per gaze (events around the rasterizer only), moving-gaze fps, non-foveated
+                forward fps, training step fwd / bwd / loss ms (median of 50)
+--mode train (config 5): every rank does forward + loss + backward of its camera (pcheck_obb_sum, fused L1+SSIM) and the
+gradients are summed over ranks; reports fwd_bwd_ms and collective_ms.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import fov3dgs_amd  # noqa: E402,F401
-from fov3dgs_amd import _native, multiview, synthetic as syn  # noqa: E402
-from fov3dgs_amd.gaussian_renderer import render as render_plain  # noqa: E402
-from fov3dgs_amd.gaussian_renderer_fov import render as render_fov  # noqa: E402
-from fov3dgs_amd.profiling import StageTimer  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GAZES = [(0.25 * i, 0.25 * j) for i in range(1, 4) for j in range(1, 4)]  # render_compose_gazes_fps.py:26
+PROFILE_TAG = "r02"
 
 
-class FrozenCloud:
-    """Inference-time view of a cloud: activations evaluated once, getters return resident tensors."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=63)
+    ap.add_argument("--warmup", type=int, default=9)
+    ap.add_argument("--mode", choices=("render", "train"), default="render")
+    ap.add_argument("--points", type=int, default=6_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--packed-only", action="store_true", help="time only the packed-model frames (profiling passes)")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also collect every rank's frame on rank 0 (asynchronous RCCL gather overlapped with the next "
+                         "frame). Off by default: the views are independent and the path has no exchange step.")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch / rendezvous only (gloo without a GPU): rank 0 prints a line with n_gpus and exits")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
 
-    def __init__(self, cloud):
-        with torch.no_grad():
-            self.get_xyz = cloud.get_xyz.detach()
-            self.get_scaling = cloud.get_scaling.detach().contiguous()
-            self.get_rotation = cloud.get_rotation.detach().contiguous()
-            self.get_opacity = cloud.get_opacity.detach().contiguous()
-            self.get_features = cloud.get_features.detach().contiguous()
-            self.get_rest_features = cloud.get_rest_features.detach().contiguous()
-        self.get_features_detach_rest = self.get_features
-        self.active_sh_degree = cloud.active_sh_degree
 
-
-class Pipe:
-    debug = False
+def launch_ranks(args):
+    """--gpus N > 1 outside torchrun: start the N ranks as a child process tree (this process never touches a GPU)."""
+    import socket
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        rc = 1
+    sys.exit(rc)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def barrier_sync(world):
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
+class Pipe:
+    debug = False
 
 
-def frame_stats(lib, vid, out_state, W, H, T):
+def lib_sha16():
+    from fov3dgs_amd import _native
+    with open(_native.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)  # does not return
+    import numpy as np
+    import torch
+    import fov3dgs_amd  # noqa: F401
+    from fov3dgs_amd import _native, multiview, synthetic as syn
+    from fov3dgs_amd.gaussian_renderer import render as render_plain
+    from fov3dgs_amd.gaussian_renderer_fov import render as render_fov
+    from fov3dgs_amd.profiling import StageTimer
+
+    rank, world, local_rank = multiview.init_distributed()
+    if args.dry_launch:
+        if world > 1:
+            t = torch.ones(1)
+            torch.distributed.all_reduce(t)  # the rendezvous works
+            assert int(t.item()) == world
+        if rank == 0:
+            print(json.dumps({"metric": "frames/sec at 1080p foveated (bicycle-scale)", "value": None, "unit": "frames/s",
+                              "n_gpus": world, "dry_launch": True, "backend": torch.distributed.get_backend() if world > 1 else None}),
+                  flush=True)
+        return
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    lib = _native.load()
+    K, Wm = args.steps, args.warmup
+    W, H = args.width, args.height
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+
+    def barrier_sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    t0 = time.time()
+    cloud_cpu = syn.scene_bicycle_scale(P=args.points, seed=1)
+    fov_cpu = syn.foveation_layers(cloud_cpu, seed=2)
+    cloud = cloud_cpu.to(dev)
+
+    class FrozenCloud:
+        """Inference-time view of a cloud: activations evaluated once, getters return resident tensors."""
+
+        def __init__(self, c):
+            with torch.no_grad():
+                self.get_xyz = c.get_xyz.detach()
+                self.get_scaling = c.get_scaling.detach().contiguous()
+                self.get_rotation = c.get_rotation.detach().contiguous()
+                self.get_opacity = c.get_opacity.detach().contiguous()
+                self.get_features = c.get_features.detach().contiguous()
+                self.get_rest_features = c.get_rest_features.detach().contiguous()
+            self.get_features_detach_rest = self.get_features
+            self.active_sh_degree = c.active_sh_degree
+
+    pc = FrozenCloud(cloud)
+    highest, shs_dcs, opac = [t.to(dev) for t in fov_cpu]
+    n_views = 8
+    my_view = rank % n_views
+    cam = syn.camera_ring(my_view, n_views, W, H).to(dev)
+    bg = torch.zeros(3, device=dev)
+    if rank == 0:
+        log(f"[bench] scene ready in {time.time() - t0:.1f}s: P={args.points} {W}x{H} world={world} mode={args.mode}")
+
+    if args.mode == "train":
+        return train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync)
+
+    def frame(gaze, packed, **kw):
+        return render_fov(cam, pc, bg, alpha=0.05, gazeArray=gaze, blending=True, highest_levels=highest, shs_dcs=shs_dcs,
+                          opacities=opac, packed=packed, **kw)
+
+    def timed_run(packed):
+        """W warm-ups + exactly K timed frames (gaze i % 9), barrier + synchronize on both sides. -> (seconds, stage ms)"""
+        pending = None
+        with torch.no_grad():
+            for i in range(Wm):
+                out = frame(GAZES[i % 9], packed)
+                if world > 1 and args.gather:
+                    multiview.gather_images(out["render"], dst=0)
+            barrier_sync()
+            timer = StageTimer(K)
+            t_start = time.perf_counter()
+            with timer:
+                for i in range(K):
+                    out = frame(GAZES[i % 9], packed)
+                    if world > 1 and args.gather:
+                        if pending is not None:
+                            pending[0].wait()
+                        pending = multiview.gather_images(out["render"], dst=0, async_op=True) + (out["render"],)
+                if pending is not None:
+                    pending[0].wait()
+            barrier_sync()
+            elapsed = time.perf_counter() - t_start
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        st = timer.stage_ms()
+        timer.close()
+        return elapsed, {k: float(np.mean([s[k] for s in st])) for k in _native.STAGES}
+
+    if args.packed_only:
+        elapsed_p, mean_ms_p = timed_run("auto")
+        elapsed, mean_ms = elapsed_p, mean_ms_p
+    else:
+        elapsed, mean_ms = timed_run(None)        # the reference's tensor interface: the headline
+        elapsed_p, mean_ms_p = timed_run("auto")  # static-model layout
+    if rank != 0:
+        return
+
+    # ---- untimed post-pass: instance statistics of the timed gazes (for the algorithmic bytes) ----
+    vid = _native.VARIANT_FOV_PCHECK_OBB
+    from fov3dgs_amd import rasterizer as rz
+    stats = []
+    with torch.no_grad():
+        for gaze in GAZES:
+            rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
+                                                  cam.world_view_transform, cam.full_proj_transform, 3,
+                                                  cam.camera_center, False, False)
+            res = rz._forward_native(vid, rs, pc.get_xyz, pc.get_rest_features, torch.Tensor([]), opac, pc.get_scaling,
+                                     pc.get_rotation, torch.Tensor([]), shs_dcs, highest, gaze, 0.05)
+            torch.cuda.synchronize()
+            stats.append(frame_stats(torch, lib, vid, (res[0], res[2], res[5]), W, H, T))
+        vm = cam.world_view_transform
+        z = pc.get_xyz @ vm[:3, 2] + vm[3, 2]
+        V_in = int((z > 0.2).sum().item())
+    # timed step i uses gaze i % 9: weight the per-gaze statistics accordingly
+    wts = np.array([len(range(g, K, 9)) for g in range(9)], dtype=np.float64)
+    st = {k: float(np.sum([s[k] * w for s, w in zip(stats, wts)]) / wts.sum()) for k in stats[0]}
+    P, Px = args.points, W * H
+    alg_bytes = {
+        # SURVEY.md 8(d) per-unit figures x units of one launch
+        # B_pre = 20 P + 224 V_in + 48 V (+24 V OBB axes), split over this build's two kernels: the cull pass streams
+        # xyz/scale/rotation and writes radii; binning projects the survivors, reads opacity + SH and writes the
+        # per-Gaussian record and the OBB axes
+        "project": 20 * P + 28 * V_in,
+        "bin": 196 * V_in + (48 + 24) * st["V"],
+        "render": 32 * st["D_single"] + 52 * st["D_blend"] + 12 * Px,
+        # this build's binning moves (depth,id) once per stage instead of a 6-pass radix sort
+        "emit": 12 * st["D"] + 44 * st["V"],
+        "tile_sort": 12 * st["D"],
+        "tile_scan": 16 * T,
+        "tile_levels": 20 * T,
+    }
+    prof = load_profiles()
+    roof_ms = mean_ms  # the headline run's stage times
+
+    def roof(stage):
+        ach = alg_bytes[stage] / (roof_ms[stage] * 1e-3) / 1e9
+        d = dict(kernel=stage, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                 algorithmic_bytes=int(alg_bytes[stage]), kernel_ms=round(roof_ms[stage], 4))
+        d["traffic"], d["traffic_source"] = prof.traffic(stage, packed=args.packed_only)
+        return d
+    dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: roof_ms[k])
+    roofline = dict(bound="hbm", **roof(dominant))
+    roofline["blend"] = roof("render")
+    roofline["blend"].update(prof.blend_sq())
+    frame_bytes = sum(alg_bytes.values())
+    ms_step = elapsed / K * 1e3
+    roofline["frame"] = dict(algorithmic_bytes=int(frame_bytes), ms=round(ms_step, 4),
+                             achieved=round(frame_bytes / (ms_step * 1e-3) / 1e9, 2), frac=round(frame_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
+    roofline["per_kernel"] = {k: dict(ms=round(roof_ms[k], 4), alg_GBs=round(alg_bytes[k] / max(roof_ms[k], 1e-9) / 1e6, 1))
+                              for k in _native.STAGES}
+
+    extra = {}
+    if world == 1 and not args.no_extra:
+        extra = extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H, W)
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(cloud_cpu, fov_cpu, syn.camera_ring(my_view, n_views, W, H), GAZES[4], T, gx, gy)
+        except Exception as e:  # the baseline must never take the bench line down
+            cpu = dict(value=None, unit="frames/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")
+
+    line = {
+        "metric": "frames/sec at 1080p foveated (bicycle-scale)", "value": round(world * K / elapsed, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_packed": round(world * K / elapsed_p, 3), "ms_per_step_packed": round(elapsed_p / K * 1e3, 4),
+        "config": {"workload": "S-6M bicycle-scale cloud, 4-layer foveated render (fov_pcheck_obb), the reference's 9 fixed gazes "
+                               "(0.25 i, 0.25 j) in turn, one camera per GPU" + (", frames gathered on rank 0" if (world > 1 and args.gather) else ""),
+                   "gaussians": P, "width": W, "height": H, "alpha": 0.05, "sh_degree": 3,
+                   "visible": int(st["V"]), "in_front": V_in, "instances": int(st["D"]),
+                   "instances_blend_tiles": int(st["D_blend"]), "max_tile_list": int(max(s["max_list"] for s in stats)),
+                   "model_layout": "value: the reference's tensor interface (render(packed=None)); value_packed: the static-model "
+                                   "layout (packed_geom / packed_colour, made once, bit-identical image)",
+                   "parallelism": f"views{world}"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "stages_ms": {k: round(v, 4) for k, v in mean_ms.items()},
+        "stages_ms_packed": {k: round(v, 4) for k, v in mean_ms_p.items()},
+        "extra": extra,
+    }
+    print(json.dumps(line), flush=True)
+
+
+def frame_stats(torch, lib, vid, out_state, W, H, T):
     """V, D, D_single, D_blend of the last foveated forward call (reads the image workspace)."""
     num_rendered, radii, img = out_state
     rptr = lib.fr_image_ranges(vid, W, H, img.data_ptr())
@@ -81,22 +322,219 @@ def frame_stats(lib, vid, out_state, W, H, T):
                 max_list=int(lens.max().item()), blend_tiles=int(blend.sum().item()))
 
 
+class load_profiles:
+    """The committed rocprofv3 summaries (profiles/<tag>_pmc.json, <tag>_render_sq.json). PMC bytes are only quoted when
+    the profile was made with this very library build (sha of libfovraster_hip.so recorded by tools/make_profiles.sh)."""
+    STAGE_KERNELS = {"render": ["k_render_fov"], "project": ["k_project"], "bin": ["k_bin", "k_hist_colscan"],
+                     "tile_sort": ["k_tile_msort", "k_split_long"], "emit": ["k_emit"]}
+
+    def __init__(self):
+        self.pmc = self.sq = None
+        self.sha = lib_sha16()
+        for name in ("pmc", "render_sq"):
+            try:
+                with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.json")) as f:
+                    setattr(self, "pmc" if name == "pmc" else "sq", json.load(f))
+            except Exception:
+                pass
+
+    def traffic(self, stage, packed):
+        if self.pmc is None:
+            return None, "no profiles/%s_pmc.json" % PROFILE_TAG
+        src = f"profiles/{PROFILE_TAG}_pmc.json (lib {self.pmc.get('lib_sha16')}, {self.pmc.get('layout')})"
+        if self.pmc.get("lib_sha16") != self.sha:
+            return None, src + f": made with another build of the library (this one is {self.sha}) -- not quoted"
+        k = self.pmc["kernels"]
+        f_fetch = self.pmc.get("calibration", {}).get("fetch_factor", 2.0)
+        f_write = self.pmc.get("calibration", {}).get("write_factor", 1.0)
+        try:
+            b = sum(f_fetch * k[n]["FETCH_SIZE_KiB_per_frame"] + f_write * k[n]["WRITE_SIZE_KiB_per_frame"]
+                    for n in self.STAGE_KERNELS[stage] if n in k) * 1024
+        except Exception:
+            return None, src + ": kernel missing"
+        return int(b), src + f"; bytes = {f_fetch} x FETCH_SIZE + {f_write} x WRITE_SIZE (factors calibrated on the k_pack_* launches of the same pass)"
+
+    def blend_sq(self):
+        if self.sq is None:
+            return {}
+        e = next((v for n, v in self.sq.get("kernels", {}).items() if n.startswith("k_render_fov")), None)
+        if e is None:
+            return {}
+        out = {"sq_source": f"profiles/{PROFILE_TAG}_render_sq.json (lib {self.sq.get('lib_sha16')}" + ("" if self.sq.get("lib_sha16") == self.sha else f"; this build is {self.sha}") + ")"}
+        for k in ("valu_frac", "occupancy_waves_per_simd", "wait_inst_frac", "wait_any_frac", "valu_insts", "lds_wait_frac"):
+            if k in e:
+                out[k] = e[k]
+        return out
+
+
+def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H, W):
+    import torch.nn.functional as F
+    from fov3dgs_amd.loss_utils import l1_ssim_loss
+    extra = {}
+    # --- the reference's FPS protocol (render_compose_gazes_fps.py:50-64): per gaze 10 warm-ups, then 5 renders with a
+    # synchronize after each, events around the rasterizer call only; the reference's tensor interface
+    starter, ender = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    per_gaze = {}
+    with torch.no_grad():
+        for packed, tag in ((None, "reference_protocol_fps"), ("auto", "reference_protocol_fps_packed")):
+            fps_all = []
+            for gaze in GAZES:
+                for _ in range(10):
+                    frame(gaze, packed, starter=starter, ender=ender)
+                    torch.cuda.synchronize()
+                ms = 0.0
+                for _ in range(5):
+                    frame(gaze, packed, starter=starter, ender=ender)
+                    torch.cuda.synchronize()
+                    ms += starter.elapsed_time(ender)
+                fps_all.append(5 / (ms / 1000))
+                if packed is None:
+                    per_gaze[f"{gaze[0]:.2f},{gaze[1]:.2f}"] = round(fps_all[-1], 1)
+            extra[tag] = round(float(np.mean(fps_all)), 2)
+        extra["per_gaze_fps"] = per_gaze
+        # --- moving gaze (Lissajous path, a new gaze every frame), wall clock
+        for i in range(10):
+            frame(syn.lissajous_gaze(i, 90), None)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(90):
+            frame(syn.lissajous_gaze(10 + i, 90), None)
+        torch.cuda.synchronize()
+        extra["moving_gaze_fps"] = round(90 / (time.perf_counter() - t1), 2)
+        # --- non-foveated forward (config 2)
+        for _ in range(3):
+            render_plain(cam, pc, Pipe(), bg, cuda_type="pcheck_obb")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            render_plain(cam, pc, Pipe(), bg, cuda_type="pcheck_obb")
+        torch.cuda.synchronize()
+        extra["nonfov_forward_fps"] = round(20 / (time.perf_counter() - t1), 2)
+    # --- training step (config 4): eff_finetune.py's render -> 0.8 L1 + 0.2 (1 - SSIM) -> backward, no optimizer;
+    # forward / loss / backward timed apart with events, median of 50 (BASELINE.md 3)
+    tr = cloud.requires_grad_(True)
+    target = torch.rand(3, H, W, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    rows = []
+    for it in range(55):
+        for p in tr.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ev[0].record()
+        o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
+        ev[1].record()
+        loss = l1_ssim_loss(o["render"], target, 0.2)
+        ev[2].record()
+        loss.backward()
+        ev[3].record()
+        torch.cuda.synchronize()
+        rows.append((ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), (time.perf_counter() - t1) * 1e3))
+    med = np.median(np.array(rows[5:]), axis=0)
+    extra["train_fwd_ms"], extra["train_loss_fwd_ms"], extra["train_bwd_ms"], extra["train_step_ms"] = [round(float(x), 3) for x in med]
+    extra["train_note"] = ("pcheck_obb_sum forward (incl. the model's fused activations) / fused L1+SSIM forward / backward of both "
+                           "(loss + rasterizer + activations), events on the stream; train_step_ms = wall clock; median of 50")
+    # the reference's formulation of the loss (five grouped conv2d's + elementwise ops + autograd) in torch on the same GPU
+    g1 = torch.tensor([math.exp(-(i - 5) ** 2 / 4.5) for i in range(11)], device=dev)
+    g1 = g1 / g1.sum()
+    win = (g1[:, None] @ g1[None, :])[None, None].expand(3, 1, 11, 11).contiguous()
+
+    def torch_loss(img, gt):
+        a, b = img[None], gt[None]
+        mu1, mu2 = F.conv2d(a, win, padding=5, groups=3), F.conv2d(b, win, padding=5, groups=3)
+        s1 = F.conv2d(a * a, win, padding=5, groups=3) - mu1 * mu1
+        s2 = F.conv2d(b * b, win, padding=5, groups=3) - mu2 * mu2
+        s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
+        m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+        return 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - m.mean())
+    tl = []
+    img0 = o["render"].detach()
+    for it in range(8):
+        img = img0.clone().requires_grad_(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        torch_loss(img, target).backward()
+        torch.cuda.synchronize()
+        tl.append((time.perf_counter() - t1) * 1e3)
+    extra["loss_fwd_bwd_torch_ms"] = round(float(np.median(tl[2:])), 3)
+    return extra
+
+
+def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync):
+    """Config 5: one camera per rank, forward + loss + backward, then the gradient sum over ranks."""
+    import numpy as np
+    import torch
+    from fov3dgs_amd.loss_utils import l1_ssim_loss
+    K, Wm = args.steps, args.warmup
+    H, W = args.height, args.width
+    tr = cloud.requires_grad_(True)
+    target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))
+    params = list(tr.parameters())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    fb, co, info = [], [], None
+
+    def step(timed):
+        nonlocal info
+        for p in params:
+            p.grad = None
+        ev[0].record()
+        o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
+        l1_ssim_loss(o["render"], target, 0.2).backward()
+        ev[1].record()
+        info = multiview.allreduce_gradients(params, visible=o["visibility_filter"])
+        ev[2].record()
+        if timed:
+            torch.cuda.synchronize()
+            fb.append(ev[0].elapsed_time(ev[1]))
+            co.append(ev[1].elapsed_time(ev[2]))
+    for _ in range(Wm):
+        step(False)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step(True)
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, float(np.median(fb)), float(np.median(co))], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed, fbm, com = [float(x) for x in t.tolist()]
+    else:
+        fbm, com = float(np.median(fb)), float(np.median(co))
+    if rank != 0:
+        return
+    nbytes = (info or {}).get("bytes", 0)
+    algbw = nbytes / (com * 1e-3) / 1e9 if com > 0 and world > 1 else None
+    line = {"metric": "fwd+bwd ms/iter (multi-view training step, one camera per GPU)", "value": round(elapsed / K * 1e3, 4), "unit": "ms/iter",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": False,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S-6M cloud, pcheck_obb_sum forward + fused 0.8 L1 + 0.2 (1 - SSIM) + backward per rank, gradient "
+                                   "sum over ranks (multiview.allreduce_gradients)", "gaussians": args.points, "width": W, "height": H,
+                       "parallelism": f"views{world}"},
+            "fwd_bwd_ms": round(fbm, 4), "collective_ms": round(com, 4), "views_per_s": round(world * K / elapsed, 3),
+            "collective": dict(info or {}, algbw_GBs=None if algbw is None else round(algbw, 2),
+                               busbw_GBs=None if algbw is None else round(algbw * 2 * (world - 1) / world, 2))}
+    print(json.dumps(line), flush=True)
+
+
 def cpu_baseline(cloud_cpu, fov_cpu, cam, gaze, T_tiles, gx, gy):
-    """Time the CPU oracle (scalar C port, 1 core) on a bounded sample: every Gaussian is preprocessed and
-    culled (the per-frame part that does not depend on the window), binning + sort + blending are restricted
-    to a 32x32-tile window around the image centre, and a 1x1 window isolates the window-independent part.
-    Frame time = t(1x1) + (t(32x32) - t(1x1)) / 1023 * (tiles - 1); best of two runs each."""
+    """The CPU oracle (C port of the reference algorithm, OpenMP over Gaussians and tiles) on all host cores. Every
+    Gaussian is preprocessed and culled; binning + sort + blending run over the whole frame when a 32x32-tile probe says
+    that fits the time budget, else over the probe window and extrapolated (said so in `sample`)."""
     from oracle import oracle as orc
     from tests.helpers import cam_dict, scene_dict
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
     scene = scene_dict(cloud_cpu, "fov_pcheck_obb", fov_cpu)
     wx, wy = min(32, gx), min(32, gy)
     x0, y0 = (gx - wx) // 2, (gy - wy) // 2
     cd = cam_dict(cam, gaze=gaze, alpha=0.05)
+    cd["capacity_hint"] = 16_000_000
 
-    def timed(win):
+    def timed(win, reps=2):
         cd["tile_window"] = win
         best = 1e9
-        for _ in range(2):
+        for _ in range(reps):
             t0 = time.perf_counter()
             orc.forward("fov_pcheck_obb", scene, cd)
             best = min(best, time.perf_counter() - t0)
@@ -105,247 +543,24 @@ def cpu_baseline(cloud_cpu, fov_cpu, cam, gaze, T_tiles, gx, gy):
     t_win = timed((x0, y0, x0 + wx, y0 + wy))
     t_one = timed((x0 + wx // 2, y0 + wy // 2, x0 + wx // 2 + 1, y0 + wy // 2 + 1))
     per_tile = max(t_win - t_one, 0.0) / (wx * wy - 1)
-    t_frame = t_one + per_tile * (T_tiles - 1)
-    return dict(value=1.0 / t_frame, unit="frames/s", cores=1, kind="port",
-                sample=(f"oracle/fovraster_oracle.c (scalar C, 1 thread): all {len(cloud_cpu)} Gaussians preprocessed+culled; "
-                        f"{wx}x{wy}-tile centre window binned/sorted/blended in {t_win:.2f}s, 1x1 window {t_one:.2f}s; frame "
-                        f"time extrapolated to {T_tiles} tiles = {t_frame:.2f}s"),
+    est = t_one + per_tile * (T_tiles - 1)
+    if est < 12.0:
+        t_frame = timed(None, reps=2)
+        how = f"whole frame ({T_tiles} tiles) binned / sorted / blended: {t_frame:.2f} s"
+    else:
+        t_frame = est
+        how = (f"{wx}x{wy}-tile centre window binned / sorted / blended in {t_win:.2f} s, 1x1 window {t_one:.2f} s; frame time "
+               f"EXTRAPOLATED to {T_tiles} tiles = {t_frame:.2f} s")
+    return dict(value=round(1.0 / t_frame, 5), unit="frames/s", cores=cores, kind="port",
+                sample=f"oracle/fovraster_oracle.c (C port, OpenMP, {cores} threads), centre gaze: all {len(cloud_cpu)} Gaussians preprocessed + culled; " + how,
                 seconds_measured=round(time.perf_counter() - t_total0, 2))
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--points", type=int, default=6_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: also collect every rank's frame on rank 0 (asynchronous RCCL gather overlapped with the next "
-                         "frame). Off by default: the views are independent and the path has no exchange step.")
-    args = ap.parse_args()
-
-    rank, world, local_rank = multiview.init_distributed()
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    lib = _native.load()
-    K, Wm = args.steps, args.warmup
-    W, H = args.width, args.height
-    gx, gy = (W + 15) // 16, (H + 15) // 16
-    T = gx * gy
-
-    t0 = time.time()
-    cloud_cpu = syn.scene_bicycle_scale(P=args.points, seed=1)
-    fov_cpu = syn.foveation_layers(cloud_cpu, seed=2)
-    cloud = cloud_cpu.to(dev)
-    pc = FrozenCloud(cloud)
-    highest, shs_dcs, opac = [t.to(dev) for t in fov_cpu]
-    n_views = max(world, 8)
-    cam = syn.camera_ring(multiview.views_for_rank(rank, world, world)[0] * (n_views // world), n_views, W, H).to(dev)
-    bg = torch.zeros(3, device=dev)
-    if rank == 0:
-        log(f"[bench] scene ready in {time.time() - t0:.1f}s: P={args.points} {W}x{H} world={world}")
-
-    last = {}
-
-    def step(i):
-        gaze = syn.lissajous_gaze(i, 90)
-        out = render_fov(cam, pc, bg, alpha=0.05, gazeArray=gaze, blending=True, highest_levels=highest,
-                         shs_dcs=shs_dcs, opacities=opac, packed="auto")
-        return out
-
-    pending = None
-    with torch.no_grad():
-        for i in range(Wm):
-            out = step(i)
-            if world > 1 and args.gather:
-                multiview.gather_images(out["render"], dst=0)
-        barrier_sync(world)
-        timer = StageTimer(K)
-        t_start = time.perf_counter()
-        with timer:
-            for i in range(K):
-                out = step(Wm + i)
-                if world > 1 and args.gather:
-                    if pending is not None:
-                        pending[0].wait()
-                    pending = multiview.gather_images(out["render"], dst=0, async_op=True) + (out["render"],)
-            if pending is not None:
-                pending[0].wait()
-        barrier_sync(world)
-        elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    stages = timer.stage_ms()
-    timer.close()
-    mean_ms = {k: float(np.mean([s[k] for s in stages])) for k in _native.STAGES}
-
-    if rank != 0:
-        return
-
-    # ---- untimed post-pass: instance statistics of the same frames (for algorithmic bytes) ----
-    vid = _native.VARIANT_FOV_PCHECK_OBB
-    from fov3dgs_amd import rasterizer as rz
-    stats = []
-    with torch.no_grad():
-        rs = None
-        for i in range(0, K, max(1, K // 12)):
-            gaze = syn.lissajous_gaze(Wm + i, 90)
-            rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
-                                                  cam.world_view_transform, cam.full_proj_transform, 3,
-                                                  cam.camera_center, False, False)
-            res = rz._forward_native(vid, rs, pc.get_xyz, pc.get_rest_features, torch.Tensor([]), opac, pc.get_scaling,
-                                     pc.get_rotation, torch.Tensor([]), shs_dcs, highest, gaze, 0.05)
-            torch.cuda.synchronize()
-            stats.append(frame_stats(lib, vid, (res[0], res[2], res[5]), W, H, T))
-        vm = cam.world_view_transform
-        z = pc.get_xyz @ vm[:3, 2] + vm[3, 2]
-        V_in = int((z > 0.2).sum().item())
-    st = {k: float(np.mean([s[k] for s in stats])) for k in stats[0]}
-    P, Px = args.points, W * H
-    alg_bytes = {
-        # SURVEY.md 8(d) per-unit figures x units of one launch
-        # B_pre = 20 P + 224 V_in + 48 V (+24 V OBB axes), split over this build's two kernels: the cull pass streams
-        # xyz/scale/rotation and writes radii; binning projects the survivors, reads opacity + SH and writes the
-        # per-Gaussian record and the OBB axes
-        "project": 20 * P + 28 * V_in,
-        "bin": 196 * V_in + (48 + 24) * st["V"],
-        "render": 32 * st["D_single"] + 52 * st["D_blend"] + 12 * Px,
-        # this build's binning moves (depth,id) once per stage instead of a 6-pass radix sort
-        "emit": 12 * st["D"] + 44 * st["V"],
-        "tile_sort": 12 * st["D"],
-        "tile_scan": 16 * T,
-        "tile_levels": 20 * T,
-    }
-    dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: mean_ms[k])
-    achieved = alg_bytes[dominant] / (mean_ms[dominant] * 1e-3) / 1e9
-    traffic = None
-    try:  # HBM bytes per launch of that kernel from the committed PMC pass (profiles/), if it exists
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["kernels"]
-        knames = {"render": ["k_render_fov"], "project": ["k_project"], "bin": ["k_bin", "k_hist_colscan"],
-                  "tile_sort": ["k_tile_msort"], "emit": ["k_emit"]}[dominant]
-        traffic = int(sum(2 * pmc[k]["FETCH_SIZE_KiB_per_frame"] + pmc[k]["WRITE_SIZE_KiB_per_frame"] for k in knames) * 1024)
-    except Exception:
-        pass
-    roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                    algorithmic_bytes=int(alg_bytes[dominant]), kernel_ms=round(mean_ms[dominant], 4),
-                    per_kernel={k: dict(ms=round(mean_ms[k], 4), alg_GBs=round(alg_bytes[k] / max(mean_ms[k], 1e-9) / 1e6, 1))
-                                for k in _native.STAGES})
-
-    extra = {}
-    if world == 1 and not args.no_extra:
-        with torch.no_grad():
-            for _ in range(3):
-                render_plain(cam, pc, Pipe(), bg, cuda_type="pcheck_obb")
-            torch.cuda.synchronize()
-            n = 20
-            t1 = time.perf_counter()
-            for _ in range(n):
-                render_plain(cam, pc, Pipe(), bg, cuda_type="pcheck_obb")
-            torch.cuda.synchronize()
-            extra["nonfov_forward_fps"] = round(n / (time.perf_counter() - t1), 2)
-            # the same foveated frames without the packed copy of the static model that render() makes and caches by
-            # itself (gaussian_renderer_fov._auto_packed; include/fovraster.h packed_geom / packed_colour)
-            for i in range(Wm):
-                render_fov(cam, pc, bg, alpha=0.05, gazeArray=syn.lissajous_gaze(i, 90), blending=True,
-                           highest_levels=highest, shs_dcs=shs_dcs, opacities=opac, packed=None)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(K):
-                render_fov(cam, pc, bg, alpha=0.05, gazeArray=syn.lissajous_gaze(Wm + i, 90), blending=True,
-                           highest_levels=highest, shs_dcs=shs_dcs, opacities=opac, packed=None)
-            torch.cuda.synchronize()
-            extra["unpacked_model_fps"] = round(K / (time.perf_counter() - t1), 2)
-        tr = cloud.requires_grad_(True)
-        target = torch.rand(3, H, W, device=dev)
-        ts = []
-        for it in range(14):
-            for p in tr.parameters():
-                p.grad = None
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
-            loss = (o["render"] - target).abs().mean()
-            loss.backward()
-            torch.cuda.synchronize()
-            ts.append((time.perf_counter() - t1) * 1e3)
-        extra["train_fwd_bwd_ms"] = round(float(np.median(ts[2:])), 3)
-        extra["train_loss"] = "L1 (rasterizer fwd+bwd incl. torch activations)"
-        # the eff_finetune.py step with its real loss, 0.8 L1 + 0.2 (1 - SSIM): the fused HIP loss (csrc/loss.hip) next
-        # to the reference's formulation (five grouped conv2d's + elementwise ops + autograd) in torch on the same GPU
-        from fov3dgs_amd.loss_utils import l1_ssim_loss
-        import torch.nn.functional as F
-        g1 = torch.tensor([math.exp(-(i - 5) ** 2 / 4.5) for i in range(11)], device=dev)
-        g1 = g1 / g1.sum()
-        win = (g1[:, None] @ g1[None, :])[None, None].expand(3, 1, 11, 11).contiguous()
-
-        def torch_loss(img, gt):
-            a, b = img[None], gt[None]
-            mu1, mu2 = F.conv2d(a, win, padding=5, groups=3), F.conv2d(b, win, padding=5, groups=3)
-            s1 = F.conv2d(a * a, win, padding=5, groups=3) - mu1 * mu1
-            s2 = F.conv2d(b * b, win, padding=5, groups=3) - mu2 * mu2
-            s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
-            m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
-            return 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - m.mean())
-
-        for name, fn in (("fused", lambda i, t: l1_ssim_loss(i, t, 0.2)), ("torch", torch_loss)):
-            ts, tl = [], []
-            for it in range(10):
-                for p in tr.parameters():
-                    p.grad = None
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
-                fn(o["render"], target).backward()
-                torch.cuda.synchronize()
-                ts.append((time.perf_counter() - t1) * 1e3)
-                img = o["render"].detach().requires_grad_(True)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                fn(img, target).backward()
-                torch.cuda.synchronize()
-                tl.append((time.perf_counter() - t1) * 1e3)
-            extra[f"train_step_l1_ssim_{name}_ms"] = round(float(np.median(ts[2:])), 3)
-            extra[f"loss_fwd_bwd_{name}_ms"] = round(float(np.median(tl[2:])), 3)
-
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        try:
-            cpu = cpu_baseline(cloud_cpu, fov_cpu, cam, syn.lissajous_gaze(Wm, 90), T, gx, gy)
-            cpu["value"] = round(cpu["value"], 5)
-        except Exception as e:  # the baseline must never take the bench line down
-            cpu = dict(value=None, unit="frames/s", cores=1, kind="port", sample=f"failed: {e}")
-
-    fps = world * K / elapsed
-    line = {
-        "metric": "frames/sec at 1080p foveated (bicycle-scale)", "value": round(fps, 3), "unit": "frames/s",
-        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "S-6M bicycle-scale cloud, 4-layer foveated render (fov_pcheck_obb), moving gaze, "
-                               "one camera per GPU" + (", frames gathered on rank 0" if (world > 1 and args.gather) else ""),
-                   "gaussians": P, "width": W, "height": H, "alpha": 0.05, "sh_degree": 3,
-                   "visible": int(st["V"]), "in_front": V_in, "instances": int(st["D"]),
-                   "instances_blend_tiles": int(st["D_blend"]), "max_tile_list": int(st["max_list"]),
-                   "model_layout": "static model: render() packs it once during warm-up (packed_geom/packed_colour, "
-                                   "bit-identical image); extra.unpacked_model_fps = same frames without",
-                   "parallelism": f"views{world}"},
-        "roofline": roofline,
-        "cpu_baseline": cpu,
-        "stages_ms": {k: round(v, 4) for k, v in mean_ms.items()},
-        "extra": extra,
-    }
-    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
     main()
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+    try:
+        import torch
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+    except Exception:
+        pass

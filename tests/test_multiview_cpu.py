@@ -36,7 +36,21 @@ def _worker(rank, world, port, q):
     params = [torch.nn.Parameter(torch.zeros(7, 3)), torch.nn.Parameter(torch.zeros(11))]
     for i, p in enumerate(params):
         p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
-    multiview.allreduce_gradients(params, bucket_bytes=64)  # tiny buckets: exercises the flush logic
+    info = multiview.allreduce_gradients(params)
+    assert info["mode"] == "dense" and info["bytes"] == (7 * 3 + 11) * 4
+    # row-sparse exchange: rank r's view touches rows {r, 5}; rows outside the union stay exactly zero everywhere
+    sp = [torch.nn.Parameter(torch.zeros(40, 3)), torch.nn.Parameter(torch.zeros(40, 2, 2))]
+    vis = torch.zeros(40, dtype=torch.bool)
+    vis[[rank, 5]] = True
+    for i, p in enumerate(sp):
+        p.grad = torch.zeros_like(p)
+        p.grad[vis] = float((rank + 1) * (i + 1))
+    info2 = multiview.allreduce_gradients(sp, visible=vis)
+    assert info2["mode"] == "rows" and info2["rows"] == 3 and info2["of"] == 40
+    want0 = torch.zeros(40, 3); want0[0] = 1.0; want0[1] = 2.0; want0[5] = 3.0
+    assert torch.equal(sp[0].grad, want0) and torch.equal(sp[1].grad[:, 0, 0], 2 * want0[:, 0])
+    # a union that covers most rows falls back to the dense exchange
+    assert multiview.allreduce_gradients(sp, visible=torch.ones(40, dtype=torch.bool))["mode"] == "dense"
     q.put((rank, views, None if gathered is None else [g.mean().item() for g in gathered],
            allg.mean(dim=(1, 2, 3)).tolist(), [p.grad.mean().item() for p in params]))
     dist.barrier()

@@ -15,9 +15,10 @@ for P in "$P1" "$P2" "$P3"; do
   i=$((i+1)); rm -rf /tmp/sq_$i
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/sq_$i -o p -- python3 bench.py $ARGS > /tmp/sq_$i.log 2>&1
 done
-python3 - "$TAG" "$ARGS" <<'PY'
+SHA=$(sha256sum fov-3dgs_amd/libfovraster_hip.so | cut -c1-16)
+python3 - "$TAG" "$ARGS" "$SHA" <<'PY'
 import csv, collections, json, os, re, sys
-tag, args = sys.argv[1], sys.argv[2]
+tag, args, sha = sys.argv[1], sys.argv[2], sys.argv[3]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for i in (1, 2, 3):
@@ -49,11 +50,20 @@ for name, d in agg.items():
             if c in e: e[c + "_per_WAVE_CYCLES"] = round(e[c] / wc, 4)
         if e.get("SQ_WAVES"): e["wave_cycles_x4_per_wave"] = round(4 * wc / e["SQ_WAVES"], 1)
     if e.get("GRBM_GUI_ACTIVE") and wc:
-        # mean resident waves per SIMD over the kernel = wave quad-cycles x 4 / (GPU cycles x 1024 SIMDs)
-        e["mean_waves_per_simd"] = round(4 * wc / (e["GRBM_GUI_ACTIVE"] * 1024), 3)
-        if "SQ_ACTIVE_INST_VALU" in e: e["valu_busy_frac_of_simd_cycles"] = round(4 * e["SQ_ACTIVE_INST_VALU"] / (e["GRBM_GUI_ACTIVE"] * 1024), 4)
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs (4.2 M for a 231 us kernel = 526 k cycles at 2.28 GHz each); the chip
+        # has 1024 SIMDs, a wave64 VALU instruction occupies its SIMD for one quad-cycle
+        cyc = e["GRBM_GUI_ACTIVE"] / 8.0
+        e["gpu_cycles"] = round(cyc)
+        if "avg_duration_us_profiled" in e: e["clock_GHz"] = round(cyc / e["avg_duration_us_profiled"] / 1e3, 3)
+        e["occupancy_waves_per_simd"] = round(4 * wc / (cyc * 1024), 3)          # mean resident waves per SIMD (max 8)
+        if "SQ_ACTIVE_INST_VALU" in e: e["valu_frac"] = round(4 * e["SQ_ACTIVE_INST_VALU"] / (cyc * 1024), 4)  # share of SIMD cycles with a VALU instruction executing
+        if "SQ_INSTS_VALU" in e: e["valu_insts"] = round(e["SQ_INSTS_VALU"])
+        if "SQ_WAIT_INST_ANY" in e: e["wait_inst_frac"] = round(e["SQ_WAIT_INST_ANY"] / wc, 4)   # wave-cycles waiting to issue
+        if "SQ_WAIT_ANY" in e: e["wait_any_frac"] = round(e["SQ_WAIT_ANY"] / wc, 4)              # wave-cycles parked on s_waitcnt
+        if "SQ_WAIT_INST_LDS" in e: e["lds_wait_frac"] = round(e["SQ_WAIT_INST_LDS"] / wc, 4)
     out[name] = e
 doc = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py " + args + "  (three separate passes)",
+       "lib_sha16": sha,
        "note": "per-launch averages; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; GRBM_GUI_ACTIVE = GPU cycles of the dispatch",
        "kernels": out}
 p = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "profiles", f"{tag}_render_sq.json")
