@@ -293,7 +293,7 @@ int fr_backward(const fr_backward_args *a)
 	{ set_error("backward exists only for the original and pcheck_obb_sum/_max/_loss_weighted_max_count variants (the reference's inference variants have none)"); return FR_ERR_INVALID; }
 	if (a->P == 0) return FR_OK;
 	if (!a->geometry || !a->image || (a->R > 0 && !a->binning) || !a->dL_dpix || !a->radii) { set_error("missing workspace / gradient pointer"); return FR_ERR_INVALID; }
-	if (!a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor || !a->dL_dmean3D || (!a->dL_dcov3D && a->cov3D_precomp) || !a->dL_dscale || !a->dL_drot)
+	if (!a->dL_dmean2D || !a->dL_dopacity || !a->dL_dmean3D || (!a->dL_dcov3D && a->cov3D_precomp) || (!a->dL_dcolor && a->colors_precomp) || !a->dL_dscale || !a->dL_drot)
 	{ set_error("missing gradient output pointer"); return FR_ERR_INVALID; }
 	if (a->shs && !a->dL_dsh) { set_error("dL_dsh is null"); return FR_ERR_INVALID; }
 	if (a->shs_rest && (!a->shs || !a->dL_dsh_rest)) { set_error("shs_rest needs shs and dL_dsh_rest"); return FR_ERR_INVALID; }

@@ -6,59 +6,79 @@
 //   computeCov2DCUDA          backward.cu:144-274
 //   preprocessCUDA (backward) backward.cu:346-396  (+ computeColorFromSH bwd :20-139, computeCov3D bwd :278-341)
 //
-// MI355X design: the reference issues 9 float atomics per contributing (pixel, Gaussian) pair.
-// Here every lane first sums over its PPL pixels, the 64 lanes of the wave are then reduced with
-// DPP adds (all lanes look at the same Gaussian in lock-step), and one lane issues the 9 atomics:
-// 256x fewer L2 atomics per tile-instance at PPL=4. computeCov2D and the preprocess backward are
-// fused into one per-Gaussian kernel.
+// MI355X design. The reference issues 9 float atomics per contributing (pixel, Gaussian) pair into four [P, .] arrays.
+// Here (k_render_bwd) a work item is one band of a tile (one wave, two pixels per lane, as in the forward blend); for
+// every list entry that reaches the band the 64 lanes' nine partial sums are reduced with gfx950's cross-row swaps
+// (v_permlane32_swap / v_permlane16_swap fold eight values into two registers in 12 instructions, four DPP steps finish
+// each row; 26 instructions instead of 54 for nine separate butterflies) so that the totals end up in nine DIFFERENT
+// lanes, which add them with ONE atomic instruction into ONE 64-byte row per Gaussian (`acc`, indexed by the
+// Gaussian's position in the forward pass's visible list: dense, zeroed by the forward pass, read back coalesced).
+// k_preprocess_bwd then walks the visible list: cov2D / projection / SH / cov3D chain rule fused, one pass.
 #include "common.h"
 
 namespace fr {
 
 __device__ __forceinline__ float bwd_exp(float p) { return __builtin_amdgcn_exp2f(p * 1.4426950408889634f); }
 
+typedef unsigned int bwd_u2 __attribute__((ext_vector_type(2)));
+// lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l]  (tools/scratch/permlane_test.hip)
+__device__ __forceinline__ float fold32(float a, float b)
+{
+	const bwd_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+	return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// rows of 16 lanes: (a0 + a1, b0 + b1, a2 + a3, b2 + b3)
+__device__ __forceinline__ float fold16(float a, float b)
+{
+	const bwd_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+	return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// sum over each row of 16 lanes, in all its lanes
+__device__ __forceinline__ float row_sum16(float x)
+{
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false)); // row_half_mirror
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false)); // row_mirror
+	return x;
+}
+// sum over the wave, valid in lane 63
 __device__ __forceinline__ float wave_sum_b(float x)
 {
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false));
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xC, 0xF, false));
-	return x; // total lives in lane 63
+	x = row_sum16(x);
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false)); // row_bcast15 -> rows 1, 3
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xC, 0xF, false)); // row_bcast31 -> rows 2, 3
+	return x;
 }
 
 struct BwdRenderArgs {
 	int W, H, gx;
 	const uint2 *ranges;
-	const uint32_t *tile_order;
+	const uint32_t *render_items; // forward's work items: tile << 3 | band
+	uint32_t n_items;
 	const uint32_t *point_list;
 	const float4 *rec;
 	const float *bg;
 	const float *final_T;
 	const uint32_t *n_contrib;
 	const float *dL_dpix;
-	float *dL_dmean2D;  // [P,3]
-	float *dL_dconic;   // [P,4]
-	float *dL_dopacity; // [P]
-	float *dL_dcolor;   // [P,3]
+	float *acc; // [V][16] gradient sums per visible-list entry, see GeomWS::acc
 };
 
-template <bool CUTOFF, int PPL>
-__global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
+template <bool CUTOFF>
+__global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 {
-	constexpr int NT = 256 / PPL;
-	constexpr int NW = NT / 64; // waves per tile, each owning a band of 16 / NW rows (see tile_row)
-	__shared__ float4 s0[NT];
-	__shared__ float4 s1[NT];
-	__shared__ float s2[NT];
-	__shared__ int sid[NT];
-	__shared__ unsigned long long s_reach[NW][NW]; // [band][staging wave]: staged entries that can touch the band
+	constexpr int PPL = 2;
+	__shared__ float4 s0[64];  // x, y, conic a, conic b
+	__shared__ float4 s1[64];  // conic c, opacity, r, g
+	__shared__ float2 s2[64];  // b, row of the gradient sums (int bits)
 
-	const int tile = (int)a.tile_order[blockIdx.x]; // longest lists first
+	if (blockIdx.x >= a.n_items) return;
+	const uint32_t item = a.render_items[blockIdx.x]; // longest lists first
+	const int tile = (int)(item >> 3), wv = (int)(item & 1u);
 	const int tx = tile % a.gx, ty = tile / a.gx;
-	const int tid = threadIdx.x;
-	const int lane = tid & 63;
+	const int lane = threadIdx.x;
+	const int tid = wv * 64 + lane;
 	const int lx = tid & 15;
 	const int px = tx * FR_TILE + lx;
 	const float pxf = (float)px;
@@ -69,10 +89,11 @@ __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 	const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
-	float T[PPL], Tfin[PPL], pyf[PPL], acc0[PPL], acc1[PPL], acc2[PPL], lastA[PPL], lc0[PPL], lc1[PPL], lc2[PPL];
+	// per pixel: transmittance behind the current entry, the colour accumulated behind it, the last alpha / colour
+	float T[PPL], Tfin[PPL], pyf[PPL], behind0[PPL], behind1[PPL], behind2[PPL], prevA[PPL], prev0[PPL], prev1[PPL], prev2[PPL];
 	float dp0[PPL], dp1[PPL], dp2[PPL], bgdot[PPL];
 	int lastc[PPL];
-	int max_last = 0;
+	int wave_last = 0;
 #pragma unroll
 	for (int k = 0; k < PPL; k++)
 	{
@@ -83,166 +104,127 @@ __global__ void __launch_bounds__(256 / PPL) k_render_bwd(const BwdRenderArgs a)
 		Tfin[k] = inside ? a.final_T[pid] : 0.0f;
 		T[k] = Tfin[k];
 		lastc[k] = inside ? (int)a.n_contrib[pid] : 0;
-		max_last = max(max_last, lastc[k]);
+		wave_last = max(wave_last, lastc[k]);
 		dp0[k] = inside ? a.dL_dpix[pid] : 0.0f;
 		dp1[k] = inside ? a.dL_dpix[plane + pid] : 0.0f;
 		dp2[k] = inside ? a.dL_dpix[2 * plane + pid] : 0.0f;
 		bgdot[k] = bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k];
-		acc0[k] = acc1[k] = acc2[k] = 0.0f; lastA[k] = 0.0f; lc0[k] = lc1[k] = lc2[k] = 0.0f;
+		behind0[k] = behind1[k] = behind2[k] = 0.0f; prevA[k] = 0.0f; prev0[k] = prev1[k] = prev2[k] = 0.0f;
 	}
-	// nothing behind the deepest contributor of this wave / tile needs to be visited
-	int wave_last = max_last;
+	// nothing behind the deepest contributor of this wave's pixels needs to be visited
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
-	__shared__ int tile_last_s;
-	if (tid == 0) tile_last_s = 0;
-	__syncthreads();
-	if (lane == 0) atomicMax(&tile_last_s, wave_last);
-	__syncthreads();
-	const int tile_last = tile_last_s; // entries [0, tile_last) can contribute
-	if (tile_last == 0) return;
+	if (wave_last == 0) return;
 
-	// walk the list back to front, starting at the tile's deepest contributor; NT (= 64) entries per batch,
-	// the next batch's records are prefetched into registers while this one is processed
-	uint32_t pid = 0;
+	// walk the list back to front from there, 64 entries per batch; the next batch's records are prefetched into
+	// registers while this one is processed
 	float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
-	float p2 = 0.f;
-	if (tid < tile_last)
+	float2 p2 = make_float2(0, 0);
+	auto fetch = [&](int e)
 	{
-		pid = a.point_list[range.x + tile_last - 1 - tid];
-		const float4 *r = a.rec + 3 * (size_t)pid;
-		p0 = r[0]; p1 = r[1]; p2 = r[2].x;
-	}
-	for (int top = tile_last; top > 0; top -= NT)
+		const uint32_t id = a.point_list[range.x + e];
+		const float4 *r = a.rec + 3 * (size_t)id;
+		p0 = r[0]; p1 = r[1];
+		const float4 r2 = r[2];
+		p2 = make_float2(r2.x, r2.w);
+	};
+	if (lane < wave_last) fetch(wave_last - 1 - lane);
+	for (int top = wave_last; top > 0; top -= 64)
 	{
-		__syncthreads();
-		const int cnt = min(NT, top);
-		const bool staged = tid < cnt;
-		if (staged) { s0[tid] = p0; s1[tid] = p1; s2[tid] = p2; sid[tid] = (int)pid; }
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous batch has been read by all lanes
+		__builtin_amdgcn_wave_barrier();
+		const bool staged = lane < min(64, top);
+		if (staged) { s0[lane] = p0; s1[lane] = p1; s2[lane] = p2; }
+		unsigned long long reach;
 		{
-			// entries that cannot touch a wave's rows are skipped for that wave: same thresholds as the per-pixel
-			// tests below (power < -4.5, alpha < 1/255 <=> power < -ln(255 opacity)), see splat_reaches()
+			// entries that cannot touch this wave's rows are skipped: same thresholds as the per-pixel tests below
+			// (power < -4.5, alpha < 1/255 <=> power < -ln(255 opacity)), see splat_reaches()
 			const float thr_a = -__logf(255.0f * p1.y) - 0.01f;
 			const float thr = CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a;
-#pragma unroll
-			for (int w = 0; w < NW; w++)
-			{
-				const bool reach = staged && band_reaches<PPL>(w, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr);
-				const unsigned long long m = __ballot(reach);
-				if (lane == 0) s_reach[w][tid >> 6] = m;
-			}
+			reach = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
 		}
-		if (top - NT - tid > 0)
+		if (top - 64 - lane > 0) fetch(top - 64 - 1 - lane);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // lanes read entries other lanes staged
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		for (unsigned long long rm = reach; rm; rm &= rm - 1)
 		{
-			pid = a.point_list[range.x + top - NT - 1 - tid];
-			const float4 *r = a.rec + 3 * (size_t)pid;
-			p0 = r[0]; p1 = r[1]; p2 = r[2].x;
-		}
-		__syncthreads();
-		for (int sw = 0; sw < NW; sw++)
-		for (unsigned long long rm = uniform_u64(s_reach[tid >> 6][sw]); rm; rm &= rm - 1)
-		{
-			const int j = sw * 64 + __builtin_ctzll(rm);
+			const int j = __builtin_ctzll(rm);
 			const int pos = top - 1 - j; // 0-based position in the tile list
-			if (pos >= wave_last) continue; // wave-uniform
 			const float4 g0 = s0[j];
 			const float4 g1 = s1[j];
-			const float cb = s2[j];
+			const float2 g2 = s2[j];
 			const float dx = g0.x - pxf;
 			const float adx2 = (g0.z * dx) * dx;
 			const float bdx = g0.w * dx;
-			float r_c0 = 0, r_c1 = 0, r_c2 = 0, r_mx = 0, r_my = 0, r_ka = 0, r_kb = 0, r_kc = 0, r_op = 0;
+			float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // colour r g b, mean2D x y, conic a b c, opacity
 			bool any = false;
 #pragma unroll
 			for (int k = 0; k < PPL; k++)
 			{
-				if (pos >= lastc[k]) continue;
 				const float dy = g0.y - pyf[k];
 				const float s = fmaf(g1.x * dy, dy, adx2);
 				const float power = fmaf(-0.5f, s, -(bdx * dy));
-				if (power > 0.0f) continue;
-				if (CUTOFF && power < -4.5f) continue;
 				const float G = bwd_exp(power);
 				const float alpha = fminf(0.99f, g1.y * G);
-				if (alpha < 1.0f / 255.0f) continue;
-				T[k] = T[k] / (1.f - alpha);
-				const float dchannel_dcolor = alpha * T[k];
-				float dL_dalpha;
+				// backward.cu:468-497: behind the pixel's last contributor / outside the support / negligible
+				const bool on = pos < lastc[k] && !(power > 0.0f) && !(CUTOFF && power < -4.5f) && !(alpha < 1.0f / 255.0f);
+				if (on)
 				{
-					acc0[k] = lastA[k] * lc0[k] + (1.f - lastA[k]) * acc0[k]; lc0[k] = g1.z;
-					acc1[k] = lastA[k] * lc1[k] + (1.f - lastA[k]) * acc1[k]; lc1[k] = g1.w;
-					acc2[k] = lastA[k] * lc2[k] + (1.f - lastA[k]) * acc2[k]; lc2[k] = cb;
-					dL_dalpha = (g1.z - acc0[k]) * dp0[k] + (g1.w - acc1[k]) * dp1[k] + (cb - acc2[k]) * dp2[k];
+					T[k] = T[k] / (1.f - alpha);
+					const float wgt = alpha * T[k]; // d channel / d colour
+					behind0[k] = prevA[k] * prev0[k] + (1.f - prevA[k]) * behind0[k]; prev0[k] = g1.z;
+					behind1[k] = prevA[k] * prev1[k] + (1.f - prevA[k]) * behind1[k]; prev1[k] = g1.w;
+					behind2[k] = prevA[k] * prev2[k] + (1.f - prevA[k]) * behind2[k]; prev2[k] = g2.x;
+					float dL_dalpha = (g1.z - behind0[k]) * dp0[k] + (g1.w - behind1[k]) * dp1[k] + (g2.x - behind2[k]) * dp2[k];
+					v[0] += wgt * dp0[k];
+					v[1] += wgt * dp1[k];
+					v[2] += wgt * dp2[k];
+					dL_dalpha *= T[k];
+					prevA[k] = alpha;
+					dL_dalpha += (-Tfin[k] / (1.f - alpha)) * bgdot[k]; // the background's share
+					const float dL_dG = g1.y * dL_dalpha;
+					const float gdx = G * dx, gdy = G * dy;
+					v[3] += dL_dG * (-gdx * g0.z - gdy * g0.w) * ddelx_dx;
+					v[4] += dL_dG * (-gdy * g1.x - gdx * g0.w) * ddely_dy;
+					v[5] += -0.5f * gdx * dx * dL_dG;
+					v[6] += -0.5f * gdx * dy * dL_dG;
+					v[7] += -0.5f * gdy * dy * dL_dG;
+					v[8] += G * dL_dalpha;
+					any = true;
 				}
-				r_c0 += dchannel_dcolor * dp0[k];
-				r_c1 += dchannel_dcolor * dp1[k];
-				r_c2 += dchannel_dcolor * dp2[k];
-				dL_dalpha *= T[k];
-				lastA[k] = alpha;
-				dL_dalpha += (-Tfin[k] / (1.f - alpha)) * bgdot[k];
-				const float dL_dG = g1.y * dL_dalpha;
-				const float gdx = G * dx, gdy = G * dy;
-				const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
-				const float dG_ddely = -gdy * g1.x - gdx * g0.w;
-				r_mx += dL_dG * dG_ddelx * ddelx_dx;
-				r_my += dL_dG * dG_ddely * ddely_dy;
-				r_ka += -0.5f * gdx * dx * dL_dG;
-				r_kb += -0.5f * gdx * dy * dL_dG;
-				r_kc += -0.5f * gdy * dy * dL_dG;
-				r_op += G * dL_dalpha;
-				any = true;
 			}
 			if (__any(any))
 			{
-				r_c0 = wave_sum_b(r_c0); r_c1 = wave_sum_b(r_c1); r_c2 = wave_sum_b(r_c2);
-				r_mx = wave_sum_b(r_mx); r_my = wave_sum_b(r_my);
-				r_ka = wave_sum_b(r_ka); r_kb = wave_sum_b(r_kb); r_kc = wave_sum_b(r_kc);
-				r_op = wave_sum_b(r_op);
-				if (lane == 63)
+				// eight sums folded into two registers: afterwards row r of 16 lanes holds value 2 r in t0 and 2 r + 1 in t1
+				const float f0 = fold32(v[0], v[4]), f1 = fold32(v[1], v[5]), f2 = fold32(v[2], v[6]), f3 = fold32(v[3], v[7]);
+				const float t0 = row_sum16(fold16(f0, f2)), t1 = row_sum16(fold16(f1, f3));
+				const float t8 = wave_sum_b(v[8]); // lane 63
+				const int sel = lane & 15;
+				const bool writer = sel < 2 || lane == 63;
+				if (writer)
 				{
-					const int id = sid[j];
-					atomicAdd(&a.dL_dcolor[3 * (size_t)id], r_c0);
-					atomicAdd(&a.dL_dcolor[3 * (size_t)id + 1], r_c1);
-					atomicAdd(&a.dL_dcolor[3 * (size_t)id + 2], r_c2);
-					atomicAdd(&a.dL_dmean2D[3 * (size_t)id], r_mx);
-					atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 1], r_my);
-					atomicAdd(&a.dL_dconic[4 * (size_t)id], r_ka);
-					atomicAdd(&a.dL_dconic[4 * (size_t)id + 1], r_kb);
-					atomicAdd(&a.dL_dconic[4 * (size_t)id + 3], r_kc);
-					atomicAdd(&a.dL_dopacity[id], r_op);
+					const int comp = lane == 63 ? 8 : 2 * (lane >> 4) + sel;
+					const float val = lane == 63 ? t8 : (sel ? t1 : t0);
+					atomicAdd(a.acc + 16 * (size_t)__float_as_int(g2.y) + comp, val); // nine lanes, one cache line
 				}
 			}
 		}
 	}
 }
 
-// ---- per-Gaussian chain rule ----------------------------------------------------------------
-struct M3b { float c[3][3]; };
-__device__ __forceinline__ M3b mb_cols(float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2)
-{
-	M3b m; m.c[0][0] = a0; m.c[0][1] = a1; m.c[0][2] = a2; m.c[1][0] = b0; m.c[1][1] = b1; m.c[1][2] = b2;
-	m.c[2][0] = c0; m.c[2][1] = c1; m.c[2][2] = c2; return m;
-}
-__device__ __forceinline__ M3b mb_mul(const M3b &a, const M3b &b)
-{
-	M3b r;
-#pragma unroll
-	for (int col = 0; col < 3; col++)
-#pragma unroll
-		for (int row = 0; row < 3; row++)
-			r.c[col][row] = a.c[0][row] * b.c[col][0] + a.c[1][row] * b.c[col][1] + a.c[2][row] * b.c[col][2];
-	return r;
-}
-__device__ __forceinline__ M3b mb_t(const M3b &a)
-{
-	M3b r;
-#pragma unroll
-	for (int col = 0; col < 3; col++)
-#pragma unroll
-		for (int row = 0; row < 3; row++) r.c[col][row] = a.c[row][col];
-	return r;
-}
-
+// ---- per-Gaussian chain rule ------------------------------------------------------------------
+// Written from the matrix form of the forward pass rather than entry by entry.
+//   forward.cu:74-113:  M = U Sigma U^T (2x2), U = Jac R (2x3): Jac = d(pixel) / d(camera point) with the clamped
+//                        tangents, R = world-to-camera rotation, Sigma the 3D covariance;  a = M00 + 0.3, b = M01,
+//                        c = M11 + 0.3;  conic Q = [[a b][b c]]^-1.
+//   Given Ghat = [[gA gB][gB gC]], the gradient of the loss w.r.t. the conic as k_render_bwd sums it (gB is half the
+//   derivative w.r.t. the off-diagonal parameter, backward.cu:536-538):
+//       H  := dL/dM = -Q Ghat Q   (from d(X^-1) = -X^-1 dX X^-1; symmetric)
+//       dL/dSigma = U^T H U,      dL/dU = 2 H U Sigma,      dL/dJac = dL/dU R^T,
+//   and dL/dt through the four non-constant entries of Jac. The reference writes the same chain out per matrix entry
+//   (backward.cu:144-274) with the quotient rule on the recomputed covariance; its 1e-7 guard on det^2 is kept as the
+//   factor `guard` below.
 struct BwdPreArgs {
 	int P, D, M, W, H;
 	float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
@@ -251,111 +233,137 @@ struct BwdPreArgs {
 	const int *radii;
 	const float4 *rec;
 	const float *cov3D_ws;
-	const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
+	const float4 *acc;         // gradient sums per visible-list entry (k_render_bwd)
+	float *dL_dmean2D, *dL_dconic, *dL_dcolor, *dL_dopacity; // dense [P, .] outputs filled from them (dL_dconic / dL_dcolor optional)
 	float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscale, *dL_drot;
 	const uint32_t *vis_list;  // forward's compact list of projected Gaussians
 	const uint32_t *vis_count; // its length (device)
 };
 
-// row: the 64-byte row the forward pass left for this vis_list entry (xyz | raw scale | rotation | 3D covariance), or
-// null when the covariances were an input: one coalesced row instead of gathers from four tensors.
-__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx, const float4 *row)
+struct V3 { float x, y, z; };
+__device__ __forceinline__ float dot3(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 axpy3(float s, const V3 &a, const V3 &b) { return { s * a.x + b.x, s * a.y + b.y, s * a.z + b.z }; }
+// y = S x for the symmetric matrix stored as (xx, xy, xz, yy, yz, zz)
+__device__ __forceinline__ V3 symv(const float *S, const V3 &v)
 {
-	const float *vm = a.viewmatrix, *proj = a.projmatrix;
-	float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-	if (row != nullptr) { r0 = row[0]; r1 = row[1]; r2 = row[2]; r3 = row[3]; }
-	const float m[3] = { row ? r0.x : a.means3D[3 * idx], row ? r0.y : a.means3D[3 * idx + 1], row ? r0.z : a.means3D[3 * idx + 2] };
-	const float cov_row[6] = { r2.z, r2.w, r3.x, r3.y, r3.z, r3.w };
-	const float *cov3D = row ? cov_row : a.cov3D_precomp + 6 * (size_t)idx;
-	const float fx = a.focal_x, fy = a.focal_y;
-	float dmean[3];
-	float dcov[6];
-	// ---- 2D covariance backward: backward.cu:144-274 ----
+	return { S[0] * v.x + S[1] * v.y + S[2] * v.z, S[1] * v.x + S[3] * v.y + S[4] * v.z, S[2] * v.x + S[4] * v.y + S[5] * v.z };
+}
+
+// Real spherical-harmonics basis up to degree 3 in the reference's sign convention (forward.cu:30-59) and its
+// gradient w.r.t. the unit direction: colour = sum_k basis_k sh_k, so dL/dsh_k = basis_k g and
+// dL/ddir = sum_k (sh_k . g) grad basis_k -- one dot product and three multiply-adds per coefficient.
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float *bas /*[16]*/, V3 *grd /*[16]*/)
+{
+	bas[0] = FR_SH_C0; grd[0] = { 0, 0, 0 };
+	if (deg < 1) return;
+	bas[1] = -FR_SH_C1 * y; grd[1] = { 0, -FR_SH_C1, 0 };
+	bas[2] = FR_SH_C1 * z;  grd[2] = { 0, 0, FR_SH_C1 };
+	bas[3] = -FR_SH_C1 * x; grd[3] = { -FR_SH_C1, 0, 0 };
+	if (deg < 2) return;
+	const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+	bas[4] = FR_SH_C2_0 * xy;                  grd[4] = { FR_SH_C2_0 * y, FR_SH_C2_0 * x, 0 };
+	bas[5] = FR_SH_C2_1 * yz;                  grd[5] = { 0, FR_SH_C2_1 * z, FR_SH_C2_1 * y };
+	bas[6] = FR_SH_C2_2 * (2.f * zz - xx - yy); grd[6] = { -2.f * FR_SH_C2_2 * x, -2.f * FR_SH_C2_2 * y, 4.f * FR_SH_C2_2 * z };
+	bas[7] = FR_SH_C2_3 * xz;                  grd[7] = { FR_SH_C2_3 * z, 0, FR_SH_C2_3 * x };
+	bas[8] = FR_SH_C2_4 * (xx - yy);           grd[8] = { 2.f * FR_SH_C2_4 * x, -2.f * FR_SH_C2_4 * y, 0 };
+	if (deg < 3) return;
+	bas[9] = FR_SH_C3_0 * y * (3.f * xx - yy);            grd[9] = { 6.f * FR_SH_C3_0 * xy, 3.f * FR_SH_C3_0 * (xx - yy), 0 };
+	bas[10] = FR_SH_C3_1 * xy * z;                        grd[10] = { FR_SH_C3_1 * yz, FR_SH_C3_1 * xz, FR_SH_C3_1 * xy };
+	bas[11] = FR_SH_C3_2 * y * (4.f * zz - xx - yy);      grd[11] = { -2.f * FR_SH_C3_2 * xy, FR_SH_C3_2 * (4.f * zz - xx - 3.f * yy), 8.f * FR_SH_C3_2 * yz };
+	bas[12] = FR_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); grd[12] = { -6.f * FR_SH_C3_3 * xz, -6.f * FR_SH_C3_3 * yz, 3.f * FR_SH_C3_3 * (2.f * zz - xx - yy) };
+	bas[13] = FR_SH_C3_4 * x * (4.f * zz - xx - yy);      grd[13] = { FR_SH_C3_4 * (4.f * zz - 3.f * xx - yy), -2.f * FR_SH_C3_4 * xy, 8.f * FR_SH_C3_4 * xz };
+	bas[14] = FR_SH_C3_5 * z * (xx - yy);                 grd[14] = { 2.f * FR_SH_C3_5 * xz, -2.f * FR_SH_C3_5 * yz, FR_SH_C3_5 * (xx - yy) };
+	bas[15] = FR_SH_C3_6 * x * (xx - 3.f * yy);           grd[15] = { 3.f * FR_SH_C3_6 * (xx - yy), -6.f * FR_SH_C3_6 * xy, 0 };
+}
+
+// slot: the Gaussian's position in the visible list (its row of gradient sums; with `stash` != null also its 64-byte row
+// (xyz | raw scale | rotation | 3D covariance) the forward pass left there: one coalesced row instead of four gathers)
+__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx, const int slot, const float4 *stash)
+{
+	const float *vm = a.viewmatrix, *pm = a.projmatrix;
+	float4 st0 = make_float4(0, 0, 0, 0), st1 = st0, st2 = st0, st3 = st0;
+	if (stash != nullptr) { st0 = stash[0]; st1 = stash[1]; st2 = stash[2]; st3 = stash[3]; }
+	const V3 mean = stash ? V3{ st0.x, st0.y, st0.z } : V3{ a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2] };
+	float Sigma[6];
+	if (stash) { Sigma[0] = st2.z; Sigma[1] = st2.w; Sigma[2] = st3.x; Sigma[3] = st3.y; Sigma[4] = st3.z; Sigma[5] = st3.w; }
+	else
 	{
-		const float dconic[3] = { a.dL_dconic[4 * (size_t)idx], a.dL_dconic[4 * (size_t)idx + 1], a.dL_dconic[4 * (size_t)idx + 3] };
-		float t[3];
-		t[0] = vm[0] * m[0] + vm[4] * m[1] + vm[8] * m[2] + vm[12];
-		t[1] = vm[1] * m[0] + vm[5] * m[1] + vm[9] * m[2] + vm[13];
-		t[2] = vm[2] * m[0] + vm[6] * m[1] + vm[10] * m[2] + vm[14];
-		const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
-		const float txtz = t[0] / t[2], tytz = t[1] / t[2];
-		t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
-		t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
-		const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-		const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-		const M3b J = mb_cols(fx / t[2], 0, -(fx * t[0]) / (t[2] * t[2]), 0, fy / t[2], -(fy * t[1]) / (t[2] * t[2]), 0, 0, 0);
-		const M3b Wm = mb_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
-		const M3b Vrk = mb_cols(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
-		const M3b Tm = mb_mul(Wm, J);
-		const M3b c2 = mb_mul(mb_mul(mb_t(Tm), mb_t(Vrk)), Tm);
-		const float ca = c2.c[0][0] + 0.3f, cbb = c2.c[0][1], cc = c2.c[1][1] + 0.3f;
-		const float denom = ca * cc - cbb * cbb;
-		float dL_da = 0, dL_db = 0, dL_dc = 0;
-		const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-#define TT(i, j) Tm.c[i][j]
-#define VV(i, j) Vrk.c[i][j]
-		if (denom2inv != 0)
-		{
-			dL_da = denom2inv * (-cc * cc * dconic[0] + 2 * cbb * cc * dconic[1] + (denom - ca * cc) * dconic[2]);
-			dL_dc = denom2inv * (-ca * ca * dconic[2] + 2 * ca * cbb * dconic[1] + (denom - ca * cc) * dconic[0]);
-			dL_db = denom2inv * 2 * (cbb * cc * dconic[0] - (denom + 2 * cbb * cbb) * dconic[1] + ca * cbb * dconic[2]);
-			dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
-			dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
-			dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
-			dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
-			dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
-			dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
-		}
-		else
-		{
 #pragma unroll
-			for (int i = 0; i < 6; i++) dcov[i] = 0;
-		}
-		const float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
-			(TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
-		const float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
-			(TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
-		const float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
-			(TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
-		const float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
-			(TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
-		const float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
-			(TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
-		const float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
-			(TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
-#undef TT
-#undef VV
-		const float dL_dJ00 = Wm.c[0][0] * dL_dT00 + Wm.c[0][1] * dL_dT01 + Wm.c[0][2] * dL_dT02;
-		const float dL_dJ02 = Wm.c[2][0] * dL_dT00 + Wm.c[2][1] * dL_dT01 + Wm.c[2][2] * dL_dT02;
-		const float dL_dJ11 = Wm.c[1][0] * dL_dT10 + Wm.c[1][1] * dL_dT11 + Wm.c[1][2] * dL_dT12;
-		const float dL_dJ12 = Wm.c[2][0] * dL_dT10 + Wm.c[2][1] * dL_dT11 + Wm.c[2][2] * dL_dT12;
-		const float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-		const float dL_dtx = x_grad_mul * -fx * tz2 * dL_dJ02;
-		const float dL_dty = y_grad_mul * -fy * tz2 * dL_dJ12;
-		const float dL_dtz = -fx * tz2 * dL_dJ00 - fy * tz2 * dL_dJ11 + (2 * fx * t[0]) * tz3 * dL_dJ02 + (2 * fy * t[1]) * tz3 * dL_dJ12;
-		dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
-		dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
-		dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
-#pragma unroll
-		for (int i = 0; i < 6; i++) if (a.dL_dcov3D != nullptr) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+		for (int i = 0; i < 6; i++) Sigma[i] = a.cov3D_precomp[6 * (size_t)idx + i];
 	}
-	// ---- projection backward: backward.cu:370-387 ----
+	// what k_render_bwd summed for this Gaussian
+	const float4 ac0 = a.acc[4 * (size_t)slot], ac1 = a.acc[4 * (size_t)slot + 1], ac2 = a.acc[4 * (size_t)slot + 2];
+	const float g_col[3] = { ac0.x, ac0.y, ac0.z };
+	const float g_px = ac0.w, g_py = ac1.x;           // d / d mean2D
+	const float gA = ac1.y, gB = ac1.z, gC = ac1.w;   // d / d conic (gB: half the off-diagonal derivative)
+	a.dL_dmean2D[3 * (size_t)idx] = g_px; a.dL_dmean2D[3 * (size_t)idx + 1] = g_py;
+	a.dL_dopacity[idx] = ac2.x;
+	if (a.dL_dcolor != nullptr) { a.dL_dcolor[3 * (size_t)idx] = g_col[0]; a.dL_dcolor[3 * (size_t)idx + 1] = g_col[1]; a.dL_dcolor[3 * (size_t)idx + 2] = g_col[2]; }
+	if (a.dL_dconic != nullptr) { a.dL_dconic[4 * (size_t)idx] = gA; a.dL_dconic[4 * (size_t)idx + 1] = gB; a.dL_dconic[4 * (size_t)idx + 3] = gC; }
+
+	// rows of the camera rotation: t = R mean + translation, R[i][r] = vm[4 r + i]
+	const V3 Rx = { vm[0], vm[4], vm[8] }, Ry = { vm[1], vm[5], vm[9] }, Rz = { vm[2], vm[6], vm[10] };
+	const float tz = dot3(Rz, mean) + vm[14];
+	const float tx_raw = dot3(Rx, mean) + vm[12], ty_raw = dot3(Ry, mean) + vm[13];
+	const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+	const float ux = tx_raw / tz, uy = ty_raw / tz;
+	const bool clamp_x = ux < -limx || ux > limx, clamp_y = uy < -limy || uy > limy; // forward.cu:82-87: no gradient through a clamped tangent
+	const float tx = fminf(limx, fmaxf(-limx, ux)) * tz, ty = fminf(limy, fmaxf(-limy, uy)) * tz;
+	const float fx = a.focal_x, fy = a.focal_y, iz = 1.f / tz, iz2 = iz * iz;
+	// U = Jac R, rows u0, u1
+	const float j00 = fx * iz, j02 = -(fx * tx) * iz2, j11 = fy * iz, j12 = -(fy * ty) * iz2;
+	const V3 u0 = axpy3(j00, Rx, { j02 * Rz.x, j02 * Rz.y, j02 * Rz.z });
+	const V3 u1 = axpy3(j11, Ry, { j12 * Rz.x, j12 * Rz.y, j12 * Rz.z });
+	// H = -Q Ghat Q with the conic Q the forward pass stored
+	const float4 rc0 = a.rec[3 * (size_t)idx];
+	const float qa = rc0.z, qb = rc0.w, qc = a.rec[3 * (size_t)idx + 1].x;
+	const float k00 = qa * gA + qb * gB, k01 = qa * gB + qb * gC, k10 = qb * gA + qc * gB, k11 = qb * gB + qc * gC; // Q Ghat
+	const float detq = qa * qc - qb * qb;                     // = 1 / det M
+	const float guard = -1.0f / (1.0f + 0.0000001f * detq * detq); // -(det^2 / (det^2 + 1e-7)), backward.cu:190
+	const float h00 = guard * (k00 * qa + k01 * qb), h01 = guard * (k00 * qb + k01 * qc), h11 = guard * (k10 * qb + k11 * qc);
+	// Y = H U (rows y0, y1); dL/dSigma = U^T Y, packed with the off-diagonals counted twice
+	const V3 y0 = axpy3(h00, u0, { h01 * u1.x, h01 * u1.y, h01 * u1.z });
+	const V3 y1 = axpy3(h01, u0, { h11 * u1.x, h11 * u1.y, h11 * u1.z });
+	float gSigma[6];
+	gSigma[0] = u0.x * y0.x + u1.x * y1.x;
+	gSigma[3] = u0.y * y0.y + u1.y * y1.y;
+	gSigma[5] = u0.z * y0.z + u1.z * y1.z;
+	gSigma[1] = (u0.x * y0.y + u1.x * y1.y) + (u0.y * y0.x + u1.y * y1.x);
+	gSigma[2] = (u0.x * y0.z + u1.x * y1.z) + (u0.z * y0.x + u1.z * y1.x);
+	gSigma[4] = (u0.y * y0.z + u1.y * y1.z) + (u0.z * y0.y + u1.z * y1.y);
+	if (a.dL_dcov3D != nullptr)
 	{
-		const float hw = proj[3] * m[0] + proj[7] * m[1] + proj[11] * m[2] + proj[15];
-		const float m_w = 1.0f / (hw + 0.0000001f);
-		const float mul1 = (proj[0] * m[0] + proj[4] * m[1] + proj[8] * m[2] + proj[12]) * m_w * m_w;
-		const float mul2 = (proj[1] * m[0] + proj[5] * m[1] + proj[9] * m[2] + proj[13]) * m_w * m_w;
-		const float d2x = a.dL_dmean2D[3 * (size_t)idx], d2y = a.dL_dmean2D[3 * (size_t)idx + 1];
-		dmean[0] += (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
-		dmean[1] += (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
-		dmean[2] += (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
+#pragma unroll
+		for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = gSigma[i];
 	}
-	// ---- SH backward: backward.cu:20-139 ----
+	// dL/dU = 2 Y Sigma (rows w0, w1); dL/dJac[i][k] = dL/dU row i . R row k
+	const V3 w0 = symv(Sigma, y0), w1 = symv(Sigma, y1);
+	const float gj00 = 2.f * dot3(w0, Rx), gj02 = 2.f * dot3(w0, Rz), gj11 = 2.f * dot3(w1, Ry), gj12 = 2.f * dot3(w1, Rz);
+	// Jac = [[fx/tz, 0, -fx tx/tz^2], [0, fy/tz, -fy ty/tz^2]]
+	const float iz3 = iz2 * iz;
+	const float g_tx = clamp_x ? 0.f : -fx * iz2 * gj02;
+	const float g_ty = clamp_y ? 0.f : -fy * iz2 * gj12;
+	const float g_tz = -iz2 * (fx * gj00 + fy * gj11) + 2.f * iz3 * (fx * tx * gj02 + fy * ty * gj12);
+	// back through t = R mean + translation
+	V3 g_mean = { Rx.x * g_tx + Ry.x * g_ty + Rz.x * g_tz, Rx.y * g_tx + Ry.y * g_ty + Rz.y * g_tz, Rx.z * g_tx + Ry.z * g_ty + Rz.z * g_tz };
+
+	// ---- screen position: pixel = ((p_hom.xy / p_hom.w) + 1) S / 2 (backward.cu:370-387; the S / 2 is already in g_px, g_py)
+	{
+		const float hx = pm[0] * mean.x + pm[4] * mean.y + pm[8] * mean.z + pm[12];
+		const float hy = pm[1] * mean.x + pm[5] * mean.y + pm[9] * mean.z + pm[13];
+		const float hw = pm[3] * mean.x + pm[7] * mean.y + pm[11] * mean.z + pm[15];
+		const float iw = 1.0f / (hw + 0.0000001f);
+		const float nx = hx * iw * iw, ny = hy * iw * iw; // d(h.x / w) / d w = -h.x / w^2
+		g_mean.x += (pm[0] * iw - pm[3] * nx) * g_px + (pm[1] * iw - pm[3] * ny) * g_py;
+		g_mean.y += (pm[4] * iw - pm[7] * nx) * g_px + (pm[5] * iw - pm[7] * ny) * g_py;
+		g_mean.z += (pm[8] * iw - pm[11] * nx) * g_px + (pm[9] * iw - pm[11] * ny) * g_py;
+	}
+	// ---- colour from spherical harmonics (backward.cu:20-139)
 	if (a.colors_precomp == nullptr && a.shs != nullptr)
 	{
-		// Coefficients and their gradients are kept in registers in the concatenated order (k, channel) -> 3k + ch
-		// and moved 16 bytes at a time: every lane works on its own Gaussian, i.e. its own cache lines, and 48
-		// dword loads + 48 dword stores per Gaussian kept the address unit busy for most of this kernel.
+		// Coefficients are read and their gradients written 16 bytes at a time in the concatenated order
+		// (k, channel) -> 3 k + channel: every lane works on its own Gaussian, i.e. its own cache lines, and 48 dword
+		// loads + 48 dword stores per Gaussian kept the address unit busy for most of this kernel.
 		// Split storage (shs = DC [P,1,3], shs_rest = [P,M-1,3]): slots 3.. come from / go to the rest tensors.
 		const bool split = a.shs_rest != nullptr;
 		const int nrest = split ? (a.M - 1) * 3 : a.M * 3 - 3;     // floats available after the DC triple
@@ -363,159 +371,94 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		float *dsh_r = split ? a.dL_dsh_rest + (size_t)idx * (a.M - 1) * 3 : a.dL_dsh + (size_t)idx * a.M * 3 + 3;
 		float *dsh0 = split ? a.dL_dsh + 3 * (size_t)idx : a.dL_dsh + (size_t)idx * a.M * 3;
 		typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-		float shv[48], g[48];
+		float coef[48], gcoef[48];
 #pragma unroll
-		for (int i = 0; i < 48; i++) { shv[i] = 0.0f; g[i] = 0.0f; }
+		for (int i = 0; i < 48; i++) { coef[i] = 0.0f; gcoef[i] = 0.0f; }
 		const int nuse = 3 * ((a.D + 1) * (a.D + 1)) - 3; // rest floats the active degree reads / writes
 		if (nrest >= 45)
 		{
 #pragma unroll
-			for (int q = 0; q < 11; q++) { const f4u v = *(const f4u *)(sh_r + 4 * q); shv[3 + 4 * q] = v.x; shv[4 + 4 * q] = v.y; shv[5 + 4 * q] = v.z; shv[6 + 4 * q] = v.w; }
-			shv[47] = sh_r[44];
+			for (int q = 0; q < 11; q++) { const f4u t = *(const f4u *)(sh_r + 4 * q); coef[3 + 4 * q] = t.x; coef[4 + 4 * q] = t.y; coef[5 + 4 * q] = t.z; coef[6 + 4 * q] = t.w; }
+			coef[47] = sh_r[44];
 		}
 		else
 		{
 #pragma unroll
-			for (int i = 0; i < 45; i++) if (i < nuse) shv[3 + i] = sh_r[i];
+			for (int i = 0; i < 45; i++) if (i < nuse) coef[3 + i] = sh_r[i];
 		}
+		// a channel clamped at zero in the forward pass passes no gradient (forward.cu:63-70)
 		const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)idx + 2].z);
-		const float dox = m[0] - a.campos[0], doy = m[1] - a.campos[1], doz = m[2] - a.campos[2];
-		const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-		const float x = dox / len, y = doy / len, z = doz / len;
-		float dRGB[3];
+		const V3 g = { (clamp_bits & 1u) ? 0.f : g_col[0], (clamp_bits & 2u) ? 0.f : g_col[1], (clamp_bits & 4u) ? 0.f : g_col[2] };
+		const V3 off = { mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2] };
+		const float len2 = dot3(off, off), ilen = 1.0f / sqrtf(len2);
+		const V3 dir = { off.x * ilen, off.y * ilen, off.z * ilen };
+		float bas[16];
+		V3 grd[16];
 #pragma unroll
-		for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * (size_t)idx + ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
-		float ddx[3] = { 0, 0, 0 }, ddy[3] = { 0, 0, 0 }, ddz[3] = { 0, 0, 0 };
-		const int deg = a.D;
-#define SHV(k, ch) shv[3 * (k) + (ch)]
-#define DSH(k, w) { const float w_ = (w); g[3 * (k)] = w_ * dRGB[0]; g[3 * (k) + 1] = w_ * dRGB[1]; g[3 * (k) + 2] = w_ * dRGB[2]; }
-		dsh0[0] = FR_SH_C0 * dRGB[0]; dsh0[1] = FR_SH_C0 * dRGB[1]; dsh0[2] = FR_SH_C0 * dRGB[2];
-		if (deg > 0)
+		for (int k = 0; k < 16; k++) { bas[k] = 0.f; grd[k] = { 0, 0, 0 }; }
+		sh_basis_grad(a.D, dir.x, dir.y, dir.z, bas, grd);
+		dsh0[0] = bas[0] * g.x; dsh0[1] = bas[0] * g.y; dsh0[2] = bas[0] * g.z;
+		V3 g_dir = { 0, 0, 0 };
+#pragma unroll
+		for (int k = 1; k < 16; k++)
 		{
-			DSH(1, -FR_SH_C1 * y); DSH(2, FR_SH_C1 * z); DSH(3, -FR_SH_C1 * x);
-#pragma unroll
-			for (int ch = 0; ch < 3; ch++)
-			{
-				ddx[ch] = -FR_SH_C1 * SHV(3, ch);
-				ddy[ch] = -FR_SH_C1 * SHV(1, ch);
-				ddz[ch] = FR_SH_C1 * SHV(2, ch);
-			}
-			if (deg > 1)
-			{
-				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-				DSH(4, FR_SH_C2_0 * xy); DSH(5, FR_SH_C2_1 * yz); DSH(6, FR_SH_C2_2 * (2.f * zz - xx - yy));
-				DSH(7, FR_SH_C2_3 * xz); DSH(8, FR_SH_C2_4 * (xx - yy));
-#pragma unroll
-				for (int ch = 0; ch < 3; ch++)
-				{
-					ddx[ch] += FR_SH_C2_0 * y * SHV(4, ch) + FR_SH_C2_2 * 2.f * -x * SHV(6, ch) + FR_SH_C2_3 * z * SHV(7, ch) + FR_SH_C2_4 * 2.f * x * SHV(8, ch);
-					ddy[ch] += FR_SH_C2_0 * x * SHV(4, ch) + FR_SH_C2_1 * z * SHV(5, ch) + FR_SH_C2_2 * 2.f * -y * SHV(6, ch) + FR_SH_C2_4 * 2.f * -y * SHV(8, ch);
-					ddz[ch] += FR_SH_C2_1 * y * SHV(5, ch) + FR_SH_C2_2 * 2.f * 2.f * z * SHV(6, ch) + FR_SH_C2_3 * x * SHV(7, ch);
-				}
-				if (deg > 2)
-				{
-					DSH(9, FR_SH_C3_0 * y * (3.f * xx - yy));
-					DSH(10, FR_SH_C3_1 * xy * z);
-					DSH(11, FR_SH_C3_2 * y * (4.f * zz - xx - yy));
-					DSH(12, FR_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy));
-					DSH(13, FR_SH_C3_4 * x * (4.f * zz - xx - yy));
-					DSH(14, FR_SH_C3_5 * z * (xx - yy));
-					DSH(15, FR_SH_C3_6 * x * (xx - 3.f * yy));
-#pragma unroll
-					for (int ch = 0; ch < 3; ch++)
-					{
-						ddx[ch] += (
-							FR_SH_C3_0 * SHV(9, ch) * 3.f * 2.f * xy +
-							FR_SH_C3_1 * SHV(10, ch) * yz +
-							FR_SH_C3_2 * SHV(11, ch) * -2.f * xy +
-							FR_SH_C3_3 * SHV(12, ch) * -3.f * 2.f * xz +
-							FR_SH_C3_4 * SHV(13, ch) * (-3.f * xx + 4.f * zz - yy) +
-							FR_SH_C3_5 * SHV(14, ch) * 2.f * xz +
-							FR_SH_C3_6 * SHV(15, ch) * 3.f * (xx - yy));
-						ddy[ch] += (
-							FR_SH_C3_0 * SHV(9, ch) * 3.f * (xx - yy) +
-							FR_SH_C3_1 * SHV(10, ch) * xz +
-							FR_SH_C3_2 * SHV(11, ch) * (-3.f * yy + 4.f * zz - xx) +
-							FR_SH_C3_3 * SHV(12, ch) * -3.f * 2.f * yz +
-							FR_SH_C3_4 * SHV(13, ch) * -2.f * xy +
-							FR_SH_C3_5 * SHV(14, ch) * -2.f * yz +
-							FR_SH_C3_6 * SHV(15, ch) * -3.f * 2.f * xy);
-						ddz[ch] += (
-							FR_SH_C3_1 * SHV(10, ch) * xy +
-							FR_SH_C3_2 * SHV(11, ch) * 4.f * 2.f * yz +
-							FR_SH_C3_3 * SHV(12, ch) * 3.f * (2.f * zz - xx - yy) +
-							FR_SH_C3_4 * SHV(13, ch) * 4.f * 2.f * xz +
-							FR_SH_C3_5 * SHV(14, ch) * (xx - yy));
-					}
-				}
-			}
+			gcoef[3 * k] = bas[k] * g.x; gcoef[3 * k + 1] = bas[k] * g.y; gcoef[3 * k + 2] = bas[k] * g.z;
+			const float wk = coef[3 * k] * g.x + coef[3 * k + 1] * g.y + coef[3 * k + 2] * g.z;
+			g_dir = axpy3(wk, grd[k], g_dir);
 		}
-#undef SHV
-#undef DSH
 		// gradients of the rest coefficients of the active degree (the others stay at the caller's zero fill)
 #pragma unroll
 		for (int q = 0; q < 12; q++)
 		{
-			if (4 * q + 4 <= nuse) *(f4u *)(dsh_r + 4 * q) = (f4u){ g[3 + 4 * q], g[4 + 4 * q], g[5 + 4 * q], g[6 + 4 * q] };
+			if (4 * q + 4 <= nuse) *(f4u *)(dsh_r + 4 * q) = (f4u){ gcoef[3 + 4 * q], gcoef[4 + 4 * q], gcoef[5 + 4 * q], gcoef[6 + 4 * q] };
 			else
 			{
 #pragma unroll
-				for (int j = 0; j < 4; j++) if (4 * q + j < nuse) dsh_r[4 * q + j] = g[3 + 4 * q + j];
+				for (int j = 0; j < 4; j++) if (4 * q + j < nuse) dsh_r[4 * q + j] = gcoef[3 + 4 * q + j];
 			}
 		}
-		const float dvx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
-		const float dvy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
-		const float dvz = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
-		// dnormvdv: auxiliary.h:107-117
-		const float sum2 = dox * dox + doy * doy + doz * doz;
-		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-		dmean[0] += ((+sum2 - dox * dox) * dvx - doy * dox * dvy - doz * dox * dvz) * invsum32;
-		dmean[1] += (-dox * doy * dvx + (sum2 - doy * doy) * dvy - doz * doy * dvz) * invsum32;
-		dmean[2] += (-dox * doz * dvx - doy * doz * dvy + (sum2 - doz * doz) * dvz) * invsum32;
+		// dir = off / |off|: d dir / d off = (I - dir dir^T) / |off|
+		const float along = dot3(dir, g_dir);
+		g_mean.x += (g_dir.x - along * dir.x) * ilen;
+		g_mean.y += (g_dir.y - along * dir.y) * ilen;
+		g_mean.z += (g_dir.z - along * dir.z) * ilen;
 	}
-	a.dL_dmean3D[3 * (size_t)idx] = dmean[0];
-	a.dL_dmean3D[3 * (size_t)idx + 1] = dmean[1];
-	a.dL_dmean3D[3 * (size_t)idx + 2] = dmean[2];
-	// ---- 3D covariance backward: backward.cu:278-341 ----
+	a.dL_dmean3D[3 * (size_t)idx] = g_mean.x;
+	a.dL_dmean3D[3 * (size_t)idx + 1] = g_mean.y;
+	a.dL_dmean3D[3 * (size_t)idx + 2] = g_mean.z;
+	// ---- 3D covariance: Sigma = A^T A, A = diag(s) B(q), B the matrix forward.cu:127-137 builds from the quaternion
+	// (backward.cu:278-341). With Gs the symmetric gradient matrix (off-diagonals halved): dL/dA = 2 A Gs,
+	// dL/ds_i = B_i . (dL/dA)_i, dL/dB_i = s_i (dL/dA)_i (rows), then through the quadratic entries of B.
 	if (a.cov3D_precomp == nullptr && a.scales != nullptr)
 	{
-		const float4 q = row ? make_float4(r1.z, r1.w, r2.x, r2.y) : ((const float4 *)a.rotations)[idx];
+		const float4 q = stash ? make_float4(st1.z, st1.w, st2.x, st2.y) : ((const float4 *)a.rotations)[idx];
 		const float r = q.x, x = q.y, y = q.z, z = q.w;
-		const M3b R = mb_cols(
-			1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-			2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-			2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
-		const float s[3] = { a.scale_modifier * (row ? r0.w : a.scales[3 * idx]), a.scale_modifier * (row ? r1.x : a.scales[3 * idx + 1]),
-			a.scale_modifier * (row ? r1.y : a.scales[3 * idx + 2]) };
-		const M3b S = mb_cols(s[0], 0, 0, 0, s[1], 0, 0, 0, s[2]);
-		M3b Mm = mb_mul(S, R);
-		const M3b dSigma = mb_cols(
-			dcov[0], 0.5f * dcov[1], 0.5f * dcov[2],
-			0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
-			0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
+		const float s[3] = { a.scale_modifier * (stash ? st0.w : a.scales[3 * idx]), a.scale_modifier * (stash ? st1.x : a.scales[3 * idx + 1]),
+			a.scale_modifier * (stash ? st1.y : a.scales[3 * idx + 2]) };
+		const V3 B[3] = { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y) },
+			{ 2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x) },
+			{ 2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y) } };
+		const float Gs[6] = { gSigma[0], 0.5f * gSigma[1], 0.5f * gSigma[2], gSigma[3], 0.5f * gSigma[4], gSigma[5] };
+		float gs[3];
+		V3 D[3]; // dL/dB rows
 #pragma unroll
 		for (int i = 0; i < 3; i++)
-#pragma unroll
-			for (int j = 0; j < 3; j++) Mm.c[i][j] = 2.0f * Mm.c[i][j];
-		const M3b dM = mb_mul(Mm, dSigma);
-		const M3b Rt = mb_t(R);
-		M3b dMt = mb_t(dM);
-		float ds[3];
-#pragma unroll
-		for (int i = 0; i < 3; i++) ds[i] = Rt.c[i][0] * dMt.c[i][0] + Rt.c[i][1] * dMt.c[i][1] + Rt.c[i][2] * dMt.c[i][2];
-#pragma unroll
-		for (int i = 0; i < 3; i++)
-#pragma unroll
-			for (int j = 0; j < 3; j++) dMt.c[i][j] *= s[i];
-#define Dm(i, j) dMt.c[i][j]
-		float4 dq;
-		dq.x = 2 * z * (Dm(0, 1) - Dm(1, 0)) + 2 * y * (Dm(2, 0) - Dm(0, 2)) + 2 * x * (Dm(1, 2) - Dm(2, 1));
-		dq.y = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) - 4 * x * (Dm(2, 2) + Dm(1, 1));
-		dq.z = 2 * x * (Dm(1, 0) + Dm(0, 1)) + 2 * r * (Dm(2, 0) - Dm(0, 2)) + 2 * z * (Dm(1, 2) + Dm(2, 1)) - 4 * y * (Dm(2, 2) + Dm(0, 0));
-		dq.w = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) - 4 * z * (Dm(1, 1) + Dm(0, 0));
-#undef Dm
-		a.dL_dscale[3 * (size_t)idx] = ds[0]; a.dL_dscale[3 * (size_t)idx + 1] = ds[1]; a.dL_dscale[3 * (size_t)idx + 2] = ds[2];
-		((float4 *)a.dL_drot)[idx] = dq;
+		{
+			const V3 e = symv(Gs, B[i]);            // (B Gs) row i; dL/dA row i = 2 s_i e
+			gs[i] = 2.f * s[i] * dot3(B[i], e);
+			const float f = 2.f * s[i] * s[i];
+			D[i] = { f * e.x, f * e.y, f * e.z };
+		}
+		// B's entries are quadratic in (r, x, y, z): collect the antisymmetric and symmetric pairs of dL/dB
+		const float a01 = D[0].y - D[1].x, a20 = D[2].x - D[0].z, a12 = D[1].z - D[2].y;
+		const float p01 = D[0].y + D[1].x, p02 = D[0].z + D[2].x, p12 = D[1].z + D[2].y;
+		float4 gq;
+		gq.x = 2.f * (z * a01 + y * a20 + x * a12);
+		gq.y = 2.f * (y * p01 + z * p02 + r * a12) - 4.f * x * (D[1].y + D[2].z);
+		gq.z = 2.f * (x * p01 + r * a20 + z * p12) - 4.f * y * (D[0].x + D[2].z);
+		gq.w = 2.f * (r * a01 + x * p02 + y * p12) - 4.f * z * (D[0].x + D[1].y);
+		a.dL_dscale[3 * (size_t)idx] = gs[0]; a.dL_dscale[3 * (size_t)idx + 1] = gs[1]; a.dL_dscale[3 * (size_t)idx + 2] = gs[2];
+		((float4 *)a.dL_drot)[idx] = gq;
 	}
 }
 
@@ -527,13 +470,9 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x)
 	{
 		const int idx = (int)a.vis_list[i];
-		if (a.radii[idx] > 0) preprocess_bwd_one(a, idx, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i);
+		if (a.radii[idx] > 0) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i);
 	}
 }
-
-#ifndef FR_BWD_PPL
-#define FR_BWD_PPL 4
-#endif
 
 int launch_backward(const fr_backward_args *a)
 {
@@ -547,14 +486,14 @@ int launch_backward(const fr_backward_args *a)
 	if (a->R > 0)
 	{
 		BwdRenderArgs r;
-		r.W = a->W; r.H = a->H; r.gx = gx; r.ranges = img.ranges; r.tile_order = img.tile_order; r.point_list = bin.point_list; r.rec = geom.rec;
+		r.W = a->W; r.H = a->H; r.gx = gx; r.ranges = img.ranges; r.render_items = img.render_items; r.n_items = 2u * (uint32_t)T;
+		r.point_list = bin.point_list; r.rec = geom.rec;
 		r.bg = a->background; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.dL_dpix = a->dL_dpix;
-		r.dL_dmean2D = a->dL_dmean2D; r.dL_dconic = a->dL_dconic; r.dL_dopacity = a->dL_dopacity; r.dL_dcolor = a->dL_dcolor;
-		constexpr int PPL = FR_BWD_PPL;
+		r.acc = (float *)geom.acc;
 		if (a->variant == FR_VARIANT_ORIGINAL)
-			hipLaunchKernelGGL((k_render_bwd<false, PPL>), dim3(T), dim3(256 / PPL), 0, stream, r);
+			hipLaunchKernelGGL((k_render_bwd<false>), dim3(r.n_items), dim3(64), 0, stream, r);
 		else
-			hipLaunchKernelGGL((k_render_bwd<true, PPL>), dim3(T), dim3(256 / PPL), 0, stream, r);
+			hipLaunchKernelGGL((k_render_bwd<true>), dim3(r.n_items), dim3(64), 0, stream, r);
 		int rc = check_launch("render_bwd", stream, a->debug);
 		if (rc) return rc;
 	}
@@ -567,8 +506,8 @@ int launch_backward(const fr_backward_args *a)
 	p.means3D = a->means3D; p.scales = a->scales; p.rotations = a->rotations; p.shs = a->shs; p.shs_rest = a->shs_rest;
 	p.cov3D_precomp = a->cov3D_precomp; p.colors_precomp = a->colors_precomp;
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
-	p.radii = a->radii; p.rec = geom.rec; p.cov3D_ws = geom.cov3D;
-	p.dL_dmean2D = a->dL_dmean2D; p.dL_dconic = a->dL_dconic; p.dL_dcolor = a->dL_dcolor;
+	p.radii = a->radii; p.rec = geom.rec; p.cov3D_ws = geom.cov3D; p.acc = geom.acc;
+	p.dL_dmean2D = a->dL_dmean2D; p.dL_dconic = a->dL_dconic; p.dL_dcolor = a->dL_dcolor; p.dL_dopacity = a->dL_dopacity;
 	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dsh_rest = a->dL_dsh_rest; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
 	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1;
 	const int pblocks = (a->P + 255) / 256;

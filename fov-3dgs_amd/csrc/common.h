@@ -43,11 +43,14 @@ __host__ __device__ inline size_t align_up(size_t x, size_t a = 256) { return (x
 // Geometry workspace (per Gaussian). rec = 3 float4 per Gaussian:
 //   [0] = (mean2D.x, mean2D.y, conic.a, conic.b)
 //   [1] = (conic.c, opacity, r, g)          RF: (conic.c, highest_level, 0, 0)
-//   [2] = (b, depth, clamp bits, unused)
+//   [2] = (b, depth, clamp bits, position in vis_list as int bits)
 struct GeomWS {
 	float4 *rec;        // [3P]
 	float *cov3D;       // training variants: [16P] one 64-byte row per vis_list entry, in list order, written by k_bin for the
 	                    // backward pass: (xyz | raw scale | rotation | 3D covariance) -- one coalesced row instead of four gathers
+	float4 *acc;        // training variants: [4P] one 64-byte row of gradient sums per vis_list entry, in list order, zeroed by k_bin,
+	                    //      accumulated by k_render_bwd (one atomic instruction per list entry and wave), read by k_preprocess_bwd:
+	                    //      (dL/d colour r, g, b, dL/d mean2D x | y, dL/d conic a, b, c | dL/d opacity, -, -, - | -)
 	float4 *wrec;       // [4P] walk record of vis_list entry i at [4i..4i+3], written by k_bin in list order for k_emit:
 	                    //      (cx, cy, e1x, e1y | e2x, e2y, len1, len2 | id + flags << 30, depth bits, x0 + y0 << 16, width |
 	                    //      tiles, highest level, -, -); flags: 1 = lands in a tile, 2 = the OBB test applies
@@ -68,6 +71,8 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 	// need room for the developer timers
 	const bool keeps = variant != FR_VARIANT_PCHECK_OBB && variant != FR_VARIANT_FOV_PCHECK_OBB;
 	g.cov3D = (float *)(base + off); off = align_up(off + P * (keeps ? 16 : 6) * sizeof(float));
+	g.acc = nullptr;
+	if (keeps) { g.acc = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4)); }
 	g.lvl = nullptr; g.lrange = nullptr;
 	g.wrec = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4));
 	if (variant == FR_VARIANT_FOV_PCHECK_OBB) {

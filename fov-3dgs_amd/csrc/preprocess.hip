@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		be_blend = (lvmask & 16u) != 0;
 	};
 	// Per-Gaussian epilogue once its tile count is known: radius of culled-everywhere splats, colour(s), final record.
-	auto finish = [&](const int idx, const uint32_t count, const float hl, const float lowest, const float highest,
+	auto finish = [&](const int idx, const int item, const uint32_t count, const float hl, const float lowest, const float highest,
 		const bool be_blend, const float conic_c, const float depth) __attribute__((always_inline))
 	{
 		if (count == 0) { a.radii[idx] = 0; return; } // culled everywhere (RS rasterizer_impl.cu:141-145)
@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		float4 *rec = a.geom.rec + 3 * (size_t)idx;
 		if (FOV) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
 		else rec[1] = make_float4(conic_c, PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx], rgb[0], rgb[1]);
-		rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), 0.0f);
+		rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(item)); // item: where the backward pass keeps this Gaussian's sums
 	};
 #ifdef FR_BIN_TIMERS
 	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0;
@@ -890,6 +890,12 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
 		}
 		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q, a.write_cov3D ? (float4 *)a.geom.cov3D + 4 * (size_t)item : nullptr);
+		if (a.write_cov3D)
+		{
+			// the backward pass adds into this entry's row of gradient sums: cleared here, in list order (coalesced)
+			float4 *ac = a.geom.acc + 4 * (size_t)item;
+			ac[0] = ac[1] = ac[2] = ac[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+		}
 		if (pr.alive)
 		{
 			if (CULL && pr.tnum > 1)
@@ -1014,7 +1020,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
 		TM_END(tm_p);
-		if (pr.alive && !deferred) finish(idx, count, hl, lowest, highest, be_blend, r1.x, r2.y);
+		if (pr.alive && !deferred) finish(idx, item, count, hl, lowest, highest, be_blend, r1.x, r2.y);
 		// walk record for k_emit (and for the giant phase below), in list order: coalesced 64-byte rows
 		if (item < V)
 		{
@@ -1056,7 +1062,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		float lowest = ghl, highest = 0.0f;
 		bool be_blend = false;
 		if (FOV && gcount != 0) range_from_mask(s_gmask[threadIdx.x], lowest, highest, be_blend);
-		finish(gi, gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y);
+		finish(gi, s_gitem[threadIdx.x], gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y);
 	}
 #ifdef FR_BIN_TIMERS
 	if (lane == 0)

@@ -263,9 +263,10 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
 
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                      grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None,
-                     want_cov3D_grad=False):
+                     want_cov3D_grad=False, want_color_grad=False):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations[, dL_dsh_rest])
-    (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3]; dL_dcov3D is None unless cov3Ds_precomp is given or want_cov3D_grad)"""
+    (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3]; dL_dcov3D / dL_dcolors are None unless
+    cov3Ds_precomp / colors_precomp are given or want_cov3D_grad / want_color_grad)"""
     lib = _native.load()
     dev = means3D.device
     P = means3D.size(0)
@@ -285,11 +286,13 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
         M0 = 0 if sh_c is None else sh_c.size(1)
         M = M0 + (0 if rest_c is None else rest_c.size(1))
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-        dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
-        dL_dconic, dL_dopacity = z(P, 2, 2), z(P, 1)
-        # only an output when the 3D covariances are an input; otherwise an intermediate nobody reads (144 MB at 6 M)
+        dL_dmeans3D, dL_dmeans2D, dL_dopacity = z(P, 3), z(P, 3), z(P, 1)
+        # outputs only when the 3D covariances / colours are inputs; otherwise intermediates the library keeps per
+        # visible Gaussian in its geometry workspace (240 MB less to allocate and zero per step at 6 M)
         has_cov = want_cov3D_grad or (cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0)
+        has_col = want_color_grad or (colors_precomp is not None and colors_precomp.numel() != 0)
         dL_dcov3D = z(P, 6) if has_cov else None
+        dL_dcolors = z(P, 3) if has_col else None
         dL_dsh, dL_dscales, dL_drotations = z(P, M0, 3), z(P, 3), z(P, 4)
         dL_dsh_rest = z(P, M - M0, 3) if rest_c is not None else None
         if P != 0:
@@ -310,8 +313,8 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
             put("dL_dpix", grad_out_color)
             a.radii = radii.data_ptr()
             a.geometry, a.binning, a.image = geomBuffer.data_ptr(), _ptr(binningBuffer if binningBuffer.numel() else None), imgBuffer.data_ptr()
-            a.dL_dmean2D, a.dL_dconic, a.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr()
-            a.dL_dcolor, a.dL_dmean3D = dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr()
+            a.dL_dmean2D, a.dL_dconic, a.dL_dopacity = dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr()
+            a.dL_dcolor, a.dL_dmean3D = (dL_dcolors.data_ptr() if dL_dcolors is not None else None), dL_dmeans3D.data_ptr()
             a.dL_dcov3D = dL_dcov3D.data_ptr() if dL_dcov3D is not None else None
             a.dL_dsh = dL_dsh.data_ptr() if M else None
             a.dL_dsh_rest = dL_dsh_rest.data_ptr() if dL_dsh_rest is not None else None

@@ -150,11 +150,11 @@ typedef struct fr_backward_args {
 	const char *geometry, *binning, *image; /* the three workspaces filled by fr_forward */
 	const float *dL_dpix;        /* [3,H,W] */
 	/* outputs: caller-allocated AND ZERO-FILLED (the reference allocates them with torch::zeros,
-	 * rasterize_points.cu:171-179) */
+	 * rasterize_points.cu:171-179); rows of Gaussians the view does not touch are left as they are */
 	float *dL_dmean2D;           /* [P,3] */
-	float *dL_dconic;            /* [P,2,2] */
+	float *dL_dconic;            /* [P,2,2]; may be NULL: an intermediate of the reference (its sums are kept per visible-list entry here) */
 	float *dL_dopacity;          /* [P,1] */
-	float *dL_dcolor;            /* [P,3] */
+	float *dL_dcolor;            /* [P,3]; may be NULL unless colors_precomp is given (otherwise an intermediate) */
 	float *dL_dmean3D;           /* [P,3] */
 	float *dL_dcov3D;            /* [P,6]; may be NULL when cov3D_precomp is NULL (then it is an intermediate nobody reads) */
 	float *dL_dsh;               /* [P,M,3] */

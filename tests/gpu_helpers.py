@@ -82,7 +82,7 @@ def hip_backward(variant, fwd, dL_dpix, dev="cuda:0"):
                          t["opacities"], t["scales"] if t["scales"] is not None else empty,
                          t["rotations"] if t["rotations"] is not None else empty,
                          t["cov3D_precomp"] if t["cov3D_precomp"] is not None else empty, _t(dL_dpix, dev),
-                         t["shs"] if t["shs"] is not None else empty, geom, fwd["num_rendered"], binb, img, want_cov3D_grad=True)
+                         t["shs"] if t["shs"] is not None else empty, geom, fwd["num_rendered"], binb, img, want_cov3D_grad=True, want_color_grad=True)
     torch.cuda.synchronize()
     names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
     return {n: v.cpu().numpy() for n, v in zip(names, g)}

@@ -206,7 +206,7 @@ def test_training_step_full_size(s6m):
     geom, binb, img = got["buffers"]
     E = torch.Tensor([])
     res = _backward_native(s6m.native.VARIANT_IDS["pcheck_obb_sum"], s6m.rs, s6m.xyz, got["radii"], E, s6m.opac, s6m.sc, s6m.rot, E,
-                           torch.as_tensor(dpix, device=s6m.dev), s6m.sh, geom, got["num_rendered"], binb, img, want_cov3D_grad=True)
+                           torch.as_tensor(dpix, device=s6m.dev), s6m.sh, geom, got["num_rendered"], binb, img, want_cov3D_grad=True, want_color_grad=True)
     torch.cuda.synchronize()
     names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
     touched = None

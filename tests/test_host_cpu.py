@@ -56,7 +56,8 @@ def test_workspace_sizes_are_host_computable():
     lib = _native.load()
     g0 = lib.fr_geometry_bytes(0, 1000)
     g3 = lib.fr_geometry_bytes(3, 1000)
-    assert g3 > g0 >= 1000 * (48 + 24)
+    g2 = lib.fr_geometry_bytes(2, 1000)
+    assert g3 > g2 >= 1000 * (48 + 24) and g0 > g2  # RF keeps per-level colours, the training variants their backward rows
     assert lib.fr_image_bytes(0, 1920, 1080) >= 1920 * 1080 * 8
     assert lib.fr_binning_bytes(0, 10) >= 120 and lib.fr_binning_bytes(0, 0) >= 0
 
