@@ -38,7 +38,7 @@ int check_launch(const char *what, hipStream_t stream, bool debug)
 static int validate_forward(const fr_forward_args *a)
 {
 	if (!a) { set_error("null args"); return FR_ERR_INVALID; }
-	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_PCHECK_OBB_LWMC) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
+	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_NAIVE_FOV_PCHECK_OBB) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
 	if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return FR_ERR_INVALID; }
 	if (a->P > (1 << 30) || a->W > 16 * 65535 || a->H > 16 * 65535) { set_error("too large: P=%d (max 2^30) W=%d H=%d (max 65535 tiles per axis)", a->P, a->W, a->H); return FR_ERR_INVALID; }
 	if ((int64_t)((a->W + FR_TILE - 1) / FR_TILE) * ((a->H + FR_TILE - 1) / FR_TILE) >= (1 << 29)) { set_error("too many tiles (W=%d H=%d)", a->W, a->H); return FR_ERR_INVALID; }
@@ -53,6 +53,12 @@ static int validate_forward(const fr_forward_args *a)
 		if (a->shs_rest) { set_error("shs_rest is not used by the foveated variant (its shs already is the rest part)"); return FR_ERR_INVALID; }
 		if (!a->shs || !a->shs_dcs || !a->highest_levels) { set_error("foveated variant needs shs (rest), shs_dcs and highest_levels"); return FR_ERR_INVALID; }
 		if (a->M != 15) { set_error("foveated variant expects M=15 rest coefficients, got %d", a->M); return FR_ERR_INVALID; }
+	}
+	else if (a->variant == FR_VARIANT_NAIVE_FOV_PCHECK_OBB)
+	{
+		if (!a->shs || a->colors_precomp || a->shs_rest || !a->highest_levels) { set_error("the shared-model foveated variant needs shs [P,M,3] and highest_levels (no colors_precomp / shs_rest)"); return FR_ERR_INVALID; }
+		if (a->M < (a->D + 1) * (a->D + 1)) { set_error("M=%d too small for SH degree %d", a->M, a->D); return FR_ERR_INVALID; }
+		if (a->packed_geom || a->packed_colour || a->packed_cull) { set_error("the shared-model foveated variant has no packed layout"); return FR_ERR_INVALID; }
 	}
 	else
 	{
@@ -144,7 +150,7 @@ int fr_forward(fr_forward_args *a)
 	c.fov_split = a->variant == FR_VARIANT_FOV_PCHECK_OBB ? 1 : 0;
 	if (c.fov_split) FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, stream));
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
-	if (a->variant != FR_VARIANT_FOV_PCHECK_OBB) // RF: k_tile_levels clears them
+	if (!is_fov(a->variant)) // RF: k_tile_levels clears them
 		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
 	if (has_stats(a->variant))
 	{
@@ -152,7 +158,7 @@ int fr_forward(fr_forward_args *a)
 		FR_HIP(hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, stream));
 	}
 	mark(FR_STAGE_TILE_LEVELS);
-	if (a->variant == FR_VARIANT_FOV_PCHECK_OBB) { rc = launch_tile_levels(c); if (rc) return rc; }
+	if (is_fov(a->variant)) { rc = launch_tile_levels(c); if (rc) return rc; }
 	mark(FR_STAGE_PROJECT);
 	rc = launch_project(c); if (rc) return rc;
 	mark(FR_STAGE_BIN);

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 int launch_tile_scan(FwdCtx &c)
 {
 	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals, c.img.tile_order,
-		c.totals_host_dev, c.totals_seq, c.img.tile_lv ? c.img.tile_lv + 4 * (size_t)c.T : (const float *)nullptr, c.img.render_items);
+		c.totals_host_dev, c.totals_seq, c.fov_split ? c.img.tile_lv + 4 * (size_t)c.T : (const float *)nullptr, c.img.render_items);
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 

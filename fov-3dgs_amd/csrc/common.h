@@ -35,6 +35,8 @@ namespace fr {
 // variant traits
 __host__ __device__ inline bool has_stats(int v) { return v == FR_VARIANT_PCHECK_OBB_SUM || v == FR_VARIANT_PCHECK_OBB_MAX || v == FR_VARIANT_PCHECK_OBB_LWMC; }
 __host__ __device__ inline bool has_backward(int v) { return v == FR_VARIANT_ORIGINAL || has_stats(v); }
+// variants that bin by eccentricity level (tile level map, level filter): RF and the shared-model baseline
+__host__ __device__ constexpr inline bool is_fov(int v) { return v == FR_VARIANT_FOV_PCHECK_OBB || v == FR_VARIANT_NAIVE_FOV_PCHECK_OBB; }
 
 // ---- workspace layouts -------------------------------------------------------------------
 // All sub-arrays are 256-byte aligned inside the caller's buffers.
@@ -69,7 +71,7 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 	g.rec = (float4 *)(base + off); off = align_up(off + P * 3 * sizeof(float4));
 	// variants with a backward pass keep a 64-byte row per vis_list entry for it (see GeomWS::cov3D); the others only
 	// need room for the developer timers
-	const bool keeps = variant != FR_VARIANT_PCHECK_OBB && variant != FR_VARIANT_FOV_PCHECK_OBB;
+	const bool keeps = has_backward(variant);
 	g.cov3D = (float *)(base + off); off = align_up(off + P * (keeps ? 16 : 6) * sizeof(float));
 	g.acc = nullptr;
 	if (keeps) { g.acc = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4)); }
@@ -120,7 +122,7 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.render_items = (uint32_t *)(base + off); off = align_up(off + 4 * T * sizeof(uint32_t));
 	s.tile_order = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.tile_lv = nullptr;
-	if (variant == FR_VARIANT_FOV_PCHECK_OBB) { s.tile_lv = (float *)(base + off); off = align_up(off + 5 * T * sizeof(float)); }
+	if (is_fov(variant)) { s.tile_lv = (float *)(base + off); off = align_up(off + 5 * T * sizeof(float)); }
 	s.hist = nullptr;
 	if (T <= FR_LDS_HIST_MAX_TILES) { s.hist = (uint32_t *)(base + off); off = align_up(off + (size_t)FR_BIN_BLOCKS * T * sizeof(uint32_t)); }
 	s.bytes = off + 256;

@@ -647,7 +647,10 @@ template <int VARIANT, bool LDSH, bool PACKED = false>
 __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
-	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
+	constexpr bool FOV = is_fov(VARIANT);                            // level map + level filter
+	constexpr bool LEVELCOL = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;  // per-level colours / opacities (RF); the shared-model
+	                                                                 // baseline has one colour per Gaussian like the plain variants
+	static_assert(!(PACKED && FOV && !LEVELCOL), "the shared-model foveated variant has no packed layout");
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
 	const int lane = threadIdx.x & 63;
 	// RF: every pair step looks its tile's level (and, if kept, its blend flag) up; from global memory those
@@ -760,7 +763,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		const float *mp = PACKED ? a.packed_geom + 16 * (size_t)idx : a.means3D + 3 * (size_t)idx;
 		const float dirx = mp[0] - a.campos[0], diry = mp[1] - a.campos[1], dirz = mp[2] - a.campos[2];
 		const float *pcol = PACKED ? a.packed_colour + 64 * (size_t)idx : nullptr;
-		if (!FOV)
+		if (!LEVELCOL)
 		{
 			if (a.colors_precomp == nullptr)
 			{
@@ -812,9 +815,12 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			}
 		}
 		float4 *rec = a.geom.rec + 3 * (size_t)idx;
-		if (FOV) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
+		if (LEVELCOL) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
 		else rec[1] = make_float4(conic_c, PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx], rgb[0], rgb[1]);
-		rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(item)); // item: where the backward pass keeps this Gaussian's sums
+		// third part: item = where the backward pass keeps this Gaussian's sums; the shared-model foveated variant (no
+		// backward, no clamp bits needed) carries the Gaussian's highest level there instead
+		if (FOV && !LEVELCOL) rec[2] = make_float4(rgb[2], depth, hl, 0.0f);
+		else rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(item));
 	};
 #ifdef FR_BIN_TIMERS
 	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0;
@@ -1426,7 +1432,7 @@ int launch_project(FwdCtx &c)
 		// workgroups would run on a half-empty chip)
 		static int resident[6] = { 0, 0, 0, 0, 0, 0 };
 		const bool packed = a->packed_cull != nullptr;
-		const int vslot = a->variant == FR_VARIANT_ORIGINAL ? 0 : (a->variant == FR_VARIANT_FOV_PCHECK_OBB ? 1 : 2);
+		const int vslot = a->variant == FR_VARIANT_ORIGINAL ? 0 : (is_fov(a->variant) ? 1 : 2); // the cull pass only knows "level box or not"
 		const int slot = vslot + (packed ? 3 : 0);
 		if (resident[slot] == 0)
 		{
@@ -1465,13 +1471,16 @@ int launch_bin(FwdCtx &c)
 	int nblk = bin_blocks(a->P);
 	const dim3 block(FR_BIN_THREADS);
 	// LDS per workgroup: tile histogram (+ RF: tile_min and blend bits when two workgroups still fit a CU)
-	p.lds_tiles = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
+	p.lds_tiles = (is_fov(a->variant) && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
 	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
 	if (lds > 64u * 1024u)
 	{
 		static const hipError_t once = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_FOV_PCHECK_OBB, true>,
 			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
 		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
+		static const hipError_t once2 = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+		if (once2 != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once2)); return FR_ERR_HIP; }
 	}
 	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the
 	// ordinary path 5 %); it needs both packed tensors and the LDS histogram path
@@ -1510,6 +1519,10 @@ int launch_bin(FwdCtx &c)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
 	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_PRE(FR_VARIANT_FOV_PCHECK_OBB); break;
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: // (no packed instantiation: validate_forward refuses the packed tensors)
+		if (ldsh) launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, lds);
+		else launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, 0);
+		break;
 	default: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
 	}
 #undef LAUNCH_PRE
@@ -1529,7 +1542,7 @@ int launch_emit(FwdCtx &c)
 	e.cursor = c.img.tile_count; e.entries = c.bin.entries; e.hist = c.img.hist;
 	const bool ldsh = c.img.hist != nullptr;
 	const dim3 grid(c.bin_wgs), block(FR_EMIT_THREADS);
-	e.lds_tiles = (a->variant == FR_VARIANT_FOV_PCHECK_OBB && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
+	e.lds_tiles = (is_fov(a->variant) && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
 	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (e.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
 	if (lds > 64u * 1024u)
 	{
@@ -1542,7 +1555,8 @@ int launch_emit(FwdCtx &c)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_EMIT(FR_VARIANT_ORIGINAL); break;
-	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_EMIT(FR_VARIANT_FOV_PCHECK_OBB); break;
+	case FR_VARIANT_FOV_PCHECK_OBB:
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: LAUNCH_EMIT(FR_VARIANT_FOV_PCHECK_OBB); break; // the level filter is the same
 	default: LAUNCH_EMIT(FR_VARIANT_PCHECK_OBB); break;
 	}
 #undef LAUNCH_EMIT

@@ -591,6 +591,148 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 	}
 }
 
+// ---------------- NAIVE_FOV_PCHECK_OBB: the shared-model foveated baseline (SMFR) ----------------
+// …_naive_pcheck_obb/cuda_rasterizer/forward.cu:482-580 (single-level tiles) and :258-480 (two-level tiles): one colour
+// and one opacity per Gaussian, so both level states of a two-level tile see the same alpha and stay in ONE wave here
+// (the exponential, alpha and colour fetch are shared; only the two transmittance chains differ). Quirks kept as
+// written: the alpha < 1/255 skip applies to a Gaussian only while the pixel's L1 state is still open (once L1 is
+// finished, L2 also accumulates negligible alphas, forward.cu:388-425); L2 skips Gaussians whose highest level lies
+// below the tile's upper level; L1 starts finished where the pixel's estimated level is beyond L2.
+__device__ __forceinline__ void blend2_given(Px2 &s, bool ok_x, bool ok_y, v2f alpha, float4 c)
+{
+	// ok: every skip test but saturation has passed (incl. T > 0)
+	const v2f tt = s.T * (1.0f - alpha);
+	v2f w = alpha * s.T;
+	const bool sat_x = tt.x < 0.0001f, sat_y = tt.y < 0.0001f;
+	w.x = (ok_x && !sat_x) ? w.x : 0.0f;
+	w.y = (ok_y && !sat_y) ? w.y : 0.0f;
+	s.C0 = __builtin_elementwise_fma((v2f){ c.x, c.x }, w, s.C0);
+	s.C1 = __builtin_elementwise_fma((v2f){ c.y, c.y }, w, s.C1);
+	s.C2 = __builtin_elementwise_fma((v2f){ c.z, c.z }, w, s.C2);
+	s.T.x = ok_x ? (sat_x ? -s.T.x : tt.x) : s.T.x;
+	s.T.y = ok_y ? (sat_y ? -s.T.y : tt.y) : s.T.y;
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(64) k_render_smfr(const RenderArgs a)
+{
+	static_assert(PPL == 2, "work items encode two bands per tile");
+	__shared__ float4 s0[64];   // x, y, A, B
+	__shared__ float4 s1[64];   // C, opacity, highest level, -
+	__shared__ float4 scol[64]; // r, g, b, -
+	const int lane = threadIdx.x;
+	if (blockIdx.x >= a.n_items) return;
+	const uint32_t item = a.render_items[blockIdx.x];
+	const int tile = (int)(item >> 3), wv = (int)(item & 1u);
+	const int tx = tile % a.gx, ty = tile / a.gx;
+	const int tid = wv * 64 + lane;
+	const int lx = tid & 15;
+	const int px = tx * FR_TILE + lx;
+	const float pxf = (float)px;
+	const uint2 range = a.ranges[tile];
+	const int n = (int)(range.y - range.x);
+	const float tlf = a.tile_lv[a.T + tile];                    // tile_min
+	const bool two_level = a.tile_lv[4 * (size_t)a.T + tile] != 0.0f;
+	const int L1 = f2i(tlf);
+	const int L2 = L1 + 1;
+	const float L2f = tlf + 1.0f;
+	const float tgx = a.tile_lv[2 * (size_t)a.T + tile], tgy = a.tile_lv[3 * (size_t)a.T + tile];
+	Px2 S1, S2;
+	float pyf[PPL], est[PPL];
+	bool inside[PPL];
+#pragma unroll
+	for (int k = 0; k < PPL; k++)
+	{
+		const int ly = tile_row<PPL>(tid, k);
+		const int py = ty * FR_TILE + ly;
+		pyf[k] = (float)py;
+		inside[k] = px < a.W && py < a.H;
+		est[k] = tlf + ((float)lx * tgx + (float)ly * tgy) / (float)FR_TILE;
+		const bool done1 = !inside[k] || (two_level && est[k] > (float)L2);
+		const bool done2 = !inside[k] || !two_level;
+		S1.T[k] = done1 ? -1.0f : 1.0f;
+		S2.T[k] = done2 ? -1.0f : 1.0f;
+	}
+	S1.C0 = S1.C1 = S1.C2 = S2.C0 = S2.C1 = S2.C2 = (v2f){ 0.f, 0.f };
+	float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, pc = p0;
+	auto fetch = [&](int e)
+	{
+		const uint32_t id = a.point_list[range.x + e];
+		const float4 *r = a.rec + 3 * (size_t)id;
+		p0 = r[0];
+		const float4 r1 = r[1], r2 = r[2];
+		p1 = make_float4(r1.x, r1.y, r2.z, 0.0f);   // conic c, opacity, highest level (k_bin keeps it in the clamp slot)
+		pc = make_float4(r1.z, r1.w, r2.x, 0.0f);
+	};
+	if (lane < n) fetch(lane);
+	for (int base = 0; base < n; base += 64)
+	{
+		const float tmax0 = fmaxf(fmaxf(S1.T.x, S1.T.y), fmaxf(S2.T.x, S2.T.y));
+		if (!__any(tmax0 > 0.0f)) break;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const bool staged = base + lane < n;
+		if (staged) { s0[lane] = p0; s1[lane] = p1; scol[lane] = pc; }
+		unsigned long long reach_mask;
+		{
+			// single-level tiles: alpha < 1/255 everywhere <=> power < -ln(255 opacity); in two-level tiles the L2 state may
+			// take negligible alphas (see above), so only the support cutoff bounds the reach there
+			const float thr = two_level ? -4.5f : fmaxf(-4.5f, -__logf(255.0f * p1.y) - 0.01f);
+			reach_mask = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
+		}
+		if (base + 64 + lane < n) fetch(base + 64 + lane);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const v2f pyp = (v2f){ pyf[0], pyf[1] };
+		for (unsigned long long rm = reach_mask; rm; rm &= rm - 1)
+		{
+			const int j = __builtin_ctzll(rm);
+			const float tmax = fmaxf(fmaxf(S1.T.x, S1.T.y), fmaxf(S2.T.x, S2.T.y));
+			if (!__any(tmax > 0.0f)) break;
+			const float4 g0 = s0[j], g1 = s1[j], col = scol[j];
+			const float dx = g0.x - pxf;
+			const v2f pw = power2(g0.y - pyp, g1.x, (g0.z * dx) * dx, g0.w * dx);
+			const bool inx = !(pw.x > 0.0f || pw.x < -4.5f), iny = !(pw.y > 0.0f || pw.y < -4.5f);
+			v2f alpha = g1.y * exp2_pair(pw);
+			alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y);
+			const bool vis_x = !(alpha.x < 1.0f / 255.0f), vis_y = !(alpha.y < 1.0f / 255.0f);
+			const bool open1_x = S1.T.x > 0.0f, open1_y = S1.T.y > 0.0f; // L1 still open BEFORE this Gaussian
+			blend2_given(S1, inx && open1_x && vis_x, iny && open1_y && vis_y, alpha, col);
+			if (two_level)
+			{
+				const bool l2_ok = !((g1.z + 1.0f) < L2f);
+				// naive forward.cu:388-406: an open L1 that finds alpha negligible skips the Gaussian for L2 as well
+				blend2_given(S2, inx && l2_ok && S2.T.x > 0.0f && (!open1_x || vis_x), iny && l2_ok && S2.T.y > 0.0f && (!open1_y || vis_y), alpha, col);
+			}
+		}
+	}
+	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+	const size_t plane = (size_t)a.W * a.H;
+#pragma unroll
+	for (int k = 0; k < PPL; k++)
+	{
+		if (!inside[k]) continue;
+		const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
+		const float t1 = fabsf(S1.T[k]), t2 = fabsf(S2.T[k]);
+		float o0 = fmaf(bg0, t1, S1.C0[k]), o1 = fmaf(bg1, t1, S1.C1[k]), o2 = fmaf(bg2, t1, S1.C2[k]);
+		if (two_level)
+		{
+			const float q0 = fmaf(bg0, t2, S2.C0[k]), q1 = fmaf(bg1, t2, S2.C1[k]), q2 = fmaf(bg2, t2, S2.C2[k]);
+			float x = fabsf(est[k] - ((float)L1 + 0.5f)) / 0.5f;
+			x = fmaxf(0.0f, fminf(1.0f, x));
+			const float bT = 3 * x * x - 2 * x * x * x;
+			const float w1 = 1 - bT;
+			o0 = o0 * w1 + q0 * (1.f - w1);
+			o1 = o1 * w1 + q1 * (1.f - w1);
+			o2 = o2 * w1 + q2 * (1.f - w1);
+		}
+		a.out_color[pid] = o0;
+		a.out_color[plane + pid] = o1;
+		a.out_color[2 * plane + pid] = o2;
+	}
+}
+
 int launch_render(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
@@ -613,6 +755,7 @@ int launch_render(FwdCtx &c)
 	case FR_VARIANT_PCHECK_OBB: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB, true); break;
 	case FR_VARIANT_PCHECK_OBB_MAX: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_MAX, true); break;
 	case FR_VARIANT_PCHECK_OBB_LWMC: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_LWMC, false); break;
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: hipLaunchKernelGGL((k_render_smfr<2>), dim3(r.n_items), dim3(64), 0, c.stream, r); break;
 	default:
 		hipLaunchKernelGGL((k_render_fov<2>), dim3(r.n_items), dim3(64), 0, c.stream, r);
 		break;

@@ -531,3 +531,69 @@ def _make_fov():
                                        blending, packed)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
+
+
+def _make_naive_fov():
+    """Autograd function + module for the shared-model foveated baseline ("SMFR"; reference package
+    …_naive_pcheck_obb/diff_gaussian_rasterization_naive_pcheck_obb/__init__.py:20-262): the foveated extension's
+    tile levels and lists with the plain model's single colour / opacity per Gaussian. Inference only."""
+    variant_id = _native.VARIANT_NAIVE_FOV_PCHECK_OBB
+
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                    raster_settings, highest_levels, gazeArray, alpha, blending):
+            args = (variant_id, raster_settings, means3D, shs, colors_precomp, opacities, scales, rotations,
+                    cov3Ds_precomp, None, highest_levels, _gaze_pair(gazeArray), float(alpha))
+            if raster_settings.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    res = _forward_native(*args, persistent=True)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                res = _forward_native(*args, persistent=True)
+            num_rendered, color, radii = res[:3]
+            ctx.num_rendered = num_rendered
+            ctx.mark_non_differentiable(radii)
+            return color, radii
+
+        @staticmethod
+        def backward(ctx, grad_out_color, _):
+            # the reference's backward() of this extension returns None for every input (its kernels are forward-only)
+            return (None,) * 13
+
+    def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                            raster_settings, highest_levels, gazeArray, alpha, blending):
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings, highest_levels, gazeArray, alpha, blending)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            with torch.no_grad():
+                return _mark_visible(positions, self.raster_settings)
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None, shs_dcs=None, highest_levels=None, gazeArray=None, alpha=None, blending=None):
+            raster_settings = self.raster_settings
+            if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+                raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                    ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            empty = torch.Tensor([])
+            shs = empty if shs is None else shs
+            colors_precomp = empty if colors_precomp is None else colors_precomp
+            scales = empty if scales is None else scales
+            rotations = empty if rotations is None else rotations
+            cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+            return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                       cov3D_precomp, raster_settings, highest_levels, gazeArray, alpha, blending)
+
+    return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 3
+#define FR_ABI_VERSION 4
 
 /* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
  * fov3dgs/gaussian_wrapper.py:11-23) */
@@ -48,8 +48,13 @@ enum {
 	/* pruning-metric variants of the training rasterizer (prune.py / metric_mask_learn.py); forward
 	 * statistics differ from …_sum, backward is identical */
 	FR_VARIANT_PCHECK_OBB_MAX = 4, /* …_pcheck_obb_max: count per in-support pixel, contributions = max alpha*T */
-	FR_VARIANT_PCHECK_OBB_LWMC = 5 /* …_pcheck_obb_loss_weighted_max_count: per-pixel loss credited to its
-	                                * max-contribution Gaussian */
+	FR_VARIANT_PCHECK_OBB_LWMC = 5, /* …_pcheck_obb_loss_weighted_max_count: per-pixel loss credited to its
+	                                 * max-contribution Gaussian */
+	/* the paper's shared-model foveated baseline ("SMFR", fps/naiveFR): …_naive_pcheck_obb. Tile levels, the level
+	 * filter and the instance lists of FOV_PCHECK_OBB, but ONE colour / opacity per Gaussian (shs [P,16,3],
+	 * opacities [P,1], highest_levels [P,1]; no shs_dcs), blended per naive forward.cu:258-480 (two-level tiles)
+	 * and :482-580 (single-level tiles). Inference only, no packed layout. */
+	FR_VARIANT_NAIVE_FOV_PCHECK_OBB = 6
 };
 
 enum {

@@ -81,7 +81,10 @@ typedef float real;
 #define BLOCK_SIZE 256
 #define FOV_NUM 4 /* RF auxiliary.h:26 */
 
-enum { ORC_R0 = 0, ORC_RS = 1, ORC_RP = 2, ORC_RF = 3, ORC_RMAX = 4, ORC_LWMC = 5 };
+enum { ORC_R0 = 0, ORC_RS = 1, ORC_RP = 2, ORC_RF = 3, ORC_RMAX = 4, ORC_LWMC = 5, ORC_SMFR = 6 };
+/* ORC_SMFR = …_naive_pcheck_obb, the paper's shared-model foveated baseline: RF's tile levels, level filter and lists,
+ * one colour / opacity per Gaussian (NV = diff-gaussian-rasterization_naive_pcheck_obb/cuda_rasterizer/). */
+#define ORC_IS_FOV(v) ((v) == ORC_RF || (v) == ORC_SMFR)
 /* ORC_RMAX = …_pcheck_obb_max, ORC_LWMC = …_pcheck_obb_loss_weighted_max_count: RS with different
  * per-Gaussian statistics (pruning metrics of prune.py / metric_mask_learn.py); same backward as RS. */
 
@@ -632,7 +635,7 @@ static int64_t bin_and_sort(const orc_in *in, orc_out *o)
 	const int P = in->P, W = in->W, H = in->H;
 	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y, T = gx * gy;
 	const int twn = (W + 15) / BLOCK_X;
-	const int cull = in->variant != ORC_R0, fov = in->variant == ORC_RF;
+	const int cull = in->variant != ORC_R0, fov = ORC_IS_FOV(in->variant);
 	int64_t d0 = 0;
 	for (int i = 0; i < P; i++) d0 += o->tiles_rect[i];
 	o->num_rect = d0;
@@ -925,15 +928,108 @@ static void render_fov(const orc_in *in, orc_out *o)
 		}
 }
 
+/* ---------------- blend: SMFR (shared-model foveated baseline) ----------------
+ * single-level tiles NV forward.cu:482-580; two-level tiles NV forward.cu:258-480. One colour and opacity per
+ * Gaussian; in two-level tiles an OPEN L1 state skips a Gaussian with alpha < 1/255 for both states (the `continue`
+ * at :403-405), a finished L1 lets L2 take any alpha (no test at :409-425). */
+static void render_smfr(const orc_in *in, orc_out *o)
+{
+	const int W = in->W, H = in->H;
+	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+	const int twn = (W + 15) / BLOCK_X;
+	const real start_blend = (real)0.5f, blend_width = (real)0.5f;
+	ORC_PARALLEL_FOR(dynamic, 4)
+	for (int tile = 0; tile < gx * gy; tile++)
+		{
+			const int ty = tile / gx, tx = tile % gx;
+			if (!in_window(in, tx, ty)) continue;
+			const uint32_t r0 = o->ranges[2 * (ty * gx + tx)], r1 = o->ranges[2 * (ty * gx + tx) + 1];
+			const int n = (int)(r1 - r0);
+			const uint32_t cur = (uint32_t)(tx + twn * ty);
+			const int blending = o->tile_blend[cur];
+			const real tlf = o->tile_min[cur];
+			const int tli = f2i(tlf);
+			for (int ly = 0; ly < BLOCK_Y; ly++)
+				for (int lx = 0; lx < BLOCK_X; lx++)
+				{
+					const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+					if (!(pxi < W && pyi < H)) continue;
+					const real pixf[2] = { (real)pxi, (real)pyi };
+					const size_t pid = (size_t)W * pyi + pxi;
+					real T1 = 1, T2 = 1, C1[3] = { 0, 0, 0 }, C2[3] = { 0, 0, 0 };
+					const real est = tlf + ((real)lx * o->tile_gx[cur] + (real)ly * o->tile_gy[cur]) / (real)BLOCK_X;
+					const int L1 = tli, L2 = tli + 1;
+					const real L2f = tlf + (real)1.0f;
+					int L1_done = blending ? (est > (real)L2) : 0, L2_done = blending ? 0 : 1;
+					for (int j = 0; j < n; j++)
+					{
+						const uint32_t g = o->point_list[r0 + j];
+						const real dx = o->means2D[2 * g] - pixf[0], dy = o->means2D[2 * g + 1] - pixf[1];
+						const real ca = o->conic[3 * g], cb = o->conic[3 * g + 1], cc = o->conic[3 * g + 2];
+						const real power = (real)-0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+						if (power > (real)0 || power < (real)-4.5f) continue;
+						const real alpha = r_fmin((real)0.99f, in->opacities[g] * r_exp(power));
+						const int askip = alpha < (real)1.0f / (real)255.0f;
+						if (!blending)
+						{
+							if (askip) continue;
+							const real tT = T1 * (1 - alpha);
+							if (tT < (real)0.0001f) break;
+							const real w = alpha * T1;
+							for (int ch = 0; ch < 3; ch++) C1[ch] += o->rgb[3 * g + ch] * w;
+							T1 = tT;
+							continue;
+						}
+						if (!L1_done)
+						{
+							if (askip) continue;
+							const real tT = T1 * (1 - alpha);
+							L1_done = tT < (real)0.0001f;
+							if (!L1_done)
+							{
+								const real w = alpha * T1;
+								for (int ch = 0; ch < 3; ch++) C1[ch] += o->rgb[3 * g + ch] * w;
+								T1 = tT;
+							}
+						}
+						if (!L2_done && !((in->highest_levels[g] + 1) < L2f))
+						{
+							const real tT = T2 * (1 - alpha);
+							L2_done = tT < (real)0.0001f;
+							if (!L2_done)
+							{
+								const real w = alpha * T2;
+								for (int ch = 0; ch < 3; ch++) C2[ch] += o->rgb[3 * g + ch] * w;
+								T2 = tT;
+							}
+						}
+						if (L1_done && L2_done) break;
+					}
+					if (!blending)
+					{
+						for (int ch = 0; ch < 3; ch++) o->color[(size_t)ch * H * W + pid] = C1[ch] + in->bg[ch] * T1;
+						continue;
+					}
+					for (int ch = 0; ch < 3; ch++) { C1[ch] = C1[ch] + in->bg[ch] * T1; C2[ch] = C2[ch] + in->bg[ch] * T2; }
+					real x = r_fabs(est - ((real)L1 + start_blend)) / blend_width;
+					x = r_fmax((real)0, r_fmin((real)1, x));
+					const real bT = 3 * x * x - 2 * x * x * x;
+					const real w1 = 1 - bT;
+					for (int ch = 0; ch < 3; ch++) o->color[(size_t)ch * H * W + pid] = C1[ch] * w1 + C2[ch] * ((real)1 - w1);
+				}
+		}
+}
+
 /* ---------------- public: forward ---------------- */
 int64_t orc_forward(const orc_in *in, orc_out *o)
 {
 	if (in->P == 0) { o->num_rect = 0; o->num_rendered = 0; return 0; }
 	if (preprocess(in, o) != 0) return -1;
-	if (in->variant == ORC_RF) tile_levels(in, o);
+	if (ORC_IS_FOV(in->variant)) tile_levels(in, o);
 	int64_t n = bin_and_sort(in, o);
 	if (n > o->capacity) return n; /* caller must retry with capacity >= n */
 	if (in->variant == ORC_RF) { compute_fov_colors(in, o); render_fov(in, o); }
+	else if (in->variant == ORC_SMFR) render_smfr(in, o); /* NV rasterizer_impl.cu:463-483: the colour is the plain SH colour */
 	else render_plain(in, o);
 	return n;
 }

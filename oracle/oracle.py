@@ -19,7 +19,7 @@ BUILD = os.path.join(HERE, "_build")
 SRC = os.path.join(HERE, "fovraster_oracle.c")
 
 VARIANTS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3, "pcheck_obb_max": 4,
-            "pcheck_obb_loss_weighted_max_count": 5}
+            "pcheck_obb_loss_weighted_max_count": 5, "naive_pcheck_obb": 6}
 FOV_NUM = 4
 
 

@@ -180,6 +180,28 @@ def test_foveated_forward_full_size(s6m, gaze_id):
                              frame_instances=int(got["num_rendered"]), two_level_tiles_in_window=int(want["tile_blend"][tiles].sum()))
 
 
+def test_shared_model_baseline_full_size(s6m):
+    """SURVEY 8f rank 4 at full size: the SMFR baseline on the S-6M cloud (plain model + the foveated model's highest levels)."""
+    gaze = syn.lissajous_gaze(10, 90)
+    win = gaze_window(gaze)
+    scene = dict(s6m.scene_plain, highest_levels=s6m.scene_fov["highest_levels"])
+    want = orc.forward("naive_pcheck_obb", scene, s6m.cam_dict(gaze=gaze, window=win))
+    rz, E = s6m.rz, torch.Tensor([])
+    with torch.no_grad():
+        res = rz._forward_native(s6m.native.VARIANT_IDS["naive_pcheck_obb"], s6m.rs, s6m.xyz, s6m.sh, E, s6m.opac, s6m.sc, s6m.rot, E, None,
+                                 s6m.highest, gaze, 0.05)
+        torch.cuda.synchronize()
+    vid = s6m.native.VARIANT_IDS["naive_pcheck_obb"]
+    D, color, radii, geom, binb, img = res[:6]
+    view = lambda buf, ptr, count, dtype: buf[ptr - buf.data_ptr():ptr - buf.data_ptr() + 4 * count].view(dtype)
+    got = dict(num_rendered=D, ranges=view(img, s6m.lib.fr_image_ranges(vid, W, H, img.data_ptr()), 2 * T, torch.int32).view(T, 2).long(),
+               point_list=view(binb, s6m.lib.fr_binning_point_list(vid, D, binb.data_ptr()), D, torch.int32))
+    tag = "naive_pcheck_obb (SMFR) S-6M"
+    np.testing.assert_array_equal(radii.cpu().numpy(), want["radii"], err_msg=tag + ": radii over all Gaussians")
+    compare_lists(got, want, win, tag)
+    check_image(crop(color, win).cpu().numpy(), crop(want["color"], win), name=tag)
+
+
 BWD_WIN = (30, 20, 90, 48)  # 60 x 28 tiles
 
 

@@ -614,3 +614,34 @@ def test_fov_level_colours_match_oracle(gaze):
                                  max_abs=float(np.abs(lvl[m, l, :3] - want["fov_colors"][m, l]).max()),
                                  bitwise_equal=float(np.mean(lvl[m, l, :3].view(np.uint32) == want["fov_colors"][m, l].view(np.uint32))))
         assert len(seen_levels) == 4
+
+
+@pytest.mark.parametrize("gaze", ((0.4, 0.55), (0.9, 0.1)))
+def test_shared_model_foveated_baseline(gaze):
+    """the SMFR baseline (…_naive_pcheck_obb) -- lists bit-exact, image within tolerance, and the
+    gaussian_renderer_fov_naive.render() entry point."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    scene_f, cam = small_case("fov_pcheck_obb", P=6000, seed=23, gaze=gaze, width=640, height=400)
+    plain, _ = small_case("pcheck_obb", P=6000, seed=23, width=640, height=400)
+    scene = dict(plain, highest_levels=scene_f["highest_levels"])
+    want = orc.forward("naive_pcheck_obb", scene, cam)
+    assert want["tile_blend"].sum() > 30
+    got = hip_forward("naive_pcheck_obb", scene, cam)
+    assert got["num_rendered"] == want["num_rendered"]
+    np.testing.assert_array_equal(got["radii"], want["radii"])
+    np.testing.assert_array_equal(got["ranges"], want["ranges"])
+    np.testing.assert_array_equal(got["point_list"], want["point_list"])
+    check_image(got["color"], want["color"], name=f"SMFR gaze={gaze}")
+    # entry point
+    from fov3dgs_amd.gaussian_renderer_fov_naive import render
+    dev = "cuda:0"
+    cloud = small_cloud(6000, 23).to(dev)
+    camo = small_camera(640, 400).to(dev)
+    with torch.no_grad():
+        out = render(camo, cloud, torch.tensor([0.1, 0.2, 0.3], device=dev), alpha=0.05, gazeArray=torch.tensor(gaze), blending=True,
+                     highest_levels=torch.as_tensor(scene["highest_levels"]).to(dev))
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii"}
+    # (the model's activations run on the GPU here: a few radii may differ in the last place of a scale, see S6M in
+    # tests/test_full_size_parity.py; the image stays within tolerance)
+    check_image(out["render"].cpu().numpy(), want["color"], frac=2e-3, name=f"SMFR render() gaze={gaze}")

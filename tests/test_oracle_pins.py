@@ -249,3 +249,28 @@ def test_edge_cases():
         np.testing.assert_allclose(o["color"][ch], cam["bg"][ch])
     assert not orc.mark_visible(behind, cam).any()
     assert orc.mark_visible(scene, cam).sum() > 0
+
+
+def test_shared_model_foveated_baseline_pins():
+    """The SMFR restatement (…_naive_pcheck_obb) against the two variants it is made of: with every Gaussian present at
+    all levels (highest_levels == 3) its instance lists are pcheck_obb's and every single-level tile is blended exactly
+    like pcheck_obb's (same formula, NV forward.cu:482-580 vs RP forward.cu:243-384); with the foveated model's
+    highest_levels its radii and lists are RF's (same filter, NV rasterizer_impl.cu:264-357 vs RF :264-383)."""
+    import numpy as np
+    from tests.helpers import small_case
+    scene_f, cam = small_case("fov_pcheck_obb", P=3000, seed=5, gaze=(0.3, 0.6), width=320, height=208)
+    plain, _ = small_case("pcheck_obb", P=3000, seed=5, width=320, height=208)
+    sm = dict(plain, highest_levels=np.full((3000, 1), 3.0, np.float32))
+    a, b = orc.forward("naive_pcheck_obb", sm, cam), orc.forward("pcheck_obb", plain, cam)
+    assert a["num_rendered"] == b["num_rendered"] > 10000
+    np.testing.assert_array_equal(a["point_list"], b["point_list"])
+    two = a["tile_blend"].reshape(13, 20) != 0
+    assert 20 < two.sum() < 200
+    single_px = ~np.repeat(np.repeat(two, 16, 0), 16, 1)[:208, :320]
+    np.testing.assert_array_equal(a["color"][:, single_px], b["color"][:, single_px])
+    assert 1e-5 < np.abs(a["color"] - b["color"])[:, ~single_px].max() < 0.2  # two-level tiles mix two states
+    c = orc.forward("naive_pcheck_obb", dict(plain, highest_levels=scene_f["highest_levels"]), cam)
+    f = orc.forward("fov_pcheck_obb", scene_f, cam)
+    np.testing.assert_array_equal(c["radii"], f["radii"])
+    np.testing.assert_array_equal(c["point_list"], f["point_list"])
+    np.testing.assert_array_equal(c["ranges"], f["ranges"])
