@@ -12,10 +12,10 @@ LIB_PATH = os.path.join(HERE, "libfovraster_hip.so")
 ABI_VERSION = 4
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
-VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC, VARIANT_NAIVE_FOV_PCHECK_OBB = 4, 5, 6
+VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC, VARIANT_NAIVE_FOV_PCHECK_OBB, VARIANT_MMFR_PCHECK_OBB = 4, 5, 6, 7
 STAGES = ("tile_levels", "project", "bin", "tile_scan", "emit", "tile_sort", "render")
 VARIANT_IDS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3, "pcheck_obb_max": 4,
-               "pcheck_obb_loss_weighted_max_count": 5, "naive_pcheck_obb": 6}
+               "pcheck_obb_loss_weighted_max_count": 5, "naive_pcheck_obb": 6, "mmfr_pcheck_obb": 7}
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -40,6 +40,7 @@ class ForwardArgs(C.Structure):
         ("loss_map", _FP),
         ("shs_rest", _FP),
         ("packed_geom", _FP), ("packed_colour", _FP), ("packed_cull", _FP),
+        ("cur_level", C.c_float),
     ]
 
 

@@ -38,7 +38,7 @@ int check_launch(const char *what, hipStream_t stream, bool debug)
 static int validate_forward(const fr_forward_args *a)
 {
 	if (!a) { set_error("null args"); return FR_ERR_INVALID; }
-	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_NAIVE_FOV_PCHECK_OBB) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
+	if (a->variant < FR_VARIANT_ORIGINAL || a->variant > FR_VARIANT_MMFR_PCHECK_OBB) { set_error("unknown variant %d", a->variant); return FR_ERR_INVALID; }
 	if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return FR_ERR_INVALID; }
 	if (a->P > (1 << 30) || a->W > 16 * 65535 || a->H > 16 * 65535) { set_error("too large: P=%d (max 2^30) W=%d H=%d (max 65535 tiles per axis)", a->P, a->W, a->H); return FR_ERR_INVALID; }
 	if ((int64_t)((a->W + FR_TILE - 1) / FR_TILE) * ((a->H + FR_TILE - 1) / FR_TILE) >= (1 << 29)) { set_error("too many tiles (W=%d H=%d)", a->W, a->H); return FR_ERR_INVALID; }
@@ -54,7 +54,7 @@ static int validate_forward(const fr_forward_args *a)
 		if (!a->shs || !a->shs_dcs || !a->highest_levels) { set_error("foveated variant needs shs (rest), shs_dcs and highest_levels"); return FR_ERR_INVALID; }
 		if (a->M != 15) { set_error("foveated variant expects M=15 rest coefficients, got %d", a->M); return FR_ERR_INVALID; }
 	}
-	else if (a->variant == FR_VARIANT_NAIVE_FOV_PCHECK_OBB)
+	else if (a->variant == FR_VARIANT_NAIVE_FOV_PCHECK_OBB || a->variant == FR_VARIANT_MMFR_PCHECK_OBB)
 	{
 		if (!a->shs || a->colors_precomp || a->shs_rest || !a->highest_levels) { set_error("the shared-model foveated variant needs shs [P,M,3] and highest_levels (no colors_precomp / shs_rest)"); return FR_ERR_INVALID; }
 		if (a->M < (a->D + 1) * (a->D + 1)) { set_error("M=%d too small for SH degree %d", a->M, a->D); return FR_ERR_INVALID; }

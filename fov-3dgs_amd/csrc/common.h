@@ -36,7 +36,7 @@ namespace fr {
 __host__ __device__ inline bool has_stats(int v) { return v == FR_VARIANT_PCHECK_OBB_SUM || v == FR_VARIANT_PCHECK_OBB_MAX || v == FR_VARIANT_PCHECK_OBB_LWMC; }
 __host__ __device__ inline bool has_backward(int v) { return v == FR_VARIANT_ORIGINAL || has_stats(v); }
 // variants that bin by eccentricity level (tile level map, level filter): RF and the shared-model baseline
-__host__ __device__ constexpr inline bool is_fov(int v) { return v == FR_VARIANT_FOV_PCHECK_OBB || v == FR_VARIANT_NAIVE_FOV_PCHECK_OBB; }
+__host__ __device__ constexpr inline bool is_fov(int v) { return v == FR_VARIANT_FOV_PCHECK_OBB || v == FR_VARIANT_NAIVE_FOV_PCHECK_OBB || v == FR_VARIANT_MMFR_PCHECK_OBB; }
 
 // ---- workspace layouts -------------------------------------------------------------------
 // All sub-arrays are 256-byte aligned inside the caller's buffers.

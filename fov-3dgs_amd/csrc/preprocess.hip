@@ -87,8 +87,12 @@ __device__ float tile_level(int tx, int ty, int W, int H, float gaze_x, float ga
 // lv_bbox[k] (zeroed by the caller): bounding box of the tiles with tile_min < k, see walk_rect().
 // A workgroup owns a 16 x 16 patch of tiles: every level is evaluated once (plus the patch's one-tile halo) and
 // shared through LDS -- the level function (acos, tan, three sqrt) is ~500 instructions.
+// mmfr_level >= 0: the multi-model baseline's map for that level (mmfr rasterizer_impl.cu:246-262,277-304): tile_min is
+// clamped at 0 and kept in row 0 (the blend kernel's value); row 1, which the level filter of the binning kernels and
+// the level boxes read, becomes 0 for the tiles this level renders (tile_min in (level - 0.5, level + 1)) and 5 for the
+// skipped ones -- with highest_levels == 0 the filter `row 1 < highest_level + 1` is then exactly "not skipped".
 __global__ void __launch_bounds__(256) k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x, float gaze_y, float alpha, float *out,
-	uint32_t *lv_bbox, uint32_t *slab_ctr)
+	uint32_t *lv_bbox, uint32_t *slab_ctr, float mmfr_level)
 {
 	// the counters of the two kernels that follow are cleared here (one fill command less at the head of the frame)
 	if (blockIdx.x == 0)
@@ -121,12 +125,16 @@ __global__ void __launch_bounds__(256) k_tile_levels(int T, int gx, int gy, int 
 	else if (up != -1) gyv = up - lf;
 	else if (down != -1) gyv = lf - down;
 	const float max_delta = (float)(0.5 * (double)(fabsf(gxv) + fabsf(gyv)));
-	const float tmin = lf - max_delta;
+	const bool mmfr = mmfr_level >= 0.0f;
+	float tmin = lf - max_delta;
+	if (mmfr && tmin < 0.0f) tmin = 0.0f;
 	const float tmin_i = (float)f2i(tmin);
 	const bool blending = ((tmin - tmin_i) > 0.5f) && (tmin_i < (float)(FR_FOV_LEVELS - 1));
+	const float real_tmin = tmin;
+	if (mmfr) tmin = (real_tmin > mmfr_level - 0.5f && real_tmin < mmfr_level + 1.0f) ? 0.0f : 5.0f; // the filter key
 	if (live)
 	{
-		out[idx] = lf;
+		out[idx] = mmfr ? real_tmin : lf;
 		out[T + idx] = tmin;
 		out[2 * T + idx] = gxv;
 		out[3 * T + idx] = gyv;
@@ -1400,7 +1408,8 @@ int launch_tile_levels(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	hipLaunchKernelGGL(k_tile_levels, dim3(((c.gx + 15) / 16) * ((c.gy + 15) / 16)), dim3(256), 0, c.stream,
-		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv, c.img.lv_bbox, c.geom.slab_ctr);
+		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv, c.img.lv_bbox, c.geom.slab_ctr,
+		a->variant == FR_VARIANT_MMFR_PCHECK_OBB ? a->cur_level : -1.0f);
 	return check_launch("tile_levels", c.stream, a->debug);
 }
 
@@ -1519,6 +1528,7 @@ int launch_bin(FwdCtx &c)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
 	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_PRE(FR_VARIANT_FOV_PCHECK_OBB); break;
+	case FR_VARIANT_MMFR_PCHECK_OBB:      // plain colours + the level filter (on the skip key, see k_tile_levels): the same kernel
 	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: // (no packed instantiation: validate_forward refuses the packed tensors)
 		if (ldsh) launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, lds);
 		else launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, 0);
@@ -1556,6 +1566,7 @@ int launch_emit(FwdCtx &c)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_EMIT(FR_VARIANT_ORIGINAL); break;
 	case FR_VARIANT_FOV_PCHECK_OBB:
+	case FR_VARIANT_MMFR_PCHECK_OBB:
 	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: LAUNCH_EMIT(FR_VARIANT_FOV_PCHECK_OBB); break; // the level filter is the same
 	default: LAUNCH_EMIT(FR_VARIANT_PCHECK_OBB); break;
 	}

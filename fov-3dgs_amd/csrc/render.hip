@@ -109,6 +109,7 @@ struct RenderArgs {
 	const float *loss_map;  // LWMC
 	const uint32_t *render_items; // work items, longest list first (k_tile_scan): tile << 3 | band | level state << 1 | two-level << 2 ...
 	uint32_t n_items;             // ... and their number
+	float cur_level;              // MMFR
 };
 
 // ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB ----------------
@@ -733,6 +734,114 @@ __global__ void __launch_bounds__(64) k_render_smfr(const RenderArgs a)
 	}
 }
 
+// ---------------- MMFR_PCHECK_OBB: one level's share of the multi-model foveated baseline ----------------
+// …_mmfr_pcheck_obb/cuda_rasterizer/forward.cu:255-420 (two-level tiles) and :422-540 (single-level tiles): plain
+// front-to-back blend of this level's model; skipped tiles stay zero; in a two-level tile a pixel whose estimated level
+// est = tile_min + gradient . offset has int(est) != cur_level and lies below the blend zone contributes nothing, and
+// every pixel is weighted by w1 = 1 - smoothstep((est - (int(est) + 0.5)) / 0.5) if int(est) == cur_level, else 1 - w1.
+template <int PPL>
+__global__ void __launch_bounds__(64) k_render_mmfr(const RenderArgs a)
+{
+	static_assert(PPL == 2, "work items encode two bands per tile");
+	__shared__ float4 s0[64];   // x, y, A, B
+	__shared__ float2 s1[64];   // C, opacity
+	__shared__ float4 scol[64]; // r, g, b, -
+	const int lane = threadIdx.x;
+	if (blockIdx.x >= a.n_items) return;
+	const uint32_t item = a.render_items[blockIdx.x];
+	const int tile = (int)(item >> 3), wv = (int)(item & 1u);
+	const int tx = tile % a.gx, ty = tile / a.gx;
+	const int tid = wv * 64 + lane;
+	const int lx = tid & 15;
+	const int px = tx * FR_TILE + lx;
+	const float pxf = (float)px;
+	const bool skipped = a.tile_lv[a.T + tile] != 0.0f;          // the filter key k_tile_levels leaves in row 1
+	const uint2 range = a.ranges[tile];
+	const int n = skipped ? 0 : (int)(range.y - range.x);
+	const float tlf = a.tile_lv[tile];                             // row 0: tile_min clamped at 0
+	const bool two_level = a.tile_lv[4 * (size_t)a.T + tile] != 0.0f;
+	const float tgx = a.tile_lv[2 * (size_t)a.T + tile], tgy = a.tile_lv[3 * (size_t)a.T + tile];
+	Px2 S;
+	float pyf[PPL], wgt[PPL];
+	bool inside[PPL];
+#pragma unroll
+	for (int k = 0; k < PPL; k++)
+	{
+		const int ly = tile_row<PPL>(tid, k);
+		const int py = ty * FR_TILE + ly;
+		pyf[k] = (float)py;
+		inside[k] = px < a.W && py < a.H;
+		bool done = !inside[k];
+		wgt[k] = 1.0f;
+		if (two_level)
+		{
+			const float est = tlf + ((float)lx * tgx + (float)ly * tgy) / (float)FR_TILE;
+			const int L1 = f2i(est);
+			float x = (est - ((float)L1 + 0.5f)) / 0.5f;
+			const bool mine = (float)L1 == a.cur_level;
+			if (x < 0.0f && !mine) done = true;
+			x = fmaxf(0.0f, fminf(1.0f, x));
+			const float bT = 3 * x * x - 2 * x * x * x;
+			const float w1 = 1 - bT;
+			wgt[k] = mine ? w1 : (float)(1.0 - (double)w1); // `1.0 - L1_w` is evaluated in double in the reference
+		}
+		S.T[k] = done ? -1.0f : 1.0f;
+	}
+	S.C0 = S.C1 = S.C2 = (v2f){ 0.f, 0.f };
+	float4 p0 = make_float4(0, 0, 0, 0), pc = p0;
+	float2 p1 = make_float2(0, 0);
+	auto fetch = [&](int e)
+	{
+		const uint32_t id = a.point_list[range.x + e];
+		const float4 *r = a.rec + 3 * (size_t)id;
+		p0 = r[0];
+		const float4 r1 = r[1];
+		p1 = make_float2(r1.x, r1.y);
+		pc = make_float4(r1.z, r1.w, r[2].x, 0.0f);
+	};
+	if (lane < n) fetch(lane);
+	for (int base = 0; base < n; base += 64)
+	{
+		if (!__any(fmaxf(S.T.x, S.T.y) > 0.0f)) break;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const bool staged = base + lane < n;
+		if (staged) { s0[lane] = p0; s1[lane] = p1; scol[lane] = pc; }
+		const float thr = fmaxf(-4.5f, -__logf(255.0f * p1.y) - 0.01f);
+		const unsigned long long reach_mask = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
+		if (base + 64 + lane < n) fetch(base + 64 + lane);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const v2f pyp = (v2f){ pyf[0], pyf[1] };
+		for (unsigned long long rm = reach_mask; rm; rm &= rm - 1)
+		{
+			const int j = __builtin_ctzll(rm);
+			if (!__any(fmaxf(S.T.x, S.T.y) > 0.0f)) break;
+			const float4 g0 = s0[j];
+			const float2 g1 = s1[j];
+			const float4 col = scol[j];
+			const float dx = g0.x - pxf;
+			const v2f pw = power2(g0.y - pyp, g1.x, (g0.z * dx) * dx, g0.w * dx);
+			blend2(S, !(pw.x > 0.0f || pw.x < -4.5f), !(pw.y > 0.0f || pw.y < -4.5f), exp2_pair(pw), make_float4(col.x, col.y, col.z, g1.y));
+		}
+	}
+	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+	const size_t plane = (size_t)a.W * a.H;
+#pragma unroll
+	for (int k = 0; k < PPL; k++)
+	{
+		if (!inside[k]) continue;
+		const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
+		const float t1 = fabsf(S.T[k]);
+		const float w = skipped ? 0.0f : wgt[k];
+		// skipped tiles are never written by the reference (the image starts as zeros); w == 1 in single-level tiles
+		a.out_color[pid] = skipped ? 0.0f : (two_level ? fmaf(bg0, t1, S.C0[k]) * w : fmaf(bg0, t1, S.C0[k]));
+		a.out_color[plane + pid] = skipped ? 0.0f : (two_level ? fmaf(bg1, t1, S.C1[k]) * w : fmaf(bg1, t1, S.C1[k]));
+		a.out_color[2 * plane + pid] = skipped ? 0.0f : (two_level ? fmaf(bg2, t1, S.C2[k]) * w : fmaf(bg2, t1, S.C2[k]));
+	}
+}
+
 int launch_render(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
@@ -742,7 +851,7 @@ int launch_render(FwdCtx &c)
 	r.tile_lv = c.img.tile_lv; r.tile_order = c.img.tile_order; r.T = c.T; r.bg = a->background; r.out_color = a->out_color;
 	r.final_T = c.img.final_T; r.n_contrib = c.img.n_contrib;
 	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions; r.loss_map = a->loss_map;
-	r.render_items = c.img.render_items; r.n_items = (uint32_t)c.n_items;
+	r.render_items = c.img.render_items; r.n_items = (uint32_t)c.n_items; r.cur_level = a->cur_level;
 	constexpr int PPL = 2;
 	// INDEP_: the two bands of a tile are separate single-wave workgroups (work items); else one 128-thread workgroup per tile
 #define FR_LAUNCH_RENDER(V, INDEP_) do { \
@@ -756,6 +865,7 @@ int launch_render(FwdCtx &c)
 	case FR_VARIANT_PCHECK_OBB_MAX: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_MAX, true); break;
 	case FR_VARIANT_PCHECK_OBB_LWMC: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_LWMC, false); break;
 	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: hipLaunchKernelGGL((k_render_smfr<2>), dim3(r.n_items), dim3(64), 0, c.stream, r); break;
+	case FR_VARIANT_MMFR_PCHECK_OBB: hipLaunchKernelGGL((k_render_mmfr<2>), dim3(r.n_items), dim3(64), 0, c.stream, r); break;
 	default:
 		hipLaunchKernelGGL((k_render_fov<2>), dim3(r.n_items), dim3(64), 0, c.stream, r);
 		break;

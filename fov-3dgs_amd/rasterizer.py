@@ -188,7 +188,7 @@ _stage_events_hook = None
 
 def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                     shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
-                    sh_rest=None, packed=None):
+                    sh_rest=None, packed=None, cur_level=0.0):
     """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease)
     persistent=True: the workspaces are the per-device grow-only set (valid until the next call); otherwise they
     stay reserved for as long as `lease` (the last element) is referenced."""
@@ -225,6 +225,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         a.tanfovx, a.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
         a.scale_modifier = float(rs.scale_modifier)
         a.gaze_x, a.gaze_y, a.alpha = float(gaze[0]), float(gaze[1]), float(alpha)
+        a.cur_level = float(cur_level)
         a.stream = torch.cuda.current_stream(dev).cuda_stream
         put("background", rs.bg)
         put("means3D", means3D)
@@ -595,5 +596,84 @@ def _make_naive_fov():
             cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                        cov3D_precomp, raster_settings, highest_levels, gazeArray, alpha, blending)
+
+    return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
+
+
+_level_zeros = {}
+
+
+def _zero_levels(P, device):
+    """[P,1] zeros: the multi-model variant's stand-in for highest_levels (its skip test reuses the level filter)."""
+    key = (P, device)
+    t = _level_zeros.get(key)
+    if t is None:
+        _level_zeros.clear()
+        t = _level_zeros[key] = torch.zeros((P, 1), dtype=torch.float32, device=device)
+    return t
+
+
+def _make_mmfr():
+    """Autograd function + module for ONE level of the multi-model foveated baseline ("MMFR"; reference package
+    …_mmfr_pcheck_obb/diff_gaussian_rasterization_mmfr_pcheck_obb/__init__.py:20-262). Inference only."""
+    variant_id = _native.VARIANT_MMFR_PCHECK_OBB
+
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                    raster_settings, cur_level, gazeArray, alpha, blending):
+            if not means3D.is_cuda:
+                _require_gpu(means3D)
+            args = (variant_id, raster_settings, means3D, shs, colors_precomp, opacities, scales, rotations,
+                    cov3Ds_precomp, None, _zero_levels(means3D.size(0), means3D.device), _gaze_pair(gazeArray), float(alpha))
+            if raster_settings.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    res = _forward_native(*args, persistent=True, cur_level=float(cur_level))
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                res = _forward_native(*args, persistent=True, cur_level=float(cur_level))
+            num_rendered, color, radii = res[:3]
+            ctx.num_rendered = num_rendered
+            ctx.mark_non_differentiable(radii)
+            return color, radii
+
+        @staticmethod
+        def backward(ctx, grad_out_color, _):
+            return (None,) * 13
+
+    def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                            raster_settings, cur_level, gazeArray, alpha, blending):
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings, cur_level, gazeArray, alpha, blending)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            with torch.no_grad():
+                return _mark_visible(positions, self.raster_settings)
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None, shs_dcs=None, cur_level=None, gazeArray=None, alpha=None, blending=None):
+            raster_settings = self.raster_settings
+            if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+                raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                    ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            empty = torch.Tensor([])
+            shs = empty if shs is None else shs
+            colors_precomp = empty if colors_precomp is None else colors_precomp
+            scales = empty if scales is None else scales
+            rotations = empty if rotations is None else rotations
+            cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+            return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                       cov3D_precomp, raster_settings, cur_level, gazeArray, alpha, blending)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer

@@ -54,7 +54,14 @@ enum {
 	 * filter and the instance lists of FOV_PCHECK_OBB, but ONE colour / opacity per Gaussian (shs [P,16,3],
 	 * opacities [P,1], highest_levels [P,1]; no shs_dcs), blended per naive forward.cu:258-480 (two-level tiles)
 	 * and :482-580 (single-level tiles). Inference only, no packed layout. */
-	FR_VARIANT_NAIVE_FOV_PCHECK_OBB = 6
+	FR_VARIANT_NAIVE_FOV_PCHECK_OBB = 6,
+	/* the paper's multi-model foveated baseline ("MMFR", fps/MMFR-Q): …_mmfr_pcheck_obb. ONE call renders the share of
+	 * eccentricity level `cur_level` from that level's own model (plain inputs: shs [P,16,3], opacities [P,1]); the caller
+	 * adds the calls of all levels up (gaussian_renderer_fov_mmfr/__init__.py:76-162). Tiles whose tile_min (clamped at 0)
+	 * lies outside (cur_level - 0.5, cur_level + 1) are skipped (left zero); two-level tiles weight every pixel by the
+	 * smoothstep of its estimated level (mmfr forward.cu:255-420). highest_levels must be given and hold ZEROS [P,1]
+	 * (the skip test reuses the level filter). Inference only, no packed layout. */
+	FR_VARIANT_MMFR_PCHECK_OBB = 7
 };
 
 enum {
@@ -136,6 +143,7 @@ typedef struct fr_forward_args {
 	const float *packed_geom;
 	const float *packed_colour;
 	const float *packed_cull;
+	float cur_level;             /* MMFR: the level (0..3) this call renders */
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,

@@ -81,10 +81,12 @@ typedef float real;
 #define BLOCK_SIZE 256
 #define FOV_NUM 4 /* RF auxiliary.h:26 */
 
-enum { ORC_R0 = 0, ORC_RS = 1, ORC_RP = 2, ORC_RF = 3, ORC_RMAX = 4, ORC_LWMC = 5, ORC_SMFR = 6 };
+enum { ORC_R0 = 0, ORC_RS = 1, ORC_RP = 2, ORC_RF = 3, ORC_RMAX = 4, ORC_LWMC = 5, ORC_SMFR = 6, ORC_MMFR = 7 };
+/* ORC_MMFR = …_mmfr_pcheck_obb, one level's share of the multi-model foveated baseline
+ * (MM = diff-gaussian-rasterization_mmfr_pcheck_obb/cuda_rasterizer/). */
 /* ORC_SMFR = …_naive_pcheck_obb, the paper's shared-model foveated baseline: RF's tile levels, level filter and lists,
  * one colour / opacity per Gaussian (NV = diff-gaussian-rasterization_naive_pcheck_obb/cuda_rasterizer/). */
-#define ORC_IS_FOV(v) ((v) == ORC_RF || (v) == ORC_SMFR)
+#define ORC_IS_FOV(v) ((v) == ORC_RF || (v) == ORC_SMFR || (v) == ORC_MMFR)
 /* ORC_RMAX = …_pcheck_obb_max, ORC_LWMC = …_pcheck_obb_loss_weighted_max_count: RS with different
  * per-Gaussian statistics (pruning metrics of prune.py / metric_mask_learn.py); same backward as RS. */
 
@@ -103,6 +105,7 @@ typedef struct {
 	/* optional tile window [x0,x1) x [y0,y1) restricting binning + blending (bench cpu_baseline
 	 * sampling only; all zeros = whole frame) */
 	int32_t win[4];
+	real cur_level; /* MMFR: the level this call renders */
 } orc_in;
 
 static int in_window(const orc_in *in, int tx, int ty)
@@ -509,6 +512,7 @@ static void tile_levels(const orc_in *in, orc_out *o)
 		else if (down != -1) gyv = lf - down;
 		real max_delta = (real)(0.5 * (double)(r_fabs(gxv) + r_fabs(gyv)));
 		real tmin = lf - max_delta;
+		if (in->variant == ORC_MMFR && tmin < 0) tmin = 0; /* MM rasterizer_impl.cu:249-251 */
 		o->tile_min[idx] = tmin;
 		real tmin_i = (real)f2i(tmin);
 		o->tile_blend[idx] = ((tmin - tmin_i) > (real)0.5f && (tmin_i < (real)(FOV_NUM - 1))) ? 1 : 0;
@@ -534,9 +538,16 @@ static int inst_cmp(const void *a, const void *b)
  * (tiles_touched, the radii reset, RF level_ranges -- the per-Gaussian outputs of OBB_test / filter); emit != NULL:
  * the duplicateWithKeys pass, instances inside the tile window are written to emit[0..] with sequence numbers seq0..
  * Returns the number of in-window instances. */
+/* MM rasterizer_impl.cu:277-304 compute_tile_skips_cuda */
+static int mmfr_skips(const orc_in *in, real tile_min)
+{
+	const real lb = in->cur_level - (real)0.5f, hb = in->cur_level + 1;
+	return !(tile_min > lb && tile_min < hb);
+}
 static int64_t walk_one(const orc_in *in, orc_out *o, int idx, int gx, int gy, int twn, int cull, int fov, inst_t *emit, int64_t seq0)
 {
 	if (!(o->radii[idx] > 0)) return 0;
+	const int mmfr = in->variant == ORC_MMFR; /* MM rasterizer_impl.cu:308-390: keep iff the tile is not skipped (and the OBB hits) */
 	int64_t n = 0;
 #define ORC_EMIT(X, Y) do { if (in_window(in, (X), (Y))) { if (emit) { emit[n].tile = (uint32_t)((Y) * gx + (X)); emit[n].depth = o->depths[idx]; \
 	emit[n].id = (uint32_t)idx; emit[n].seq = (uint64_t)(seq0 + n); } n++; } } while (0)
@@ -545,7 +556,7 @@ static int64_t walk_one(const orc_in *in, orc_out *o, int idx, int gx, int gy, i
 	getRect(px, py, o->radii[idx], rmin, rmax, gx, gy);
 	uint32_t tnum = (uint32_t)(rmax[1] - rmin[1]) * (uint32_t)(rmax[0] - rmin[0]);
 	uint32_t count = 0;
-	real hl = fov ? in->highest_levels[idx] : 0;
+	real hl = (fov && !mmfr) ? in->highest_levels[idx] : 0;
 	real lowest = hl, highest = 0;
 	int be_blend = 0;
 	if (!cull)
@@ -564,7 +575,7 @@ static int64_t walk_one(const orc_in *in, orc_out *o, int idx, int gx, int gy, i
 		{
 			uint32_t ti = (uint32_t)(rmin[1] * twn + rmin[0]);
 			real level = o->tile_min[ti];
-			keep = level < (hl + 1);
+			keep = mmfr ? !mmfr_skips(in, level) : level < (hl + 1);
 			if (keep) { lowest = level; highest = level; be_blend = o->tile_blend[ti] || be_blend; }
 		}
 		if (keep)
@@ -595,7 +606,7 @@ static int64_t walk_one(const orc_in *in, orc_out *o, int idx, int gx, int gy, i
 					uint32_t ti = (uint32_t)(y * twn + x);
 					blending = o->tile_blend[ti];
 					level = o->tile_min[ti];
-					inside = level < (hl + 1);
+					inside = mmfr ? !mmfr_skips(in, level) : level < (hl + 1);
 				}
 				if (inside)
 				{
@@ -1020,6 +1031,76 @@ static void render_smfr(const orc_in *in, orc_out *o)
 		}
 }
 
+/* ---------------- blend: MMFR, one level ----------------
+ * MM forward.cu:255-420 (two-level tiles) and :422-540 (single-level tiles); skipped tiles keep the zero the image
+ * starts with (MM rasterize_points.cu:79). */
+static void render_mmfr(const orc_in *in, orc_out *o)
+{
+	const int W = in->W, H = in->H;
+	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+	const int twn = (W + 15) / BLOCK_X;
+	const real start_blend = (real)0.5f, blend_width = (real)0.5f;
+	ORC_PARALLEL_FOR(dynamic, 4)
+	for (int tile = 0; tile < gx * gy; tile++)
+		{
+			const int ty = tile / gx, tx = tile % gx;
+			if (!in_window(in, tx, ty)) continue;
+			const uint32_t r0 = o->ranges[2 * (ty * gx + tx)], r1 = o->ranges[2 * (ty * gx + tx) + 1];
+			const int n = (int)(r1 - r0);
+			const uint32_t cur = (uint32_t)(tx + twn * ty);
+			const int blending = o->tile_blend[cur];
+			const real tlf = o->tile_min[cur];
+			const int skipped = mmfr_skips(in, tlf);
+			for (int ly = 0; ly < BLOCK_Y; ly++)
+				for (int lx = 0; lx < BLOCK_X; lx++)
+				{
+					const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+					if (!(pxi < W && pyi < H)) continue;
+					const size_t pid = (size_t)W * pyi + pxi;
+					if (skipped) { for (int ch = 0; ch < 3; ch++) o->color[(size_t)ch * H * W + pid] = 0; continue; }
+					const real pixf[2] = { (real)pxi, (real)pyi };
+					real T1 = 1, C1[3] = { 0, 0, 0 };
+					int done = 0, L1 = 0;
+					real x = 0;
+					if (blending)
+					{
+						const real est = tlf + ((real)lx * o->tile_gx[cur] + (real)ly * o->tile_gy[cur]) / (real)BLOCK_X;
+						L1 = f2i(est);
+						x = (est - ((real)L1 + start_blend)) / blend_width;
+						if (x < 0 && (real)L1 != in->cur_level) done = 1;
+					}
+					for (int j = 0; j < n && !done; j++)
+					{
+						const uint32_t g = o->point_list[r0 + j];
+						const real dx = o->means2D[2 * g] - pixf[0], dy = o->means2D[2 * g + 1] - pixf[1];
+						const real ca = o->conic[3 * g], cb = o->conic[3 * g + 1], cc = o->conic[3 * g + 2];
+						const real power = (real)-0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+						if (power > (real)0 || power < (real)-4.5f) continue;
+						const real alpha = r_fmin((real)0.99f, in->opacities[g] * r_exp(power));
+						if (alpha < (real)1.0f / (real)255.0f) continue;
+						const real tT = T1 * (1 - alpha);
+						if (tT < (real)0.0001f) break;
+						const real w = alpha * T1;
+						for (int ch = 0; ch < 3; ch++) C1[ch] += o->rgb[3 * g + ch] * w;
+						T1 = tT;
+					}
+					real used = 1;
+					if (blending)
+					{
+						x = r_fmax((real)0, r_fmin((real)1, x));
+						const real bT = 3 * x * x - 2 * x * x * x;
+						const real w1 = 1 - bT;
+						used = ((real)L1 == in->cur_level) ? w1 : (real)(1.0 - (double)w1);
+					}
+					for (int ch = 0; ch < 3; ch++)
+					{
+						const real c = C1[ch] + in->bg[ch] * T1;
+						o->color[(size_t)ch * H * W + pid] = blending ? c * used : c;
+					}
+				}
+		}
+}
+
 /* ---------------- public: forward ---------------- */
 int64_t orc_forward(const orc_in *in, orc_out *o)
 {
@@ -1030,6 +1111,7 @@ int64_t orc_forward(const orc_in *in, orc_out *o)
 	if (n > o->capacity) return n; /* caller must retry with capacity >= n */
 	if (in->variant == ORC_RF) { compute_fov_colors(in, o); render_fov(in, o); }
 	else if (in->variant == ORC_SMFR) render_smfr(in, o); /* NV rasterizer_impl.cu:463-483: the colour is the plain SH colour */
+	else if (in->variant == ORC_MMFR) render_mmfr(in, o);
 	else render_plain(in, o);
 	return n;
 }

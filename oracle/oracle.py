@@ -19,7 +19,7 @@ BUILD = os.path.join(HERE, "_build")
 SRC = os.path.join(HERE, "fovraster_oracle.c")
 
 VARIANTS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3, "pcheck_obb_max": 4,
-            "pcheck_obb_loss_weighted_max_count": 5, "naive_pcheck_obb": 6}
+            "pcheck_obb_loss_weighted_max_count": 5, "naive_pcheck_obb": 6, "mmfr_pcheck_obb": 7}
 FOV_NUM = 4
 
 
@@ -72,7 +72,7 @@ def _structs(real):
                     ("gaze_x", real), ("gaze_y", real), ("alpha", real)] + \
                    [(n, C.c_void_p) for n in ("bg", "viewmatrix", "projmatrix", "campos", "means3D", "scales",
                                               "rotations", "opacities", "shs", "cov3D_precomp", "colors_precomp",
-                                              "shs_dcs", "highest_levels", "loss_map")] + [("win", C.c_int32 * 4)]
+                                              "shs_dcs", "highest_levels", "loss_map")] + [("win", C.c_int32 * 4), ("cur_level", real)]
 
     class OrcOut(C.Structure):
         _fields_ = [(n, C.c_void_p) for n in ("depths", "radii", "means2D", "cov3D", "conic", "rgb", "clamped",
@@ -134,6 +134,7 @@ def _prep_inputs(variant, scene, cam, dtype, keep):
     inp.shs_dcs = _ptr(arr(scene.get("shs_dcs")))
     inp.highest_levels = _ptr(arr(scene.get("highest_levels")))
     inp.loss_map = _ptr(arr(scene.get("loss_map")))
+    inp.cur_level = float(cam.get("cur_level", 0.0))
     win = cam.get("tile_window")  # (x0, y0, x1, y1) in tiles; bench cpu_baseline sampling only
     if win is not None:
         for i in range(4):

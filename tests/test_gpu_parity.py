@@ -645,3 +645,33 @@ def test_shared_model_foveated_baseline(gaze):
     # (the model's activations run on the GPU here: a few radii may differ in the last place of a scale, see S6M in
     # tests/test_full_size_parity.py; the image stays within tolerance)
     check_image(out["render"].cpu().numpy(), want["color"], frac=2e-3, name=f"SMFR render() gaze={gaze}")
+
+
+def test_multi_model_foveated_baseline():
+    """the MMFR baseline (…_mmfr_pcheck_obb) -- every level's render against the oracle (lists
+    bit-exact, image within tolerance), and gaussian_renderer_fov_mmfr.render() = the sum of the level renders."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    gaze = (0.35, 0.6)
+    levels = []
+    for level in range(4):
+        scene, cam = small_case("pcheck_obb", P=5000, seed=40 + level, gaze=gaze, width=640, height=400)  # a model per level
+        scene = dict(scene, highest_levels=np.zeros((5000, 1), np.float32))
+        cam = dict(cam, cur_level=float(level))
+        want = orc.forward("mmfr_pcheck_obb", scene, cam)
+        got = hip_forward("mmfr_pcheck_obb", scene, cam)
+        tag = f"MMFR level {level}"
+        assert got["num_rendered"] == want["num_rendered"] > 0, tag
+        np.testing.assert_array_equal(got["radii"], want["radii"], err_msg=tag)
+        np.testing.assert_array_equal(got["ranges"], want["ranges"], err_msg=tag)
+        np.testing.assert_array_equal(got["point_list"], want["point_list"], err_msg=tag)
+        check_image(got["color"], want["color"], name=tag)
+        levels.append(want["color"])
+    from fov3dgs_amd.gaussian_renderer_fov_mmfr import render
+    dev = "cuda:0"
+    models = [small_cloud(5000, 40 + level).to(dev) for level in range(4)]
+    camo = small_camera(640, 400).to(dev)
+    with torch.no_grad():
+        out = render(camo, torch.tensor([0.1, 0.2, 0.3], device=dev), alpha=0.05, gazeArray=torch.tensor(gaze), blending=True,
+                     multi_gs=models, layer_num=4)
+    check_image(out["render"].cpu().numpy(), sum(levels), frac=2e-3, name="MMFR render()")

@@ -65,7 +65,7 @@ def test_workspace_sizes_are_host_computable():
 def test_invalid_arguments_are_reported_not_executed():
     lib = _native.load()
     a = _native.ForwardArgs()
-    a.variant = 7
+    a.variant = 8
     assert lib.fr_forward(C.byref(a)) == -1 and b"variant" in lib.fr_last_error()
     a.variant, a.P, a.W, a.H = 0, 5, 0, 16
     assert lib.fr_forward(C.byref(a)) == -1

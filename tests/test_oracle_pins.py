@@ -274,3 +274,21 @@ def test_shared_model_foveated_baseline_pins():
     np.testing.assert_array_equal(c["radii"], f["radii"])
     np.testing.assert_array_equal(c["point_list"], f["point_list"])
     np.testing.assert_array_equal(c["ranges"], f["ranges"])
+
+
+def test_multi_model_baseline_partition_of_unity():
+    """The MMFR restatement (…_mmfr_pcheck_obb): the level bands (cur_level - 0.5, cur_level + 1) cover every tile, a
+    single-level tile is rendered by exactly one level, and the smoothstep weights of a two-level tile's two levels add
+    up to one -- so the four level renders of ONE model must add up to that model's plain pcheck_obb image."""
+    import numpy as np
+    from tests.helpers import small_case
+    for gaze in ((0.3, 0.6), (0.95, 0.05)):
+        plain, cam = small_case("pcheck_obb", P=3000, seed=5, gaze=gaze, width=320, height=208)
+        total, counts = 0, []
+        for level in range(4):
+            o = orc.forward("mmfr_pcheck_obb", plain, dict(cam, cur_level=float(level)))
+            total = total + o["color"]
+            counts.append(o["num_rendered"])
+        want = orc.forward("pcheck_obb", plain, cam)
+        assert sum(counts) >= want["num_rendered"] and min(counts) > 0
+        np.testing.assert_allclose(total, want["color"], rtol=0, atol=3e-7)
