@@ -1,7 +1,7 @@
 """Tolerance checks of the GPU parity tests. Every call records what it measured (tests/parity_report.py).
 
 Tolerances (fp32 path; BASELINE north_star: per-pixel match within 1e-4):
-  * image: |diff| <= 1e-4 on all but `frac` of the pixels and <= `hard` everywhere. The blend thresholds
+  * image: |diff| <= 1e-4 on all but `frac` (1e-6) of the pixels and <= `hard` (2e-3) everywhere. The blend thresholds
     (alpha < 1/255, T < 1e-4, power < -4.5, power > 0) are discontinuous, and the HIP kernel uses the hardware exp2
     and fused multiply-adds while the oracle follows the reference's literal fp32 expression, so a pair that sits
     within an ulp of a threshold may flip; each flip moves a pixel by at most ~alpha (<= 1.2e-2 at the -4.5 cutoff).
@@ -15,9 +15,12 @@ import numpy as np
 
 from tests import parity_report
 
-IMAGE_FRAC = 1e-3   # pixels allowed above 1e-4 (measured worst case over the suite: see tests/parity_report.json)
-IMAGE_HARD = 2e-2
-GRAD_OUTLIERS = 2e-3
+# Bounds a few times above the worst case measured over the whole GPU suite (tests/parity_report.json, 132 comparisons):
+# every image is within 1e-4 at EVERY pixel except one comparison (4096x2160, 26.5 M values) where 2.3e-7 of them -- a
+# threshold flip -- are up to 7.1e-4 off; gradient entries outside rtol: at most 4.7e-5 of a tensor.
+IMAGE_FRAC = 1e-6   # share of pixels allowed above 1e-4
+IMAGE_HARD = 2e-3   # ... and how far those may be off
+GRAD_OUTLIERS = 2e-4
 
 
 def _where():

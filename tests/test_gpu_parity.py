@@ -531,7 +531,7 @@ def test_randomised_sweep():
         np.testing.assert_array_equal(got["radii"], want["radii"], err_msg=tag)
         np.testing.assert_array_equal(got["ranges"], want["ranges"], err_msg=tag)
         np.testing.assert_array_equal(got["point_list"], want["point_list"], err_msg=tag)
-        check_image(got["color"], want["color"], frac=2e-3, name=tag)
+        check_image(got["color"], want["color"], name=tag)
         if P >= 1 and scene.get("scales") is not None and scene.get("shs") is not None:
             # the packed static-model layout: bit-identical to the ordinary tensors
             pk = hip_forward(variant, scene, cd, packed=True)
@@ -644,7 +644,7 @@ def test_shared_model_foveated_baseline(gaze):
     assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii"}
     # (the model's activations run on the GPU here: a few radii may differ in the last place of a scale, see S6M in
     # tests/test_full_size_parity.py; the image stays within tolerance)
-    check_image(out["render"].cpu().numpy(), want["color"], frac=2e-3, name=f"SMFR render() gaze={gaze}")
+    check_image(out["render"].cpu().numpy(), want["color"], name=f"SMFR render() gaze={gaze}")
 
 
 def test_multi_model_foveated_baseline():
@@ -674,4 +674,4 @@ def test_multi_model_foveated_baseline():
     with torch.no_grad():
         out = render(camo, torch.tensor([0.1, 0.2, 0.3], device=dev), alpha=0.05, gazeArray=torch.tensor(gaze), blending=True,
                      multi_gs=models, layer_num=4)
-    check_image(out["render"].cpu().numpy(), sum(levels), frac=2e-3, name="MMFR render()")
+    check_image(out["render"].cpu().numpy(), sum(levels), name="MMFR render()")
