@@ -13,7 +13,8 @@
 // each row; 26 instructions instead of 54 for nine separate butterflies) so that the totals end up in nine DIFFERENT
 // lanes, which add them with ONE atomic instruction into ONE 64-byte row per Gaussian (`acc`, indexed by the
 // Gaussian's position in the forward pass's visible list: dense, zeroed by the forward pass, read back coalesced).
-// k_preprocess_bwd then walks the visible list: cov2D / projection / SH / cov3D chain rule fused, one pass.
+// k_preprocess_bwd then walks all Gaussians in index order and writes every gradient row once: zeros or the fused
+// cov2D / projection / SH / cov3D chain rule (see there).
 #include "common.h"
 
 namespace fr {
@@ -462,8 +463,13 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	}
 }
 
-// Grid-stride over the forward pass's visible list: dense waves instead of one thread per Gaussian with
-// ~90 % of the lanes returning immediately. Entries culled after projection (radii reset to 0) are skipped.
+// Grid-stride over the forward pass's visible list: dense waves instead of one thread per Gaussian with ~70 % of the
+// lanes returning immediately. Entries culled after projection (radii reset to 0) are skipped. The rows of all other
+// Gaussians are zero: launch_backward clears the output tensors on a helper stream WHILE k_render_bwd runs (that kernel
+// is bound by arithmetic and atomics, the fill by HBM writes), so the caller need not zero-fill them. (Tried: one
+// kernel that walks all Gaussians in index order, clears every chunk's rows with coalesced stores and works the
+// chunk's visible ones off from an LDS list -- every row written once, no fill at all: 722 us against 539 + fill; at
+// 158 registers the kernel does not have the occupancy to stream 1.5 GB of zeros.)
 __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 {
 	const int V = (int)*a.vis_count;
@@ -472,6 +478,20 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 		const int idx = (int)a.vis_list[i];
 		if (a.radii[idx] > 0) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i);
 	}
+}
+
+static int launch_render_bwd(const fr_backward_args *a, const GeomWS &geom, const ImageWS &img, const BinWS &bin, int gx, int T, hipStream_t stream)
+{
+	BwdRenderArgs r;
+	r.W = a->W; r.H = a->H; r.gx = gx; r.ranges = img.ranges; r.render_items = img.render_items; r.n_items = 2u * (uint32_t)T;
+	r.point_list = bin.point_list; r.rec = geom.rec;
+	r.bg = a->background; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.dL_dpix = a->dL_dpix;
+	r.acc = (float *)geom.acc;
+	if (a->variant == FR_VARIANT_ORIGINAL)
+		hipLaunchKernelGGL((k_render_bwd<false>), dim3(r.n_items), dim3(64), 0, stream, r);
+	else
+		hipLaunchKernelGGL((k_render_bwd<true>), dim3(r.n_items), dim3(64), 0, stream, r);
+	return check_launch("render_bwd", stream, a->debug);
 }
 
 int launch_backward(const fr_backward_args *a)
@@ -483,19 +503,37 @@ int launch_backward(const fr_backward_args *a)
 	BinWS bin = carve_bin(a->R, (char *)a->binning);
 	auto mark = [&](int i) { if (a->stage_events && a->stage_events[i]) (void)hipEventRecord((hipEvent_t)a->stage_events[i], stream); };
 	mark(0);
-	if (a->R > 0)
+	// The gradient tensors are written in full by this call: their rows are cleared here, on the helper stream, while
+	// k_render_bwd runs on the caller's (1.5 GB of fills at 6 M Gaussians, ~0.3 ms that the reference -- and round 1 --
+	// spend before the backward pass starts).
 	{
-		BwdRenderArgs r;
-		r.W = a->W; r.H = a->H; r.gx = gx; r.ranges = img.ranges; r.render_items = img.render_items; r.n_items = 2u * (uint32_t)T;
-		r.point_list = bin.point_list; r.rec = geom.rec;
-		r.bg = a->background; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.dL_dpix = a->dL_dpix;
-		r.acc = (float *)geom.acc;
-		if (a->variant == FR_VARIANT_ORIGINAL)
-			hipLaunchKernelGGL((k_render_bwd<false>), dim3(r.n_items), dim3(64), 0, stream, r);
-		else
-			hipLaunchKernelGGL((k_render_bwd<true>), dim3(r.n_items), dim3(64), 0, stream, r);
-		int rc = check_launch("render_bwd", stream, a->debug);
-		if (rc) return rc;
+		const bool have_sh = a->colors_precomp == nullptr && a->shs != nullptr;
+		const size_t P = (size_t)a->P;
+		const size_t m0 = have_sh ? (a->shs_rest ? 1 : (size_t)a->M) : 0;
+		struct { void *p; size_t bytes; } fills[] = {
+			{ a->dL_dmean3D, 12 * P }, { a->dL_dmean2D, 12 * P }, { a->dL_dopacity, 4 * P }, { a->dL_dscale, 12 * P }, { a->dL_drot, 16 * P },
+			{ a->dL_dsh, 12 * m0 * P }, { a->dL_dsh_rest, have_sh && a->shs_rest ? 12 * ((size_t)a->M - 1) * P : 0 },
+			{ a->dL_dcolor, 12 * P }, { a->dL_dconic, 16 * P }, { a->dL_dcov3D, 24 * P } };
+		AuxStream *ax = (a->R > 0 && !a->debug) ? aux_stream() : nullptr;
+		hipStream_t fs = stream;
+		if (ax)
+		{
+			if (hipEventRecord(ax->fork, stream) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess) { (void)hipGetLastError(); ax = nullptr; }
+			else fs = ax->s;
+		}
+		for (auto &f : fills)
+			if (f.p && f.bytes)
+			{
+				const hipError_t e = hipMemsetAsync(f.p, 0, f.bytes, fs);
+				if (e != hipSuccess) { set_error("hipMemsetAsync(gradient): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
+			}
+		if (ax) (void)hipEventRecord(ax->join, ax->s); // waited for below, after k_render_bwd has been launched
+		if (a->R > 0)
+		{
+			const int rc0 = launch_render_bwd(a, geom, img, bin, gx, T, stream);
+			if (rc0) return rc0;
+		}
+		if (ax) (void)hipStreamWaitEvent(stream, ax->join, 0);
 	}
 	mark(1);
 	BwdPreArgs p;

@@ -162,8 +162,9 @@ typedef struct fr_backward_args {
 	const int32_t *radii;        /* [P] from forward */
 	const char *geometry, *binning, *image; /* the three workspaces filled by fr_forward */
 	const float *dL_dpix;        /* [3,H,W] */
-	/* outputs: caller-allocated AND ZERO-FILLED (the reference allocates them with torch::zeros,
-	 * rasterize_points.cu:171-179); rows of Gaussians the view does not touch are left as they are */
+	/* outputs: caller-allocated, WRITTEN IN FULL by the call (rows of Gaussians the view does not touch become zero; the
+	 * reference allocates them with torch::zeros, rasterize_points.cu:171-179, and only writes the visible rows): no
+	 * initialisation needed */
 	float *dL_dmean2D;           /* [P,3] */
 	float *dL_dconic;            /* [P,2,2]; may be NULL: an intermediate of the reference (its sums are kept per visible-list entry here) */
 	float *dL_dopacity;          /* [P,1] */
