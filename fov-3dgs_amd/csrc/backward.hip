@@ -372,9 +372,9 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		float *dsh_r = split ? a.dL_dsh_rest + (size_t)idx * (a.M - 1) * 3 : a.dL_dsh + (size_t)idx * a.M * 3 + 3;
 		float *dsh0 = split ? a.dL_dsh + 3 * (size_t)idx : a.dL_dsh + (size_t)idx * a.M * 3;
 		typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-		float coef[48], gcoef[48];
+		float coef[48];
 #pragma unroll
-		for (int i = 0; i < 48; i++) { coef[i] = 0.0f; gcoef[i] = 0.0f; }
+		for (int i = 0; i < 48; i++) coef[i] = 0.0f;
 		const int nuse = 3 * ((a.D + 1) * (a.D + 1)) - 3; // rest floats the active degree reads / writes
 		if (nrest >= 45)
 		{
@@ -389,7 +389,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		}
 		// a channel clamped at zero in the forward pass passes no gradient (forward.cu:63-70)
 		const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)idx + 2].z);
-		const V3 g = { (clamp_bits & 1u) ? 0.f : g_col[0], (clamp_bits & 2u) ? 0.f : g_col[1], (clamp_bits & 4u) ? 0.f : g_col[2] };
+		const float g[3] = { (clamp_bits & 1u) ? 0.f : g_col[0], (clamp_bits & 2u) ? 0.f : g_col[1], (clamp_bits & 4u) ? 0.f : g_col[2] };
 		const V3 off = { mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2] };
 		const float len2 = dot3(off, off), ilen = 1.0f / sqrtf(len2);
 		const V3 dir = { off.x * ilen, off.y * ilen, off.z * ilen };
@@ -398,26 +398,28 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 #pragma unroll
 		for (int k = 0; k < 16; k++) { bas[k] = 0.f; grd[k] = { 0, 0, 0 }; }
 		sh_basis_grad(a.D, dir.x, dir.y, dir.z, bas, grd);
-		dsh0[0] = bas[0] * g.x; dsh0[1] = bas[0] * g.y; dsh0[2] = bas[0] * g.z;
+		dsh0[0] = bas[0] * g[0]; dsh0[1] = bas[0] * g[1]; dsh0[2] = bas[0] * g[2];
 		V3 g_dir = { 0, 0, 0 };
 #pragma unroll
 		for (int k = 1; k < 16; k++)
 		{
-			gcoef[3 * k] = bas[k] * g.x; gcoef[3 * k + 1] = bas[k] * g.y; gcoef[3 * k + 2] = bas[k] * g.z;
-			const float wk = coef[3 * k] * g.x + coef[3 * k + 1] * g.y + coef[3 * k + 2] * g.z;
+			const float wk = coef[3 * k] * g[0] + coef[3 * k + 1] * g[1] + coef[3 * k + 2] * g[2];
 			g_dir = axpy3(wk, grd[k], g_dir);
 		}
-		// gradients of the rest coefficients of the active degree (the others stay at the caller's zero fill)
+		// gradients of the rest coefficients of the active degree (the others stay zero), formed as they are stored:
+		// flat index f = 3 k + channel -> basis_k * g_channel (no second 48-register array)
+#define FR_GSH(f) (bas[(f) / 3] * g[(f) % 3])
 #pragma unroll
 		for (int q = 0; q < 12; q++)
 		{
-			if (4 * q + 4 <= nuse) *(f4u *)(dsh_r + 4 * q) = (f4u){ gcoef[3 + 4 * q], gcoef[4 + 4 * q], gcoef[5 + 4 * q], gcoef[6 + 4 * q] };
+			if (4 * q + 4 <= nuse) *(f4u *)(dsh_r + 4 * q) = (f4u){ FR_GSH(3 + 4 * q), FR_GSH(4 + 4 * q), FR_GSH(5 + 4 * q), FR_GSH(6 + 4 * q) };
 			else
 			{
 #pragma unroll
-				for (int j = 0; j < 4; j++) if (4 * q + j < nuse) dsh_r[4 * q + j] = gcoef[3 + 4 * q + j];
+				for (int j = 0; j < 4; j++) if (4 * q + j < nuse && 3 + 4 * q + j < 48) dsh_r[4 * q + j] = FR_GSH(3 + 4 * q + j);
 			}
 		}
+#undef FR_GSH
 		// dir = off / |off|: d dir / d off = (I - dir dir^T) / |off|
 		const float along = dot3(dir, g_dir);
 		g_mean.x += (g_dir.x - along * dir.x) * ilen;
