@@ -22,6 +22,7 @@ namespace fr {
 __device__ __forceinline__ float bwd_exp(float p) { return __builtin_amdgcn_exp2f(p * 1.4426950408889634f); }
 
 typedef unsigned int bwd_u2 __attribute__((ext_vector_type(2)));
+typedef float bv2 __attribute__((ext_vector_type(2)));
 // lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l]  (tools/scratch/permlane_test.hip)
 __device__ __forceinline__ float fold32(float a, float b)
 {
@@ -90,28 +91,29 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 	const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
-	// per pixel: transmittance behind the current entry, the colour accumulated behind it, the last alpha / colour
-	float T[PPL], Tfin[PPL], pyf[PPL], behind0[PPL], behind1[PPL], behind2[PPL], prevA[PPL], prev0[PPL], prev1[PPL], prev2[PPL];
-	float dp0[PPL], dp1[PPL], dp2[PPL], bgdot[PPL];
+	// per pixel (the lane's two pixels as packed pairs, v_pk_* arithmetic): transmittance behind the current entry, the
+	// colour accumulated behind it, the last alpha / colour
+	static_assert(PPL == 2, "the lane's pixels are handled as one packed pair");
+	bv2 T, Tfin, pyp, behind0, behind1, behind2, prevA, prev0, prev1, prev2, dp0, dp1, dp2, bgdot;
 	int lastc[PPL];
 	int wave_last = 0;
 #pragma unroll
 	for (int k = 0; k < PPL; k++)
 	{
 		const int py = ty * FR_TILE + tile_row<PPL>(tid, k);
-		pyf[k] = (float)py;
+		pyp[k] = (float)py;
 		const bool inside = px < a.W && py < a.H;
 		const size_t pid = (size_t)a.W * py + px;
 		Tfin[k] = inside ? a.final_T[pid] : 0.0f;
-		T[k] = Tfin[k];
 		lastc[k] = inside ? (int)a.n_contrib[pid] : 0;
 		wave_last = max(wave_last, lastc[k]);
 		dp0[k] = inside ? a.dL_dpix[pid] : 0.0f;
 		dp1[k] = inside ? a.dL_dpix[plane + pid] : 0.0f;
 		dp2[k] = inside ? a.dL_dpix[2 * plane + pid] : 0.0f;
-		bgdot[k] = bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k];
-		behind0[k] = behind1[k] = behind2[k] = 0.0f; prevA[k] = 0.0f; prev0[k] = prev1[k] = prev2[k] = 0.0f;
 	}
+	T = Tfin;
+	bgdot = bg0 * dp0 + bg1 * dp1 + bg2 * dp2;
+	behind0 = behind1 = behind2 = prevA = prev0 = prev1 = prev2 = (bv2){ 0.f, 0.f };
 	// nothing behind the deepest contributor of this wave's pixels needs to be visited
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
@@ -158,42 +160,61 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 			const float dx = g0.x - pxf;
 			const float adx2 = (g0.z * dx) * dx;
 			const float bdx = g0.w * dx;
+			const bv2 dy = g0.y - pyp;
+			const bv2 s = __builtin_elementwise_fma(g1.x * dy, dy, (bv2){ adx2, adx2 });
+			const bv2 power = __builtin_elementwise_fma((bv2){ -0.5f, -0.5f }, s, -(bdx * dy));
+			const bv2 pe = power * 1.4426950408889634f;
+			const bv2 G = (bv2){ __builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y) };
+			bv2 alpha = g1.y * G;
+			alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y);
+			// backward.cu:468-497: behind the pixel's last contributor / outside the support / negligible. Everything
+			// below is predicated: a pixel that is not `on` keeps its state and adds exact zeros (its G is cleared first,
+			// so no infinity of a far-away splat can meet a zero factor).
+			const bool on_x = pos < lastc[0] && !(power.x > 0.0f) && !(CUTOFF && power.x < -4.5f) && !(alpha.x < 1.0f / 255.0f);
+			const bool on_y = pos < lastc[1] && !(power.y > 0.0f) && !(CUTOFF && power.y < -4.5f) && !(alpha.y < 1.0f / 255.0f);
+			const bool any = on_x || on_y;
 			float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // colour r g b, mean2D x y, conic a b c, opacity
-			bool any = false;
-#pragma unroll
-			for (int k = 0; k < PPL; k++)
+			if (__any(any))
 			{
-				const float dy = g0.y - pyf[k];
-				const float s = fmaf(g1.x * dy, dy, adx2);
-				const float power = fmaf(-0.5f, s, -(bdx * dy));
-				const float G = bwd_exp(power);
-				const float alpha = fminf(0.99f, g1.y * G);
-				// backward.cu:468-497: behind the pixel's last contributor / outside the support / negligible
-				const bool on = pos < lastc[k] && !(power > 0.0f) && !(CUTOFF && power < -4.5f) && !(alpha < 1.0f / 255.0f);
-				if (on)
-				{
-					T[k] = T[k] / (1.f - alpha);
-					const float wgt = alpha * T[k]; // d channel / d colour
-					behind0[k] = prevA[k] * prev0[k] + (1.f - prevA[k]) * behind0[k]; prev0[k] = g1.z;
-					behind1[k] = prevA[k] * prev1[k] + (1.f - prevA[k]) * behind1[k]; prev1[k] = g1.w;
-					behind2[k] = prevA[k] * prev2[k] + (1.f - prevA[k]) * behind2[k]; prev2[k] = g2.x;
-					float dL_dalpha = (g1.z - behind0[k]) * dp0[k] + (g1.w - behind1[k]) * dp1[k] + (g2.x - behind2[k]) * dp2[k];
-					v[0] += wgt * dp0[k];
-					v[1] += wgt * dp1[k];
-					v[2] += wgt * dp2[k];
-					dL_dalpha *= T[k];
-					prevA[k] = alpha;
-					dL_dalpha += (-Tfin[k] / (1.f - alpha)) * bgdot[k]; // the background's share
-					const float dL_dG = g1.y * dL_dalpha;
-					const float gdx = G * dx, gdy = G * dy;
-					v[3] += dL_dG * (-gdx * g0.z - gdy * g0.w) * ddelx_dx;
-					v[4] += dL_dG * (-gdy * g1.x - gdx * g0.w) * ddely_dy;
-					v[5] += -0.5f * gdx * dx * dL_dG;
-					v[6] += -0.5f * gdx * dy * dL_dG;
-					v[7] += -0.5f * gdy * dy * dL_dG;
-					v[8] += G * dL_dalpha;
-					any = true;
-				}
+				const bv2 Gm = (bv2){ on_x ? G.x : 0.0f, on_y ? G.y : 0.0f };
+				const bv2 om = 1.0f - alpha;
+				// 1 / (1 - alpha): v_rcp_f32 and one Newton step (the reference divides twice per pixel: ~24 instructions)
+				bv2 r = (bv2){ __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
+				r = r * __builtin_elementwise_fma(-om, r, (bv2){ 2.0f, 2.0f });
+				const bv2 Tn = T * r;
+				T.x = on_x ? Tn.x : T.x; T.y = on_y ? Tn.y : T.y;
+				const bv2 wgt = alpha * Tn;                                    // d channel / d colour
+				const bv2 wm = (bv2){ on_x ? wgt.x : 0.0f, on_y ? wgt.y : 0.0f };
+				const bv2 keep = 1.0f - prevA;
+				const bv2 nb0 = __builtin_elementwise_fma(prevA, prev0, keep * behind0);
+				const bv2 nb1 = __builtin_elementwise_fma(prevA, prev1, keep * behind1);
+				const bv2 nb2 = __builtin_elementwise_fma(prevA, prev2, keep * behind2);
+				behind0.x = on_x ? nb0.x : behind0.x; behind0.y = on_y ? nb0.y : behind0.y;
+				behind1.x = on_x ? nb1.x : behind1.x; behind1.y = on_y ? nb1.y : behind1.y;
+				behind2.x = on_x ? nb2.x : behind2.x; behind2.y = on_y ? nb2.y : behind2.y;
+				prev0.x = on_x ? g1.z : prev0.x; prev0.y = on_y ? g1.z : prev0.y;
+				prev1.x = on_x ? g1.w : prev1.x; prev1.y = on_y ? g1.w : prev1.y;
+				prev2.x = on_x ? g2.x : prev2.x; prev2.y = on_y ? g2.x : prev2.y;
+				bv2 dL_dalpha = (g1.z - nb0) * dp0;
+				dL_dalpha = __builtin_elementwise_fma(g1.w - nb1, dp1, dL_dalpha);
+				dL_dalpha = __builtin_elementwise_fma(g2.x - nb2, dp2, dL_dalpha);
+				const bv2 c0 = wm * dp0, c1 = wm * dp1, c2 = wm * dp2;
+				v[0] = c0.x + c0.y; v[1] = c1.x + c1.y; v[2] = c2.x + c2.y;
+				dL_dalpha = dL_dalpha * Tn;
+				prevA.x = on_x ? alpha.x : prevA.x; prevA.y = on_y ? alpha.y : prevA.y;
+				dL_dalpha = __builtin_elementwise_fma(-(Tfin * r), bgdot, dL_dalpha); // the background's share
+				const bv2 dA = (bv2){ on_x ? dL_dalpha.x : 0.0f, on_y ? dL_dalpha.y : 0.0f };
+				const bv2 dL_dG = g1.y * dA;
+				const bv2 gdx = Gm * dx, gdy = Gm * dy;
+				const bv2 mx = dL_dG * (-(gdx * g0.z) - gdy * g0.w);
+				const bv2 my = dL_dG * (-(gdy * g1.x) - gdx * g0.w);
+				const bv2 ka = (gdx * dx) * dL_dG, kb = (gdx * dy) * dL_dG, kc = (gdy * dy) * dL_dG, ko = Gm * dA;
+				v[3] = (mx.x + mx.y) * ddelx_dx;
+				v[4] = (my.x + my.y) * ddely_dy;
+				v[5] = -0.5f * (ka.x + ka.y);
+				v[6] = -0.5f * (kb.x + kb.y);
+				v[7] = -0.5f * (kc.x + kc.y);
+				v[8] = ko.x + ko.y;
 			}
 			if (__any(any))
 			{
