@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Fill the R2_* placeholders of DESIGN.md / README.md from profiles/r02_bench_line.json (python tools/fill_docs.py), or
-re-fill an already filled copy from the git version that still has them (python tools/fill_docs.py --from-git REV)."""
-import json, os, re, subprocess, sys
+"""(Re-)fill the bench numbers of DESIGN.md / README.md from profiles/r02_bench_line.json: python tools/fill_docs.py"""
+import json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_line.json")))
 st, ex, rf = d["stages_ms"], d["extra"], d["roofline"]
@@ -14,13 +13,12 @@ vals = {
     "R2_NONFOV": f"{ex['nonfov_forward_fps']:.0f}", "R2_TFWD": f"{ex['train_fwd_ms']:.2f}", "R2_TLOSS": f"{ex['train_loss_fwd_ms']:.2f}",
     "R2_TBWD": f"{ex['train_bwd_ms']:.2f}", "R2_TSTEP": f"{ex['train_step_ms']:.2f}", "R2_CPU": f"{d['cpu_baseline']['value']:.2f}",
 }
-rev = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--from-git" else None
+# numbers sit between invisible markers: <!--R2_VALUE-->1238<!--/-->; a bare R2_VALUE (first fill) gets its markers here
 for name in ("DESIGN.md", "README.md"):
     p = os.path.join(ROOT, name)
-    s = subprocess.check_output(["git", "show", f"{rev}:{name}"], cwd=ROOT, text=True) if rev else open(p).read()
+    s = open(p).read()
     for k in sorted(vals, key=len, reverse=True):
-        s = s.replace(k, vals[k])
-    left = re.findall(r"R2_[A-Z_]+", s)
-    assert not left, left
+        s = re.sub(r"(?<![-A-Z_])" + k + r"(?![A-Z_-])", f"<!--{k}-->{vals[k]}<!--/-->", s)
+        s = re.sub(r"<!--" + k + r"-->[^<]*<!--/-->", f"<!--{k}-->{vals[k]}<!--/-->", s)
     open(p, "w").write(s)
 print(vals)
