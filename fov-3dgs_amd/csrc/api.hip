@@ -220,9 +220,9 @@ int fr_forward(fr_forward_args *a)
 	c.heavy4 = (int)totals[2]; c.heavy2 = (int)totals[3];
 	c.n_items = (int)totals[5];
 
-	char *bptr = a->binning_resize(a->resize_user[1], carve_bin(totals[0], nullptr).bytes);
+	char *bptr = a->binning_resize(a->resize_user[1], carve_bin(totals[0], nullptr, c.T).bytes);
 	if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }
-	c.bin = carve_bin(totals[0], bptr);
+	c.bin = carve_bin(totals[0], bptr, c.T);
 	if (totals[0] > 0) { rc = launch_emit(c); if (rc) return rc; }
 	mark(FR_STAGE_TILE_SORT);
 	if (totals[0] > 0) { rc = launch_tile_sort(c, (int)totals[0], (int)totals[1]); if (rc) return rc; }

@@ -135,15 +135,19 @@ struct BinWS {
 	uint32_t *point_list; // [D] gaussian ids, sorted per tile
 	uint64_t *entries2;   // [D] long lists regrouped into depth-ordered chunks (k_split_long)
 	uint2 *chunks;        // [FR_SORT_MAX_CHUNKS(D)] ranges of those chunks inside entries2 / point_list
+	uint32_t *round_flags; // RS / LWMC blend: one bit per (tile, 256-entry round), see k_render (last: earlier offsets do not depend on T)
 	size_t bytes;
 };
-__host__ __device__ inline BinWS carve_bin(int64_t D, char *base)
+// flag f(tile, round) = floor(range_start / 256) + tile + round < D / 256 + T + 1
+__host__ __device__ inline size_t round_flag_words(int64_t D, int64_t T) { return (size_t)((D / 256 + T + 64) / 32 + 1); }
+__host__ __device__ inline BinWS carve_bin(int64_t D, char *base, int64_t T = 1 << 20)
 {
 	BinWS b; size_t off = 0;
 	b.entries = (uint64_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint64_t));
 	b.point_list = (uint32_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint32_t));
 	b.entries2 = (uint64_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint64_t));
 	b.chunks = (uint2 *)(base + off); off = align_up(off + FR_SORT_MAX_CHUNKS(D) * sizeof(uint2));
+	b.round_flags = (uint32_t *)(base + off); off = align_up(off + round_flag_words(D, T) * sizeof(uint32_t));
 	b.bytes = off + 256;
 	return b;
 }

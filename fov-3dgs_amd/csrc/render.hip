@@ -110,50 +110,46 @@ struct RenderArgs {
 	const uint32_t *render_items; // work items, longest list first (k_tile_scan): tile << 3 | band | level state << 1 | two-level << 2 ...
 	uint32_t n_items;             // ... and their number
 	float cur_level;              // MMFR
+	uint32_t *round_flags;        // RS / LWMC: one bit per (tile, 256-entry round): the round's counts have an owner
 };
 
-// ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB ----------------
-// Instances are staged NT (= threads of the group) at a time: with PPL = 4 that is 64 records = 2.3 KiB of
-// LDS per wave, so occupancy is bounded by registers, not LDS. The records of the NEXT batch are
-// prefetched into registers before the current batch is blended (the point_list -> record gather is two
-// dependent global loads). RS semantics that depend on the reference's 256-entry batches
-// (gaussians_count: +1 per entry of every batch a still-live tile fetches, RS forward.cu:349-361) are kept
-// by taking the "tile finished" decision only at multiples of 256 entries.
+// ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB / _MAX / _LWMC ----------------
+// One single-wave workgroup per work item (a band of eight rows of a tile; render_items, longest list first), every
+// wave on its own: own batches of 64 entries, own reach mask, no workgroup barrier. The records of the NEXT batch are
+// prefetched into registers before the current batch is blended (the point_list -> record gather is two dependent
+// global loads).
+// RS / LWMC count, per Gaussian, the list entries a tile FETCHES: gaussians_count += 1 for every entry of every
+// 256-entry round the tile starts, and a round starts unless all 256 threads were done when it would (RS
+// forward.cu:349-361) -- i.e. iff at least one of the two bands is not done at the round's first entry. Round 1 kept
+// both bands in one workgroup with a barrier-coupled vote for that (400 us against 180 us for the same lists without
+// the statistics, 37 % of the wave-cycles parked). Here the bands stay independent and CLAIM rounds: a wave that is not
+// done at a round boundary sets the round's bit in round_flags (one atomicOr per wave and round); whoever finds the bit
+// clear owns the round and adds the counts of its (up to) 256 entries as it walks them -- to the end of the round even
+// if its own band finishes in between. A round nobody claims was not started.
 template <int VARIANT, int PPL>
-__global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
+__global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 {
-	constexpr int NT = 256 / PPL;        // threads per tile == staging batch
 	constexpr bool CUTOFF = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool SUM = VARIANT == FR_VARIANT_PCHECK_OBB_SUM;   // contributions += alpha*T, count per fetched entry
 	constexpr bool PMAX = VARIANT == FR_VARIANT_PCHECK_OBB_MAX;  // contributions = max alpha*T, count per in-support pixel
 	constexpr bool LWMC = VARIANT == FR_VARIANT_PCHECK_OBB_LWMC; // per-pixel loss to its max-contribution Gaussian
-	constexpr bool FETCHCNT = SUM || LWMC;                       // gaussians_count per fetched entry (256-batches)
+	constexpr bool FETCHCNT = SUM || LWMC;                       // gaussians_count per fetched entry (256-rounds)
 	constexpr bool NEEDID = SUM || PMAX || LWMC;
 	constexpr bool AUX = VARIANT != FR_VARIANT_PCHECK_OBB; // final_T / n_contrib kept for backward
-	// INDEP: the waves of a tile are independent workgroups of 64 threads (own batches of 64 entries, own reach mask,
-	// no barrier), as in k_render_fov. The flavours that count fetched entries need the tile-wide "finished" decision
-	// at every 256th entry and keep the shared-batch form (one workgroup of NT threads per tile).
-	constexpr bool INDEP = !FETCHCNT;
-	constexpr int NB = INDEP ? 64 : NT; // threads per workgroup == entries per batch
-
-	__shared__ float4 s0[NB];
-	__shared__ float4 s1[NB];
-	__shared__ float s2[NB];
-	__shared__ int sid[NEEDID ? NB : 1];
-	constexpr int NW = NT / 64;  // waves per tile, each owning a band of 16 / NW rows
-	__shared__ unsigned long long s_reach[NW][NW]; // shared batches: [band][staging wave] = staged entries that can touch the band
-
-	// One workgroup per work item, longest lists first: INDEP: one band of a tile = an entry of render_items; shared
-	// batches: one tile = an entry of tile_order (both laid out by k_tile_scan).
 	static_assert(PPL == 2, "work items encode two bands per tile");
-	const int st = threadIdx.x;                                          // staging slot of this thread
-	const uint32_t idx = blockIdx.x;
-	if (INDEP && idx >= a.n_items) return;
-	const uint32_t item = INDEP ? a.render_items[idx] : a.tile_order[idx] << 3;
-	const int tile = (int)(item >> 3);
+	constexpr int HP = PPL / 2;
+
+	__shared__ float4 s0[64];
+	__shared__ float4 s1[64];
+	__shared__ float s2[64];
+	__shared__ int sid[NEEDID ? 64 : 1];
+
+	const int st = threadIdx.x; // lane = staging slot
+	if (blockIdx.x >= a.n_items) return;
+	const uint32_t item = a.render_items[blockIdx.x];
+	const int tile = (int)(item >> 3), wv = (int)(item & 1u); // band of this wave
 	const int tx = tile % a.gx, ty = tile / a.gx;
-	const int wv = INDEP ? (int)(item & 1u) : (int)(threadIdx.x >> 6); // band of this wave
-	const int tid = INDEP ? wv * 64 + st : st;                          // position among the tile's NT threads (row mapping)
+	const int tid = wv * 64 + st;                              // position among the tile's 128 threads (row mapping)
 	const int lx = tid & 15;
 	const int px = tx * FR_TILE + lx;
 	const float pxf = (float)px;
@@ -161,8 +157,6 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 	const int n = (int)(range.y - range.x);
 
 	// pixel state as packed row pairs, finished pixels carry -T (see Px2)
-	static_assert(PPL == 4 || PPL == 2, "the packed blend handles pairs of rows");
-	constexpr int HP = PPL / 2;
 	Px2 S[HP];
 	float pyf[PPL];
 	uint32_t last[PPL];
@@ -193,72 +187,67 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 		const float4 *r = a.rec + 3 * (size_t)pid;
 		p0 = r[0]; p1 = r[1]; p2 = r[2].x;
 	}
-	bool finished = false; // SUM: every pixel saturated, only counting until the next 256 boundary
-	for (int base = 0; base < n; base += NB)
+	bool counting = false; // FETCHCNT: this wave owns the counts of the current 256-entry round
+	for (int base = 0; base < n; base += 64)
 	{
 		float tmax0 = -1.0f;
 #pragma unroll
 		for (int h = 0; h < HP; h++) tmax0 = fmaxf(tmax0, fmaxf(S[h].T.x, S[h].T.y));
-		bool wg_done;
-		if (INDEP)
-		{
-			wg_done = !__any(tmax0 > 0.0f);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous batch has been read by all lanes
-			__builtin_amdgcn_wave_barrier();
-		}
-		else wg_done = __syncthreads_and(!(tmax0 > 0.0f)) != 0; // also fences the LDS reuse
+		const bool wave_done = !__any(tmax0 > 0.0f);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous batch has been read by all lanes
+		__builtin_amdgcn_wave_barrier();
 		if (FETCHCNT)
 		{
-			if ((base & 255) == 0) { if (wg_done) break; }
-			finished = wg_done;
+			if ((base & 255) == 0)
+			{
+				counting = false;
+				if (!wave_done)
+				{
+					// the flag of round r of this tile: distinct for all (tile, round) pairs because a tile's range starts at least
+					// ceil(n / 256) - 1 flag positions after its predecessor's and the tile index adds one more
+					const uint32_t f = (range.x >> 8) + (uint32_t)tile + ((uint32_t)base >> 8);
+					uint32_t old = 0;
+					if (st == 0) old = atomicOr(a.round_flags + (f >> 5), 1u << (f & 31u));
+					counting = (((uint32_t)__builtin_amdgcn_readfirstlane((int)old) >> (f & 31u)) & 1u) == 0;
+				}
+			}
+			if (wave_done && !counting) break;
 		}
-		else if (wg_done) break;
+		else if (wave_done) break;
 		const bool staged = base + st < n;
+		if (FETCHCNT && counting && staged) atomicAdd(&a.gaussians_count[pid], 1);
+		if (FETCHCNT && wave_done)
+		{
+			// this band is finished but owns the round: only its remaining counts are due
+			if (base + 64 + st < n) pid = a.point_list[range.x + base + 64 + st];
+			continue;
+		}
 		if (staged)
 		{
 			s0[st] = p0; s1[st] = p1; s2[st] = p2;
 			if (NEEDID) sid[st] = (int)pid;
-			if (FETCHCNT) atomicAdd(&a.gaussians_count[pid], 1);
 		}
-		unsigned long long reach_own = 0;
+		unsigned long long reach_own;
 		{
-			// which bands can this entry touch at all (see splat_reaches)? alpha < 1/255 (forward.cu:336) <=> power <
+			// which entries can touch this band at all (see splat_reaches)? alpha < 1/255 (forward.cu:336) <=> power <
 			// -ln(255 opacity); the _max flavour counts pixels BEFORE the alpha test, so only the support cutoff applies
 			const float thr_a = -__logf(255.0f * p1.y) - 0.01f;
 			const float thr = PMAX ? -4.5f : (CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a);
-			if (INDEP) reach_own = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
-			else
-			{
-#pragma unroll
-				for (int w = 0; w < NW; w++)
-				{
-					const bool reach = staged && band_reaches<PPL>(w, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr);
-					const unsigned long long m = __ballot(reach);
-					if ((st & 63) == 0) s_reach[w][st >> 6] = m;
-				}
-			}
+			reach_own = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
 		}
-		if (base + NB + st < n)
+		if (base + 64 + st < n)
 		{
-			pid = a.point_list[range.x + base + NB + st];
+			pid = a.point_list[range.x + base + 64 + st];
 			const float4 *r = a.rec + 3 * (size_t)pid;
 			p0 = r[0]; p1 = r[1]; p2 = r[2].x;
 		}
-		if (INDEP)
-		{
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // lanes read entries other lanes staged
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		}
-		else __syncthreads();
-		// SUM && finished: nothing left to blend, the loop only keeps counting (no `continue` here: this
-		// loop carries barriers, see the note in k_bin)
-		const bool blend_batch = !(FETCHCNT && finished);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // lanes read entries other lanes staged
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		v2f pyp[HP];
 #pragma unroll
 		for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
-		bool stop = !blend_batch;
-		// Entries can be taken FR_RENDER_GROUP_PLAIN at a time: the part that does not depend on the running transmittance
+		// Entries are taken FR_RENDER_GROUP_PLAIN at a time: the part that does not depend on the running transmittance
 		// (record fetch, power, support test, exp) is evaluated for all of them before the first one is blended,
 		// so their dependency chains overlap (see k_render_fov).
 		struct Ent { v2f e[HP]; bool inx[HP], iny[HP]; float4 col; int j; };
@@ -294,7 +283,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 #pragma unroll
 				for (int h = 0; h < HP; h++)
 					c += __popcll(__ballot(t.inx[h] && S[h].T.x > 0.0f)) + __popcll(__ballot(t.iny[h] && S[h].T.y > 0.0f));
-				if ((tid & 63) == 0 && c != 0) atomicAdd(&a.gaussians_count[sid[j]], c);
+				if (st == 0 && c != 0) atomicAdd(&a.gaussians_count[sid[j]], c);
 			}
 #pragma unroll
 			for (int h = 0; h < HP; h++)
@@ -320,7 +309,7 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 				if (__any(any_contrib))
 				{
 					const float tot = wave_sum(contrib_sum);
-					if ((tid & 63) == 0) atomicAdd(&a.contributions[sid[j]], tot);
+					if (st == 0) atomicAdd(&a.contributions[sid[j]], tot);
 				}
 			}
 			if (PMAX)
@@ -331,12 +320,11 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 					float m = contrib_max;
 #pragma unroll
 					for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-					if ((tid & 63) == 0) atomicMax((unsigned int *)&a.contributions[sid[j]], __float_as_uint(m));
+					if (st == 0) atomicMax((unsigned int *)&a.contributions[sid[j]], __float_as_uint(m));
 				}
 			}
 		};
-		for (int sw = 0; sw < (INDEP ? 1 : NW) && !stop; sw++)
-		for (unsigned long long rm = INDEP ? reach_own : uniform_u64(s_reach[wv][sw]); rm; )
+		for (unsigned long long rm = reach_own; rm; )
 		{
 			int jj[FR_RENDER_GROUP_PLAIN];
 			bool vv[FR_RENDER_GROUP_PLAIN];
@@ -344,13 +332,13 @@ __global__ void __launch_bounds__(256 / PPL) k_render(const RenderArgs a)
 			for (int g = 0; g < FR_RENDER_GROUP_PLAIN; g++)
 			{
 				vv[g] = rm != 0;
-				jj[g] = vv[g] ? sw * 64 + __builtin_ctzll(rm) : jj[0];
+				jj[g] = vv[g] ? __builtin_ctzll(rm) : jj[0];
 				rm &= rm - 1; // stays 0 once empty
 			}
 			float tmax = -1.0f;
 #pragma unroll
 			for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(S[h].T.x, S[h].T.y));
-			if (!__any(tmax > 0.0f)) { stop = true; break; } // wave saturated
+			if (!__any(tmax > 0.0f)) break; // wave saturated
 			Ent t[FR_RENDER_GROUP_PLAIN];
 			bool anyhit = false;
 #pragma unroll
@@ -853,10 +841,13 @@ int launch_render(FwdCtx &c)
 	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions; r.loss_map = a->loss_map;
 	r.render_items = c.img.render_items; r.n_items = (uint32_t)c.n_items; r.cur_level = a->cur_level;
 	constexpr int PPL = 2;
-	// INDEP_: the two bands of a tile are separate single-wave workgroups (work items); else one 128-thread workgroup per tile
-#define FR_LAUNCH_RENDER(V, INDEP_) do { \
-		if (INDEP_) hipLaunchKernelGGL((k_render<V, PPL>), dim3(r.n_items), dim3(64), 0, c.stream, r); \
-		else hipLaunchKernelGGL((k_render<V, PPL>), dim3(c.T), dim3(256 / PPL), 0, c.stream, r); } while (0)
+	r.round_flags = c.bin.round_flags;
+	if (has_stats(a->variant) && a->variant != FR_VARIANT_PCHECK_OBB_MAX && c.bin.round_flags)
+	{
+		const hipError_t e = hipMemsetAsync(c.bin.round_flags, 0, round_flag_words(a->num_rendered, c.T) * sizeof(uint32_t), c.stream);
+		if (e != hipSuccess) { set_error("hipMemsetAsync(round_flags): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
+	}
+#define FR_LAUNCH_RENDER(V, UNUSED_) hipLaunchKernelGGL((k_render<V, PPL>), dim3(r.n_items), dim3(64), 0, c.stream, r)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: FR_LAUNCH_RENDER(FR_VARIANT_ORIGINAL, true); break;
