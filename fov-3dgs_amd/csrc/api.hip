@@ -190,7 +190,7 @@ int fr_forward(fr_forward_args *a)
 	rc = launch_tile_scan(c); if (rc) return rc;
 	mark(FR_STAGE_EMIT);
 
-	uint32_t totals[6] = { 0, 0, 0, 0, 0, 0 };
+	uint32_t totals[7] = { 0, 0, 0, 0, 0, 0, 0 };
 	if (!pinned) FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
 	if (pinned && !a->debug)
 	{
@@ -207,18 +207,18 @@ int fr_forward(fr_forward_args *a)
 				if (__atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != frame_seq) { set_error("tile scan did not publish its totals"); return FR_ERR_HIP; }
 			}
 		for (int i = 0; i < 4; i++) totals[i] = v[i];
-		totals[5] = v[5];
+		totals[5] = v[5]; totals[6] = v[6];
 	}
 	else
 	{
 		FR_HIP(hipStreamSynchronize(stream));
-		if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; totals[5] = v[5]; }
+		if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; totals[5] = v[5]; totals[6] = v[6]; }
 	}
 	if (totals[0] > 0x7fffffffu) { set_error("too many instances (%u)", totals[0]); return FR_ERR_INVALID; }
 	a->num_rendered = (int32_t)totals[0];
 	a->max_tile_instances = (int32_t)totals[1];
 	c.heavy4 = (int)totals[2]; c.heavy2 = (int)totals[3];
-	c.n_items = (int)totals[5];
+	c.n_items = (int)totals[5]; c.heavy8 = (int)totals[6];
 
 	char *bptr = a->binning_resize(a->resize_user[1], carve_bin(totals[0], nullptr, c.T).bytes);
 	if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }

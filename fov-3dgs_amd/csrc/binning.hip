@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		// bucket b holds lists with 2^(b-1) <= n < 2^b: n >= 2048 <=> b >= 12, 512 <= n < 2048 <=> b in {10, 11}
 		uint32_t h4 = 0;
 		for (int b = 12; b <= 32; b++) h4 += bucket[b];
-		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11];
+		const uint32_t h8 = h4 - bucket[12]; // lists with >= 4096 entries
+		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11]; totals[6] = h8;
 		totals[4] = 0; // chunk counter of k_split_long
 		uint32_t nitems = 0;
 		for (int b = 32; b >= 0; b--) { const uint32_t c = ibucket[b]; ibucket[b] = nitems; nitems += c; }
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		if (totals_host)
 		{
 			totals_host[0] = carry_s; totals_host[1] = m; totals_host[2] = h4; totals_host[3] = bucket[10] + bucket[11];
-			totals_host[5] = nitems;
+			totals_host[5] = nitems; totals_host[6] = h8;
 			__threadfence_system();
 			__hip_atomic_store(&totals_host[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 // scatter); LDS holds only the histogram.
 #define FR_SPLIT_REGS 16 // keys per thread held in registers by k_split_long (lists up to 16384 entries)
 __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const uint32_t *tile_order, const uint64_t *entries,
-	uint64_t *entries2, uint2 *chunks, uint32_t *chunk_ctr)
+	uint64_t *entries2, uint2 *chunks, uint32_t *chunk_ctr, uint32_t split_min)
 {
 	__shared__ uint32_t s_hist[FR_SORT_FINE_BUCKETS];      // counts -> exclusive offsets -> scatter cursors
 	__shared__ uint32_t s_start[FR_SORT_FINE_BUCKETS + 1]; // compacted chunk starts
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 	__shared__ uint32_t s_slot;
 	const uint2 rg = ranges[tile_order[blockIdx.x]];
 	const uint32_t n = rg.y - rg.x;
-	if (n < FR_SORT_SPLIT_MIN) return;
+	if (n < split_min) return;
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const uint64_t *src = entries + rg.x;
 	uint64_t *dst = entries2 + rg.x;
@@ -401,7 +402,15 @@ int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
 	const uint2 *rg = c.img.ranges;
 	const uint32_t *ord = c.img.tile_order;
 	static const bool serial = getenv("FR_SERIAL_SORT") != nullptr;
-	const int nlong = c.heavy4; // lists with >= FR_SORT_SPLIT_MIN entries: the first entries of tile_order
+	// Lists with >= FR_SORT_SPLIT_MIN (2048) entries are regrouped by depth into ~960-entry chunks and sorted chunk by
+	// chunk: two kernels, two passes over the entries, but no workgroup sorts more than a chunk -- right when a frame has
+	// a few hundred such lists (their latency is the stage's critical path). A frame with THOUSANDS of them (the
+	// non-foveated / training frames: half the tiles hold 2048-4095 entries) is throughput-bound instead: there the
+	// 2048..4095 class is sorted directly, one 512-thread workgroup per list in LDS, and only lists of 4096 and more are
+	// split (FR_SORT_DIRECT_TILES decides).
+	const bool direct = c.heavy4 - c.heavy8 >= FR_SORT_DIRECT_TILES;
+	const int split_min = direct ? 2 * FR_SORT_SPLIT_MIN : FR_SORT_SPLIT_MIN;
+	const int nlong = direct ? c.heavy8 : c.heavy4; // lists that are split: the first entries of tile_order
 	// long lists exist: the short ones are sorted meanwhile on the helper stream
 	AuxStream *ax = (nlong > 0 && !serial && !c.a->debug) ? aux_stream() : nullptr;
 	hipStream_t small = c.stream;
@@ -414,11 +423,14 @@ int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
 	if (nlong > 0)
 	{
 		uint32_t *chunk_ctr = c.img.totals + 4;
-		hipLaunchKernelGGL(k_split_long, dim3(nlong), dim3(1024), 0, c.stream, rg, ord, c.bin.entries, c.bin.entries2, c.bin.chunks, chunk_ctr);
+		hipLaunchKernelGGL(k_split_long, dim3(nlong), dim3(1024), 0, c.stream, rg, ord, c.bin.entries, c.bin.entries2, c.bin.chunks, chunk_ctr, (uint32_t)split_min);
 		const size_t max_chunks = FR_SORT_MAX_CHUNKS(num_instances);
 		hipLaunchKernelGGL((k_tile_msort<256, 8, true>), dim3((unsigned)max_chunks), dim3(256), 2304 * sizeof(uint64_t), c.stream,
 			c.bin.chunks, (const uint32_t *)nullptr, c.bin.entries2, c.bin.point_list, 0, 0, chunk_ctr);
 	}
+	if (direct)
+		hipLaunchKernelGGL((k_tile_msort<512, 8, false>), dim3(c.heavy4), dim3(512), 4608 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+			FR_SORT_SPLIT_MIN - 1, split_min, (const uint32_t *)nullptr);
 	if (max_tile > 512)
 		hipLaunchKernelGGL((k_tile_msort<256, 8, false>), grid, dim3(256), 2304 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
 			512, FR_SORT_SPLIT_MIN, (const uint32_t *)nullptr);

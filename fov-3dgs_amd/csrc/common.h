@@ -22,6 +22,9 @@
 #define FR_GIANT_MAX 64         // giant splats a workgroup can set aside (more: handled like big ones)
 #define FR_SORT_SPLIT_LOG2 11       // (4096 / 8192 / 1024 measured slower)
 #define FR_SORT_SPLIT_MIN (1 << FR_SORT_SPLIT_LOG2) // tile lists with at least this many entries are split by depth before sorting
+#ifndef FR_SORT_DIRECT_TILES
+#define FR_SORT_DIRECT_TILES 1024   // this many lists of 2048..4095 entries: sort that class directly (see launch_tile_sort)
+#endif
 #define FR_SORT_CHUNK_TARGET 960    // ... into chunks of about this many entries (just under the 1024-key sort size)
 #define FR_SORT_FINE_BUCKETS 2048   // depth buckets of the split
 // chunks are cut at multiples of the target in the running count, so a list of n entries yields at most
@@ -96,7 +99,7 @@ struct ImageWS {
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
 	uint32_t *lv_bbox;    // [5][FR_LV_BBOX_STRIDE] RF: box of the tiles with tile_min < k as {gx - x0, gy - y0, x1, y1} (0 = empty), k = 0..4
-	uint32_t *totals;     // [8]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, #blend items, -...}
+	uint32_t *totals;     // [8]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, #blend items, #tiles with >= 4096, -}
 	uint32_t *render_items; // [4T] blend work items, longest lists first: tile << 3 | band | level state << 1 | two-level << 2 (k_tile_scan)
 	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
@@ -353,6 +356,7 @@ struct FwdCtx {
 	int fov_split;      // RF: the two level states of a two-level tile go to different waves (out_color was zero-filled)
 	int bin_wgs;        // workgroups k_bin ran with (k_emit replays the same number)
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
+	int heavy8;         // tiles with >= 4096 instances
 	int n_items;        // entries of ImageWS::render_items
 	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4] (+ sequence word), or null
 	uint32_t totals_seq;       // this frame's sequence number for that word
