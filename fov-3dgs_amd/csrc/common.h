@@ -16,6 +16,8 @@
 // them run at a time (2 waves/SIMD), the other finds the slab counters empty -- 384-thread workgroups (3 waves/SIMD)
 // measured no faster (0.253 vs 0.247 ms): the kernel follows its heaviest slabs, not its occupancy
 #define FR_BIN_BLOCKS 512
+#define FR_PROJ_MAX_WAVES 8192                 // k_project's grid is capped to this many waves ...
+#define FR_CROW_PAD (64 * FR_PROJ_MAX_WAVES)     // ... each of which may leave its last chunk's worth of row slots unused
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop
@@ -64,6 +66,9 @@ struct GeomWS {
 	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {-, number of entries in vis_list, ...}; k_bin's eight slab pull
 	                    // counters live at [32 * (1 + r)], one 128-byte line each
 	uint32_t *vis_list; // [P]  indices of the Gaussians that survive projection (unordered)
+	float4 *crow;       // [3 (P + FR_CROW_PAD)] candidate rows (xyz, scale | scale.yz, rotation.xy | rotation.zw, highest level, index),
+	                    //      written by k_project's waves into regions of their own in the order they meet the survivors ...
+	uint32_t *vis_src;  // [P]  ... and where the row of vis_list entry i is (k_bin reads rows instead of four gathers)
 	int32_t *slab_next;   // [ceil(P / 64)] per-wave chains of the 64-entry vis_list slabs k_bin's waves pulled ...
 	int32_t *wave_head;   // [FR_BIN_BLOCKS * FR_BIN_THREADS / 64] ... and the last slab of every wave (-1: none)
 	size_t bytes;
@@ -86,6 +91,8 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 	}
 	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + FR_SLAB_CTR_WORDS * sizeof(uint32_t));
 	g.vis_list = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
+	g.crow = (float4 *)(base + off); off = align_up(off + (P + FR_CROW_PAD) * 3 * sizeof(float4));
+	g.vis_src = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
 	g.slab_next = (int32_t *)(base + off); off = align_up(off + ((P + 63) / 64 + 1) * sizeof(int32_t));
 	g.wave_head = (int32_t *)(base + off); off = align_up(off + FR_BIN_BLOCKS * (FR_BIN_THREADS / 64) * sizeof(int32_t));
 	g.bytes = off + 256;

@@ -549,6 +549,29 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	const int lane = threadIdx.x & 63;
 	uint32_t *list = s_list[threadIdx.x >> 6];
 	uint32_t n = 0; // entries staged by this wave (wave-uniform)
+	// Unpacked model: a survivor's eleven input floats are in this wave's registers right now, and k_bin would have to
+	// fetch them again through four gathers that touch every cache line of means3D / scales / rotations / highest_levels
+	// (a line holds 8-10 Gaussians, one in eight survives: 264 MB of lines per frame for 34 MB of rows). So the survivor
+	// stores its ROW (48 bytes, GeomWS::crow) at once, at the next free position of a region that belongs to this wave
+	// (no counter involved: the wave's k-th survivor goes to slot k of its region), and the flush notes beside each
+	// vis_list entry where its row is (vis_src). Entries of one flush are consecutive rows, so a k_bin wave reads a
+	// contiguous 3 KB. (Rows staged in LDS and flushed in list order need 48 B x survivors per wave: the chip's whole
+	// LDS holds 0.9 frames' worth, every wave flushes mid-loop and 4096 atomics on one counter queue up for 45 us.)
+	constexpr bool ROWS = !PACKED && FOV; // the level box leaves one Gaussian in eight; at one in three (plain frames) the rows cost
+	                                       // more than k_bin's gathers, whose lines are then mostly used (training step +1.5 %)
+	const int nwaves_all = (int)gridDim.x * (FR_PROJ_THREADS / 64);
+	const int nchunks_all = (a.P + 63) / 64;
+	const uint32_t row_base = (uint32_t)((int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6)) *
+		(uint32_t)(((nchunks_all + nwaves_all - 1) / nwaves_all) * 64); // this wave's region: 64 slots per chunk it visits
+	uint32_t nrow = 0; // rows stored so far (never reset)
+	auto copy_out = [&](const uint32_t base) __attribute__((always_inline))
+	{
+		for (uint32_t i = lane; i < n; i += 64)
+		{
+			a.geom.vis_list[base + i] = list[i];
+			if (ROWS) a.geom.vis_src[base + i] = row_base + (nrow - n) + i; // the staged entries are the last n rows
+		}
+	};
 	auto flush = [&]() __attribute__((always_inline))
 	{
 		uint32_t base = 0;
@@ -558,7 +581,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		for (uint32_t i = lane; i < n; i += 64) a.geom.vis_list[base + i] = list[i];
+		copy_out(base);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		n = 0;
@@ -611,8 +634,20 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
 		}
 		const unsigned long long m = __ballot(maybe);
-		if (maybe) list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+		if (maybe)
+		{
+			const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			list[n + rank] = (uint32_t)idx;
+			if (ROWS)
+			{
+				float4 *row = a.geom.crow + 3 * (size_t)(row_base + nrow + rank);
+				row[0] = make_float4(cur.p[0], cur.p[1], cur.p[2], cur.sc[0]);
+				row[1] = make_float4(cur.sc[1], cur.sc[2], cur.q.x, cur.q.y);
+				row[2] = make_float4(cur.q.z, cur.q.w, cur.hl, __uint_as_float((uint32_t)idx));
+			}
+		}
 		n += (uint32_t)__popcll(m);
+		nrow += (uint32_t)__popcll(m);
 		if (n > FR_PROJ_WLIST - 64) flush();
 	};
 	// FR_PROJ_DEPTH chunks in flight per wave, each in its own register set that is refilled in place
@@ -642,7 +677,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	__syncthreads();
 	uint32_t out = s_left_base;
 	for (int w = 0; w < (int)(threadIdx.x >> 6); w++) out += s_left[w];
-	for (uint32_t i = lane; i < n; i += 64) a.geom.vis_list[out + i] = list[i];
+	copy_out(out);
 }
 
 // Stage 2 (RS rasterizer_impl.cu:70-146, RF :264-383 + :490-530): for every survivor, count the tiles it
@@ -651,9 +686,11 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 // LDSH: the counters are an LDS-private histogram (T <= 16 Ki tiles) written once per workgroup to
 // hist[block][tile] -- no global atomics at all; otherwise (huge tile grids) global atomics on tile_count.
 #define BUMP_TILE(ti) do { if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
-template <int VARIANT, bool LDSH, bool PACKED = false>
+// CROW: the candidate's inputs come as the row k_project stored (GeomWS::crow via vis_src).
+template <int VARIANT, bool LDSH, bool PACKED = false, bool CROW = false>
 __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 {
+	static_assert(!(PACKED && CROW), "the packed model layout has its own rows");
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = is_fov(VARIANT);                            // level map + level filter
 	constexpr bool LEVELCOL = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;  // per-level colours / opacities (RF); the shared-model
@@ -763,12 +800,13 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	};
 	// Per-Gaussian epilogue once its tile count is known: radius of culled-everywhere splats, colour(s), final record.
 	auto finish = [&](const int idx, const int item, const uint32_t count, const float hl, const float lowest, const float highest,
-		const bool be_blend, const float conic_c, const float depth) __attribute__((always_inline))
+		const bool be_blend, const float conic_c, const float depth, const float *pos) __attribute__((always_inline))
 	{
 		if (count == 0) { a.radii[idx] = 0; return; } // culled everywhere (RS rasterizer_impl.cu:141-145)
 		float rgb[3] = { 0, 0, 0 };
 		uint32_t clamp_bits = 0;
-		const float *mp = PACKED ? a.packed_geom + 16 * (size_t)idx : a.means3D + 3 * (size_t)idx;
+		// pos: the caller still holds the position (null: fetch it)
+		const float *mp = pos ? pos : (PACKED ? a.packed_geom + 16 * (size_t)idx : a.means3D + 3 * (size_t)idx);
 		const float dirx = mp[0] - a.campos[0], diry = mp[1] - a.campos[1], dirz = mp[2] - a.campos[2];
 		const float *pcol = PACKED ? a.packed_colour + 64 * (size_t)idx : nullptr;
 		if (!LEVELCOL)
@@ -875,13 +913,23 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	float2 el = make_float2(0, 0);
 	float hl = 0, lowest = 0, highest = 0;
 	bool be_blend = false, boxtest = false;
+	RawGaussian w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0);
 	if (item < V)
 	{
 		// the candidate's full projection (covariance chain, conic, radius: forward.cu:155-262), its OBB axes and
 		// the rectangle to walk; candidates that turn out to reach no tile get radius 0, like every culled Gaussian
-		idx = (int)a.geom.vis_list[item];
-		RawGaussian w; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0);
-		if (PACKED)
+		if (!CROW) idx = (int)a.geom.vis_list[item];
+		if (CROW)
+		{
+			const float4 *cr = a.geom.crow + 3 * (size_t)a.geom.vis_src[item];
+			const float4 g0 = cr[0], g1 = cr[1], g2 = cr[2];
+			w.p[0] = g0.x; w.p[1] = g0.y; w.p[2] = g0.z;
+			w.sc[0] = g0.w; w.sc[1] = g1.x; w.sc[2] = g1.y;
+			w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
+			if (FOV) { hl = g2.z; lowest = hl; }
+			idx = (int)__float_as_uint(g2.w);
+		}
+		else if (PACKED)
 		{
 			// one 64-byte row instead of four or five mostly-unused cache lines
 			const float4 *pg = (const float4 *)a.packed_geom + 4 * (size_t)idx;
@@ -1034,7 +1082,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
 		TM_END(tm_p);
-		if (pr.alive && !deferred) finish(idx, item, count, hl, lowest, highest, be_blend, r1.x, r2.y);
+		if (pr.alive && !deferred) finish(idx, item, count, hl, lowest, highest, be_blend, r1.x, r2.y, w.p);
 		// walk record for k_emit (and for the giant phase below), in list order: coalesced 64-byte rows
 		if (item < V)
 		{
@@ -1076,7 +1124,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		float lowest = ghl, highest = 0.0f;
 		bool be_blend = false;
 		if (FOV && gcount != 0) range_from_mask(s_gmask[threadIdx.x], lowest, highest, be_blend);
-		finish(gi, s_gitem[threadIdx.x], gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y);
+		finish(gi, s_gitem[threadIdx.x], gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y, nullptr);
 	}
 #ifdef FR_BIN_TIMERS
 	if (lane == 0)
@@ -1457,7 +1505,8 @@ int launch_project(FwdCtx &c)
 			resident[slot] = per_cu * prop.multiProcessorCount;
 		}
 		const int pchunks = (a->P + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS;
-		const dim3 pgrid(pchunks < resident[slot] ? pchunks : resident[slot]), pblock(FR_PROJ_THREADS);
+		const int pmax = resident[slot] < FR_PROJ_MAX_WAVES / (FR_PROJ_THREADS / 64) ? resident[slot] : FR_PROJ_MAX_WAVES / (FR_PROJ_THREADS / 64);
+		const dim3 pgrid(pchunks < pmax ? pchunks : pmax), pblock(FR_PROJ_THREADS);
 #define LAUNCH_PROJ(V) do { if (packed) hipLaunchKernelGGL((k_project<V, true>), pgrid, pblock, 0, c.stream, p); \
 	else hipLaunchKernelGGL((k_project<V>), pgrid, pblock, 0, c.stream, p); } while (0)
 		switch (vslot)
@@ -1482,60 +1531,54 @@ int launch_bin(FwdCtx &c)
 	// LDS per workgroup: tile histogram (+ RF: tile_min and blend bits when two workgroups still fit a CU)
 	p.lds_tiles = (is_fov(a->variant) && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
 	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
-	if (lds > 64u * 1024u)
-	{
-		static const hipError_t once = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_FOV_PCHECK_OBB, true>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
-		static const hipError_t once2 = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-		if (once2 != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once2)); return FR_ERR_HIP; }
-	}
 	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the
-	// ordinary path 5 %); it needs both packed tensors and the LDS histogram path
+	// ordinary path 5 %); it needs both packed tensors and the LDS histogram path. Otherwise, when k_project stored the
+	// candidates' rows (foveated variants, unpacked cull pass, scales + rotations given), the kernel that reads those.
 	const bool packed = ldsh && a->packed_geom && a->packed_colour;
-	if (lds > 64u * 1024u && packed)
-	{
-		static const hipError_t once = hipFuncSetAttribute((const void *)k_bin<FR_VARIANT_FOV_PCHECK_OBB, true, true>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
-	}
+	const bool crow = ldsh && !packed && is_fov(a->variant) && a->packed_cull == nullptr && a->cov3D_precomp == nullptr;
 	// Never more workgroups than the device keeps resident: the slabs are handed out dynamically, so workgroups of a
 	// second round start when the first ones are done, find the counters empty and only cost their LDS set-up, an
 	// all-zero histogram row and the tail of the kernel (measured: 256 of 512 workgroups, 175 -> 211 us).
 	auto launch = [&](const void *fn, void (*kern)(const PreArgs), size_t dyn) {
-		static thread_local struct { const void *fn; size_t dyn; int wgs; } cache[12];
+		static thread_local struct { const void *fn; size_t dyn; int wgs; } cache[24];
 		static thread_local int ncache = 0;
 		int wgs = 0;
 		for (int i = 0; i < ncache; i++) if (cache[i].fn == fn && cache[i].dyn == dyn) wgs = cache[i].wgs;
 		if (wgs == 0)
 		{
+			if (dyn > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+			{ set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(hipGetLastError())); return FR_ERR_HIP; }
 			int per_cu = 0, dev = 0;
 			hipDeviceProp_t prop;
 			if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
 				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FR_BIN_THREADS, dyn) != hipSuccess || per_cu < 1)
 			{ per_cu = 1; prop.multiProcessorCount = 256; (void)hipGetLastError(); }
 			wgs = per_cu * prop.multiProcessorCount;
-			if (ncache < 12) { cache[ncache].fn = fn; cache[ncache].dyn = dyn; cache[ncache].wgs = wgs; ncache++; }
+			if (ncache < 24) { cache[ncache].fn = fn; cache[ncache].dyn = dyn; cache[ncache].wgs = wgs; ncache++; }
 		}
 		nblk = nblk < wgs ? nblk : wgs;
 		hipLaunchKernelGGL(kern, dim3(nblk), block, dyn, c.stream, p);
+		return FR_OK;
 	};
-#define LAUNCH_PRE(V) do { if (packed) launch((const void *)k_bin<V, true, true>, k_bin<V, true, true>, lds); \
-	else if (ldsh) launch((const void *)k_bin<V, true>, k_bin<V, true>, lds); \
-	else launch((const void *)k_bin<V, false>, k_bin<V, false>, 0); } while (0)
+	int lrc = FR_OK;
+#define LAUNCH_PRE(V) do { if (packed) lrc = launch((const void *)k_bin<V, true, true>, k_bin<V, true, true>, lds); \
+	else if (crow) lrc = launch((const void *)k_bin<V, true, false, true>, k_bin<V, true, false, true>, lds); \
+	else if (ldsh) lrc = launch((const void *)k_bin<V, true>, k_bin<V, true>, lds); \
+	else lrc = launch((const void *)k_bin<V, false>, k_bin<V, false>, 0); } while (0)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
 	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_PRE(FR_VARIANT_FOV_PCHECK_OBB); break;
 	case FR_VARIANT_MMFR_PCHECK_OBB:      // plain colours + the level filter (on the skip key, see k_tile_levels): the same kernel
 	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: // (no packed instantiation: validate_forward refuses the packed tensors)
-		if (ldsh) launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, lds);
-		else launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, 0);
+		if (crow) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true, false, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true, false, true>, lds);
+		else if (ldsh) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, lds);
+		else lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, 0);
 		break;
 	default: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
 	}
 #undef LAUNCH_PRE
+	if (lrc) return lrc;
 	c.bin_wgs = nblk;
 	int rc = check_launch("preprocess", c.stream, a->debug);
 	if (rc || !ldsh) return rc;

@@ -18,9 +18,10 @@ with torch.no_grad():
 rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev),
                                       1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
 E = torch.Tensor([])
-for name, vid in (("pcheck_obb_sum", 1), ("fov_pcheck_obb", 3)):
+GAZES = [(0.5, 0.5)] + [(x, y) for x in (0.25, 0.5, 0.75) for y in (0.25, 0.5, 0.75) if (x, y) != (0.5, 0.5)]
+for name, vid, gaze in [("pcheck_obb_sum", 1, None)] + [("fov %.2f,%.2f" % g, 3, g) for g in GAZES]:
     if vid == 3:
-        r = rz._forward_native(vid, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], syn.lissajous_gaze(20, 90), 0.05)
+        r = rz._forward_native(vid, rs, xyz, rest, E, fov[2], sc, rot, E, fov[1], fov[0], gaze, 0.05)
     else:
         r = rz._forward_native(vid, rs, xyz, full, E, opa, sc, rot, E, None, None, (0.5, 0.5), 0.05)
     torch.cuda.synchronize()
