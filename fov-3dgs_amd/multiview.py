@@ -16,11 +16,19 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and local_rank >= torch.cuda.device_count():
+        # more ranks than GPUs on this node (a test box): the ranks share devices, and RCCL refuses two ranks on one GPU
+        local_rank %= torch.cuda.device_count()
+        shared = True
+    else:
+        shared = False
     if world > 1 and not dist.is_initialized():
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and not shared and int(os.environ.get("LOCAL_WORLD_SIZE", "1")) <= torch.cuda.device_count():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
     return rank, world, local_rank
 
