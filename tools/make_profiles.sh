@@ -31,8 +31,9 @@ for d, c in (("/tmp/prof_f", "FETCH_SIZE"), ("/tmp/prof_w", "WRITE_SIZE")):
         if "fr::" not in k or r["Counter_Name"] != c: continue
         full = k.replace("void ", "").split("fr::")[1].split("(")[0]
         base = re.sub(r"<.*", "", full)
-        # template instances of the packed static-model layout: k_bin<V, CULL, PACKED>, k_project<V, PACKED>
-        packed = (base == "k_bin" and full.rstrip(">").endswith("true") and full.count(",") == 2) or (base == "k_project" and full.rstrip(">").endswith("true"))
+        # template instances of the packed static-model layout: k_bin<V, LDSH, PACKED[, CROW]>, k_project<V, PACKED>
+        targs = [t.strip() for t in full[full.index("<") + 1:full.rindex(">")].split(",")] if "<" in full else []
+        packed = (base == "k_bin" and len(targs) >= 3 and targs[2] == "true") or (base == "k_project" and len(targs) >= 2 and targs[1] == "true")
         agg[base + ("_packed" if packed else "")].append(float(r["Counter_Value"]))
     raw[c] = agg
     for name, v in agg.items():
@@ -55,7 +56,7 @@ calibration = {"launches": cal,
                "write_factor": round(sum(c["written_bytes"] for c in cal.values()) / sum(c["WRITE_SIZE_bytes"] for c in cal.values()), 3) if cal else 1.0,
                "note": "fetch_factor from the 16-byte-per-lane streaming reads of k_pack_geom / k_pack_cull (gfx950 FETCH_SIZE counts those at half size, MI355X_MICROARCH.md); k_pack_colour's mix of 4- and 16-byte reads shows a smaller factor: for gather-heavy kernels 2 x FETCH is an upper bound"}
 doc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate WRITE_SIZE pass) -- python3 bench.py --no-cpu-baseline --no-extra",
-       "lib_sha16": sha, "layout": "headline frames = the reference's tensors (k_bin<3,true,false>, k_project<3,false>); *_packed = the static-model instances",
+       "lib_sha16": sha, "layout": "headline frames = the reference's tensors (k_bin<3,true,false,true>, k_project<3,false>); *_packed = the static-model instances",
        "note": "per-launch averages (KiB as rocprofv3 reports them) and per-frame totals over the 9 + 63 frames of each layout",
        "calibration": calibration, "kernels": out}
 json.dump(doc, open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "profiles", f"{tag}_pmc.json"), "w"), indent=1)
