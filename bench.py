@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also collect every rank's frame on rank 0 (asynchronous RCCL gather overlapped with the next "
                          "frame). Off by default: the views are independent and the path has no exchange step.")
+    ap.add_argument("--activation-pass", action="store_true",
+                    help="--mode train: activate the model's parameters with the fused pass instead of inside the rasterizer's kernels")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch / rendezvous only (gloo without a GPU): rank 0 prints a line with n_gpus and exits")
     ap.add_argument("--master-port", type=int, default=0)
@@ -415,25 +417,36 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
     tr = cloud.requires_grad_(True)
     target = torch.rand(3, H, W, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    rows = []
-    for it in range(55):
-        for p in tr.parameters():
-            p.grad = None
+    for fuse in (True, False):  # the model's raw parameters activated inside the kernels / by the fused activation pass
+        tr.fuse_activations = fuse
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(55)]
+        t1 = 0.0
+        for it in range(55):
+            if it == 5:  # the 50 timed steps run back to back as in a training loop (the forward's own synchronisation
+                torch.cuda.synchronize()  # for the instance count is the only one)
+                t1 = time.perf_counter()
+            ev = evs[it]
+            for p in tr.parameters():
+                p.grad = None
+            ev[0].record()
+            o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
+            ev[1].record()
+            loss = l1_ssim_loss(o["render"], target, 0.2)
+            ev[2].record()
+            loss.backward()
+            ev[3].record()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ev[0].record()
-        o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
-        ev[1].record()
-        loss = l1_ssim_loss(o["render"], target, 0.2)
-        ev[2].record()
-        loss.backward()
-        ev[3].record()
-        torch.cuda.synchronize()
-        rows.append((ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), (time.perf_counter() - t1) * 1e3))
-    med = np.median(np.array(rows[5:]), axis=0)
-    extra["train_fwd_ms"], extra["train_loss_fwd_ms"], extra["train_bwd_ms"], extra["train_step_ms"] = [round(float(x), 3) for x in med]
-    extra["train_note"] = ("pcheck_obb_sum forward (incl. the model's fused activations) / fused L1+SSIM forward / backward of both "
-                           "(loss + rasterizer + activations), events on the stream; train_step_ms = wall clock; median of 50")
+        wall = (time.perf_counter() - t1) / 50 * 1e3
+        rows = [(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])) for e in evs[5:]]
+        med = [round(float(x), 3) for x in np.median(np.array(rows), axis=0)] + [round(wall, 3)]
+        if fuse:
+            extra["train_raw_fwd_ms"], extra["train_raw_loss_fwd_ms"], extra["train_raw_bwd_ms"], extra["train_raw_step_ms"] = med
+        else:
+            extra["train_fwd_ms"], extra["train_loss_fwd_ms"], extra["train_bwd_ms"], extra["train_step_ms"] = med
+    extra["train_note"] = ("pcheck_obb_sum forward (incl. the model's activations: one fused pass over all P Gaussians each way; "
+                           "train_raw_*: the model's raw parameters handed to the rasterizer, activations inside its kernels) / fused "
+                           "L1+SSIM forward / backward of both (loss + rasterizer + activations), events on the stream, median of 50; "
+                           "*_step_ms = wall clock of 50 back-to-back steps / 50")
     # the reference's formulation of the loss (five grouped conv2d's + elementwise ops + autograd) in torch on the same GPU
     g1 = torch.tensor([math.exp(-(i - 5) ** 2 / 4.5) for i in range(11)], device=dev)
     g1 = g1 / g1.sum()
@@ -468,33 +481,35 @@ def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, 
     K, Wm = args.steps, args.warmup
     H, W = args.height, args.width
     tr = cloud.requires_grad_(True)
+    tr.fuse_activations = not args.activation_pass
     target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))
     params = list(tr.parameters())
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    fb, co, info = [], [], None
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    info = None
 
-    def step(timed):
+    def step(ev):
         nonlocal info
         for p in params:
             p.grad = None
-        ev[0].record()
+        if ev:
+            ev[0].record()
         o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
         l1_ssim_loss(o["render"], target, 0.2).backward()
-        ev[1].record()
+        if ev:
+            ev[1].record()
         info = multiview.allreduce_gradients(params, visible=o["visibility_filter"])
-        ev[2].record()
-        if timed:
-            torch.cuda.synchronize()
-            fb.append(ev[0].elapsed_time(ev[1]))
-            co.append(ev[1].elapsed_time(ev[2]))
+        if ev:
+            ev[2].record()
     for _ in range(Wm):
-        step(False)
+        step(None)
     barrier_sync()
     t0 = time.perf_counter()
-    for _ in range(K):
-        step(True)
+    for i in range(K):  # back to back, as a training loop runs them: no synchronisation between steps
+        step(evs[i])
     barrier_sync()
     elapsed = time.perf_counter() - t0
+    fb = [e[0].elapsed_time(e[1]) for e in evs]
+    co = [e[1].elapsed_time(e[2]) for e in evs]
     if world > 1:
         t = torch.tensor([elapsed, float(np.median(fb)), float(np.median(co))], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -508,8 +523,9 @@ def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, 
     line = {"metric": "fwd+bwd ms/iter (multi-view training step, one camera per GPU)", "value": round(elapsed / K * 1e3, 4), "unit": "ms/iter",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": False,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "S-6M cloud, pcheck_obb_sum forward + fused 0.8 L1 + 0.2 (1 - SSIM) + backward per rank, gradient "
-                                   "sum over ranks (multiview.allreduce_gradients)", "gaussians": args.points, "width": W, "height": H,
+            "config": {"workload": "S-6M cloud, pcheck_obb_sum forward + fused 0.8 L1 + 0.2 (1 - SSIM) + backward per rank (model "
+                                   "activations " + ("inside the rasterizer's kernels" if tr.fuse_activations else "as one fused pass each way")
+                                   + "), gradient sum over ranks (multiview.allreduce_gradients)", "gaussians": args.points, "width": W, "height": H,
                        "parallelism": f"views{world}"},
             "fwd_bwd_ms": round(fbm, 4), "collective_ms": round(com, 4), "views_per_s": round(world * K / elapsed, 3),
             "collective": dict(info or {}, algbw_GBs=None if algbw is None else round(algbw, 2),

@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfovraster_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
 VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC, VARIANT_NAIVE_FOV_PCHECK_OBB, VARIANT_MMFR_PCHECK_OBB = 4, 5, 6, 7
@@ -41,6 +41,7 @@ class ForwardArgs(C.Structure):
         ("shs_rest", _FP),
         ("packed_geom", _FP), ("packed_colour", _FP), ("packed_cull", _FP),
         ("cur_level", C.c_float),
+        ("raw_activations", C.c_int32),
     ]
 
 
@@ -59,10 +60,11 @@ class BackwardArgs(C.Structure):
         ("stage_events", C.POINTER(C.c_void_p)),
         ("shs_rest", _FP),
         ("dL_dsh_rest", _FP),
+        ("raw_activations", C.c_int32),
     ]
 
 
-EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible", "fr_pack_geom", "fr_pack_colour", "fr_pack_cull", "fr_activate_forward", "fr_activate_backward", "fr_l1_ssim_blocks", "fr_l1_ssim_forward", "fr_l1_ssim_backward",
+EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible", "fr_pack_geom", "fr_pack_colour", "fr_pack_cull", "fr_activate_forward", "fr_activate_backward", "fr_l1_ssim_blocks", "fr_l1_ssim_forward", "fr_l1_ssim_finish", "fr_l1_ssim_backward",
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
            "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records",
            "fr_geometry_vis_list", "fr_geometry_vis_count", "fr_geometry_walk_records", "fr_geometry_level_colours",
@@ -118,7 +120,9 @@ def load():
     lib.fr_l1_ssim_blocks.restype = C.c_int64
     lib.fr_l1_ssim_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, C.c_void_p]
     lib.fr_l1_ssim_forward.restype = C.c_int
-    lib.fr_l1_ssim_backward.argtypes = [C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, C.c_float, C.c_float, _FP, C.c_void_p]
+    lib.fr_l1_ssim_finish.argtypes = [C.c_int32, C.c_int32, C.c_int32, _FP, C.c_float, _FP, C.c_void_p]
+    lib.fr_l1_ssim_finish.restype = C.c_int
+    lib.fr_l1_ssim_backward.argtypes = [C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, C.c_float, C.c_float, _FP, _FP, C.c_void_p]
     lib.fr_l1_ssim_backward.restype = C.c_int
     for n in ("fr_geometry_bytes",):
         getattr(lib, n).argtypes = [C.c_int32, C.c_int32]

@@ -16,12 +16,9 @@ __global__ void __launch_bounds__(256) k_activate_fwd(int P, const float *__rest
 	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= (size_t)P) return;
 #pragma unroll
-	for (int k = 0; k < 3; k++) s[3 * i + k] = expf(rs[3 * i + k]);
-	const float4 v = ((const float4 *)rq)[i];
-	const float n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
-	const float d = fmaxf(n, 1e-12f);
-	((float4 *)q)[i] = make_float4(v.x / d, v.y / d, v.z / d, v.w / d);
-	o[i] = 1.0f / (1.0f + expf(-ro[i]));
+	for (int k = 0; k < 3; k++) s[3 * i + k] = act_scale(rs[3 * i + k]);
+	((float4 *)q)[i] = act_rotation(((const float4 *)rq)[i]);
+	o[i] = act_opacity(ro[i]);
 }
 
 // gs / gq / go: gradients w.r.t. the activated values (any may be null = zero)

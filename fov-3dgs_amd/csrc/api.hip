@@ -73,6 +73,8 @@ static int validate_forward(const fr_forward_args *a)
 	{ set_error("packed_geom, packed_colour and packed_cull go together"); return FR_ERR_INVALID; }
 	if (a->packed_geom && (!has_sr || !a->shs || a->colors_precomp || a->M != (fov ? 15 : 16)))
 	{ set_error("the packed model needs scales + rotations and shs with all 16 coefficients (M=%d)", a->M); return FR_ERR_INVALID; }
+	if (a->raw_activations && (is_fov(a->variant) || !has_sr || a->packed_geom))
+	{ set_error("raw_activations: plain variants with scales + rotations, without the packed layout"); return FR_ERR_INVALID; }
 	if (has_stats(a->variant) && (!a->gaussians_count || !a->contributions)) { set_error("this variant needs gaussians_count and contributions"); return FR_ERR_INVALID; }
 	if (a->variant == FR_VARIANT_PCHECK_OBB_LWMC && !a->loss_map) { set_error("pcheck_obb_loss_weighted_max_count needs loss_map"); return FR_ERR_INVALID; }
 	return FR_OK;
@@ -285,11 +287,17 @@ int fr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float *img, const 
 	return launch_l1_ssim_forward(C, H, W, img, target, dmaps, partials, (hipStream_t)stream);
 }
 
+int fr_l1_ssim_finish(int32_t C, int32_t H, int32_t W, const float *partials, float lambda_dssim, float *out3, void *stream)
+{
+	if (C <= 0 || H <= 0 || W <= 0 || C > 65535 || !partials || !out3) { set_error("bad l1_ssim_finish arguments"); return FR_ERR_INVALID; }
+	return launch_l1_ssim_finish((int)fr_l1_ssim_blocks(C, H, W), (double)C * H * W, partials, lambda_dssim, out3, (hipStream_t)stream);
+}
+
 int fr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float *img, const float *target, const float *dmaps, float w_l1, float w_ssim,
-	float *dL_dimg, void *stream)
+	const float *grad_scale, float *dL_dimg, void *stream)
 {
 	if (C <= 0 || H <= 0 || W <= 0 || C > 65535 || !img || !target || !dmaps || !dL_dimg) { set_error("bad l1_ssim_backward arguments"); return FR_ERR_INVALID; }
-	return launch_l1_ssim_backward(C, H, W, img, target, dmaps, w_l1, w_ssim, dL_dimg, (hipStream_t)stream);
+	return launch_l1_ssim_backward(C, H, W, img, target, dmaps, w_l1, w_ssim, grad_scale, dL_dimg, (hipStream_t)stream);
 }
 
 int fr_backward(const fr_backward_args *a)
@@ -303,6 +311,7 @@ int fr_backward(const fr_backward_args *a)
 	{ set_error("missing gradient output pointer"); return FR_ERR_INVALID; }
 	if (a->shs && !a->dL_dsh) { set_error("dL_dsh is null"); return FR_ERR_INVALID; }
 	if (a->shs_rest && (!a->shs || !a->dL_dsh_rest)) { set_error("shs_rest needs shs and dL_dsh_rest"); return FR_ERR_INVALID; }
+	if (a->raw_activations && a->cov3D_precomp) { set_error("raw_activations needs scales + rotations"); return FR_ERR_INVALID; }
 	return launch_backward(a);
 }
 

@@ -260,6 +260,7 @@ struct BwdPreArgs {
 	float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscale, *dL_drot;
 	const uint32_t *vis_list;  // forward's compact list of projected Gaussians
 	const uint32_t *vis_count; // its length (device)
+	int raw;                   // dL_dscale / dL_drot / dL_dopacity w.r.t. the model's raw parameters (fr_backward_args.raw_activations)
 };
 
 struct V3 { float x, y, z; };
@@ -319,6 +320,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	const float g_px = ac0.w, g_py = ac1.x;           // d / d mean2D
 	const float gA = ac1.y, gB = ac1.z, gC = ac1.w;   // d / d conic (gB: half the off-diagonal derivative)
 	a.dL_dmean2D[3 * (size_t)idx] = g_px; a.dL_dmean2D[3 * (size_t)idx + 1] = g_py;
+	// (raw parameters: through the sigmoid, o (1 - o), and below through exp and the normalisation -- what k_activate_bwd does
+	// for all P Gaussians, here only for the rows that are not zero anyway)
 	a.dL_dopacity[idx] = ac2.x;
 	if (a.dL_dcolor != nullptr) { a.dL_dcolor[3 * (size_t)idx] = g_col[0]; a.dL_dcolor[3 * (size_t)idx + 1] = g_col[1]; a.dL_dcolor[3 * (size_t)idx + 2] = g_col[2]; }
 	if (a.dL_dconic != nullptr) { a.dL_dconic[4 * (size_t)idx] = gA; a.dL_dconic[4 * (size_t)idx + 1] = gB; a.dL_dconic[4 * (size_t)idx + 3] = gC; }
@@ -338,7 +341,9 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	const V3 u1 = axpy3(j11, Ry, { j12 * Rz.x, j12 * Rz.y, j12 * Rz.z });
 	// H = -Q Ghat Q with the conic Q the forward pass stored
 	const float4 rc0 = a.rec[3 * (size_t)idx];
-	const float qa = rc0.z, qb = rc0.w, qc = a.rec[3 * (size_t)idx + 1].x;
+	const float4 rc1 = a.rec[3 * (size_t)idx + 1]; // (conic c, opacity, ...)
+	const float qa = rc0.z, qb = rc0.w, qc = rc1.x;
+	if (a.raw) a.dL_dopacity[idx] = ac2.x * rc1.y * (1.0f - rc1.y);
 	const float k00 = qa * gA + qb * gB, k01 = qa * gB + qb * gC, k10 = qb * gA + qc * gB, k11 = qb * gB + qc * gC; // Q Ghat
 	const float detq = qa * qc - qb * qb;                     // = 1 / det M
 	const float guard = -1.0f / (1.0f + 0.0000001f * detq * detq); // -(det^2 / (det^2 + 1e-7)), backward.cu:190
@@ -481,6 +486,18 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		gq.y = 2.f * (y * p01 + z * p02 + r * a12) - 4.f * x * (D[1].y + D[2].z);
 		gq.z = 2.f * (x * p01 + r * a20 + z * p12) - 4.f * y * (D[0].x + D[2].z);
 		gq.w = 2.f * (r * a01 + x * p02 + y * p12) - 4.f * z * (D[0].x + D[1].y);
+		if (a.raw && stash)
+		{
+			// d exp(raw) = scale; d (v / |v|) = (g - u (u . g)) / |v| with u the unit quaternion of the forward pass
+			gs[0] *= st0.w; gs[1] *= st1.x; gs[2] *= st1.y;
+			const float inv = a.acc[4 * (size_t)slot + 3].x;
+			if (inv > 0.f)
+			{
+				const float along = q.x * gq.x + q.y * gq.y + q.z * gq.z + q.w * gq.w;
+				gq = make_float4((gq.x - q.x * along) * inv, (gq.y - q.y * along) * inv, (gq.z - q.z * along) * inv, (gq.w - q.w * along) * inv);
+			}
+			else gq = make_float4(gq.x * -inv, gq.y * -inv, gq.z * -inv, gq.w * -inv); // clamped denominator: x / 1e-12
+		}
 		a.dL_dscale[3 * (size_t)idx] = gs[0]; a.dL_dscale[3 * (size_t)idx + 1] = gs[1]; a.dL_dscale[3 * (size_t)idx + 2] = gs[2];
 		((float4 *)a.dL_drot)[idx] = gq;
 	}
@@ -570,7 +587,7 @@ int launch_backward(const fr_backward_args *a)
 	p.radii = a->radii; p.rec = geom.rec; p.cov3D_ws = geom.cov3D; p.acc = geom.acc;
 	p.dL_dmean2D = a->dL_dmean2D; p.dL_dconic = a->dL_dconic; p.dL_dcolor = a->dL_dcolor; p.dL_dopacity = a->dL_dopacity;
 	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dsh_rest = a->dL_dsh_rest; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
-	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1;
+	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1; p.raw = a->raw_activations;
 	const int pblocks = (a->P + 255) / 256;
 	hipLaunchKernelGGL(k_preprocess_bwd, dim3(pblocks < 2048 ? pblocks : 2048), dim3(256), 0, stream, p);
 	int rc2 = check_launch("preprocess_bwd", stream, a->debug);

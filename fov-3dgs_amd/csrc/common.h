@@ -355,6 +355,19 @@ __device__ __forceinline__ bool band_reaches(int w, int tx, int ty, float gx, fl
 void set_error(const char *fmt, ...);
 int check_launch(const char *what, hipStream_t stream, bool debug);
 
+// GaussianModel's activations (scene/gaussian_model.py:200-240) as the kernels apply them: k_activate_fwd as a pass of its
+// own, k_project / k_bin on the fly when the caller hands over raw parameters (fr_forward_args.raw_activations).
+__device__ __forceinline__ float act_scale(float raw) { return expf(raw); }
+__device__ __forceinline__ float act_opacity(float raw) { return 1.0f / (1.0f + expf(-raw)); }
+__device__ __forceinline__ float4 act_rotation(float4 v, float *inv_norm = nullptr)
+{
+	const float n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+	const float d = fmaxf(n, 1e-12f);
+	// for the backward pass: 1 / |v|, negative (-1e12) where the denominator was clamped (no projection term there)
+	if (inv_norm) *inv_norm = n > 1e-12f ? 1.0f / n : -1e12f;
+	return make_float4(v.x / d, v.y / d, v.z / d, v.w / d);
+}
+
 // stage launchers (implemented in the .hip files)
 struct FwdCtx {
 	fr_forward_args *a;
@@ -380,8 +393,9 @@ int launch_pack_geom(int P, const float *means3D, const float *scales, const flo
 int launch_pack_cull(int P, const float *means3D, const float *scales, const float *rotations, float *out, hipStream_t stream);
 int launch_pack_colour(int P, const float *shs, const float *shs_rest, const float *shs_dcs, float *out, hipStream_t stream);
 int launch_l1_ssim_forward(int C, int H, int W, const float *x, const float *y, float *dmaps, float *partials, hipStream_t stream);
+int launch_l1_ssim_finish(int nblocks, double n, const float *partials, float lam, float *out3, hipStream_t stream);
 int launch_l1_ssim_backward(int C, int H, int W, const float *x, const float *y, const float *dmaps, float w_l1, float w_ssim,
-	float *dL_dx, hipStream_t stream);
+	const float *grad_scale, float *dL_dx, hipStream_t stream);
 int launch_activate_forward(int P, const float *rs, const float *rq, const float *ro, float *s, float *q, float *o, hipStream_t stream);
 int launch_activate_backward(int P, const float *rs, const float *rq, const float *ro, const float *gs, const float *gq, const float *go,
 	float *ds, float *dq, float *dop, hipStream_t stream);

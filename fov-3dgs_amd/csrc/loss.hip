@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) k_l1_ssim_fwd(int C, int H, int W, const 
 }
 
 __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int C, int H, int W, const float *__restrict__ x, const float *__restrict__ y,
-	const float *__restrict__ dmaps, float w_l1, float w_ssim, float *__restrict__ dL_dx)
+	const float *__restrict__ dmaps, float w_l1, float w_ssim, const float *__restrict__ grad_scale, float *__restrict__ dL_dx)
 {
 	__shared__ float sm[3][FR_LOSS_SH][FR_LOSS_SW + 1];
 	__shared__ float hs[3][FR_LOSS_SH][FR_LOSS_TW + 1];
@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int C, int H, int W, const 
 		}
 	}
 	const int px = bx + tx;
+	const float gs = grad_scale ? *grad_scale : 1.0f; // the loss' upstream gradient, still on the device
 #pragma unroll
 	for (int o = 0; o < 2; o++)
 	{
@@ -195,7 +196,8 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int C, int H, int W, const 
 		const float xv = x[oo], yv = y[oo];
 		const float d = xv - yv;
 		const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-		dL_dx[oo] = w_l1 * sgn + w_ssim * (acc[o][0] + 2.0f * xv * acc[o][1] + yv * acc[o][2]);
+		const float g = w_l1 * sgn + w_ssim * (acc[o][0] + 2.0f * xv * acc[o][1] + yv * acc[o][2]);
+		dL_dx[oo] = grad_scale ? g * gs : g;
 	}
 }
 
@@ -206,11 +208,40 @@ int launch_l1_ssim_forward(int C, int H, int W, const float *x, const float *y, 
 	return check_launch("l1_ssim_forward", stream, false);
 }
 
+// The per-tile partial sums -> (loss, l1, ssim), one workgroup: every thread adds its stride of the partials in double,
+// the 1024 sums are added in a fixed tree (no atomics: the same bits on every run). Replaces a reduction, two divisions,
+// two conversions and four scalar kernels of the host framework (~60 us of launches for ~100 KB of data).
+__global__ void __launch_bounds__(1024) k_l1_ssim_finish(int nblocks, double n, const float *__restrict__ partials, float lam, float *__restrict__ out3)
+{
+	__shared__ double s0[1024], s1[1024];
+	double a = 0.0, b = 0.0;
+	for (int i = threadIdx.x; i < nblocks; i += 1024) { a += (double)partials[2 * i]; b += (double)partials[2 * i + 1]; }
+	s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+	__syncthreads();
+	for (int off = 512; off > 0; off >>= 1)
+	{
+		if ((int)threadIdx.x < off) { s0[threadIdx.x] += s0[threadIdx.x + off]; s1[threadIdx.x] += s1[threadIdx.x + off]; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+	{
+		const float l1 = (float)(s0[0] / n), ss = (float)(s1[0] / n);
+		out3[0] = (1.0f - lam) * l1 + lam * (1.0f - ss);
+		out3[1] = l1; out3[2] = ss;
+	}
+}
+
+int launch_l1_ssim_finish(int nblocks, double n, const float *partials, float lam, float *out3, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, stream, nblocks, n, partials, lam, out3);
+	return check_launch("l1_ssim_finish", stream, false);
+}
+
 int launch_l1_ssim_backward(int C, int H, int W, const float *x, const float *y, const float *dmaps, float w_l1, float w_ssim,
-	float *dL_dx, hipStream_t stream)
+	const float *grad_scale, float *dL_dx, hipStream_t stream)
 {
 	const dim3 grid((W + FR_LOSS_TW - 1) / FR_LOSS_TW, (H + FR_LOSS_TH - 1) / FR_LOSS_TH, C);
-	hipLaunchKernelGGL(k_l1_ssim_bwd, grid, dim3(256), 0, stream, C, H, W, x, y, dmaps, w_l1, w_ssim, dL_dx);
+	hipLaunchKernelGGL(k_l1_ssim_bwd, grid, dim3(256), 0, stream, C, H, W, x, y, dmaps, w_l1, w_ssim, grad_scale, dL_dx);
 	return check_launch("l1_ssim_backward", stream, false);
 }
 

@@ -253,6 +253,7 @@ struct PreArgs {
 	uint32_t *tile_count;
 	uint32_t *hist; // [blocks][T] per-workgroup tile histograms (LDSH)
 	int write_cov3D; // keep the 3D covariances for the backward pass (training variants only)
+	int raw;         // scales / rotations / opacities are raw parameters: activate on the fly (fr_forward_args.raw_activations)
 };
 
 // Projection of one Gaussian: everything up to the tile rectangle.
@@ -630,6 +631,15 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		if (chunk < nchunks && idx < a.P)
 		{
 			if (PACKED) maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * cur.sc[0], cur.hl, wn2);
+			else if (!FOV && a.raw)
+			{
+				// raw parameters: exp is monotone, so the largest scale is exp(largest raw scale) -- one exp instead of
+				// three --, and the normalised quaternion is a unit one up to rounding (rho_unit's factor: 1 + 4 vv eps). (The
+				// rotations are still fetched: not reading them here takes 20 us off this kernel and puts 45 us on k_bin, which
+				// then finds their lines cold.)
+				const float smax = act_scale(fmaxf(cur.sc[0], fmaxf(cur.sc[1], cur.sc[2])));
+				maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * (smax * smax) * 1.00001f, cur.hl, wn2);
+			}
 			else maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
 			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
 		}
@@ -862,7 +872,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		float4 *rec = a.geom.rec + 3 * (size_t)idx;
 		if (LEVELCOL) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
-		else rec[1] = make_float4(conic_c, PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx], rgb[0], rgb[1]);
+		else rec[1] = make_float4(conic_c, PACKED ? a.packed_geom[16 * (size_t)idx + 12] : ((!FOV && a.raw) ? act_opacity(a.opacities[idx]) : a.opacities[idx]), rgb[0], rgb[1]);
 		// third part: item = where the backward pass keeps this Gaussian's sums; the shared-model foveated variant (no
 		// backward, no clamp bits needed) carries the Gaussian's highest level there instead
 		if (FOV && !LEVELCOL) rec[2] = make_float4(rgb[2], depth, hl, 0.0f);
@@ -914,6 +924,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	float hl = 0, lowest = 0, highest = 0;
 	bool be_blend = false, boxtest = false;
 	RawGaussian w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0);
+	float inv_qnorm = 1.0f;
 	if (item < V)
 	{
 		// the candidate's full projection (covariance chain, conic, radius: forward.cu:155-262), its OBB axes and
@@ -948,15 +959,23 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 #pragma unroll
 				for (int i = 0; i < 3; i++) w.sc[i] = a.scales[3 * (size_t)idx + i];
 				w.q = ((const float4 *)a.rotations)[idx];
+				if (!FOV && a.raw)
+				{
+#pragma unroll
+					for (int i = 0; i < 3; i++) w.sc[i] = act_scale(w.sc[i]);
+					w.q = act_rotation(w.q, &inv_qnorm);
+				}
 			}
 			if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
 		}
 		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q, a.write_cov3D ? (float4 *)a.geom.cov3D + 4 * (size_t)item : nullptr);
 		if (a.write_cov3D)
 		{
-			// the backward pass adds into this entry's row of gradient sums: cleared here, in list order (coalesced)
+			// the backward pass adds into this entry's row of gradient sums: cleared here, in list order (coalesced);
+			// the last quarter is not summed into: it carries 1 / |raw quaternion| to the backward pass (raw parameters)
 			float4 *ac = a.geom.acc + 4 * (size_t)item;
-			ac[0] = ac[1] = ac[2] = ac[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+			ac[0] = ac[1] = ac[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+			ac[3] = make_float4(inv_qnorm, 0.f, 0.f, 0.f);
 		}
 		if (pr.alive)
 		{
@@ -1474,7 +1493,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 	p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
 	p.packed_geom = a->packed_geom; p.packed_colour = a->packed_colour; p.packed_cull = a->packed_cull;
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.lv_bbox = c.img.lv_bbox; p.T = c.T;
-	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist;
+	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist; p.raw = a->raw_activations;
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
 	return p;
 }

@@ -47,8 +47,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     means3D = xyz
     means2D = screenspace_points
-    act = getattr(pc, "get_activated", None)  # extension: the three activations as one fused pass (activations.py)
-    if act is not None:
+    # extensions of this package, picked up when the model offers them: the RAW parameters (the rasterizer applies exp /
+    # normalize / sigmoid itself and returns the gradients w.r.t. them: no pass over all P Gaussians on either side of
+    # the step); else the three activations as one fused pass (activations.py); else the reference's three getters
+    raw = getattr(pc, "get_raw_activation_params", None) if (packed is None and not masking) else None
+    act = getattr(pc, "get_activated", None) if raw is None else None
+    if raw is not None:
+        scales, rotations, opacity = raw
+    elif act is not None:
         scales, rotations, opacity = act
     else:
         opacity = pc.get_opacity
@@ -66,6 +72,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if starter is not None:
         starter.record()
     extra = {} if packed is None else {"packed": packed}
+    if raw is not None:
+        extra["raw_activations"] = True
     if cuda_type == "pcheck_obb_loss_weighted_max_count":
         out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,
                          scales=scales, rotations=rotations, cov3D_precomp=None, loss_map=loss_map, **extra)

@@ -30,29 +30,37 @@ def _chw(t, name):
     return t.contiguous().float()
 
 
-def _forward(img, gt, want_maps):
+def _forward(img, gt, want_maps, lam=0.0):
+    """-> (out3 = device tensor (loss, l1, ssim), dmaps): the per-tile sums are added up on the device (fr_l1_ssim_finish:
+    double, fixed order, no float atomics -- deterministic), no scalar kernels of the host framework."""
     lib = _native.load()
     C, H, W = img.shape
     nb = lib.fr_l1_ssim_blocks(C, H, W)
     partials = torch.empty((nb, 2), dtype=torch.float32, device=img.device)
+    out3 = torch.empty((3,), dtype=torch.float32, device=img.device)
     dmaps = torch.empty((3, C, H, W), dtype=torch.float32, device=img.device) if want_maps else None
     with torch.cuda.device(img.device):
+        stream = torch.cuda.current_stream(img.device).cuda_stream
         rc = lib.fr_l1_ssim_forward(C, H, W, img.data_ptr(), gt.data_ptr(), dmaps.data_ptr() if want_maps else None,
-                                    partials.data_ptr(), torch.cuda.current_stream(img.device).cuda_stream)
+                                    partials.data_ptr(), stream)
+        if rc == 0:
+            rc = lib.fr_l1_ssim_finish(C, H, W, partials.data_ptr(), float(lam), out3.data_ptr(), stream)
     if rc != 0:
         raise RuntimeError(f"fovraster l1_ssim_forward failed ({rc}): {_native.last_error()}")
-    sums = partials.sum(0, dtype=torch.float64)  # deterministic: per-tile sums, no float atomics
-    n = float(C * H * W)
-    return (sums[0] / n).float(), (sums[1] / n).float(), dmaps
+    return out3, dmaps
 
 
-def _backward(img, gt, dmaps, w_l1, w_ssim):
+def _backward(img, gt, dmaps, w_l1, w_ssim, g=None):
+    """g: the upstream gradient of the loss as a device scalar (read by the kernel), or None = 1"""
     lib = _native.load()
     C, H, W = img.shape
     grad = torch.empty_like(img)
+    if g is not None:
+        g = g.detach().reshape(-1)[:1].to(device=img.device, dtype=torch.float32).contiguous()
     with torch.cuda.device(img.device):
         rc = lib.fr_l1_ssim_backward(C, H, W, img.data_ptr(), gt.data_ptr(), dmaps.data_ptr(), float(w_l1), float(w_ssim),
-                                     grad.data_ptr(), torch.cuda.current_stream(img.device).cuda_stream)
+                                     None if g is None else g.data_ptr(), grad.data_ptr(),
+                                     torch.cuda.current_stream(img.device).cuda_stream)
     if rc != 0:
         raise RuntimeError(f"fovraster l1_ssim_backward failed ({rc}): {_native.last_error()}")
     return grad
@@ -67,14 +75,14 @@ class _L1SSIM(torch.autograd.Function):
         if x.shape != y.shape:
             raise RuntimeError(f"image {tuple(x.shape)} and gt {tuple(y.shape)} differ")
         need_x, need_y = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        l1, ss, dmaps = _forward(x, y, need_x)
+        out3, dmaps = _forward(x, y, need_x, 0.0 if lam is None else lam)
         ctx.lam, ctx.shapes, ctx.dtypes = lam, (img.shape, gt.shape), (img.dtype, gt.dtype)
         # both losses are symmetric in their arguments (as the reference's l1_loss / ssim are differentiable in both):
         # the gradient w.r.t. gt is the same kernel with the roles swapped, from a second set of derivative maps
-        dmaps_y = _forward(y, x, True)[2] if need_y else None
+        dmaps_y = _forward(y, x, True)[1] if need_y else None
         empty = x.new_empty(0)
         ctx.save_for_backward(x, y, dmaps if need_x else empty, dmaps_y if need_y else empty)
-        return ss if lam is None else (1.0 - lam) * l1 + lam * (1.0 - ss)
+        return out3[2] if lam is None else out3[0]  # views of the device result: (loss, l1, ssim)
 
     @staticmethod
     def backward(ctx, g):
@@ -83,9 +91,9 @@ class _L1SSIM(torch.autograd.Function):
         w_l1, w_ssim = (0.0, 1.0 / n) if ctx.lam is None else ((1.0 - ctx.lam) / n, -ctx.lam / n)
         gx = gy = None
         if ctx.needs_input_grad[0]:
-            gx = (_backward(x, y, dmaps, w_l1, w_ssim) * g).reshape(ctx.shapes[0]).to(ctx.dtypes[0])
+            gx = _backward(x, y, dmaps, w_l1, w_ssim, g).reshape(ctx.shapes[0]).to(ctx.dtypes[0])
         if ctx.needs_input_grad[1]:
-            gy = (_backward(y, x, dmaps_y, w_l1, w_ssim) * g).reshape(ctx.shapes[1]).to(ctx.dtypes[1])
+            gy = _backward(y, x, dmaps_y, w_l1, w_ssim, g).reshape(ctx.shapes[1]).to(ctx.dtypes[1])
         return gx, gy, None
 
 

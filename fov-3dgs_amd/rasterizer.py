@@ -188,7 +188,7 @@ _stage_events_hook = None
 
 def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                     shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
-                    sh_rest=None, packed=None, cur_level=0.0):
+                    sh_rest=None, packed=None, cur_level=0.0, raw_activations=False):
     """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease)
     persistent=True: the workspaces are the per-device grow-only set (valid until the next call); otherwise they
     stay reserved for as long as `lease` (the last element) is referenced."""
@@ -226,6 +226,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         a.scale_modifier = float(rs.scale_modifier)
         a.gaze_x, a.gaze_y, a.alpha = float(gaze[0]), float(gaze[1]), float(alpha)
         a.cur_level = float(cur_level)
+        a.raw_activations = int(bool(raw_activations))
         a.stream = torch.cuda.current_stream(dev).cuda_stream
         put("background", rs.bg)
         put("means3D", means3D)
@@ -264,7 +265,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
 
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                      grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None,
-                     want_cov3D_grad=False, want_color_grad=False):
+                     want_cov3D_grad=False, want_color_grad=False, raw_activations=False):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations[, dL_dsh_rest])
     (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3]; dL_dcov3D / dL_dcolors are None unless
     cov3Ds_precomp / colors_precomp are given or want_cov3D_grad / want_color_grad)"""
@@ -302,6 +303,7 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
         if P != 0:
             a.variant, a.P, a.D, a.M, a.R = variant, P, int(rs.sh_degree), M, int(num_rendered)
             a.W, a.H, a.debug = W, H, int(bool(rs.debug))
+            a.raw_activations = int(bool(raw_activations))
             a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
             a.stream = torch.cuda.current_stream(dev).cuda_stream
             put("background", rs.bg)
@@ -353,7 +355,9 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    raster_settings, loss_map=None, sh_rest=None, packed=None, grad_mode=True):
+                    raster_settings, loss_map=None, sh_rest=None, packed=None, grad_mode=True, raw_activations=False):
+            # raw_activations (extension): opacities / scales / rotations are the model's RAW parameters, the kernels apply
+            # sigmoid / exp / normalize themselves and the backward pass returns the gradients w.r.t. the raw parameters
             # sh_rest (extension): the SH coefficients as the two tensors a model stores, sh = features_dc
             # [P,1,3], sh_rest = features_rest [P,M-1,3]; saves the torch.cat of get_features and its backward
             args = (variant_id, raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations,
@@ -368,16 +372,22 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 if loss_map is None or loss_map.numel() < raster_settings.image_height * raster_settings.image_width:
                     raise Exception("loss_map with at least image_height*image_width values is required")
             ctx.split_sh = sh_rest is not None
+            ctx.raw_activations = bool(raw_activations)
+            # no zero tensors for the gradients of the outputs nobody differentiates (radii, counts, contributions:
+            # three [P] fills per step otherwise)
+            ctx.set_materialize_grads(False)
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
                 try:
-                    res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed)
+                    res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed,
+                                          raw_activations=raw_activations)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed)
+                res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed,
+                                          raw_activations=raw_activations)
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = res[:6]
             if not keep_ws:  # nothing will call backward: do not pin the shared workspaces
                 geomBuffer = binningBuffer = imgBuffer = torch.empty(0, dtype=torch.uint8, device=means3D.device)
@@ -398,6 +408,8 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             if not has_backward:
                 # the reference's inference-only extension exports no backward entry point
                 raise RuntimeError("this rasterizer variant is inference-only (no backward in the reference)")
+            if grad_out_color is None:  # the image took no part in the loss
+                return (None,) * 14
             rs = ctx.raster_settings
             (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
              geomBuffer, binningBuffer, imgBuffer, sh_rest) = ctx.saved_tensors
@@ -407,24 +419,25 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    res = _backward_native(*args)
+                    res = _backward_native(*args, raw_activations=ctx.raw_activations)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_bw.dump")
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                     raise ex
             else:
-                res = _backward_native(*args)
+                res = _backward_native(*args, raw_activations=ctx.raw_activations)
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations) = res[:8]
             grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                      grad_rotations, grad_cov3Ds_precomp, None)
-            return grads + (None, res[8] if ctx.split_sh else None, None, None)  # loss_map, sh_rest, packed, grad_mode
+            # loss_map, sh_rest, packed, grad_mode, raw_activations
+            return grads + (None, res[8] if ctx.split_sh else None, None, None, None)
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                            raster_settings, loss_map=None, sh_rest=None, packed=None):
+                            raster_settings, loss_map=None, sh_rest=None, packed=None, raw_activations=False):
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                          cov3Ds_precomp, raster_settings, loss_map if takes_loss_map else None, sh_rest, packed,
-                                         torch.is_grad_enabled())
+                                         torch.is_grad_enabled(), raw_activations)
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):
@@ -436,13 +449,15 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 return _mark_visible(positions, self.raster_settings)
 
         def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                    cov3D_precomp=None, loss_map=None, packed=None):
+                    cov3D_precomp=None, loss_map=None, packed=None, raw_activations=False):
             raster_settings = self.raster_settings
             if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
                 raise Exception('Please provide excatly one of either SHs or precomputed colors!')
             if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                     ((scales is not None or rotations is not None) and cov3D_precomp is not None):
                 raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            if raw_activations and (cov3D_precomp is not None or packed is not None):
+                raise Exception('raw_activations needs the scale/rotation pair and no packed model')
             empty = torch.Tensor([])
             shs_rest = None
             if isinstance(shs, (tuple, list)):  # extension: (features_dc [P,1,3], features_rest [P,M-1,3])
@@ -453,7 +468,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             rotations = empty if rotations is None else rotations
             cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings, loss_map, shs_rest, packed)
+                                       cov3D_precomp, raster_settings, loss_map, shs_rest, packed, raw_activations)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
 

@@ -50,6 +50,16 @@ class GaussianCloud:
             return activate(self._scaling, self._rotation, self._opacity)
         return self.get_scaling, self.get_rotation, self.get_opacity
 
+    # opt-in (set `fuse_activations = True` on the cloud): hand the raw parameters to the rasterizer, which applies the
+    # activations in its kernels (rasterizer.GaussianRasterizer(..., raw_activations=True)); GPU only
+    fuse_activations = False
+
+    @property
+    def get_raw_activation_params(self):
+        if self.fuse_activations and self._scaling.is_cuda:
+            return self._scaling, self._rotation, self._opacity
+        return None
+
     @property
     def get_features(self):
         return torch.cat((self._features_dc, self._features_rest), dim=1)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 4
+#define FR_ABI_VERSION 5
 
 /* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
  * fov3dgs/gaussian_wrapper.py:11-23) */
@@ -144,6 +144,13 @@ typedef struct fr_forward_args {
 	const float *packed_colour;
 	const float *packed_cull;
 	float cur_level;             /* MMFR: the level (0..3) this call renders */
+	/* optional (variants with one opacity per Gaussian and no levels: ORIGINAL, PCHECK_OBB and the training variants; not
+	 * with cov3D_precomp or the packed layout): `scales`, `rotations` and `opacities` hold the model's RAW parameters
+	 * (log scale, unnormalised quaternion, opacity logit) and the kernels apply GaussianModel's activations themselves
+	 * (exp, x / max(|x|, 1e-12), sigmoid: scene/gaussian_model.py:200-240) -- the same device expressions as
+	 * fr_activate_forward, so the image is bit-identical to activating first. Saves the two streaming passes over all P
+	 * Gaussians around every training step. */
+	int32_t raw_activations;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
@@ -177,6 +184,8 @@ typedef struct fr_backward_args {
 	void **stage_events;         /* optional: 3 event handles around render-backward and preprocess-backward */
 	const float *shs_rest;       /* split SH input, see fr_forward_args.shs_rest ... */
 	float *dL_dsh_rest;          /* ... then dL_dsh is [P,1,3] and dL_dsh_rest [P,M-1,3] */
+	int32_t raw_activations;     /* as in the forward call: dL_dscale / dL_drot / dL_dopacity are then gradients w.r.t. the RAW
+	                              * parameters (what fr_activate_backward would make of them) */
 } fr_backward_args;
 
 int fr_abi_version(void);
@@ -213,12 +222,17 @@ int fr_activate_backward(int32_t P, const float *raw_scaling, const float *raw_r
  *   forward:  partials[b] = (sum |img - target|, sum ssim_map) over tile b (16 x 32 pixels) of one channel,
  *             b < fr_l1_ssim_blocks(C,H,W); the caller adds them up (l1 = sum0 / (C H W), ssim = sum1 / (C H W)).
  *             dmaps [3,C,H,W] (optional, NULL = value only) keeps what the backward needs.
- *   backward: dL_dimg = w_l1 * sign(img - target) + w_ssim * d(sum ssim_map)/d img, written in full.
- *             For loss = (1-l) L1 + l (1 - SSIM) with upstream gradient g: w_l1 = g (1-l) / (C H W), w_ssim = -g l / (C H W). */
+ *   finish:   out[0..2] = (loss, l1, ssim) from the partials on the device (sums in double, in block order: the same
+ *             numbers on every run): l1 = sum0 / (C H W), ssim = sum1 / (C H W), loss = (1-lambda) l1 + lambda (1 - ssim).
+ *   backward: dL_dimg = s (w_l1 * sign(img - target) + w_ssim * d(sum ssim_map)/d img), written in full; s = *grad_scale
+ *             (a DEVICE scalar: the upstream gradient of the loss, read by the kernel -- no host round trip, no extra
+ *             pass over the image) or 1 when grad_scale is NULL.
+ *             For loss = (1-l) L1 + l (1 - SSIM): w_l1 = (1-l) / (C H W), w_ssim = -l / (C H W). */
 int64_t fr_l1_ssim_blocks(int32_t C, int32_t H, int32_t W);
 int fr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float *img, const float *target, float *dmaps, float *partials, void *stream);
+int fr_l1_ssim_finish(int32_t C, int32_t H, int32_t W, const float *partials, float lambda_dssim, float *out3, void *stream);
 int fr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float *img, const float *target, const float *dmaps, float w_l1, float w_ssim,
-	float *dL_dimg, void *stream);
+	const float *grad_scale, float *dL_dimg, void *stream);
 
 /* Bytes fr_forward will request for the geometry / image workspaces (P, W, H dependent) and for the
  * binning workspace given a number of instances; lets a caller pre-size persistent buffers. */

@@ -281,6 +281,54 @@ def test_autograd_module_end_to_end():
     check_grad(cloud._features_rest.grad.cpu().numpy(), og["dL_dsh"][:, 1:], "f_rest")
 
 
+@pytest.mark.parametrize("variant", ["original", "pcheck_obb_sum"])
+def test_raw_parameters_in_the_kernels_match_activate_then_render(variant):
+    """fr_forward_args.raw_activations: exp / normalize / sigmoid applied inside the kernels give the image of
+    activating first bit for bit (same device expressions), and the backward pass returns the gradients w.r.t. the raw
+    parameters that the activation pass (itself checked against torch in tests/test_loss.py) would return."""
+    _need_gpu()
+    from fov3dgs_amd.activations import activate
+    from fov3dgs_amd.gaussian_wrapper import get_gs_rasterizer
+    from fov3dgs_amd.rasterizer import GaussianRasterizationSettings
+    dev = "cuda:0"
+    cam = syn.camera_1k(200, 136).to(dev)
+    rs = GaussianRasterizationSettings(136, 200, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                                       torch.tensor([0.1, 0.0, 0.2], device=dev), 1.0, cam.world_view_transform,
+                                       cam.full_proj_transform, 3, cam.camera_center, False, False)
+    cuda_type = {"original": "original", "pcheck_obb_sum": "pcheck_obb_sum"}[variant]
+    w = None
+    res = []
+    for raw in (False, True):
+        cloud = syn.scene_1k(P=2500, seed=11).to(dev)
+        with torch.no_grad():
+            cloud._rotation.mul_(torch.linspace(0.3, 4.0, 2500, device=dev).unsqueeze(1))  # far from unit length
+        cloud.requires_grad_(True)
+        if raw:
+            s, q, o = cloud._scaling, cloud._rotation, cloud._opacity
+        else:
+            s, q, o = activate(cloud._scaling, cloud._rotation, cloud._opacity)
+        out = get_gs_rasterizer(cuda_type, rs)(means3D=cloud.get_xyz, means2D=torch.zeros_like(cloud.get_xyz, requires_grad=True),
+                                               opacities=o, shs=cloud.get_features_split, scales=s, rotations=q,
+                                               **({"raw_activations": True} if raw else {}))
+        img = out[0]
+        if w is None:
+            w = torch.randn_like(img)
+        (img * w).sum().backward()
+        res.append(dict(img=img.detach().cpu().numpy(), radii=out[1].cpu().numpy(), xyz=cloud._xyz.grad.cpu().numpy(),
+                        scaling=cloud._scaling.grad.cpu().numpy(), rotation=cloud._rotation.grad.cpu().numpy(),
+                        opacity=cloud._opacity.grad.cpu().numpy(), f_dc=cloud._features_dc.grad.cpu().numpy()))
+    np.testing.assert_array_equal(res[0]["img"], res[1]["img"])
+    np.testing.assert_array_equal(res[0]["radii"], res[1]["radii"])
+    assert (res[0]["radii"] > 0).sum() > 500
+    for name in ("xyz", "scaling", "rotation", "opacity", "f_dc"):
+        assert np.abs(res[0][name]).max() > 0
+        check_grad(res[1][name], res[0][name], "raw " + name)
+    # the rasterizer refuses the combination it has no kernels for
+    with pytest.raises(Exception):
+        get_gs_rasterizer(cuda_type, rs)(means3D=cloud.get_xyz, means2D=torch.zeros_like(cloud.get_xyz), opacities=cloud._opacity,
+                                         shs=cloud.get_features, cov3D_precomp=torch.zeros(2500, 6, device=dev), raw_activations=True)
+
+
 def test_split_sh_storage_matches_concatenated():
     """fr_forward_args.shs_rest: features_dc / features_rest handed over as stored give the same image (bit for bit:
     same summation order) and the same gradients as the torch.cat'ed [P,16,3] tensor of the reference interface."""

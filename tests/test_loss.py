@@ -83,6 +83,10 @@ def test_hip_losses_match_oracle(shape):
     lu.l1_ssim_loss(x, y, 0.2).backward()
     np.testing.assert_allclose(y.grad.cpu().numpy(), want_gy.numpy(), atol=2e-7 + 1e-5 / a.numel(), rtol=2e-4)
     np.testing.assert_allclose(x.grad.cpu().numpy(), lo.l1_ssim(a, b, 0.2)[3].numpy(), atol=2e-7 + 1e-5 / a.numel(), rtol=2e-4)
+    # an upstream gradient other than 1 reaches the kernel as a device scalar
+    x3 = a.cuda().requires_grad_(True)
+    (lu.l1_ssim_loss(x3, b.cuda(), 0.2) * -2.5).backward()
+    np.testing.assert_allclose(x3.grad.cpu().numpy(), -2.5 * x.grad.cpu().numpy(), atol=1e-9, rtol=1e-6)
     xh = a.cuda().half().requires_grad_(True)   # the gradient comes back in the input's dtype
     lu.l1_ssim_loss(xh, b.cuda(), 0.2).backward()
     assert xh.grad.dtype == torch.float16
