@@ -503,6 +503,24 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	}
 }
 
+// Zero-fill of the gradient tensors: every workgroup takes a contiguous share of every tensor (16-byte stores).
+#define FR_FILL_MAX 12
+#ifndef FR_FILL_BLOCKS
+#define FR_FILL_BLOCKS 1024
+#endif
+struct FillArgs { int n; float *p[FR_FILL_MAX]; size_t words[FR_FILL_MAX]; };
+__global__ void __launch_bounds__(256) k_fill_zero(const FillArgs a)
+{
+	const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+	for (int t = 0; t < a.n; t++)
+	{
+		const size_t quads = a.words[t] / 4, tail = a.words[t] - 4 * quads;
+		float4 *q = (float4 *)a.p[t];
+		for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) q[i] = z;
+		if (blockIdx.x == 0 && threadIdx.x < tail) a.p[t][4 * quads + threadIdx.x] = 0.0f;
+	}
+}
+
 // Grid-stride over the forward pass's visible list: dense waves instead of one thread per Gaussian with ~70 % of the
 // lanes returning immediately. Entries culled after projection (radii reset to 0) are skipped. The rows of all other
 // Gaussians are zero: launch_backward clears the output tensors on a helper stream WHILE k_render_bwd runs (that kernel
@@ -561,12 +579,26 @@ int launch_backward(const fr_backward_args *a)
 			if (hipEventRecord(ax->fork, stream) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess) { (void)hipGetLastError(); ax = nullptr; }
 			else fs = ax->s;
 		}
+		// one kernel for all of them (seven fill commands in a row ran at 2.7 TB/s beside k_render_bwd, the small ones at
+		// 1 TB/s, and outlasted it by 50 us); tensors are 16-byte aligned and their sizes multiples of 4
+		FillArgs fa; fa.n = 0;
 		for (auto &f : fills)
 			if (f.p && f.bytes)
 			{
-				const hipError_t e = hipMemsetAsync(f.p, 0, f.bytes, fs);
-				if (e != hipSuccess) { set_error("hipMemsetAsync(gradient): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
+				if (((uintptr_t)f.p & 15) != 0 || fa.n == FR_FILL_MAX)
+				{
+					const hipError_t e = hipMemsetAsync(f.p, 0, f.bytes, fs);
+					if (e != hipSuccess) { set_error("hipMemsetAsync(gradient): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
+					continue;
+				}
+				fa.p[fa.n] = (float *)f.p; fa.words[fa.n] = f.bytes / 4; fa.n++;
 			}
+		if (fa.n)
+		{
+			hipLaunchKernelGGL(k_fill_zero, dim3(FR_FILL_BLOCKS), dim3(256), 0, fs, fa);
+			const int rcf = check_launch("fill_zero", fs, a->debug);
+			if (rcf) return rcf;
+		}
 		if (ax) (void)hipEventRecord(ax->join, ax->s); // waited for below, after k_render_bwd has been launched
 		if (a->R > 0)
 		{
