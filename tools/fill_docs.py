@@ -12,6 +12,8 @@ vals = {
     "R2_RENDER": f"{st['render']:.3f}", "R2_BLEND_GBS": f"{rf['blend']['achieved'] / 1000:.2f}", "R2_BLEND_FRAC": f"{rf['blend']['frac']:.2f}",
     "R2_NONFOV": f"{ex['nonfov_forward_fps']:.0f}", "R2_TFWD": f"{ex['train_fwd_ms']:.2f}", "R2_TLOSS": f"{ex['train_loss_fwd_ms']:.2f}",
     "R2_TBWD": f"{ex['train_bwd_ms']:.2f}", "R2_TSTEP": f"{ex['train_step_ms']:.2f}", "R2_CPU": f"{d['cpu_baseline']['value']:.2f}",
+    "R2_RAWFWD": f"{ex['train_raw_fwd_ms']:.2f}", "R2_RAWLOSS": f"{ex['train_raw_loss_fwd_ms']:.2f}", "R2_RAWBWD": f"{ex['train_raw_bwd_ms']:.2f}",
+    "R2_RAWSTEP": f"{ex['train_raw_step_ms']:.2f}",
 }
 # numbers sit between invisible markers: <!--R2_VALUE-->1238<!--/-->; a bare R2_VALUE (first fill) gets its markers here
 for name in ("DESIGN.md", "README.md"):
