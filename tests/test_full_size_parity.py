@@ -243,3 +243,34 @@ def test_training_step_full_size(s6m):
         check_grad(g[rows], wg[k][rows], f"{tag} {k}")
     assert touched.sum() > 10_000
     parity_report.record("count", tag + " Gaussians with a gradient from the window", n=int(touched.sum()))
+
+
+def test_raw_parameters_full_size():
+    """fr_forward_args.raw_activations on the S-6M cloud at 1080p: the training variant fed with the model's raw parameters
+    gives the image, radii and statistics of the activate-then-render path bit for bit, and the same gradients (w.r.t. the
+    raw parameters) up to the order of the float atomics."""
+    from fov3dgs_amd.activations import activate
+    from fov3dgs_amd.diff_gaussian_rasterization_pcheck_obb_sum import GaussianRasterizationSettings, GaussianRasterizer
+    dev = "cuda:0"
+    cam = syn.camera_ring(0, 8).to(dev)
+    W, H = cam.image_width, cam.image_height
+    rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev), 1.0,
+                                       cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
+    w = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) - 0.5
+    res = []
+    for raw in (False, True):
+        cloud = syn.scene_bicycle_scale(P=6_000_000, seed=1).to(dev).requires_grad_(True)
+        s, q, o = (cloud._scaling, cloud._rotation, cloud._opacity) if raw else activate(cloud._scaling, cloud._rotation, cloud._opacity)
+        out = GaussianRasterizer(rs)(means3D=cloud.get_xyz, means2D=torch.zeros_like(cloud.get_xyz, requires_grad=True), opacities=o,
+                                     shs=cloud.get_features_split, scales=s, rotations=q, **({"raw_activations": True} if raw else {}))
+        (out[0] * w).sum().backward()
+        res.append(dict(img=out[0].detach(), radii=out[1], count=out[2], contrib=out[3].detach(),
+                        grads={n: getattr(cloud, "_" + n).grad for n in ("xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest")}))
+        del cloud, out, s, q, o
+    a, b = res
+    assert torch.equal(a["img"], b["img"]) and torch.equal(a["radii"], b["radii"]) and torch.equal(a["count"], b["count"])
+    assert int((a["radii"] > 0).sum()) > 1_000_000
+    tol = float((a["contrib"] - b["contrib"]).abs().max()) / (float(a["contrib"].abs().max()) + 1e-12)
+    assert tol < 1e-5, tol  # sums of float atomics
+    for n in a["grads"]:
+        check_grad(b["grads"][n].cpu().numpy(), a["grads"][n].cpu().numpy(), "S-6M raw parameters: " + n)
