@@ -170,14 +170,17 @@ int fr_forward(fr_forward_args *a)
 	// costs ~10 us more of an idle GPU); pageable-copy fallback if that memory cannot be had.
 	// (one such block per host thread and device: the device address of mapped host memory belongs to the device
 	// that was current when it was asked for)
-	struct Pinned { uint32_t *host = nullptr, *dev = nullptr; bool tried = false; };
+	struct Pinned { uint32_t *host = nullptr, *dev = nullptr; int device = -1; };
 	static thread_local Pinned pinned_of[16];
 	int cur_dev = 0;
 	(void)hipGetDevice(&cur_dev);
 	Pinned &pn = pinned_of[cur_dev & 15];
-	if (!pn.tried)
+	if (pn.device != cur_dev)
 	{
-		pn.tried = true;
+		// (a slot is shared by devices 16 apart: whoever calls owns it, the previous owner's block is released)
+		if (pn.host) (void)hipHostFree(pn.host);
+		pn.host = pn.dev = nullptr;
+		pn.device = cur_dev;
 		void *h = nullptr, *d = nullptr;
 		if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess)
 		{ pn.host = (uint32_t *)h; pn.dev = (uint32_t *)d; for (int i = 0; i < 16; i++) pn.host[i] = 0; }
@@ -192,7 +195,7 @@ int fr_forward(fr_forward_args *a)
 	rc = launch_tile_scan(c); if (rc) return rc;
 	mark(FR_STAGE_EMIT);
 
-	uint32_t totals[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	uint32_t totals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	if (!pinned) FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
 	if (pinned && !a->debug)
 	{
@@ -209,13 +212,17 @@ int fr_forward(fr_forward_args *a)
 				if (__atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != frame_seq) { set_error("tile scan did not publish its totals"); return FR_ERR_HIP; }
 			}
 		for (int i = 0; i < 4; i++) totals[i] = v[i];
-		totals[5] = v[5]; totals[6] = v[6];
+		totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7];
 	}
 	else
 	{
 		FR_HIP(hipStreamSynchronize(stream));
-		if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; totals[5] = v[5]; totals[6] = v[6]; }
+		if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7]; }
 	}
+	// reference auxiliary.h:156-160: a point behind the near plane although the caller said the cloud was prefiltered
+	// (there: printf + __trap, which kills the context; here an error code)
+	if (a->prefiltered && totals[7] != 0)
+	{ set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return FR_ERR_PREFILTERED; }
 	if (totals[0] > 0x7fffffffu) { set_error("too many instances (%u)", totals[0]); return FR_ERR_INVALID; }
 	a->num_rendered = (int32_t)totals[0];
 	a->max_tile_instances = (int32_t)totals[1];

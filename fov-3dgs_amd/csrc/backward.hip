@@ -255,7 +255,7 @@ struct BwdPreArgs {
 	const int *radii;
 	const float4 *rec;
 	const float *cov3D_ws;
-	const float4 *acc;         // gradient sums per visible-list entry (k_render_bwd)
+	float4 *acc;               // gradient sums per visible-list entry (k_render_bwd); every row is cleared again once it has been read
 	float *dL_dmean2D, *dL_dconic, *dL_dcolor, *dL_dopacity; // dense [P, .] outputs filled from them (dL_dconic / dL_dcolor optional)
 	float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscale, *dL_drot;
 	const uint32_t *vis_list;  // forward's compact list of projected Gaussians
@@ -316,6 +316,10 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	}
 	// what k_render_bwd summed for this Gaussian
 	const float4 ac0 = a.acc[4 * (size_t)slot], ac1 = a.acc[4 * (size_t)slot + 1], ac2 = a.acc[4 * (size_t)slot + 2];
+	// fr_backward is idempotent (the reference allocates fresh zeros per call, rasterize_points.cu:171-179): the row is read
+	// exactly once per call, so the reader leaves it cleared for a second backward pass over the same forward state
+	// (retain_graph, torch.autograd.grad twice). The last quarter (1 / |raw quaternion|) belongs to the forward pass and stays.
+	a.acc[4 * (size_t)slot] = a.acc[4 * (size_t)slot + 1] = a.acc[4 * (size_t)slot + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
 	const float g_col[3] = { ac0.x, ac0.y, ac0.z };
 	const float g_px = ac0.w, g_py = ac1.x;           // d / d mean2D
 	const float gA = ac1.y, gB = ac1.z, gC = ac1.w;   // d / d conic (gB: half the off-diagonal derivative)
@@ -603,7 +607,12 @@ int launch_backward(const fr_backward_args *a)
 		if (a->R > 0)
 		{
 			const int rc0 = launch_render_bwd(a, geom, img, bin, gx, T, stream);
-			if (rc0) return rc0;
+			if (rc0)
+			{
+				// the fill is still in flight on the helper stream: the caller may free the gradient tensors once we return
+				if (ax) (void)hipStreamWaitEvent(stream, ax->join, 0);
+				return rc0;
+			}
 		}
 		if (ax) (void)hipStreamWaitEvent(stream, ax->join, 0);
 	}

@@ -23,7 +23,7 @@ namespace fr {
 // in the same longest-list-first order, so that the persistent blend waves pull the costliest items first and no
 // workgroup is launched just to find out that its tile has a single level.
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals, uint32_t *tile_order,
-	uint32_t *totals_host, uint32_t seq, const float *tile_blend, uint32_t *render_items)
+	uint32_t *totals_host, uint32_t seq, const float *tile_blend, uint32_t *render_items, const uint32_t *prefilter_flag)
 {
 	__shared__ uint32_t bucket[34];
 	__shared__ uint32_t ibucket[34];
@@ -82,6 +82,8 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		const uint32_t h8 = h4 - bucket[12]; // lists with >= 4096 entries
 		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11]; totals[6] = h8;
 		totals[4] = 0; // chunk counter of k_split_long
+		const uint32_t pf = *prefilter_flag; // k_project: a Gaussian behind the near plane although `prefiltered` was set
+		totals[7] = pf;
 		uint32_t nitems = 0;
 		for (int b = 32; b >= 0; b--) { const uint32_t c = ibucket[b]; ibucket[b] = nitems; nitems += c; }
 		totals[5] = nitems;
@@ -91,7 +93,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count,
 		if (totals_host)
 		{
 			totals_host[0] = carry_s; totals_host[1] = m; totals_host[2] = h4; totals_host[3] = bucket[10] + bucket[11];
-			totals_host[5] = nitems; totals_host[6] = h8;
+			totals_host[5] = nitems; totals_host[6] = h8; totals_host[7] = pf;
 			__threadfence_system();
 			__hip_atomic_store(&totals_host[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
@@ -370,7 +372,8 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 int launch_tile_scan(FwdCtx &c)
 {
 	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals, c.img.tile_order,
-		c.totals_host_dev, c.totals_seq, c.fov_split ? c.img.tile_lv + 4 * (size_t)c.T : (const float *)nullptr, c.img.render_items);
+		c.totals_host_dev, c.totals_seq, c.fov_split ? c.img.tile_lv + 4 * (size_t)c.T : (const float *)nullptr, c.img.render_items,
+		c.geom.slab_ctr);
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 

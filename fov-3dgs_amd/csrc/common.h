@@ -63,7 +63,7 @@ struct GeomWS {
 	                    //      tiles, highest level, -, -); flags: 1 = lands in a tile, 2 = the OBB test applies
 	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity)
 	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8
-	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {-, number of entries in vis_list, ...}; k_bin's eight slab pull
+	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {prefiltered violation flag, number of entries in vis_list, ...}; k_bin's eight slab pull
 	                    // counters live at [32 * (1 + r)], one 128-byte line each
 	uint32_t *vis_list; // [P]  indices of the Gaussians that survive projection (unordered)
 	float4 *crow;       // [3 (P + FR_CROW_PAD)] candidate rows (xyz, scale | scale.yz, rotation.xy | rotation.zw, highest level, index),
@@ -91,8 +91,14 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 	}
 	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + FR_SLAB_CTR_WORDS * sizeof(uint32_t));
 	g.vis_list = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
-	g.crow = (float4 *)(base + off); off = align_up(off + (P + FR_CROW_PAD) * 3 * sizeof(float4));
-	g.vis_src = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
+	// candidate rows: only the foveated variants' cull pass stores them (k_project's ROWS); 52 B per Gaussian the plain and
+	// training frames need not carry
+	g.crow = nullptr; g.vis_src = nullptr;
+	if (is_fov(variant))
+	{
+		g.crow = (float4 *)(base + off); off = align_up(off + (P + FR_CROW_PAD) * 3 * sizeof(float4));
+		g.vis_src = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
+	}
 	g.slab_next = (int32_t *)(base + off); off = align_up(off + ((P + 63) / 64 + 1) * sizeof(int32_t));
 	g.wave_head = (int32_t *)(base + off); off = align_up(off + FR_BIN_BLOCKS * (FR_BIN_THREADS / 64) * sizeof(int32_t));
 	g.bytes = off + 256;
@@ -106,7 +112,7 @@ struct ImageWS {
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
 	uint32_t *lv_bbox;    // [5][FR_LV_BBOX_STRIDE] RF: box of the tiles with tile_min < k as {gx - x0, gy - y0, x1, y1} (0 = empty), k = 0..4
-	uint32_t *totals;     // [8]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, #blend items, #tiles with >= 4096, -}
+	uint32_t *totals;     // [8]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, #blend items, #tiles with >= 4096, prefiltered violation}
 	uint32_t *render_items; // [4T] blend work items, longest lists first: tile << 3 | band | level state << 1 | two-level << 2 (k_tile_scan)
 	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending

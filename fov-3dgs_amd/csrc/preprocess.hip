@@ -254,6 +254,7 @@ struct PreArgs {
 	uint32_t *hist; // [blocks][T] per-workgroup tile histograms (LDSH)
 	int write_cov3D; // keep the 3D covariances for the backward pass (training variants only)
 	int raw;         // scales / rotations / opacities are raw parameters: activate on the fly (fr_forward_args.raw_activations)
+	int prefiltered; // fr_forward_args.prefiltered: a Gaussian behind the near plane is an error (slab_ctr[0] reports it)
 };
 
 // Projection of one Gaussian: everything up to the tile rectangle.
@@ -642,6 +643,8 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 			}
 			else maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
 			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
+			// auxiliary.h:156-160: the reference traps on a near-culled point of a cloud declared prefiltered
+			if (a.prefiltered && !maybe && (vm[2] * cur.p[0] + vm[6] * cur.p[1] + vm[10] * cur.p[2] + vm[14]) <= 0.2f) atomicOr(a.geom.slab_ctr, 1u);
 		}
 		const unsigned long long m = __ballot(maybe);
 		if (maybe)
@@ -1495,6 +1498,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 	p.shs_dcs = a->shs_dcs; p.highest_levels = a->highest_levels; p.tile_lv = c.img.tile_lv; p.lv_bbox = c.img.lv_bbox; p.T = c.T;
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist; p.raw = a->raw_activations;
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
+	p.prefiltered = a->prefiltered;
 	return p;
 }
 

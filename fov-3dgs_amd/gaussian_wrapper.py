@@ -1,22 +1,23 @@
-"""cuda_type -> rasterizer variant (reference: fov3dgs/gaussian_wrapper.py:11-23)."""
-from .diff_gaussian_rasterization import GaussianRasterizer as GaussianRasterizer_original
-from .diff_gaussian_rasterization_pcheck_obb import GaussianRasterizer as GaussianRasterizer_pcheck_obb
-from .diff_gaussian_rasterization_pcheck_obb_sum import GaussianRasterizer as GaussianRasterizer_pcheck_obb_sum
-from .diff_gaussian_rasterization_pcheck_obb_max import GaussianRasterizer as GaussianRasterizer_pcheck_obb_max
-from .diff_gaussian_rasterization_pcheck_obb_loss_weighted_max_count import \
-    GaussianRasterizer as GaussianRasterizer_pcheck_obb_loss_weighted_max_count
+"""`cuda_type` string -> rasterizer module of that variant (the boundary the reference exposes as
+fov3dgs/gaussian_wrapper.py:11-23 `get_gs_rasterizer`; same strings, same ValueError for an unknown one)."""
+import importlib
+
+_MODULES = {
+    "original": "diff_gaussian_rasterization",
+    "pcheck_obb": "diff_gaussian_rasterization_pcheck_obb",
+    "pcheck_obb_max": "diff_gaussian_rasterization_pcheck_obb_max",
+    "pcheck_obb_sum": "diff_gaussian_rasterization_pcheck_obb_sum",
+    "pcheck_obb_loss_weighted_max_count": "diff_gaussian_rasterization_pcheck_obb_loss_weighted_max_count",
+}
+
+
+def rasterizer_class(cuda_type):
+    """The GaussianRasterizer class behind a `cuda_type` string."""
+    name = _MODULES.get(cuda_type)
+    if name is None:
+        raise ValueError("Invalid cuda type: {}".format(cuda_type))
+    return importlib.import_module("." + name, __package__).GaussianRasterizer
 
 
 def get_gs_rasterizer(cuda_type, raster_settings):
-    if cuda_type == "original":
-        return GaussianRasterizer_original(raster_settings=raster_settings)
-    elif cuda_type == "pcheck_obb":
-        return GaussianRasterizer_pcheck_obb(raster_settings=raster_settings)
-    elif cuda_type == "pcheck_obb_sum":
-        return GaussianRasterizer_pcheck_obb_sum(raster_settings=raster_settings)
-    elif cuda_type == "pcheck_obb_max":
-        return GaussianRasterizer_pcheck_obb_max(raster_settings=raster_settings)
-    elif cuda_type == "pcheck_obb_loss_weighted_max_count":
-        return GaussianRasterizer_pcheck_obb_loss_weighted_max_count(raster_settings=raster_settings)
-    else:
-        raise ValueError("Invalid cuda type: {}".format(cuda_type))
+    return rasterizer_class(cuda_type)(raster_settings=raster_settings)

@@ -12,23 +12,27 @@ import torch.distributed as dist
 
 
 def init_distributed():
-    """-> (rank, world_size, local_rank). Reads the torchrun environment; no-op for a single process."""
+    """-> (rank, world_size, local_rank). Reads the torchrun environment; no-op for a single process.
+
+    The backend must come out the same on every rank, so it is decided from facts all ranks of a node share: RCCL
+    ("nccl") when every local rank has a GPU of its own (ranks per node <= devices; the ranks per node default to
+    WORLD_SIZE when the launcher does not say), gloo when ranks share devices (a test box: RCCL refuses two ranks on one
+    GPU) or there is no GPU at all."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available() and local_rank >= torch.cuda.device_count():
-        # more ranks than GPUs on this node (a test box): the ranks share devices, and RCCL refuses two ranks on one GPU
-        local_rank %= torch.cuda.device_count()
-        shared = True
-    else:
-        shared = False
+    have_gpu = torch.cuda.is_available()
+    ndev = torch.cuda.device_count() if have_gpu else 0
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    shared = have_gpu and local_world > ndev
+    if have_gpu:
+        local_rank %= ndev
     if world > 1 and not dist.is_initialized():
-        if torch.cuda.is_available() and not shared and int(os.environ.get("LOCAL_WORLD_SIZE", "1")) <= torch.cuda.device_count():
+        if have_gpu:
             torch.cuda.set_device(local_rank)
+        if have_gpu and not shared:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            if torch.cuda.is_available():
-                torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
     return rank, world, local_rank
 
@@ -60,7 +64,7 @@ def all_gather_images(image, async_op=False):
     return (work if async_op else None), flat.view((world,) + tuple(image.shape))
 
 
-def allreduce_gradients(params, visible=None, sparse_below=0.4):
+def allreduce_gradients(params, visible=None, sparse_below=0.4, check_rows=False):
     """Sum the per-view gradients of the replicated parameters over all ranks. -> dict with what was exchanged.
 
     dense (default): every gradient tensor is all-reduced IN PLACE, all collectives in flight at once (no flat copy: the
@@ -70,7 +74,12 @@ def allreduce_gradients(params, visible=None, sparse_below=0.4):
     view sees has an all-zero gradient row on every rank, so only the rows of the UNION of the masks are exchanged --
     one 1-byte-per-Gaussian MAX all-reduce for the union, a gather of those rows from every [P, ...] gradient into one
     [U, row] buffer, one all-reduce, a scatter back. Used when the union covers less than `sparse_below` of the
-    Gaussians (two or three views of a large scene; eight views on a ring see most of it, and dense wins)."""
+    Gaussians (two or three views of a large scene; eight views on a ring see most of it, and dense wins).
+    PRECONDITION of the row exchange (passing `visible` opts in): rows outside a rank's mask are ZERO on that rank, i.e.
+    p.grad was cleared before the step and holds nothing but this view's rasterizer gradients. With gradient
+    accumulation or a dense loss term (opacity / scale regularisers, a mask loss) rows outside the union would be left
+    un-summed -- use the dense exchange (visible=None) there. check_rows=True verifies the precondition (one reduction
+    per tensor and a host sync: for tests and debugging)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return dict(mode="none", bytes=0)
     grads = [p.grad for p in params if p.grad is not None]
@@ -83,6 +92,12 @@ def allreduce_gradients(params, visible=None, sparse_below=0.4):
         idx = torch.nonzero(union, as_tuple=False).squeeze(1)
         U = int(idx.numel())
         if U < sparse_below * P:
+            if check_rows:
+                mine = visible.reshape(P).to(torch.bool)
+                for g in grads:
+                    if bool((g.reshape(P, -1)[~mine] != 0).any()):
+                        raise RuntimeError("allreduce_gradients(visible=...): a gradient row outside this rank's visibility mask is not "
+                                           "zero (gradient accumulation or a dense loss term?) -- use the dense exchange")
             widths = [g[0].numel() for g in grads]
             rows = torch.empty((U, sum(widths)), dtype=grads[0].dtype, device=grads[0].device)
             off = 0

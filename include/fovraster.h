@@ -69,7 +69,8 @@ enum {
 	FR_ERR_INVALID = -1,   /* bad argument combination (message says which) */
 	FR_ERR_HIP = -2,       /* a HIP call or kernel failed */
 	FR_ERR_ALLOC = -3,     /* a resize callback returned NULL */
-	FR_ERR_PREFILTERED = -4 /* reserved */
+	FR_ERR_PREFILTERED = -4 /* `prefiltered` was set and a Gaussian lies behind the near plane (the reference traps:
+	                         * cuda_rasterizer/auxiliary.h:156-160); nothing was rendered */
 };
 
 /* Workspace callback: make the buffer at least `bytes` long and return its device address.
@@ -82,7 +83,7 @@ typedef struct fr_forward_args {
 	int32_t D;            /* active SH degree (0..3) */
 	int32_t M;            /* SH coefficients per Gaussian in `shs` (16; RF: 15 = rest only); 0 if shs == NULL */
 	int32_t W, H;         /* image size */
-	int32_t prefiltered;
+	int32_t prefiltered;  /* the caller promises that no Gaussian is behind the near plane; a violation is FR_ERR_PREFILTERED */
 	int32_t debug;        /* != 0: synchronise + check after every launch */
 	float tanfovx, tanfovy;
 	float scale_modifier;
@@ -167,7 +168,11 @@ typedef struct fr_backward_args {
 	const float *background, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations,
 		*cov3D_precomp, *viewmatrix, *projmatrix, *campos;
 	const int32_t *radii;        /* [P] from forward */
-	const char *geometry, *binning, *image; /* the three workspaces filled by fr_forward */
+	/* the three workspaces filled by fr_forward. The call accumulates into the geometry workspace's per-Gaussian gradient
+	 * sums and clears them again before it ends: calling fr_backward twice over one forward state gives the same
+	 * gradients twice (the reference: fresh torch::zeros per call), but two calls must not run concurrently on it. */
+	char *geometry;
+	const char *binning, *image;
 	const float *dL_dpix;        /* [3,H,W] */
 	/* outputs: caller-allocated, WRITTEN IN FULL by the call (rows of Gaussians the view does not touch become zero; the
 	 * reference allocates them with torch::zeros, rasterize_points.cu:171-179, and only writes the visible rows): no

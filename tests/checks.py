@@ -1,13 +1,31 @@
 """Tolerance checks of the GPU parity tests. Every call records what it measured (tests/parity_report.py).
 
-Tolerances (fp32 path; BASELINE north_star: per-pixel match within 1e-4):
-  * image: |diff| <= 1e-4 on all but `frac` (1e-6) of the pixels and <= `hard` (2e-3) everywhere. The blend thresholds
+Tolerances (fp32 path; BASELINE north_star: per-pixel match within 1e-4, gradients 1e-4 relative):
+  * image: |diff| <= 1e-4 on all but `frac` (1e-6) of the pixels and <= `hard` (1.5e-2) everywhere. The blend thresholds
     (alpha < 1/255, T < 1e-4, power < -4.5, power > 0) are discontinuous, and the HIP kernel uses the hardware exp2
     and fused multiply-adds while the oracle follows the reference's literal fp32 expression, so a pair that sits
-    within an ulp of a threshold may flip; each flip moves a pixel by at most ~alpha (<= 1.2e-2 at the -4.5 cutoff).
+    within an ulp of a threshold may flip; each flip moves a pixel by at most ~alpha x colour x T: <= 1.1e-2 at the -4.5
+    cutoff (0.99 e^-4.5), <= 3.9e-3 at alpha < 1/255. Whole 1080p frames (6.2 M values, ~10^10 (pixel, Gaussian) pairs)
+    do hold a handful of such pairs: `hard` is that bound, not a measured maximum; `frac` is what keeps the image tight.
     The measured fraction and maximum of every comparison are kept in tests/parity_report.json.
-  * gradients: float atomics have no defined order in the reference either; the oracle sums in double.
-    |diff| <= rtol * max(1, |ref|) + 1e-5 * max|ref| on all but `outlier_frac` of the entries (threshold flips).
+  * gradients: RELATIVE, row by row. A row is one Gaussian's slice of the tensor ([3] of dL_dmean3D, [16,3] of dL_dsh,
+    a scalar of dL_dopacity ...): ||got_i - want_i||_2 <= rtol * ||want_i||_2 + floor_i on all but `outlier_frac` of the
+    rows that carry a gradient. There is no floor tied to the tensor's LARGEST entry (round 2 had 1e-5 * max|want|,
+    which at 6 M Gaussians let any entry below ~1e-2 be 40 % off): floor_i is
+        GRAD_FLOOR (1e-7) * the median row norm of the tensor -- fp32 rounding of a row far below the typical one --
+      + `cancel` * scale_i when the caller passes per-row summand scales (`row_scale`): a sum of float atomics has no
+        defined order in the reference either (the oracle sums in double), and a row whose terms cancel carries the
+        rounding of its largest summand, not of its result.
+    Two budgets: at most GRAD_OUTLIERS (3e-3) of the rows outside rtol and at most GRAD_GROSS (2e-4) outside 100 rtol.
+    Measured on the whole S-6M frame (131 k Gaussians with a gradient, tests/parity_report.json): the median row agrees
+    to 6e-7, 99 % of the rows to 3e-6 ... 2.5e-5, and 2e-4 ... 1.7e-3 of them (dL_dopacity the most) lie outside 1e-4.
+    Those rows are not threshold flips alone: the backward pass recovers T by dividing T_final by (1 - alpha) down a
+    list of up to thousands of entries (backward.cu:503-507; a rounding drift of ~1e-5 at the front of a long list, in
+    the reference as here) and forms dL/dalpha from differences (colour - colour accumulated behind it, :516-521), so a
+    row whose terms nearly cancel carries the rounding of its summands. tests/test_oracle_pins.py measures the same
+    spread between the fp32 and fp64 builds of the oracle itself (the reference arithmetic against exact arithmetic).
+    On top of the row test the tensor as a whole must agree: cosine similarity >= 1 - GRAD_COSINE and relative L2 error
+    <= GRAD_REL_L2. A systematic error -- 1 % in the degree-3 SH gradients, say -- puts nearly every row outside rtol.
 """
 import os
 
@@ -15,12 +33,14 @@ import numpy as np
 
 from tests import parity_report
 
-# Bounds a few times above the worst case measured over the whole GPU suite (tests/parity_report.json, 132 comparisons):
-# every image is within 1e-4 at EVERY pixel except one comparison (4096x2160, 26.5 M values) where 2.3e-7 of them -- a
-# threshold flip -- are up to 7.1e-4 off; gradient entries outside rtol: at most 4.7e-5 of a tensor.
+# Bounds a few times above the worst case measured over the whole GPU suite (tests/parity_report.json):
 IMAGE_FRAC = 1e-6   # share of pixels allowed above 1e-4
-IMAGE_HARD = 2e-3   # ... and how far those may be off
-GRAD_OUTLIERS = 2e-4
+IMAGE_HARD = 1.5e-2 # ... and how far those may be off: one flipped (pixel, Gaussian) pair at the support cutoff
+GRAD_OUTLIERS = 3e-3  # share of gradient rows allowed outside rtol (cancelling rows, threshold flips)
+GRAD_GROSS = 2e-4     # ... and outside 100 x rtol
+GRAD_FLOOR = 1e-7     # x median row norm
+GRAD_COSINE = 1e-7    # 1 - cosine similarity of the whole tensor
+GRAD_REL_L2 = 1e-3    # ||got - want|| / ||want|| of the whole tensor (dominated by the few flipped pairs)
 
 
 def _where():
@@ -35,13 +55,34 @@ def check_image(got, want, frac=IMAGE_FRAC, hard=IMAGE_HARD, name=""):
     assert st["frac_gt_1e4"] <= frac, f"{st['frac_gt_1e4']:.2e} of pixels differ by more than 1e-4"
 
 
-def check_grad(got, want, name, rtol=1e-4, outlier_frac=GRAD_OUTLIERS):
-    scale = max(1.0, float(np.abs(want).max())) if want.size else 1.0
-    diff = np.abs(got - want)
-    bad = diff > rtol * np.maximum(1.0, np.abs(want)) + 1e-5 * scale
-    parity_report.record("grad", f"{_where()} {name}", frac_bad=float(bad.mean()) if bad.size else 0.0,
-                         max_abs=float(diff.max()) if diff.size else 0.0, ref_max=scale, rtol=rtol,
-                         frac_allowed=outlier_frac, n=int(diff.size),
-                         max_rel=float((diff / np.maximum(1.0, np.abs(want))).max()) if diff.size else 0.0)
+def grad_stats(got, want, rtol=1e-4, row_scale=None, cancel=4e-6):
+    """Row-relative comparison of two gradient tensors (first axis = Gaussian). -> dict of what was measured."""
+    g = np.asarray(got, np.float64).reshape(len(got), -1) if np.ndim(got) else np.asarray(got, np.float64).reshape(1, -1)
+    w = np.asarray(want, np.float64).reshape(g.shape)
+    d = g - w
+    rn = np.sqrt((w * w).sum(axis=1))
+    dn = np.sqrt((d * d).sum(axis=1))
+    live = (rn > 0) | (dn > 0)
+    n_live = int(live.sum())
+    typ = float(np.median(rn[rn > 0])) if (rn > 0).any() else 0.0
+    floor = GRAD_FLOOR * typ + (cancel * np.asarray(row_scale, np.float64).reshape(-1) if row_scale is not None else 0.0)
+    bad = live & (dn > rtol * rn + floor)
+    gross = live & (dn > 100.0 * rtol * rn + floor)
+    rel = dn[live] / np.maximum(rn[live], 1e-300)
+    wn, gn = float(np.sqrt((w * w).sum())), float(np.sqrt((g * g).sum()))
+    cos = float((g * w).sum() / (wn * gn)) if wn > 0 and gn > 0 else 1.0
+    return dict(rows=int(len(g)), rows_with_gradient=n_live, frac_bad=float(bad.sum() / max(n_live, 1)), frac_gross=float(gross.sum() / max(n_live, 1)),
+                max_abs=float(np.abs(d).max()) if d.size else 0.0, ref_max=float(np.abs(w).max()) if w.size else 0.0,
+                median_row_norm=typ, rel_l2=float(np.sqrt((d * d).sum()) / wn) if wn > 0 else 0.0, one_minus_cosine=1.0 - cos,
+                row_rel_p50=float(np.quantile(rel, 0.5)) if n_live else 0.0, row_rel_p99=float(np.quantile(rel, 0.99)) if n_live else 0.0,
+                row_rel_p9999=float(np.quantile(rel, 0.9999)) if n_live else 0.0, row_rel_max=float(rel.max()) if n_live else 0.0)
+
+
+def check_grad(got, want, name, rtol=1e-4, outlier_frac=GRAD_OUTLIERS, row_scale=None, cosine=GRAD_COSINE, rel_l2=GRAD_REL_L2, gross_frac=GRAD_GROSS):
+    st = grad_stats(got, want, rtol=rtol, row_scale=row_scale)
+    parity_report.record("grad", f"{_where()} {name}", rtol=rtol, frac_allowed=outlier_frac, gross_allowed=gross_frac, **st)
     assert np.isfinite(got).all(), name
-    assert bad.mean() <= outlier_frac, f"{name}: {bad.mean():.2e} of entries off (max diff {diff.max():.3e})"
+    assert st["frac_bad"] <= outlier_frac, f"{name}: {st['frac_bad']:.2e} of the rows outside {rtol:g} relative (max |diff| {st['max_abs']:.3e})"
+    assert st["frac_gross"] <= max(gross_frac, 1.5 / max(st["rows_with_gradient"], 1)), f"{name}: {st['frac_gross']:.2e} of the rows outside {100 * rtol:g} relative"
+    assert st["one_minus_cosine"] <= cosine, f"{name}: 1 - cosine = {st['one_minus_cosine']:.3e}"
+    assert st["rel_l2"] <= rel_l2, f"{name}: relative L2 error {st['rel_l2']:.3e}"

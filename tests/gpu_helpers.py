@@ -66,7 +66,7 @@ def hip_forward(variant, scene, cam, dev="cuda:0", debug=True, packed=False):
         out["n_contrib"] = _view(img, lib.fr_image_n_contrib(vid, W, H, img.data_ptr()), W * H, torch.int32).cpu().numpy().astype(np.uint32).reshape(H, W)
     if variant in ("pcheck_obb_sum", "pcheck_obb_max", "pcheck_obb_loss_weighted_max_count"):
         out["gaussians_count"], out["contributions"] = res[6].cpu().numpy(), res[7].cpu().numpy()
-    if variant in ("fov_pcheck_obb", "naive_pcheck_obb") or (variant == "mmfr_pcheck_obb" and False):
+    if variant in ("fov_pcheck_obb", "naive_pcheck_obb"):
         lv = _view(img, lib.fr_image_tile_levels(W, H, img.data_ptr()), 5 * T, torch.float32).cpu().numpy().reshape(5, T)
         out["tile_levels"], out["tile_min"], out["tile_gx"], out["tile_gy"] = lv[0], lv[1], lv[2], lv[3]
         out["tile_blend"] = (lv[4] != 0).astype(np.uint8)

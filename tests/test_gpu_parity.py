@@ -723,3 +723,61 @@ def test_multi_model_foveated_baseline():
         out = render(camo, torch.tensor([0.1, 0.2, 0.3], device=dev), alpha=0.05, gazeArray=torch.tensor(gaze), blending=True,
                      multi_gs=models, layer_num=4)
     check_image(out["render"].cpu().numpy(), sum(levels), name="MMFR render()")
+
+
+def test_backward_twice_gives_the_same_gradients():
+    """fr_backward is idempotent like the reference's (fresh zero tensors per call, rasterize_points.cu:171-179): a second
+    backward pass over the same forward state (retain_graph, torch.autograd.grad twice) returns the same gradients, not
+    twice the first ones (round 2 accumulated into sums only the forward pass cleared)."""
+    _need_gpu()
+    from fov3dgs_amd.gaussian_renderer import render
+    dev = "cuda:0"
+    cloud = syn.scene_1k(P=3000, seed=9).to(dev).requires_grad_(True)
+    cam = small_camera(320, 200).to(dev)
+
+    class Pipe:
+        debug = False
+    out = render(cam, cloud, Pipe(), torch.tensor([0.2, 0.3, 0.1], device=dev), cuda_type="pcheck_obb_sum")
+    w = torch.randn_like(out["render"])
+    params = [cloud._xyz, cloud._scaling, cloud._rotation, cloud._opacity, cloud._features_dc, cloud._features_rest]
+    loss = (out["render"] * w).sum()
+    g1 = torch.autograd.grad(loss, params, retain_graph=True)
+    g2 = torch.autograd.grad(loss, params, retain_graph=True)
+    loss.backward()
+    for p, a, b in zip(params, g1, g2):
+        assert int((a.reshape(len(a), -1).abs().amax(dim=1) > 0).sum()) > 500
+        # (the three passes add the same terms with float atomics in whatever order the hardware takes them)
+        check_grad(b.cpu().numpy(), a.cpu().numpy(), "second autograd.grad vs first")
+        check_grad(p.grad.cpu().numpy(), a.cpu().numpy(), "backward() after two autograd.grad calls")
+
+
+def test_prefiltered_violation_is_reported():
+    """`prefiltered` (GaussianRasterizationSettings field 11): the reference traps when a point of a cloud declared
+    prefiltered is culled by the near plane (cuda_rasterizer/auxiliary.h:156-160); here fr_forward returns
+    FR_ERR_PREFILTERED with the reference's message. A cloud that keeps the promise renders as without the flag."""
+    _need_gpu()
+    from fov3dgs_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = "cuda:0"
+    cam = syn.camera_1k(128, 128).to(dev)
+    cloud = syn.scene_1k(P=800, seed=2).to(dev)
+    rs = GaussianRasterizationSettings(128, 128, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev), 1.0,
+                                       cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, True, False)
+    with torch.no_grad():
+        xyz = cloud.get_xyz.clone()
+        m2 = torch.zeros_like(xyz)
+        kw = dict(shs=cloud.get_features, scales=cloud.get_scaling, rotations=cloud.get_rotation)
+        assert (xyz[:, 2] > 0.2).all()
+        img_pf, radii_pf = GaussianRasterizer(rs)(xyz, m2, cloud.get_opacity, **kw)
+        img, radii = GaussianRasterizer(rs._replace(prefiltered=False))(xyz, m2, cloud.get_opacity, **kw)
+        assert torch.equal(img, img_pf) and torch.equal(radii, radii_pf)
+        xyz[17, 2] = 0.1  # behind the near plane
+        with pytest.raises(RuntimeError, match="filtered although prefiltered is set"):
+            GaussianRasterizer(rs)(xyz, m2, cloud.get_opacity, **kw)
+        GaussianRasterizer(rs._replace(prefiltered=False))(xyz, m2, cloud.get_opacity, **kw)  # without the promise: culled, no error
+    # the oracle restates the same rule
+    cpu = syn.scene_1k(P=800, seed=2)
+    scene = scene_dict(cpu, "original")
+    scene["means3D"] = xyz.cpu().numpy()
+    cd = dict(cam_dict(cam.to("cpu")), prefiltered=True)
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        orc.forward("original", scene, cd)

@@ -114,3 +114,38 @@ def test_synthetic_scenes_are_deterministic():
     assert dcs.shape == (20000, 4, 3) and op.shape == (20000, 4) and (op >= 0).all() and (op <= 1).all()
     cam = syn.camera_ring(3)
     assert cam.image_width == 1920 and cam.image_height == 1080
+
+
+def test_gradient_check_is_relative_row_by_row():
+    """tests/checks.py: the gradient tolerance is relative per row (no floor tied to the tensor's largest entry): a 1 % error
+    in the degree-3 SH coefficients' gradients (slots 9..15) of rows a million times smaller than the largest one fails."""
+    from tests.checks import check_grad, grad_stats
+    rng = np.random.default_rng(0)
+    P = 20000
+    # rows spanning eight orders of magnitude, as dL_dsh of a real frame does
+    want = rng.normal(size=(P, 16, 3)) * (10.0 ** rng.uniform(-6, 2, size=(P, 1, 1)))
+    want = want.astype(np.float32)
+    noise = (want.astype(np.float64) * (1 + 3e-7 * rng.normal(size=want.shape))).astype(np.float32)  # fp32 rounding noise
+    check_grad(noise, want, "rounding noise passes")
+    spoiled = want.copy()
+    spoiled[:, 9:, :] *= 1.01
+    st = grad_stats(spoiled, want)
+    assert st["frac_bad"] > 0.99
+    with pytest.raises(AssertionError):
+        check_grad(spoiled, want, "1 % in coefficients 9..15")
+    # ... and only on the small rows (what round 2's absolute floor, 1e-5 x the tensor's maximum, let through)
+    small = np.abs(want).reshape(P, -1).max(axis=1) < 1e-3 * np.abs(want).max()
+    spoiled = want.copy()
+    spoiled[small, 9:, :] *= 1.01
+    with pytest.raises(AssertionError):
+        check_grad(spoiled, want, "1 % in the small rows only")
+    # a few flipped rows are within the outlier budget, but are recorded
+    few = want.copy()
+    few[:5] *= 1.5
+    assert 0 < grad_stats(few, want)["frac_bad"] <= 1e-3
+
+
+def test_cuda_type_table_matches_the_reference_strings():
+    from fov3dgs_amd.gaussian_wrapper import rasterizer_class
+    for name in ("original", "pcheck_obb", "pcheck_obb_max", "pcheck_obb_sum", "pcheck_obb_loss_weighted_max_count"):
+        assert rasterizer_class(name).__name__ == "GaussianRasterizer"

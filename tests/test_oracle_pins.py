@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN, cam_dict, scene_dict, small_case, syn
+from tests.helpers import GOLDEN, cam_dict, scene_dict, small_camera, small_case, syn
 from oracle import oracle as orc
 
 VARIANTS = ("original", "pcheck_obb_sum", "pcheck_obb", "fov_pcheck_obb")
@@ -292,3 +292,30 @@ def test_multi_model_baseline_partition_of_unity():
         want = orc.forward("pcheck_obb", plain, cam)
         assert sum(counts) >= want["num_rendered"] and min(counts) > 0
         np.testing.assert_allclose(total, want["color"], rtol=0, atol=3e-7)
+
+
+def test_reference_arithmetic_noise_of_the_gradients():
+    """What "1e-4 relative" can mean for the gradients: the fp32 restatement of the reference against the same arithmetic
+    in double, on the SAME forward state (lists, n_contrib, final_T of the fp32 forward, so that no discrete decision
+    differs). The backward pass recovers T by repeated division and forms dL/dalpha from colour differences
+    (R0 backward.cu:503-521); rows whose terms cancel carry the rounding of their summands. The spread measured here --
+    the reference's own fp32 arithmetic against exact arithmetic -- is what the row budgets of tests/checks.py
+    (GRAD_OUTLIERS / GRAD_GROSS) are sized for; it is recorded next to the HIP-vs-oracle numbers."""
+    from tests.checks import grad_stats
+    from tests import parity_report
+    variant = "pcheck_obb_sum"
+    scene = scene_dict(syn.scene_1k(P=6000, seed=3), variant)  # (translucent: most Gaussians reach a pixel)
+    cam = cam_dict(small_camera(320, 200))
+    o32 = orc.forward(variant, scene, cam)
+    wpix = np.random.default_rng(5).normal(size=o32["color"].shape).astype(np.float32)
+    g32 = orc.backward(variant, scene, cam, o32, wpix)
+    # the double build fed with the fp32 forward's per-Gaussian state and lists
+    o64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in o32.items()}
+    g64 = orc.backward(variant, {k: v.astype(np.float64) for k, v in scene.items()}, cam, o64, wpix.astype(np.float64), dtype=np.float64)
+    worst = 0.0
+    for k in ("dL_dmean2D", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"):
+        st = grad_stats(g32[k], g64[k])
+        parity_report.record("oracle_noise", f"fp32 vs fp64 oracle backward {k}", **st)
+        worst = max(worst, st["frac_bad"])
+        assert st["one_minus_cosine"] < 1e-7 and st["row_rel_p50"] < 1e-5, (k, st)
+    assert worst <= 3e-3, worst  # the fp32 reference arithmetic itself stays inside the budget the HIP path is held to
