@@ -14,6 +14,10 @@ the reference's fixed set (fov3dgs/render_compose_gazes_fps.py:26: centre + 8 of
 depend on --steps / --warmup. With N ranks each rank renders its own camera of an 8-camera ring (weak scaling; the views
 are independent: no data-path collective unless --gather).
 
+The K timed steps are run `--repeats` (5) times, each repeat bracketed by barrier + synchronize: value / ms_per_step are the
+MEDIAN repeat, value_spread = [slowest, fastest]. Inside the timed frames only the HIP events around the slowest stage (found
+in an untimed pass first) and around the blend stage are recorded; the other stages' times come from an untimed pass of the
+same frames (an event record is a command on the stream: all eight per frame cost 3.5 %).
 Besides `value` the line carries
   value_packed  the same frames with render(packed="auto") (static-model layout, bit-identical image; fovraster.h)
   roofline      dominant kernel: algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak; `blend` =
@@ -23,7 +27,8 @@ Besides `value` the line carries
   cpu_baseline  the CPU oracle (C port of the reference algorithm, OpenMP over Gaussians / tiles) on all host cores
   stages_ms     mean per-stage kernel time of the timed frames
   extra         reference-protocol fps per gaze (events around the rasterizer only), moving-gaze fps, non-foveated
-                forward fps, training step fwd / bwd / loss ms (median of 50)
+                forward fps, training step fwd / bwd / loss ms (median of 50); N > 1: frames/s with every frame gathered on
+                rank 0 and a multi-view training pass with its collective time (the headline's views are independent)
 --mode train (config 5): every rank does forward + loss + backward of its camera (pcheck_obb_sum, fused L1+SSIM) and the
 gradients are summed over ranks; reports fwd_bwd_ms and collective_ms.
 """
@@ -52,6 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--points", type=int, default=6_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K timed steps are run this many times (each bracketed by barrier + synchronize); value = the median "
+                         "repeat, value_spread = [min, max] (one 16 ms region cannot rank two builds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--packed-only", action="store_true", help="time only the packed-model frames (profiling passes)")
@@ -181,42 +189,73 @@ def main():
         return render_fov(cam, pc, bg, alpha=0.05, gazeArray=gaze, blending=True, highest_levels=highest, shs_dcs=shs_dcs,
                           opacities=opac, packed=packed, **kw)
 
-    def timed_run(packed):
-        """W warm-ups + exactly K timed frames (gaze i % 9), barrier + synchronize on both sides. -> (seconds, stage ms)"""
+    def timed_run(packed, event_stages):
+        """W warm-ups + `repeats` x exactly K timed frames (gaze i % 9), barrier + synchronize on both sides of every repeat.
+        Only the boundaries of `event_stages` are recorded inside the timed frames (every event record is a command on the
+        stream, ~3 us: all eight cost 3.5 % of the frame). -> (median seconds, [min, max] seconds, {stage: mean ms})"""
         pending = None
+        times, per_stage = [], {k: [] for k in event_stages}
         with torch.no_grad():
             for i in range(Wm):
                 out = frame(GAZES[i % 9], packed)
                 if world > 1 and args.gather:
                     multiview.gather_images(out["render"], dst=0)
-            barrier_sync()
-            timer = StageTimer(K)
-            t_start = time.perf_counter()
-            with timer:
-                for i in range(K):
-                    out = frame(GAZES[i % 9], packed)
-                    if world > 1 and args.gather:
-                        if pending is not None:
-                            pending[0].wait()
-                        pending = multiview.gather_images(out["render"], dst=0, async_op=True) + (out["render"],)
-                if pending is not None:
-                    pending[0].wait()
-            barrier_sync()
-            elapsed = time.perf_counter() - t_start
-        if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(t.item())
-        st = timer.stage_ms()
-        timer.close()
-        return elapsed, {k: float(np.mean([s[k] for s in st])) for k in _native.STAGES}
+            for rep in range(max(1, args.repeats)):
+                barrier_sync()
+                timer = StageTimer(K, stages=event_stages)
+                t_start = time.perf_counter()
+                with timer:
+                    for i in range(K):
+                        out = frame(GAZES[i % 9], packed)
+                        if world > 1 and args.gather:
+                            if pending is not None:
+                                pending[0].wait()
+                            pending = multiview.gather_images(out["render"], dst=0, async_op=True) + (out["render"],)
+                    if pending is not None:
+                        pending[0].wait()
+                        pending = None
+                barrier_sync()
+                elapsed = time.perf_counter() - t_start
+                if world > 1:
+                    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    elapsed = float(t.item())
+                times.append(elapsed)
+                for row in timer.stage_ms():
+                    for k in event_stages:
+                        per_stage[k].append(row[k])
+                timer.close()
+        return float(np.median(times)), [min(times), max(times)], {k: float(np.mean(v)) for k, v in per_stage.items()}
 
+    def stage_pass(packed, n=27):
+        """Untimed: every stage's kernel time (all eight events per frame), mean over n frames of the nine gazes."""
+        with torch.no_grad():
+            timer = StageTimer(n)
+            with timer:
+                for i in range(n):
+                    frame(GAZES[i % 9], packed)
+            torch.cuda.synchronize()
+            st = timer.stage_ms()
+            timer.close()
+        return {k: float(np.mean([s_[k] for s_ in st])) for k in _native.STAGES}
+
+    # which stage is the slowest is found first (untimed); the timed frames then carry the events of that stage and of the
+    # blend stage (the kernel north_star names) only
+    with torch.no_grad():
+        for i in range(3):
+            frame(GAZES[i % 9], "auto" if args.packed_only else None)
+    pre = stage_pass("auto" if args.packed_only else None)
+    dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: pre[k])
+    ev_stages = tuple(dict.fromkeys((dominant, "render")))
     if args.packed_only:
-        elapsed_p, mean_ms_p = timed_run("auto")
-        elapsed, mean_ms = elapsed_p, mean_ms_p
+        elapsed_p, spread_p, timed_ms_p = timed_run("auto", ev_stages)
+        elapsed, spread, timed_ms = elapsed_p, spread_p, timed_ms_p
     else:
-        elapsed, mean_ms = timed_run(None)        # the reference's tensor interface: the headline
-        elapsed_p, mean_ms_p = timed_run("auto")  # static-model layout
+        elapsed, spread, timed_ms = timed_run(None, ev_stages)        # the reference's tensor interface: the headline
+        elapsed_p, spread_p, timed_ms_p = timed_run("auto", ev_stages)  # static-model layout
+    mean_ms = stage_pass("auto" if args.packed_only else None)
+    mean_ms_p = stage_pass("auto")
+    multi = multi_gpu_extras(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync, frame, torch, np) if world > 1 else {}
     if rank != 0:
         return
 
@@ -255,15 +294,22 @@ def main():
         "tile_levels": 20 * T,
     }
     prof = load_profiles()
-    roof_ms = mean_ms  # the headline run's stage times
+    # kernel durations of the roofline: the events recorded INSIDE the timed frames for the two stages that carry them
+    # (measured_in says so), the untimed all-stage pass of the same frames for the rest
+    roof_ms = dict(mean_ms)
+    roof_ms.update(timed_ms)
 
     def roof(stage):
         ach = alg_bytes[stage] / (roof_ms[stage] * 1e-3) / 1e9
         d = dict(kernel=stage, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
-                 algorithmic_bytes=int(alg_bytes[stage]), kernel_ms=round(roof_ms[stage], 4))
+                 algorithmic_bytes=int(alg_bytes[stage]), kernel_ms=round(roof_ms[stage], 4),
+                 measured_in="timed region (HIP events on the launch stream)" if stage in timed_ms else "untimed all-stage pass of the same frames")
         d["traffic"], d["traffic_source"] = prof.traffic(stage, packed=args.packed_only)
+        if d["traffic"]:
+            # the formula charges bytes this build never moves (SH rows of culled Gaussians) or moves twice: the PMC bytes over the
+            # same duration say how fast the memory system really ran
+            d["frac_traffic"] = round(d["traffic"] / (roof_ms[stage] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         return d
-    dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: roof_ms[k])
     roofline = dict(bound="hbm", **roof(dominant))
     roofline["blend"] = roof("render")
     roofline["blend"].update(prof.blend_sq())
@@ -289,7 +335,9 @@ def main():
         "metric": "frames/sec at 1080p foveated (bicycle-scale)", "value": round(world * K / elapsed, 3), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeats": max(1, args.repeats), "value_spread": [round(world * K / spread[1], 3), round(world * K / spread[0], 3)],
         "value_packed": round(world * K / elapsed_p, 3), "ms_per_step_packed": round(elapsed_p / K * 1e3, 4),
+        "value_packed_spread": [round(world * K / spread_p[1], 3), round(world * K / spread_p[0], 3)],
         "config": {"workload": "S-6M bicycle-scale cloud, 4-layer foveated render (fov_pcheck_obb), the reference's 9 fixed gazes "
                                "(0.25 i, 0.25 j) in turn, one camera per GPU" + (", frames gathered on rank 0" if (world > 1 and args.gather) else ""),
                    "gaussians": P, "width": W, "height": H, "alpha": 0.05, "sh_degree": 3,
@@ -302,7 +350,7 @@ def main():
         "cpu_baseline": cpu,
         "stages_ms": {k: round(v, 4) for k, v in mean_ms.items()},
         "stages_ms_packed": {k: round(v, 4) for k, v in mean_ms_p.items()},
-        "extra": extra,
+        "extra": dict(extra, **multi),
     }
     print(json.dumps(line), flush=True)
 
@@ -471,6 +519,70 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
         tl.append((time.perf_counter() - t1) * 1e3)
     extra["loss_fwd_bwd_torch_ms"] = round(float(np.median(tl[2:])), 3)
     return extra
+
+
+def multi_gpu_extras(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync, frame, torch, np):
+    """N > 1, render mode: the views are independent, so the headline has no collective in it. What north_star's exchange
+    steps cost is measured here, untimed for the headline: (a) the same frames with every rank's image gathered on rank 0
+    (asynchronous RCCL gather overlapped with the next frame), (b) a few multi-view training steps (forward + fused loss +
+    backward per rank, then the gradient sum over ranks). -> dict for `extra` (rank 0 holds the maxima over ranks)."""
+    from fov3dgs_amd.loss_utils import l1_ssim_loss
+    out = {}
+    K = min(args.steps, 27)
+    with torch.no_grad():
+        pending = None
+        for i in range(3):
+            multiview.gather_images(frame(GAZES[i % 9], None)["render"], dst=0)
+        barrier_sync()
+        t0 = time.perf_counter()
+        for i in range(K):
+            o = frame(GAZES[i % 9], None)
+            if pending is not None:
+                pending[0].wait()
+            pending = multiview.gather_images(o["render"], dst=0, async_op=True) + (o["render"],)
+        pending[0].wait()
+        barrier_sync()
+        el = time.perf_counter() - t0
+    tr = cloud.requires_grad_(True)
+    tr.fuse_activations = True
+    H, W = args.height, args.width
+    target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))
+    params = list(tr.parameters())
+    n_train = 6
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_train)]
+    info = None
+    for it in range(2 + n_train):
+        for p_ in params:
+            p_.grad = None
+        ev = evs[it - 2] if it >= 2 else None
+        if ev:
+            ev[0].record()
+        o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
+        l1_ssim_loss(o["render"], target, 0.2).backward()
+        if ev:
+            ev[1].record()
+        info = multiview.allreduce_gradients(params, visible=o["visibility_filter"])
+        if ev:
+            ev[2].record()
+    barrier_sync()
+    fb = float(np.median([e[0].elapsed_time(e[1]) for e in evs]))
+    co = float(np.median([e[1].elapsed_time(e[2]) for e in evs]))
+    t = torch.tensor([el, fb, co], device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    el, fb, co = [float(x) for x in t.tolist()]
+    for p_ in params:
+        p_.grad = None
+    tr.requires_grad_(False)
+    nbytes = (info or {}).get("bytes", 0)
+    algbw = nbytes / (co * 1e-3) / 1e9 if co > 0 else None
+    out["gather_fps"] = round(world * K / el, 2)
+    out["gather_note"] = f"{K} frames per rank, every frame's image gathered on rank 0 (asynchronous gather of the previous frame under the next one)"
+    out["multiview_train"] = dict(fwd_bwd_ms=round(fb, 4), collective_ms=round(co, 4), backend=torch.distributed.get_backend(),
+                                  collective=dict(info or {}, algbw_GBs=None if algbw is None else round(algbw, 2),
+                                                  busbw_GBs=None if algbw is None else round(algbw * 2 * (world - 1) / world, 2)),
+                                  note=f"median of {n_train} steps: pcheck_obb_sum forward + fused L1+SSIM + backward of this rank's camera, then "
+                                       "multiview.allreduce_gradients over the ranks (max over ranks)")
+    return out
 
 
 def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync):

@@ -9,6 +9,7 @@
 namespace fr {
 
 static thread_local char g_err[512] = "";
+static thread_local int64_t g_spec_stats[3] = { 0, 0, 0 }; // frames launched ahead of their counts / of those replayed / launched after them
 
 void set_error(const char *fmt, ...)
 {
@@ -103,6 +104,7 @@ int fr_event_elapsed_ms(void *start, void *stop, float *ms)
 	return FR_OK;
 }
 const char *fr_last_error(void) { return g_err; }
+void fr_speculation_stats(int64_t out[3]) { for (int i = 0; i < 3; i++) out[i] = g_spec_stats[i]; }
 
 size_t fr_geometry_bytes(int32_t variant, int32_t P) { return carve_geom(variant, (size_t)P, nullptr).bytes; }
 size_t fr_image_bytes(int32_t variant, int32_t W, int32_t H) { return carve_image(variant, W, H, nullptr).bytes; }
@@ -150,15 +152,32 @@ int fr_forward(fr_forward_args *a)
 	// RF: the two level states of a two-level tile are blended by different waves, which ADD their halves to the image
 	// (clearing only those tiles inside k_tile_levels tripled that kernel: 11 -> 32 us; the fill command is 6 us)
 	c.fov_split = a->variant == FR_VARIANT_FOV_PCHECK_OBB ? 1 : 0;
-	if (c.fov_split) FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, stream));
-	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
-	if (!is_fov(a->variant)) // RF: k_tile_levels clears them
-		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
+	// The large fills of a frame -- the image (RF) and the training variants' two statistics arrays -- are only needed by the
+	// blend kernel at the END of the frame: they run on a helper stream beside the cull / binning kernels instead of in front
+	// of them (7 + 6 us at the head of a 1080p foveated frame), and the blend stage waits for them (rest_of_frame).
+	AuxStream *fill_ax = ((c.fov_split || has_stats(a->variant)) && !a->debug) ? aux_stream() : nullptr;
+	hipStream_t fill_stream = stream;
+	if (fill_ax)
+	{
+		if (hipEventRecord(fill_ax->fork, stream) != hipSuccess || hipStreamWaitEvent(fill_ax->s2, fill_ax->fork, 0) != hipSuccess) { (void)hipGetLastError(); fill_ax = nullptr; }
+		else fill_stream = fill_ax->s2;
+	}
+	if (c.fov_split) FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, fill_stream));
 	if (has_stats(a->variant))
 	{
-		FR_HIP(hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, stream));
-		FR_HIP(hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, stream));
+		FR_HIP(hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, fill_stream));
+		FR_HIP(hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, fill_stream));
 	}
+	if (fill_ax) (void)hipEventRecord(fill_ax->join2, fill_ax->s2);
+	// small clears in front of the first kernel: the level boxes (RF: k_tile_levels raises them with atomicMax; it clears the
+	// slab counters itself) or the slab counters; the per-tile counters only on the global-atomics path of huge tile grids
+	// (with LDS histograms every one of them is written by the column scan before it is read)
+	if (c.img.hist == nullptr)
+		FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
+	else if (is_fov(a->variant))
+		FR_HIP(hipMemsetAsync(c.img.lv_bbox, 0, 5 * FR_LV_BBOX_STRIDE * sizeof(uint32_t), stream));
+	if (!is_fov(a->variant)) // RF: k_tile_levels clears them
+		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
 	mark(FR_STAGE_TILE_LEVELS);
 	if (is_fov(a->variant)) { rc = launch_tile_levels(c); if (rc) return rc; }
 	mark(FR_STAGE_PROJECT);
@@ -193,7 +212,40 @@ int fr_forward(fr_forward_args *a)
 	c.totals_seq = frame_seq;
 	mark(FR_STAGE_TILE_SCAN);
 	rc = launch_tile_scan(c); if (rc) return rc;
-	mark(FR_STAGE_EMIT);
+
+	// Everything behind the tile scan needs the frame's counts: the number of instances D (size of the binning workspace)
+	// and the sort / blend class counts. They are on their way to this thread's pinned block. When the caller's binning
+	// buffer of the previous frame of this kind was large enough (it almost always is: the buffers are grow-only), the rest
+	// of the frame is launched NOW, on upper bounds -- the kernels read the counts from device memory and leave at once if
+	// D exceeds the capacity they were given -- and the host only then waits for the counts, while the GPU is busy with the
+	// frame: no idle GPU at the one synchronisation point (12 us with polling, 33 us without), no host code on the frame's
+	// critical path. If D does not fit (a sudden jump by more than a quarter), the stage is replayed with the right size.
+	struct Guess { int32_t variant = -1, P = 0, W = 0, H = 0; int64_t capacity = 0, items_cap = 0; int heavy4 = 0, heavy8 = 0; };
+	static thread_local Guess guesses[8];
+	Guess &gs = guesses[a->variant & 7];
+	const bool same_kind = gs.variant == a->variant && gs.P == a->P && gs.W == a->W && gs.H == a->H;
+	static const bool no_spec = getenv("FR_NO_SPECULATION") != nullptr;
+	const bool speculate = same_kind && gs.capacity > 0 && pinned && !a->debug && !no_spec;
+	const int64_t items_max = (int64_t)(c.fov_split ? 4 : 2) * c.T; // two bands per tile, twice that for an RF two-level tile
+	auto rest_of_frame = [&](int64_t capacity, bool known) -> int
+	{
+		char *bptr = a->binning_resize(a->resize_user[1], carve_bin(capacity, nullptr, c.T).bytes);
+		if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }
+		c.bin = carve_bin(capacity, bptr, c.T);
+		c.capacity = capacity; c.counts_known = known ? 1 : 0; c.hint_heavy4 = gs.heavy4; c.hint_heavy8 = gs.heavy8;
+		c.items_cap = known ? items_max : (gs.items_cap < items_max ? gs.items_cap : items_max);
+		mark(FR_STAGE_EMIT);
+		int r = FR_OK;
+		if (!known || a->num_rendered > 0) { r = launch_emit(c); if (r) return r; }
+		mark(FR_STAGE_TILE_SORT);
+		if (!known || a->num_rendered > 0) { r = launch_tile_sort(c); if (r) return r; }
+		mark(FR_STAGE_RENDER);
+		if (fill_ax) (void)hipStreamWaitEvent(stream, fill_ax->join2, 0); // the image / statistics fills of the frame's head
+		r = launch_render(c);
+		mark(FR_NUM_STAGES);
+		return r;
+	};
+	if (speculate) { rc = rest_of_frame(gs.capacity, false); if (rc) return rc; }
 
 	uint32_t totals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	if (!pinned) FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
@@ -228,17 +280,20 @@ int fr_forward(fr_forward_args *a)
 	a->max_tile_instances = (int32_t)totals[1];
 	c.heavy4 = (int)totals[2]; c.heavy2 = (int)totals[3];
 	c.n_items = (int)totals[5]; c.heavy8 = (int)totals[6];
-
-	char *bptr = a->binning_resize(a->resize_user[1], carve_bin(totals[0], nullptr, c.T).bytes);
-	if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }
-	c.bin = carve_bin(totals[0], bptr, c.T);
-	if (totals[0] > 0) { rc = launch_emit(c); if (rc) return rc; }
-	mark(FR_STAGE_TILE_SORT);
-	if (totals[0] > 0) { rc = launch_tile_sort(c, (int)totals[0], (int)totals[1]); if (rc) return rc; }
-	mark(FR_STAGE_RENDER);
-	rc = launch_render(c);
-	mark(FR_NUM_STAGES);
-	return rc;
+	// what the next frame of this kind will be launched with: a quarter of headroom over the largest frame seen
+	const int64_t want = (int64_t)totals[0] + (int64_t)totals[0] / 4 + 65536;
+	if (!same_kind) { gs.variant = a->variant; gs.P = a->P; gs.W = a->W; gs.H = a->H; gs.capacity = 0; gs.items_cap = 0; }
+	const bool fits = speculate && (int64_t)totals[0] <= gs.capacity && (int64_t)totals[5] <= (gs.items_cap < items_max ? gs.items_cap : items_max);
+	if (want > gs.capacity) gs.capacity = want;
+	const int64_t want_items = (int64_t)totals[5] + (int64_t)totals[5] / 16 + 64; // (a moving gaze changes the two-level ring by a few per cent)
+	if (want_items > gs.items_cap) gs.items_cap = want_items;
+	gs.heavy4 = (int)totals[2]; gs.heavy8 = (int)totals[6];
+	g_spec_stats[speculate ? (fits ? 0 : 1) : 2]++;
+	if (speculate && !fits) g_spec_stats[0]++;
+	if (fits) return FR_OK; // the frame is already on its way
+	// first frame of its kind, a debug call, or the speculative launch found the workspace too small (its kernels left
+	// without touching anything): the stage with the known counts
+	return rest_of_frame(speculate ? gs.capacity : (int64_t)totals[0], true);
 }
 
 int fr_pack_geom(int32_t P, const float *means3D, const float *scales, const float *rotations, const float *opacities,

@@ -191,23 +191,42 @@ __device__ __forceinline__ void reg_sort(uint64_t (&k)[ITEMS])
 		}
 }
 
-// CHUNKS = false: one tile list per workgroup (ranges[tile_order[block]]), lists with n_lo < n < n_hi;
-// CHUNKS = true: one chunk of a split long list per workgroup (ranges[block], block < *count), any length: the rare
-// chunk that does not fit (thousands of equal depths) is sorted in place in global memory by the bitonic network.
-template <int THREADS, int ITEMS, bool CHUNKS>
-__global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries,
-	uint32_t *point_list, int n_lo, int n_hi, const uint32_t *count)
+// Which lists are regrouped by depth before sorting (k_split_long): lists with >= 2048 entries, or -- `direct` -- only those
+// with >= 4096 while the 2048..4095 class is sorted directly, one 512-thread workgroup per list. Either plan sorts every
+// list; which one is faster depends on the frame: a few hundred long lists are latency-bound (split them all), THOUSANDS
+// of lists of 2048..4095 entries (non-foveated / training frames) are throughput-bound (sort that class directly). The host
+// chooses -- from the frame's class counts when it has them, from the previous frame of the kind when the stage is launched
+// ahead of them -- and the kernels find their lists from the counts in device memory (totals[2] = lists with >= 2048
+// entries, totals[6] = with >= 4096; they are the first entries of tile_order, longest first).
+struct SortPlan { bool direct; uint32_t nlong, split_min, h4, h8; };
+__device__ __forceinline__ SortPlan sort_plan(const uint32_t *totals, bool direct)
 {
-	extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
-	if (CHUNKS && blockIdx.x >= *count) return;
-	const uint2 rg = CHUNKS ? ranges[blockIdx.x] : ranges[tile_order[blockIdx.x]];
+	SortPlan p;
+	p.h4 = totals[2]; p.h8 = totals[6];
+	p.direct = direct;
+	p.nlong = p.direct ? p.h8 : p.h4;
+	p.split_min = p.direct ? 2u * FR_SORT_SPLIT_MIN : (uint32_t)FR_SORT_SPLIT_MIN;
+	return p;
+}
+// Kernels launched ahead of the frame's counts (fr_forward) leave without touching anything when the frame does not fit
+// what they were sized for -- more instances than the binning workspace holds, or more blend work items than the blend
+// grid has workgroups; the host then replays the whole stage.
+struct SpecLimits { uint32_t capacity, items_cap; };
+__device__ __forceinline__ bool frame_fits(const uint32_t *totals, const SpecLimits lim) { return totals[0] <= lim.capacity && totals[5] <= lim.items_cap; }
+
+// One list of n keys (entries + rg.x ..) sorted into point_list by the whole workgroup; LDS holds THREADS x ITEMS keys.
+// fallback: a list that does not fit is sorted in place in global memory by the bitonic network (chunks of a split list
+// with thousands of equal depths); otherwise such a list is left to another kernel.
+template <int THREADS, int ITEMS, bool FALLBACK>
+__device__ __forceinline__ void msort_list(const uint2 rg, uint64_t *entries, uint32_t *point_list, uint64_t *sk)
+{
 	const int n = (int)(rg.y - rg.x);
-	if (!CHUNKS && (n <= n_lo || n >= n_hi || n > THREADS * ITEMS)) return; // another path sorts this tile
 	const int tid = threadIdx.x;
 	uint64_t *src = entries + rg.x;
 	uint32_t *dst = point_list + rg.x;
-	if (CHUNKS && n > THREADS * ITEMS)
+	if (n > THREADS * ITEMS)
 	{
+		if (!FALLBACK) return;
 		int npow2 = 1;
 		while (npow2 < n) npow2 <<= 1;
 		bitonic_sort<true>(src, n, npow2, tid, THREADS);
@@ -276,6 +295,52 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 #undef SK
 }
 
+// One tile list per workgroup (ranges[tile_order[block]]): the lists with n_lo < n < n_hi that fit the kernel's LDS.
+template <int THREADS, int ITEMS>
+__global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries,
+	uint32_t *point_list, int n_lo, int n_hi, const uint32_t *totals, SpecLimits lim)
+{
+	extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
+	if (!frame_fits(totals, lim)) return;
+	const uint2 rg = ranges[tile_order[blockIdx.x]];
+	const int n = (int)(rg.y - rg.x);
+	if (n <= n_lo || n >= n_hi) return; // another kernel sorts this list
+	msort_list<THREADS, ITEMS, false>(rg, entries, point_list, sk);
+}
+
+// The lists of 2048..4095 entries when the frame sorts that class directly (sort_plan): tile_order[h8 .. h4). The grid is
+// normally one workgroup per list (the hardware's placement of fresh workgroups is the load balancer); the loop only covers
+// a grid that was sized ahead of the counts and came out too small.
+template <int THREADS, int ITEMS>
+__global__ void __launch_bounds__(THREADS) k_tile_msort_direct(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries,
+	uint32_t *point_list, const uint32_t *totals, SpecLimits lim)
+{
+	extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
+	if (!frame_fits(totals, lim)) return;
+	const SortPlan pl = sort_plan(totals, true);
+	for (uint32_t b = pl.h8 + blockIdx.x; b < pl.h4; b += gridDim.x)
+	{
+		msort_list<THREADS, ITEMS, false>(ranges[tile_order[b]], entries, point_list, sk);
+		__syncthreads(); // the next list reuses the LDS keys
+	}
+}
+
+// The chunks of the split long lists (k_split_long): chunks[0 .. totals[4]), any length; one workgroup per chunk (the grid is
+// the bound FR_SORT_MAX_CHUNKS of the workspace's capacity; the loop is a safety net).
+template <int THREADS, int ITEMS>
+__global__ void __launch_bounds__(THREADS) k_tile_msort_chunks(const uint2 *chunks, uint64_t *entries2, uint32_t *point_list,
+	const uint32_t *totals, SpecLimits lim)
+{
+	extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
+	if (!frame_fits(totals, lim)) return;
+	const uint32_t count = totals[4];
+	for (uint32_t c = blockIdx.x; c < count; c += gridDim.x)
+	{
+		msort_list<THREADS, ITEMS, true>(chunks[c], entries2, point_list, sk);
+		__syncthreads();
+	}
+}
+
 // Long tile lists (>= FR_SORT_SPLIT_MIN entries) are not sorted as one piece: a handful of them used to occupy one
 // CU each for 50-80 us with sixteen-way merge passes while the rest of the chip had nothing left to do. A counting
 // pass on the depth bits (a fixed monotone quantisation into FR_SORT_FINE_BUCKETS buckets) regroups the list into chunks of ~FR_SORT_CHUNK_TARGET entries with disjoint, increasing depth ranges;
@@ -284,16 +349,24 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, con
 // scatter); LDS holds only the histogram.
 #define FR_SPLIT_REGS 16 // keys per thread held in registers by k_split_long (lists up to 16384 entries)
 __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const uint32_t *tile_order, const uint64_t *entries,
-	uint64_t *entries2, uint2 *chunks, uint32_t *chunk_ctr, uint32_t split_min)
+	uint64_t *entries2, uint2 *chunks, uint32_t *totals, SpecLimits lim, int direct)
 {
 	__shared__ uint32_t s_hist[FR_SORT_FINE_BUCKETS];      // counts -> exclusive offsets -> scatter cursors
 	__shared__ uint32_t s_start[FR_SORT_FINE_BUCKETS + 1]; // compacted chunk starts
 	__shared__ uint32_t s_wave[16], s_wave2[16];
 	__shared__ uint32_t s_slot;
-	const uint2 rg = ranges[tile_order[blockIdx.x]];
-	const uint32_t n = rg.y - rg.x;
-	if (n < split_min) return;
+	if (!frame_fits(totals, lim)) return;
+	const SortPlan pl = sort_plan(totals, direct != 0);
+	uint32_t *chunk_ctr = totals + 4;
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	// the long lists are the first pl.nlong entries of tile_order (longest first); normally one workgroup per list, the loop
+	// covers a grid sized ahead of the counts that came out too small
+	for (uint32_t blk = blockIdx.x; blk < pl.nlong; blk += gridDim.x)
+	{
+	const uint2 rg = ranges[tile_order[blk]];
+	const uint32_t n = rg.y - rg.x;
+	if (n >= pl.split_min)
+	{
 	const uint64_t *src = entries + rg.x;
 	uint64_t *dst = entries2 + rg.x;
 	// 1. depth bucket: the bit pattern of a positive float orders like its value, so a fixed monotone map of the
@@ -367,6 +440,9 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 			dst[atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(key >> 32))], 1u)] = key;
 		}
 #undef FR_DEPTH_BUCKET
+	}
+	__syncthreads(); // the next list reuses the histogram
+	}
 }
 
 int launch_tile_scan(FwdCtx &c)
@@ -399,21 +475,23 @@ AuxStream *aux_stream()
 	return a.ok ? &a : nullptr;
 }
 
-int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
+// Stage "tile_sort". counts_known: the host has the tile scan's class counts; otherwise the stage is launched ahead of
+// them: the plan and the grids come from the previous frame of the kind (FwdCtx::hint_*), every kernel finds its lists from
+// the counts in device memory and loops if its grid came out too small.
+int launch_tile_sort(FwdCtx &c)
 {
 	const dim3 grid(c.T);
 	const uint2 *rg = c.img.ranges;
 	const uint32_t *ord = c.img.tile_order;
+	uint32_t *totals = c.img.totals;
+	const SpecLimits lim = { (uint32_t)c.capacity, (uint32_t)c.items_cap };
 	static const bool serial = getenv("FR_SERIAL_SORT") != nullptr;
-	// Lists with >= FR_SORT_SPLIT_MIN (2048) entries are regrouped by depth into ~960-entry chunks and sorted chunk by
-	// chunk: two kernels, two passes over the entries, but no workgroup sorts more than a chunk -- right when a frame has
-	// a few hundred such lists (their latency is the stage's critical path). A frame with THOUSANDS of them (the
-	// non-foveated / training frames: half the tiles hold 2048-4095 entries) is throughput-bound instead: there the
-	// 2048..4095 class is sorted directly, one 512-thread workgroup per list in LDS, and only lists of 4096 and more are
-	// split (FR_SORT_DIRECT_TILES decides).
-	const bool direct = c.heavy4 - c.heavy8 >= FR_SORT_DIRECT_TILES;
-	const int split_min = direct ? 2 * FR_SORT_SPLIT_MIN : FR_SORT_SPLIT_MIN;
-	const int nlong = direct ? c.heavy8 : c.heavy4; // lists that are split: the first entries of tile_order
+	const bool known = c.counts_known != 0;
+	const int h4 = known ? c.heavy4 : c.hint_heavy4, h8 = known ? c.heavy8 : c.hint_heavy8;
+	const bool direct = h4 - h8 >= FR_SORT_DIRECT_TILES;
+	// grids ahead of the counts: a quarter more than last time (at least 64 workgroups)
+	auto ahead = [&](int n) { const int g = n + n / 4 + 64; return g < c.T ? g : c.T; };
+	const int nlong = known ? (direct ? h8 : h4) : ahead(direct ? h8 : h4);
 	// long lists exist: the short ones are sorted meanwhile on the helper stream
 	AuxStream *ax = (nlong > 0 && !serial && !c.a->debug) ? aux_stream() : nullptr;
 	hipStream_t small = c.stream;
@@ -425,20 +503,23 @@ int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile)
 	}
 	if (nlong > 0)
 	{
-		uint32_t *chunk_ctr = c.img.totals + 4;
-		hipLaunchKernelGGL(k_split_long, dim3(nlong), dim3(1024), 0, c.stream, rg, ord, c.bin.entries, c.bin.entries2, c.bin.chunks, chunk_ctr, (uint32_t)split_min);
-		const size_t max_chunks = FR_SORT_MAX_CHUNKS(num_instances);
-		hipLaunchKernelGGL((k_tile_msort<256, 8, true>), dim3((unsigned)max_chunks), dim3(256), 2304 * sizeof(uint64_t), c.stream,
-			c.bin.chunks, (const uint32_t *)nullptr, c.bin.entries2, c.bin.point_list, 0, 0, chunk_ctr);
+		hipLaunchKernelGGL(k_split_long, dim3(nlong), dim3(1024), 0, c.stream, rg, ord, c.bin.entries, c.bin.entries2, c.bin.chunks, totals, lim, direct ? 1 : 0);
+		const size_t max_chunks = FR_SORT_MAX_CHUNKS(c.capacity);
+		hipLaunchKernelGGL((k_tile_msort_chunks<256, 8>), dim3((unsigned)max_chunks), dim3(256), 2304 * sizeof(uint64_t), c.stream,
+			c.bin.chunks, c.bin.entries2, c.bin.point_list, totals, lim);
 	}
 	if (direct)
-		hipLaunchKernelGGL((k_tile_msort<512, 8, false>), dim3(c.heavy4), dim3(512), 4608 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
-			FR_SORT_SPLIT_MIN - 1, split_min, (const uint32_t *)nullptr);
-	if (max_tile > 512)
-		hipLaunchKernelGGL((k_tile_msort<256, 8, false>), grid, dim3(256), 2304 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
-			512, FR_SORT_SPLIT_MIN, (const uint32_t *)nullptr);
-	hipLaunchKernelGGL((k_tile_msort<64, 8, false>), grid, dim3(64), 576 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
-		0, FR_SORT_SPLIT_MIN, (const uint32_t *)nullptr);
+	{
+		const int ndirect = known ? h4 - h8 : ahead(h4 - h8);
+		hipLaunchKernelGGL((k_tile_msort_direct<512, 8>), dim3(ndirect), dim3(512), 4608 * sizeof(uint64_t), small, rg, ord, c.bin.entries,
+			c.bin.point_list, totals, lim);
+	}
+	// (class boundaries: the 513..2047 class reads n_lo = 512, the 2048..4095 one belongs to the kernels above in either plan)
+	if (!known || c.a->max_tile_instances > 512)
+		hipLaunchKernelGGL((k_tile_msort<256, 8>), grid, dim3(256), 2304 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+			512, FR_SORT_SPLIT_MIN, totals, lim);
+	hipLaunchKernelGGL((k_tile_msort<64, 8>), grid, dim3(64), 576 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+		0, 513, totals, lim);
 	if (ax)
 	{
 		(void)hipEventRecord(ax->join, ax->s);

@@ -145,10 +145,12 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	return s;
 }
 
-// Binning workspace (per (Gaussian,tile) instance).
+// Binning workspace (per (Gaussian,tile) instance), laid out for a CAPACITY of D instances (>= the frame's number: the
+// forward call may size it before the count is known, see fr_forward). point_list comes first, so that its address -- all
+// the backward pass and the introspection entry points need -- does not depend on the capacity.
 struct BinWS {
-	uint64_t *entries;    // [D] (depth bits << 32 | gaussian id), bucketed by tile
 	uint32_t *point_list; // [D] gaussian ids, sorted per tile
+	uint64_t *entries;    // [D] (depth bits << 32 | gaussian id), bucketed by tile
 	uint64_t *entries2;   // [D] long lists regrouped into depth-ordered chunks (k_split_long)
 	uint2 *chunks;        // [FR_SORT_MAX_CHUNKS(D)] ranges of those chunks inside entries2 / point_list
 	uint32_t *round_flags; // RS / LWMC blend: one bit per (tile, 256-entry round), see k_render (last: earlier offsets do not depend on T)
@@ -159,8 +161,8 @@ __host__ __device__ inline size_t round_flag_words(int64_t D, int64_t T) { retur
 __host__ __device__ inline BinWS carve_bin(int64_t D, char *base, int64_t T = 1 << 20)
 {
 	BinWS b; size_t off = 0;
-	b.entries = (uint64_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint64_t));
 	b.point_list = (uint32_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint32_t));
+	b.entries = (uint64_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint64_t));
 	b.entries2 = (uint64_t *)(base + off); off = align_up(off + (size_t)D * sizeof(uint64_t));
 	b.chunks = (uint2 *)(base + off); off = align_up(off + FR_SORT_MAX_CHUNKS(D) * sizeof(uint2));
 	b.round_flags = (uint32_t *)(base + off); off = align_up(off + round_flag_words(D, T) * sizeof(uint32_t));
@@ -384,6 +386,13 @@ struct FwdCtx {
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
 	int heavy8;         // tiles with >= 4096 instances
 	int n_items;        // entries of ImageWS::render_items
+	// The kernels behind the tile scan read the frame's counts (ImageWS::totals) from device memory and leave at once when
+	// the frame has more instances than the binning workspace holds, so they can be launched BEFORE the host knows the
+	// counts (fr_forward): counts_known = 0 -> grids are sized by upper bounds, heavy* / n_items above are not valid.
+	int counts_known;
+	int hint_heavy4, hint_heavy8; // counts not known: the class counts of the previous frame of this kind (sort plan, grid sizes)
+	int64_t capacity;   // instances the binning workspace was carved for
+	int64_t items_cap;  // blend work items the blend grid has workgroups for (a frame with more is replayed)
 	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4] (+ sequence word), or null
 	uint32_t totals_seq;       // this frame's sequence number for that word
 	float focal_x, focal_y;
@@ -409,7 +418,7 @@ int launch_project(FwdCtx &c);
 int launch_bin(FwdCtx &c);
 int launch_tile_scan(FwdCtx &c);
 int launch_emit(FwdCtx &c);
-int launch_tile_sort(FwdCtx &c, int num_instances, int max_tile);
+int launch_tile_sort(FwdCtx &c);
 int launch_render(FwdCtx &c);
 int launch_backward(const fr_backward_args *a);
 int launch_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present, hipStream_t s);

@@ -171,21 +171,41 @@ __global__ void __launch_bounds__(256) k_tile_levels(int T, int gx, int gy, int 
 // folded into the three channel sums in the reference's order (term k is basis_k * coefficient, summed
 // k = 0..15 left to right), so the result is bit-identical to the scalar formulation.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+// the 45 / 48 coefficient floats of one Gaussian as twelve 16-byte loads (usual case: M = 16 coefficients allocated).
+// Fetched unconditionally, so the loads are issued back to back and cost ONE memory round trip; k_bin issues them at
+// the head of a slab and evaluates the colour after the tile walk (sh_eval), so that the round trip -- and the lines
+// it pulls, the largest share of the kernel's traffic -- overlaps the projection and the walk instead of following them.
+struct ShRows { f4u v[12]; };
 template <bool REST>
-__device__ __forceinline__ void sh_colour(int deg, int navail, const float *__restrict__ sh, const float *__restrict__ dc,
-	float dx, float dy, float dz, float out[3])
+__device__ __forceinline__ void sh_fetch(const float *__restrict__ sh, ShRows &r)
+{
+#pragma unroll
+	for (int q = 0; q < 11; q++) r.v[q] = *(const f4u *)(sh + 4 * q);
+	if (REST) r.v[11] = (f4u){ sh[44], 0.0f, 0.0f, 0.0f };
+	else r.v[11] = *(const f4u *)(sh + 44);
+}
+__device__ __forceinline__ void sh_basis(float dx, float dy, float dz, float basis[16])
 {
 	const float len = sqrtf(dx * dx + dy * dy + dz * dz);
 	const float x = dx / len, y = dy / len, z = dz / len;
 	const float xx = x * x, yy = y * y, zz = z * z;
 	const float xy = x * y, yz = y * z, xz = x * z;
 	// basis_k with the association of the reference's expressions; terms 1 and 3 are subtracted there
-	const float basis[16] = {
+	const float b[16] = {
 		FR_SH_C0, -(FR_SH_C1 * y), FR_SH_C1 * z, -(FR_SH_C1 * x),
 		FR_SH_C2_0 * xy, FR_SH_C2_1 * yz, FR_SH_C2_2 * (2.0f * zz - xx - yy), FR_SH_C2_3 * xz, FR_SH_C2_4 * (xx - yy),
 		FR_SH_C3_0 * y * (3.0f * xx - yy), FR_SH_C3_1 * xy * z, FR_SH_C3_2 * y * (4.0f * zz - xx - yy),
 		FR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), FR_SH_C3_4 * x * (4.0f * zz - xx - yy),
 		FR_SH_C3_5 * z * (xx - yy), FR_SH_C3_6 * x * (xx - 3.0f * yy) };
+#pragma unroll
+	for (int k = 0; k < 16; k++) basis[k] = b[k];
+}
+// colour from fetched rows; dc: coefficient 0 of a REST layout (split storage / packed rows), or null (RF: left out)
+template <bool REST>
+__device__ __forceinline__ void sh_eval(int deg, const ShRows &r, const float *dc, float dx, float dy, float dz, float out[3])
+{
+	float basis[16];
+	sh_basis(dx, dy, dz, basis);
 	constexpr int SKIP = REST ? 1 : 0;
 	const int nfl = 3 * ((deg + 1) * (deg + 1) - SKIP); // floats in use
 	float acc[3] = { 0.0f, 0.0f, 0.0f };
@@ -194,38 +214,50 @@ __device__ __forceinline__ void sh_colour(int deg, int navail, const float *__re
 #pragma unroll
 		for (int ch = 0; ch < 3; ch++) acc[ch] = basis[0] * dc[ch]; // == 0 + C0 * sh[0] of the unsplit sum
 	}
+#pragma unroll
+	for (int i = 0; i < 48 - 3 * SKIP; i++)
+		if (i < nfl) acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * r.v[i / 4][i % 4];
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) out[ch] = acc[ch] + 0.5f;
+}
+template <bool REST>
+__device__ __forceinline__ void sh_colour(int deg, int navail, const float *__restrict__ sh, const float *__restrict__ dc,
+	float dx, float dy, float dz, float out[3])
+{
+	constexpr int SKIP = REST ? 1 : 0;
 	if (navail >= 48 - 3 * SKIP)
 	{
-		// usual case (M = 16 coefficients allocated): every chunk is fetched unconditionally, so the loads are
-		// issued back to back and cost ONE memory round trip; chunks beyond the active degree are ignored
-		f4u v[12];
-#pragma unroll
-		for (int q = 0; q < 11; q++) v[q] = *(const f4u *)(sh + 4 * q);
-		if (REST) v[11] = (f4u){ sh[44], 0.0f, 0.0f, 0.0f };
-		else v[11] = *(const f4u *)(sh + 44);
-#pragma unroll
-		for (int i = 0; i < 48 - 3 * SKIP; i++)
-			if (i < nfl) acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * v[i / 4][i % 4];
+		ShRows r;
+		sh_fetch<REST>(sh, r);
+		sh_eval<REST>(deg, r, dc, dx, dy, dz, out);
+		return;
 	}
-	else
+	// fewer than 16 coefficients allocated: only what the active degree uses is read
+	float basis[16];
+	sh_basis(dx, dy, dz, basis);
+	const int nfl = 3 * ((deg + 1) * (deg + 1) - SKIP); // floats in use
+	float acc[3] = { 0.0f, 0.0f, 0.0f };
+	if (REST && dc != nullptr)
 	{
 #pragma unroll
-		for (int q = 0; q < 12; q++)
+		for (int ch = 0; ch < 3; ch++) acc[ch] = basis[0] * dc[ch];
+	}
+#pragma unroll
+	for (int q = 0; q < 12; q++)
+	{
+		if (4 * q + 4 <= nfl)
 		{
-			if (4 * q + 4 <= nfl)
-			{
-				const f4u v = *(const f4u *)(sh + 4 * q);
+			const f4u v = *(const f4u *)(sh + 4 * q);
 #pragma unroll
-				for (int j = 0; j < 4; j++) { const int i = 4 * q + j; acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * v[j]; }
-			}
-			else
-			{
+			for (int j = 0; j < 4; j++) { const int i = 4 * q + j; acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * v[j]; }
+		}
+		else
+		{
 #pragma unroll
-				for (int j = 0; j < 4; j++)
-				{
-					const int i = 4 * q + j;
-					if (i < nfl) acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * sh[i];
-				}
+			for (int j = 0; j < 4; j++)
+			{
+				const int i = 4 * q + j;
+				if (i < nfl) acc[i % 3] = acc[i % 3] + basis[i / 3 + SKIP] * sh[i];
 			}
 		}
 	}
@@ -642,7 +674,12 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 				maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * (smax * smax) * 1.00001f, cur.hl, wn2);
 			}
 			else maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
+#ifdef FR_PROJ_MASKED_RADII
 			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
+#else
+			a.radii[idx] = 0; // whole lines (a store with the survivors masked out is a partial-line write); k_bin, which runs
+			                  // after this kernel, writes the radius of every survivor
+#endif
 			// auxiliary.h:156-160: the reference traps on a near-culled point of a cloud declared prefiltered
 			if (a.prefiltered && !maybe && (vm[2] * cur.p[0] + vm[6] * cur.p[1] + vm[10] * cur.p[2] + vm[14]) <= 0.2f) atomicOr(a.geom.slab_ctr, 1u);
 		}
@@ -699,6 +736,9 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 // LDSH: the counters are an LDS-private histogram (T <= 16 Ki tiles) written once per workgroup to
 // hist[block][tile] -- no global atomics at all; otherwise (huge tile grids) global atomics on tile_count.
 #define BUMP_TILE(ti) do { if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
+#ifndef FR_BIN_PREFETCH
+#define FR_BIN_PREFETCH 1 // colour rows fetched at the head of a slab (0: after the walk, as round 2 did)
+#endif
 // CROW: the candidate's inputs come as the row k_project stored (GeomWS::crow via vis_src).
 template <int VARIANT, bool LDSH, bool PACKED = false, bool CROW = false>
 __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
@@ -812,22 +852,64 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		be_blend = (lvmask & 16u) != 0;
 	};
 	// Per-Gaussian epilogue once its tile count is known: radius of culled-everywhere splats, colour(s), final record.
+	// Colour inputs of a candidate, fetched at the head of its slab (see the slab loop): SH rows, and either the four
+	// levels' DC coefficients + opacities (RF) or coefficient 0 (split / packed storage) + the opacity.
+	struct ColourPre { ShRows sh; f4u dc0, dc1, dc2, opl; float dc[3]; float op; };
+	// (uniform) the usual storage -- SH coefficients given, all 16 allocated -- is what the early fetch handles
+	const bool rows_ok = a.colors_precomp == nullptr &&
+		(PACKED || (LEVELCOL ? a.M * 3 >= 45 : (a.shs_rest != nullptr ? (a.M - 1) * 3 >= 45 : a.M * 3 >= 48)));
+	const bool pre_ok = FR_BIN_PREFETCH && rows_ok;
+	auto prefetch_colour = [&](const int idx, ColourPre &cp) __attribute__((always_inline))
+	{
+		const float *pcol = PACKED ? a.packed_colour + 64 * (size_t)idx : nullptr;
+		if (LEVELCOL)
+		{
+			const f4u *dcp = (const f4u *)(PACKED ? pcol + 48 : a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
+			cp.dc0 = dcp[0]; cp.dc1 = dcp[1]; cp.dc2 = dcp[2];
+			cp.opl = *(const f4u *)(PACKED ? a.packed_geom + 16 * (size_t)idx + 12 : a.opacities + (size_t)idx * FR_FOV_LEVELS);
+			sh_fetch<true>(PACKED ? pcol : a.shs + (size_t)idx * a.M * 3, cp.sh);
+		}
+		else
+		{
+			cp.op = PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx];
+			if (PACKED) { sh_fetch<true>(pcol, cp.sh); cp.dc[0] = pcol[45]; cp.dc[1] = pcol[46]; cp.dc[2] = pcol[47]; }
+			else if (a.shs_rest != nullptr)
+			{
+				sh_fetch<true>(a.shs_rest + (size_t)idx * (a.M - 1) * 3, cp.sh);
+				cp.dc[0] = a.shs[3 * (size_t)idx]; cp.dc[1] = a.shs[3 * (size_t)idx + 1]; cp.dc[2] = a.shs[3 * (size_t)idx + 2];
+			}
+			else sh_fetch<false>(a.shs + (size_t)idx * a.M * 3, cp.sh);
+		}
+	};
+	// Per-Gaussian epilogue once its tile count is known: radius of culled-everywhere splats, colour(s), final record.
+	// cp_in: the colour inputs fetched at the head of the slab if have_cp, else they are fetched here (giant splats; storage
+	// with fewer than 16 coefficients takes the generic path). (A value + a flag: a pointer that may be null, or a choice
+	// between two structs by reference, sends the whole struct through scratch memory.)
 	auto finish = [&](const int idx, const int item, const uint32_t count, const float hl, const float lowest, const float highest,
-		const bool be_blend, const float conic_c, const float depth, const float *pos) __attribute__((always_inline))
+		const bool be_blend, const float conic_c, const float depth, const float *pos, const ColourPre &cp_in, const bool have_cp_in) __attribute__((always_inline))
 	{
 		if (count == 0) { a.radii[idx] = 0; return; } // culled everywhere (RS rasterizer_impl.cu:141-145)
+		ColourPre cp = cp_in;
+		if (!have_cp_in && rows_ok) prefetch_colour(idx, cp);
+		const bool have_cp = have_cp_in || rows_ok;
 		float rgb[3] = { 0, 0, 0 };
 		uint32_t clamp_bits = 0;
 		// pos: the caller still holds the position (null: fetch it)
 		const float *mp = pos ? pos : (PACKED ? a.packed_geom + 16 * (size_t)idx : a.means3D + 3 * (size_t)idx);
 		const float dirx = mp[0] - a.campos[0], diry = mp[1] - a.campos[1], dirz = mp[2] - a.campos[2];
 		const float *pcol = PACKED ? a.packed_colour + 64 * (size_t)idx : nullptr;
+		float opacity = 0.0f;
 		if (!LEVELCOL)
 		{
 			if (a.colors_precomp == nullptr)
 			{
 				float c[3];
-				if (PACKED)
+				if (have_cp)
+				{
+					if (PACKED || a.shs_rest != nullptr) sh_eval<true>(a.D, cp.sh, cp.dc, dirx, diry, dirz, c);
+					else sh_eval<false>(a.D, cp.sh, nullptr, dirx, diry, dirz, c);
+				}
+				else if (PACKED)
 					sh_colour<true>(a.D, 45, pcol, pcol + 45, dirx, diry, dirz, c);
 				else if (a.shs_rest != nullptr)
 					sh_colour<true>(a.D, (a.M - 1) * 3, a.shs_rest + (size_t)idx * (a.M - 1) * 3, a.shs + 3 * (size_t)idx, dirx, diry, dirz, c);
@@ -841,6 +923,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 #pragma unroll
 				for (int ch = 0; ch < 3; ch++) rgb[ch] = a.colors_precomp[3 * (size_t)idx + ch];
 			}
+			const float op_in = have_cp ? cp.op : (PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx]);
+			opacity = (!PACKED && !FOV && a.raw) ? act_opacity(op_in) : op_in;
 		}
 		else
 		{
@@ -850,14 +934,23 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
 			a.geom.lrange[idx] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
 			// all four levels' DC colours (12 floats) and opacities are fetched with the SH coefficients: one round trip
-			const f4u *dcp = (const f4u *)(PACKED ? pcol + 48 : a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
-			const f4u dc0 = dcp[0], dc1 = dcp[1], dc2 = dcp[2];
-			const f4u opl = *(const f4u *)(PACKED ? a.packed_geom + 16 * (size_t)idx + 12 : a.opacities + (size_t)idx * FR_FOV_LEVELS);
+			f4u dc0, dc1, dc2, opl;
+			float rest[3];
+			if (have_cp)
+			{
+				dc0 = cp.dc0; dc1 = cp.dc1; dc2 = cp.dc2; opl = cp.opl;
+				sh_eval<true>(a.D, cp.sh, nullptr, dirx, diry, dirz, rest);
+			}
+			else
+			{
+				const f4u *dcp = (const f4u *)(PACKED ? pcol + 48 : a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
+				dc0 = dcp[0]; dc1 = dcp[1]; dc2 = dcp[2];
+				opl = *(const f4u *)(PACKED ? a.packed_geom + 16 * (size_t)idx + 12 : a.opacities + (size_t)idx * FR_FOV_LEVELS);
+				if (PACKED) sh_colour<true>(a.D, 45, pcol, nullptr, dirx, diry, dirz, rest);
+				else sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, rest);
+			}
 			const float dcs[12] = { dc0.x, dc0.y, dc0.z, dc0.w, dc1.x, dc1.y, dc1.z, dc1.w, dc2.x, dc2.y, dc2.z, dc2.w };
 			const float ops[4] = { opl.x, opl.y, opl.z, opl.w };
-			float rest[3];
-			if (PACKED) sh_colour<true>(a.D, 45, pcol, nullptr, dirx, diry, dirz, rest);
-			else sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, rest);
 			static_assert(FR_FOV_LEVELS == 4, "level data is fetched as float4s");
 #pragma unroll
 			for (int l = 0; l < FR_FOV_LEVELS; l++)
@@ -875,7 +968,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		float4 *rec = a.geom.rec + 3 * (size_t)idx;
 		if (LEVELCOL) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
-		else rec[1] = make_float4(conic_c, PACKED ? a.packed_geom[16 * (size_t)idx + 12] : ((!FOV && a.raw) ? act_opacity(a.opacities[idx]) : a.opacities[idx]), rgb[0], rgb[1]);
+		else rec[1] = make_float4(conic_c, opacity, rgb[0], rgb[1]);
 		// third part: item = where the backward pass keeps this Gaussian's sums; the shared-model foveated variant (no
 		// backward, no clamp bits needed) carries the Gaussian's highest level there instead
 		if (FOV && !LEVELCOL) rec[2] = make_float4(rgb[2], depth, hl, 0.0f);
@@ -928,6 +1021,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	bool be_blend = false, boxtest = false;
 	RawGaussian w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0);
 	float inv_qnorm = 1.0f;
+	ColourPre cp;
 	if (item < V)
 	{
 		// the candidate's full projection (covariance chain, conic, radius: forward.cu:155-262), its OBB axes and
@@ -971,6 +1065,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			}
 			if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
 		}
+		// the colour rows are asked for NOW and evaluated after the walk (finish): their round trip and the lines they pull
+		// run under the projection and the tile walk
+		if (pre_ok) prefetch_colour(idx, cp);
 		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q, a.write_cov3D ? (float4 *)a.geom.cov3D + 4 * (size_t)item : nullptr);
 		if (a.write_cov3D)
 		{
@@ -1104,7 +1201,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
 		TM_END(tm_p);
-		if (pr.alive && !deferred) finish(idx, item, count, hl, lowest, highest, be_blend, r1.x, r2.y, w.p);
+		if (pr.alive && !deferred) finish(idx, item, count, hl, lowest, highest, be_blend, r1.x, r2.y, w.p, cp, pre_ok);
 		// walk record for k_emit (and for the giant phase below), in list order: coalesced 64-byte rows
 		if (item < V)
 		{
@@ -1146,7 +1243,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		float lowest = ghl, highest = 0.0f;
 		bool be_blend = false;
 		if (FOV && gcount != 0) range_from_mask(s_gmask[threadIdx.x], lowest, highest, be_blend);
-		finish(gi, s_gitem[threadIdx.x], gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y, nullptr);
+		ColourPre none = {};
+		finish(gi, s_gitem[threadIdx.x], gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y, nullptr, none, false);
 	}
 #ifdef FR_BIN_TIMERS
 	if (lane == 0)
@@ -1182,6 +1280,9 @@ struct EmitArgs {
 	uint32_t *cursor;
 	uint64_t *entries;
 	const uint32_t *hist; // [blocks][T] exclusive prefix over workgroups (LDSH)
+	const uint32_t *totals; // ImageWS::totals: [0] = the frame's number of instances (k_tile_scan)
+	uint32_t capacity;      // instances `entries` has room for ...
+	uint32_t items_cap;     // ... and blend work items the frame's blend grid covers (see fr_forward)
 };
 // LDSH: the workgroup's write cursor of every tile lives in LDS, initialised to
 // tile start + (instances of the same tile owned by lower-numbered workgroups).
@@ -1196,6 +1297,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
+	// launched before the host knows the frame's instance count (fr_forward): when the binning workspace turns out too
+	// small nothing is emitted, the host replays the stage with a larger one
+	if (a.totals[0] > a.capacity || a.totals[5] > a.items_cap) return;
 	const int lane = threadIdx.x & 63;
 	float *lds_tmin = (float *)(lds_cur + (LDSH ? a.T : 0)); // RF: tile_min staged in LDS, as in k_bin
 	const bool ldst = FOV && a.lds_tiles;
@@ -1616,6 +1720,7 @@ int launch_emit(FwdCtx &c)
 	e.P = a->P; e.gx = c.gx; e.gy = c.gy; e.T = c.T; e.radii = a->radii; e.geom = c.geom;
 	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.lv_bbox = c.img.lv_bbox; e.ranges = c.img.ranges;
 	e.cursor = c.img.tile_count; e.entries = c.bin.entries; e.hist = c.img.hist;
+	e.totals = c.img.totals; e.capacity = (uint32_t)c.capacity; e.items_cap = (uint32_t)c.items_cap;
 	const bool ldsh = c.img.hist != nullptr;
 	const dim3 grid(c.bin_wgs), block(FR_EMIT_THREADS);
 	e.lds_tiles = (is_fov(a->variant) && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;

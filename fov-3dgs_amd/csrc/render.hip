@@ -108,7 +108,8 @@ struct RenderArgs {
 	float *contributions;   // RS / MAX / LWMC
 	const float *loss_map;  // LWMC
 	const uint32_t *render_items; // work items, longest list first (k_tile_scan): tile << 3 | band | level state << 1 | two-level << 2 ...
-	uint32_t n_items;             // ... and their number
+	const uint32_t *totals;       // ... ImageWS::totals: [5] = their number (the grid may be an upper bound), [0] = the frame's instances
+	uint32_t capacity;            // instances the binning workspace holds: a frame with more is not blended (the host replays it)
 	float cur_level;              // MMFR
 	uint32_t *round_flags;        // RS / LWMC: one bit per (tile, 256-entry round): the round's counts have an owner
 };
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 	__shared__ int sid[NEEDID ? 64 : 1];
 
 	const int st = threadIdx.x; // lane = staging slot
-	if (blockIdx.x >= a.n_items) return;
+	if (blockIdx.x >= a.totals[5] || a.totals[0] > a.capacity || a.totals[5] > gridDim.x) return;
 	const uint32_t item = a.render_items[blockIdx.x];
 	const int tile = (int)(item >> 3), wv = (int)(item & 1u); // band of this wave
 	const int tx = tile % a.gx, ty = tile / a.gx;
@@ -395,6 +396,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 
 	const int lane = threadIdx.x;
 	const uint32_t idx = blockIdx.x;
+	if (idx >= a.totals[5] || a.totals[0] > a.capacity || a.totals[5] > gridDim.x) return;
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 	const size_t plane = (size_t)a.W * a.H;
 	{
@@ -610,7 +612,7 @@ __global__ void __launch_bounds__(64) k_render_smfr(const RenderArgs a)
 	__shared__ float4 s1[64];   // C, opacity, highest level, -
 	__shared__ float4 scol[64]; // r, g, b, -
 	const int lane = threadIdx.x;
-	if (blockIdx.x >= a.n_items) return;
+	if (blockIdx.x >= a.totals[5] || a.totals[0] > a.capacity || a.totals[5] > gridDim.x) return;
 	const uint32_t item = a.render_items[blockIdx.x];
 	const int tile = (int)(item >> 3), wv = (int)(item & 1u);
 	const int tx = tile % a.gx, ty = tile / a.gx;
@@ -735,7 +737,7 @@ __global__ void __launch_bounds__(64) k_render_mmfr(const RenderArgs a)
 	__shared__ float2 s1[64];   // C, opacity
 	__shared__ float4 scol[64]; // r, g, b, -
 	const int lane = threadIdx.x;
-	if (blockIdx.x >= a.n_items) return;
+	if (blockIdx.x >= a.totals[5] || a.totals[0] > a.capacity || a.totals[5] > gridDim.x) return;
 	const uint32_t item = a.render_items[blockIdx.x];
 	const int tile = (int)(item >> 3), wv = (int)(item & 1u);
 	const int tx = tile % a.gx, ty = tile / a.gx;
@@ -839,15 +841,20 @@ int launch_render(FwdCtx &c)
 	r.tile_lv = c.img.tile_lv; r.tile_order = c.img.tile_order; r.T = c.T; r.bg = a->background; r.out_color = a->out_color;
 	r.final_T = c.img.final_T; r.n_contrib = c.img.n_contrib;
 	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions; r.loss_map = a->loss_map;
-	r.render_items = c.img.render_items; r.n_items = (uint32_t)c.n_items; r.cur_level = a->cur_level;
+	r.render_items = c.img.render_items; r.totals = c.img.totals; r.capacity = (uint32_t)c.capacity; r.cur_level = a->cur_level;
 	constexpr int PPL = 2;
 	r.round_flags = c.bin.round_flags;
 	if (has_stats(a->variant) && a->variant != FR_VARIANT_PCHECK_OBB_MAX && c.bin.round_flags)
 	{
-		const hipError_t e = hipMemsetAsync(c.bin.round_flags, 0, round_flag_words(a->num_rendered, c.T) * sizeof(uint32_t), c.stream);
+		const hipError_t e = hipMemsetAsync(c.bin.round_flags, 0, round_flag_words(c.capacity, c.T) * sizeof(uint32_t), c.stream);
 		if (e != hipSuccess) { set_error("hipMemsetAsync(round_flags): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
 	}
-#define FR_LAUNCH_RENDER(V, UNUSED_) hipLaunchKernelGGL((k_render<V, PPL>), dim3(r.n_items), dim3(64), 0, c.stream, r)
+	// work items: two bands per tile, and for RF two more per two-level tile -- how many of those the frame has is only known
+	// on the device until the host has read the counts: the grid is then FwdCtx::items_cap (a little more than the previous
+	// frame of the kind had; surplus workgroups leave at once -- they sit at the END of the grid, behind all the work -- and
+	// a frame with more items than that is not blended but replayed, see frame_fits)
+	const unsigned n_items = (unsigned)(c.counts_known ? c.n_items : c.items_cap);
+#define FR_LAUNCH_RENDER(V, UNUSED_) hipLaunchKernelGGL((k_render<V, PPL>), dim3(n_items), dim3(64), 0, c.stream, r)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: FR_LAUNCH_RENDER(FR_VARIANT_ORIGINAL, true); break;
@@ -855,10 +862,10 @@ int launch_render(FwdCtx &c)
 	case FR_VARIANT_PCHECK_OBB: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB, true); break;
 	case FR_VARIANT_PCHECK_OBB_MAX: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_MAX, true); break;
 	case FR_VARIANT_PCHECK_OBB_LWMC: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_LWMC, false); break;
-	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: hipLaunchKernelGGL((k_render_smfr<2>), dim3(r.n_items), dim3(64), 0, c.stream, r); break;
-	case FR_VARIANT_MMFR_PCHECK_OBB: hipLaunchKernelGGL((k_render_mmfr<2>), dim3(r.n_items), dim3(64), 0, c.stream, r); break;
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: hipLaunchKernelGGL((k_render_smfr<2>), dim3(n_items), dim3(64), 0, c.stream, r); break;
+	case FR_VARIANT_MMFR_PCHECK_OBB: hipLaunchKernelGGL((k_render_mmfr<2>), dim3(n_items), dim3(64), 0, c.stream, r); break;
 	default:
-		hipLaunchKernelGGL((k_render_fov<2>), dim3(r.n_items), dim3(64), 0, c.stream, r);
+		hipLaunchKernelGGL((k_render_fov<2>), dim3(n_items), dim3(64), 0, c.stream, r);
 		break;
 	}
 #undef FR_LAUNCH_RENDER

@@ -54,6 +54,34 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_small_copies = {}
+
+
+def _f32_small(t, device):
+    """_f32 for the per-call camera tensors (viewmatrix, projmatrix, campos, bg: a few floats each). The reference's cameras
+    keep world_view_transform as a TRANSPOSED view (scene/cameras.py:54), so `.contiguous()` is a copy kernel on the stream
+    at the head of every frame (~6 us of a 0.7 ms frame, twice); the copy is kept for as long as the caller hands over the
+    same tensor object with the same storage, strides and autograd version (writes through `.data` are not seen: clone the
+    tensor after such a write)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device == device and t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    if t.numel() > 64:
+        return _f32(t, device)
+    key = id(t)
+    ent = _small_copies.get(key)
+    sig = (t._version, t.data_ptr(), t.stride(), t.dtype, t.device)
+    if ent is not None and ent[0]() is t and ent[1] == sig:
+        return ent[2]
+    c = _f32(t, device)
+    if len(_small_copies) > 256:
+        _small_copies.clear()
+    import weakref
+    _small_copies[key] = (weakref.ref(t), sig, c)
+    return c
+
+
 def _require_gpu(means3D):
     if not means3D.is_cuda:
         raise RuntimeError("fovraster: tensors must live on a ROCm GPU -- the rasterizer is a HIP extension and has no "
@@ -202,8 +230,8 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
     a = _native.ForwardArgs()
     keep = []
 
-    def put(name, t):
-        t = _f32(t, dev)
+    def put(name, t, small=False):
+        t = _f32_small(t, dev) if small else _f32(t, dev)
         keep.append(t)
         setattr(a, name, _ptr(t))
         return t
@@ -228,16 +256,16 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         a.cur_level = float(cur_level)
         a.raw_activations = int(bool(raw_activations))
         a.stream = torch.cuda.current_stream(dev).cuda_stream
-        put("background", rs.bg)
+        put("background", rs.bg, small=True)
         put("means3D", means3D)
         put("colors_precomp", colors_precomp)
         put("opacities", opacities)
         put("scales", scales)
         put("rotations", rotations)
         put("cov3D_precomp", cov3Ds_precomp)
-        put("viewmatrix", rs.viewmatrix)
-        put("projmatrix", rs.projmatrix)
-        put("campos", rs.campos)
+        put("viewmatrix", rs.viewmatrix, small=True)
+        put("projmatrix", rs.projmatrix, small=True)
+        put("campos", rs.campos, small=True)
         put("shs_dcs", shs_dcs)
         put("highest_levels", highest_levels)
         a.out_color, a.radii = color.data_ptr(), radii.data_ptr()
@@ -276,8 +304,8 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
     a = _native.BackwardArgs()
     keep = []
 
-    def put(name, t):
-        t = _f32(t, dev)
+    def put(name, t, small=False):
+        t = _f32_small(t, dev) if small else _f32(t, dev)
         keep.append(t)
         setattr(a, name, _ptr(t))
         return t
@@ -306,16 +334,16 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
             a.raw_activations = int(bool(raw_activations))
             a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
             a.stream = torch.cuda.current_stream(dev).cuda_stream
-            put("background", rs.bg)
+            put("background", rs.bg, small=True)
             put("means3D", means3D)
             put("colors_precomp", colors_precomp)
             put("opacities", opacities)
             put("scales", scales)
             put("rotations", rotations)
             put("cov3D_precomp", cov3Ds_precomp)
-            put("viewmatrix", rs.viewmatrix)
-            put("projmatrix", rs.projmatrix)
-            put("campos", rs.campos)
+            put("viewmatrix", rs.viewmatrix, small=True)
+            put("projmatrix", rs.projmatrix, small=True)
+            put("campos", rs.campos, small=True)
             put("dL_dpix", grad_out_color)
             a.radii = radii.data_ptr()
             a.geometry, a.binning, a.image = geomBuffer.data_ptr(), _ptr(binningBuffer if binningBuffer.numel() else None), imgBuffer.data_ptr()

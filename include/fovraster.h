@@ -21,8 +21,12 @@
  * stands for the reference's "empty tensor". The library never allocates or frees device memory:
  * the three workspaces are obtained through the caller's resize callbacks, exactly like the
  * reference's geometry/binning/image buffers, and must be kept alive by the caller for
- * fr_backward. All work is enqueued on `stream` (a hipStream_t); fr_forward synchronises that
- * stream once (to learn the number of (Gaussian,tile) instances), fr_backward never does.
+ * fr_backward. All work is enqueued on `stream` (a hipStream_t). fr_forward returns num_rendered like the
+ * reference, so it waits ONCE for that count (a 32-byte block the tile scan writes into pinned host memory) -- but not
+ * for the frame: from the second frame of a kind (variant, P, W, H) on, the kernels behind the count are already
+ * enqueued when the host starts waiting (they are sized by the previous frame's count plus a quarter and read the real
+ * counts from device memory; a frame that does not fit is replayed), so the GPU never idles at that point and the
+ * call returns while the frame is still being sorted and blended. fr_backward never synchronises.
  * All functions return 0 on success or a negative FR_ERR_* code; fr_last_error() gives the message
  * (thread-local).
  */
@@ -36,7 +40,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 5
+#define FR_ABI_VERSION 6
 
 /* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
  * fov3dgs/gaussian_wrapper.py:11-23) */
@@ -195,6 +199,11 @@ typedef struct fr_backward_args {
 
 int fr_abi_version(void);
 const char *fr_last_error(void);
+/* How the calling thread's fr_forward calls obtained their instance count (see fr_forward below): out[0] = frames whose
+ * binning / sort / blend kernels were launched BEFORE the count reached the host (sized by the previous frame of the
+ * same kind), out[1] = those of them that had to be replayed because the count exceeded that size, out[2] = frames
+ * launched after the count (first frame of a kind, debug calls). For tests and tuning. */
+void fr_speculation_stats(int64_t out[3]);
 
 /* hipEvent wrappers so a host that only speaks the C ABI can time stages on the launch stream */
 void *fr_event_create(void);

@@ -781,3 +781,44 @@ def test_prefiltered_violation_is_reported():
     cd = dict(cam_dict(cam.to("cpu")), prefiltered=True)
     with pytest.raises(RuntimeError, match="prefiltered"):
         orc.forward("original", scene, cd)
+
+
+@pytest.mark.parametrize("variant", ("pcheck_obb", "fov_pcheck_obb", "pcheck_obb_sum"))
+def test_frames_launched_ahead_of_their_instance_count(variant):
+    """fr_forward launches binning / sort / blend of the second and later frames of a kind before the instance count has
+    reached the host (include/fovraster.h). Same frame three ways: launched after the count (first call), ahead of it
+    (second call), and ahead of it with a workspace that turns out too small (a frame with > 1.25x the instances right
+    after a small one: replayed) -- lists and image identical to the oracle's each time."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    from fov3dgs_amd import _native
+    scene, cam = small_case(variant, P=5003, seed=19, width=408, height=232)  # a (P, W, H) no other test uses: no guess yet
+    want = orc.forward(variant, scene, cam)
+    s0 = _native.speculation_stats()
+    runs = [hip_forward(variant, scene, cam, debug=False) for _ in range(3)]
+    s1 = _native.speculation_stats()
+    assert (s1[0] - s0[0], s1[1] - s0[1], s1[2] - s0[2]) == (2, 0, 1), (s0, s1)
+    for got in runs:
+        assert got["num_rendered"] == want["num_rendered"]
+        np.testing.assert_array_equal(got["radii"], want["radii"])
+        np.testing.assert_array_equal(got["ranges"], want["ranges"])
+        np.testing.assert_array_equal(got["point_list"], want["point_list"])
+        check_image(got["color"], want["color"], name=variant + " launched ahead of its count")
+        if variant == "pcheck_obb_sum":
+            np.testing.assert_array_equal(got["gaussians_count"], want["gaussians_count"])
+    np.testing.assert_array_equal(runs[1]["color"], runs[2]["color"])
+    # a much heavier frame of the same kind: every splat 2.5x larger
+    big = dict(cam, scale_modifier=2.5)
+    want_big = orc.forward(variant, scene, big)
+    assert want_big["num_rendered"] > 1.6 * want["num_rendered"]
+    got_big = hip_forward(variant, scene, big, debug=False)
+    s2 = _native.speculation_stats()
+    assert (s2[0] - s1[0], s2[1] - s1[1], s2[2] - s1[2]) == (1, 1, 0), (s1, s2)
+    assert got_big["num_rendered"] == want_big["num_rendered"]
+    np.testing.assert_array_equal(got_big["ranges"], want_big["ranges"])
+    np.testing.assert_array_equal(got_big["point_list"], want_big["point_list"])
+    check_image(got_big["color"], want_big["color"], name=variant + " replayed after an undersized launch")
+    # ... and back to the small frame (the workspace is larger than needed now)
+    again = hip_forward(variant, scene, cam, debug=False)
+    np.testing.assert_array_equal(again["point_list"], want["point_list"])
+    np.testing.assert_array_equal(again["color"], runs[1]["color"])
