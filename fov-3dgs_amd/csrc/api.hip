@@ -214,18 +214,21 @@ int fr_forward(fr_forward_args *a)
 	rc = launch_tile_scan(c); if (rc) return rc;
 
 	// Everything behind the tile scan needs the frame's counts: the number of instances D (size of the binning workspace)
-	// and the sort / blend class counts. They are on their way to this thread's pinned block. When the caller's binning
-	// buffer of the previous frame of this kind was large enough (it almost always is: the buffers are grow-only), the rest
-	// of the frame is launched NOW, on upper bounds -- the kernels read the counts from device memory and leave at once if
-	// D exceeds the capacity they were given -- and the host only then waits for the counts, while the GPU is busy with the
-	// frame: no idle GPU at the one synchronisation point (12 us with polling, 33 us without), no host code on the frame's
-	// critical path. If D does not fit (a sudden jump by more than a quarter), the stage is replayed with the right size.
+	// and the sort / blend class counts. They are on their way to this thread's pinned block, which the host polls: the
+	// numbers land a few microseconds before k_tile_scan retires, so the launches that follow reach the queue while it still
+	// runs and the GPU does not wait for the host (measured: the union of a frame's kernels covers all of it but ~20 us, none
+	// of them at this point). LAUNCH-AHEAD MODE (opt-in, FR_LAUNCH_AHEAD=1): when the caller's binning buffer of the
+	// previous frame of this kind was large enough, the rest of the frame is launched BEFORE the wait, sized by that frame
+	// -- the kernels read the counts from device memory and leave at once if the frame does not fit (frame_fits), in which
+	// case the stage is replayed -- so that the call returns ~0.35 ms earlier (a host with other work to do between frames).
+	// It does not make the GPU faster: the grids are bounds, the kernels find their work through one more indirection, and the
+	// same frames take 1.3 % longer (0.753 vs 0.743 ms, four alternations on one box), which is why it is not the default.
 	struct Guess { int32_t variant = -1, P = 0, W = 0, H = 0; int64_t capacity = 0, items_cap = 0; int heavy4 = 0, heavy8 = 0; };
 	static thread_local Guess guesses[8];
 	Guess &gs = guesses[a->variant & 7];
 	const bool same_kind = gs.variant == a->variant && gs.P == a->P && gs.W == a->W && gs.H == a->H;
-	static const bool no_spec = getenv("FR_NO_SPECULATION") != nullptr;
-	const bool speculate = same_kind && gs.capacity > 0 && pinned && !a->debug && !no_spec;
+	const char *ahead_env = getenv("FR_LAUNCH_AHEAD"); // (read per call: tests switch it)
+	const bool speculate = same_kind && gs.capacity > 0 && pinned && !a->debug && ahead_env != nullptr && ahead_env[0] == '1';
 	const int64_t items_max = (int64_t)(c.fov_split ? 4 : 2) * c.T; // two bands per tile, twice that for an RF two-level tile
 	auto rest_of_frame = [&](int64_t capacity, bool known) -> int
 	{

@@ -125,11 +125,10 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 	float2 p2 = make_float2(0, 0);
 	auto fetch = [&](int e)
 	{
-		const uint32_t id = a.point_list[range.x + e];
+		const uint32_t id = a.point_list[range.x + e]; // the item: its record and its row of gradient sums share the index
 		const float4 *r = a.rec + 3 * (size_t)id;
 		p0 = r[0]; p1 = r[1];
-		const float4 r2 = r[2];
-		p2 = make_float2(r2.x, r2.w);
+		p2 = make_float2(r[2].x, __uint_as_float(id));
 	};
 	if (lane < wave_last) fetch(wave_last - 1 - lane);
 	for (int top = wave_last; top > 0; top -= 64)
@@ -344,8 +343,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	const V3 u0 = axpy3(j00, Rx, { j02 * Rz.x, j02 * Rz.y, j02 * Rz.z });
 	const V3 u1 = axpy3(j11, Ry, { j12 * Rz.x, j12 * Rz.y, j12 * Rz.z });
 	// H = -Q Ghat Q with the conic Q the forward pass stored
-	const float4 rc0 = a.rec[3 * (size_t)idx];
-	const float4 rc1 = a.rec[3 * (size_t)idx + 1]; // (conic c, opacity, ...)
+	const float4 rc0 = a.rec[3 * (size_t)slot];
+	const float4 rc1 = a.rec[3 * (size_t)slot + 1]; // (conic c, opacity, ...)
 	const float qa = rc0.z, qb = rc0.w, qc = rc1.x;
 	if (a.raw) a.dL_dopacity[idx] = ac2.x * rc1.y * (1.0f - rc1.y);
 	const float k00 = qa * gA + qb * gB, k01 = qa * gB + qb * gC, k10 = qb * gA + qc * gB, k11 = qb * gB + qc * gC; // Q Ghat
@@ -418,7 +417,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 			for (int i = 0; i < 45; i++) if (i < nuse) coef[3 + i] = sh_r[i];
 		}
 		// a channel clamped at zero in the forward pass passes no gradient (forward.cu:63-70)
-		const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)idx + 2].z);
+		const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)slot + 2].z);
 		const float g[3] = { (clamp_bits & 1u) ? 0.f : g_col[0], (clamp_bits & 2u) ? 0.f : g_col[1], (clamp_bits & 4u) ? 0.f : g_col[2] };
 		const V3 off = { mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2] };
 		const float len2 = dot3(off, off), ilen = 1.0f / sqrtf(len2);

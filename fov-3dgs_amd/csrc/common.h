@@ -47,28 +47,38 @@ __host__ __device__ constexpr inline bool is_fov(int v) { return v == FR_VARIANT
 // All sub-arrays are 256-byte aligned inside the caller's buffers.
 __host__ __device__ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// Geometry workspace (per Gaussian). rec = 3 float4 per Gaussian:
+// Geometry workspace. Everything per CANDIDATE is indexed by the candidate's position in vis_list ("item"), the list of
+// Gaussians that survive the cull pass IN INCREASING GAUSSIAN INDEX (k_project + k_compact): the binning kernel's outputs
+// are then dense rows written by consecutive lanes, and the blend kernels gather from a few tens of MB instead of from
+// 48-byte rows spread 12 % dense over P of them. (Measured on MI355X, tools/scratch/gather_rate.hip: a store instruction
+// whose 64 lanes hit 64 different lines costs a CU ~11 cycles per lane, a load ~3; round 2's per-Gaussian-index records
+// were 7-9 such stores per candidate -- more than a third of k_bin.) Because items are in index order, sorting a tile's
+// instances by (depth bits, item) gives the order the reference's stable sort by (tile, depth) of index-ordered keys does.
+// rec = 3 float4 per item:
 //   [0] = (mean2D.x, mean2D.y, conic.a, conic.b)
 //   [1] = (conic.c, opacity, r, g)          RF: (conic.c, highest_level, 0, 0)
-//   [2] = (b, depth, clamp bits, position in vis_list as int bits)
+//   [2] = (b, depth, clamp bits, Gaussian index as int bits)      SMFR: (b, depth, highest level, Gaussian index)
 struct GeomWS {
 	float4 *rec;        // [3P]
-	float *cov3D;       // training variants: [16P] one 64-byte row per vis_list entry, in list order, written by k_bin for the
+	float *cov3D;       // training variants: [16P] one 64-byte row per item, written by k_bin for the
 	                    // backward pass: (xyz | raw scale | rotation | 3D covariance) -- one coalesced row instead of four gathers
-	float4 *acc;        // training variants: [4P] one 64-byte row of gradient sums per vis_list entry, in list order, zeroed by k_bin,
+	float4 *acc;        // training variants: [4P] one 64-byte row of gradient sums per item, zeroed by k_bin,
 	                    //      accumulated by k_render_bwd (one atomic instruction per list entry and wave), read by k_preprocess_bwd:
 	                    //      (dL/d colour r, g, b, dL/d mean2D x | y, dL/d conic a, b, c | dL/d opacity, -, -, - | -)
-	float4 *wrec;       // [4P] walk record of vis_list entry i at [4i..4i+3], written by k_bin in list order for k_emit:
-	                    //      (cx, cy, e1x, e1y | e2x, e2y, len1, len2 | id + flags << 30, depth bits, x0 + y0 << 16, width |
+	float4 *wrec;       // [4P] walk record of item i at [4i..4i+3], written by k_bin for k_emit:
+	                    //      (cx, cy, e1x, e1y | e2x, e2y, len1, len2 | Gaussian index + flags << 30, depth bits, x0 + y0 << 16, width |
 	                    //      tiles, highest level, -, -); flags: 1 = lands in a tile, 2 = the OBB test applies
-	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity)
-	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8
+	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity) of item i at [4i..4i+3]
+	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8 per item
 	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {prefiltered violation flag, number of entries in vis_list, ...}; k_bin's eight slab pull
 	                    // counters live at [32 * (1 + r)], one 128-byte line each
-	uint32_t *vis_list; // [P]  indices of the Gaussians that survive projection (unordered)
-	float4 *crow;       // [3 (P + FR_CROW_PAD)] candidate rows (xyz, scale | scale.yz, rotation.xy | rotation.zw, highest level, index),
-	                    //      written by k_project's waves into regions of their own in the order they meet the survivors ...
-	uint32_t *vis_src;  // [P]  ... and where the row of vis_list entry i is (k_bin reads rows instead of four gathers)
+	uint32_t *vis_list; // [P]  indices of the Gaussians that survive the cull pass, increasing (k_compact)
+	uint32_t *vis_seg;  // [P + FR_CROW_PAD] the same indices as k_project's waves leave them: wave w of the cull pass owns the slots
+	                    //      from w * (its chunks) * 64 on and fills them in the order it meets its survivors (its chunks are consecutive)
+	uint32_t *proj_counts; // [FR_PROJ_MAX_WAVES] survivors of every wave of the cull pass
+	float4 *crow;       // [3 (P + FR_CROW_PAD)] foveated variants' candidate rows (xyz, scale | scale.yz, rotation.xy | rotation.zw, highest
+	                    //      level, index), same slots as vis_seg ...
+	uint32_t *vis_src;  // [P]  ... and the slot of item i (k_bin reads one row instead of four gathers)
 	int32_t *slab_next;   // [ceil(P / 64)] per-wave chains of the 64-entry vis_list slabs k_bin's waves pulled ...
 	int32_t *wave_head;   // [FR_BIN_BLOCKS * FR_BIN_THREADS / 64] ... and the last slab of every wave (-1: none)
 	size_t bytes;
@@ -85,12 +95,15 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 	if (keeps) { g.acc = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4)); }
 	g.lvl = nullptr; g.lrange = nullptr;
 	g.wrec = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4));
-	if (variant == FR_VARIANT_FOV_PCHECK_OBB) {
+	if (variant == FR_VARIANT_FOV_PCHECK_OBB)
+	{
 		g.lvl = (float4 *)(base + off); off = align_up(off + P * FR_FOV_LEVELS * sizeof(float4));
 		g.lrange = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
 	}
 	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + FR_SLAB_CTR_WORDS * sizeof(uint32_t));
 	g.vis_list = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
+	g.vis_seg = (uint32_t *)(base + off); off = align_up(off + (P + FR_CROW_PAD) * sizeof(uint32_t));
+	g.proj_counts = (uint32_t *)(base + off); off = align_up(off + FR_PROJ_MAX_WAVES * sizeof(uint32_t));
 	// candidate rows: only the foveated variants' cull pass stores them (k_project's ROWS); 52 B per Gaussian the plain and
 	// training frames need not carry
 	g.crow = nullptr; g.vis_src = nullptr;
@@ -414,7 +427,7 @@ int launch_l1_ssim_backward(int C, int H, int W, const float *x, const float *y,
 int launch_activate_forward(int P, const float *rs, const float *rq, const float *ro, float *s, float *q, float *o, hipStream_t stream);
 int launch_activate_backward(int P, const float *rs, const float *rq, const float *ro, const float *gs, const float *gq, const float *go,
 	float *ds, float *dq, float *dop, hipStream_t stream);
-int launch_project(FwdCtx &c);
+int launch_project(FwdCtx &c); // cull pass + the ordered compaction of its survivors
 int launch_bin(FwdCtx &c);
 int launch_tile_scan(FwdCtx &c);
 int launch_emit(FwdCtx &c);

@@ -555,17 +555,17 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 }
 
 // Stage 1: the part of the reference's preprocess every Gaussian must go through -- near plane, projected
-// centre -- plus a conservative frame test (project_gaussian<.., 0>), streaming over the whole cloud with
-// persistent waves (next chunk's inputs prefetched into registers). Typically 10-30 % of a scene survive; they
-// are appended to vis_list so that everything expensive (covariance chain, eigen axes, tile walk, SH) runs on
-// dense waves in k_bin. Every WAVE stages its survivors in an LDS list of its own and flushes it with one
-// global atomic per ~450 entries: a single device-scope counter saturates at ~90 atomics/us on MI355X, so one
-// atomic per wave and chunk (94 k per frame at 6 M Gaussians) would cost a millisecond -- and no workgroup
-// barrier is needed, so the waves of a CU drift apart and overlap their load and ALU phases.
+// centre -- plus a conservative frame test (frame_test), streaming over the whole cloud with persistent waves (the next
+// chunks' inputs prefetched into registers). Typically 10-30 % of a scene survive; everything expensive (covariance
+// chain, eigen axes, tile walk, SH) then runs on dense waves in k_bin.
+// The survivors are listed IN INDEX ORDER (GeomWS): every wave takes a run of CONSECUTIVE 64-Gaussian chunks and
+// leaves its survivors' indices (and, foveated variants, their input rows) in a region of its own, in the order it meets
+// them -- no counter, no atomics, no LDS staging (round 2 appended to one list through a device-wide counter: one atomic per
+// ~450 survivors, a 45 us queue of flushes at the end of the kernel before those were batched per workgroup) -- and
+// k_compact strings the regions together.
 #ifndef FR_PROJ_THREADS
 #define FR_PROJ_THREADS 1024
 #endif
-#define FR_PROJ_WLIST 512
 #ifndef FR_PROJ_DEPTH
 #define FR_PROJ_DEPTH 3 // (2: 0.120 ms, 3: 0.110 ms, 4: 0.131 ms on the bench scene)
 #endif
@@ -574,52 +574,27 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 #ifndef FR_PROJ_DEPTH_PACKED
 #define FR_PROJ_DEPTH_PACKED 4
 #endif
+// chunks per wave and the first slot of a wave's region, for a grid of nwaves waves over P Gaussians
+__host__ __device__ inline int proj_chunks_per_wave(int P, int nwaves) { const int nchunks = (P + 63) / 64; return (nchunks + nwaves - 1) / nwaves; }
 template <int VARIANT, bool PACKED = false>
 __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 {
 	constexpr int DEPTH = PACKED ? FR_PROJ_DEPTH_PACKED : FR_PROJ_DEPTH;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
-	__shared__ uint32_t s_list[FR_PROJ_THREADS / 64][FR_PROJ_WLIST];
 	const int lane = threadIdx.x & 63;
-	uint32_t *list = s_list[threadIdx.x >> 6];
-	uint32_t n = 0; // entries staged by this wave (wave-uniform)
 	// Unpacked model: a survivor's eleven input floats are in this wave's registers right now, and k_bin would have to
 	// fetch them again through four gathers that touch every cache line of means3D / scales / rotations / highest_levels
 	// (a line holds 8-10 Gaussians, one in eight survives: 264 MB of lines per frame for 34 MB of rows). So the survivor
-	// stores its ROW (48 bytes, GeomWS::crow) at once, at the next free position of a region that belongs to this wave
-	// (no counter involved: the wave's k-th survivor goes to slot k of its region), and the flush notes beside each
-	// vis_list entry where its row is (vis_src). Entries of one flush are consecutive rows, so a k_bin wave reads a
-	// contiguous 3 KB. (Rows staged in LDS and flushed in list order need 48 B x survivors per wave: the chip's whole
-	// LDS holds 0.9 frames' worth, every wave flushes mid-loop and 4096 atomics on one counter queue up for 45 us.)
+	// stores its ROW (48 bytes, GeomWS::crow) beside its index. A k_bin wave then reads a contiguous 3 KB.
 	constexpr bool ROWS = !PACKED && FOV; // the level box leaves one Gaussian in eight; at one in three (plain frames) the rows cost
 	                                       // more than k_bin's gathers, whose lines are then mostly used (training step +1.5 %)
-	const int nwaves_all = (int)gridDim.x * (FR_PROJ_THREADS / 64);
-	const int nchunks_all = (a.P + 63) / 64;
-	const uint32_t row_base = (uint32_t)((int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6)) *
-		(uint32_t)(((nchunks_all + nwaves_all - 1) / nwaves_all) * 64); // this wave's region: 64 slots per chunk it visits
-	uint32_t nrow = 0; // rows stored so far (never reset)
-	auto copy_out = [&](const uint32_t base) __attribute__((always_inline))
-	{
-		for (uint32_t i = lane; i < n; i += 64)
-		{
-			a.geom.vis_list[base + i] = list[i];
-			if (ROWS) a.geom.vis_src[base + i] = row_base + (nrow - n) + i; // the staged entries are the last n rows
-		}
-	};
-	auto flush = [&]() __attribute__((always_inline))
-	{
-		uint32_t base = 0;
-		if (lane == 0) base = atomicAdd(a.geom.slab_ctr + 1, n);
-		base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-		// the list was written by other lanes of this wave
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		copy_out(base);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		n = 0;
-	};
+	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
+	const int nchunks = (a.P + 63) / 64;
+	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
+	const int cpw = proj_chunks_per_wave(a.P, nwaves);
+	const int c0 = wave_gid * cpw, c1 = min(nchunks, c0 + cpw); // this wave's chunks
+	const uint32_t row_base = (uint32_t)wave_gid * (uint32_t)cpw * 64u; // ... and its region: a slot per Gaussian it visits
+	uint32_t nrow = 0; // survivors so far (wave-uniform)
 	const bool have_sr = a.cov3D_precomp == nullptr;
 	const float wn2 = view_norm2_bound(a.viewmatrix);
 	// The camera matrices go to scalar registers once: read through the argument pointers inside the loop they are
@@ -654,14 +629,11 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		w.hl = FOV ? a.highest_levels[i] : 0.0f;
 		return w;
 	};
-	const int nchunks = (a.P + 63) / 64;
-	const int wave_gid = (int)blockIdx.x * (FR_PROJ_THREADS / 64) + (int)(threadIdx.x >> 6);
-	const int nwaves = (int)gridDim.x * (FR_PROJ_THREADS / 64);
 	auto step = [&](const RawGaussian &cur, const int chunk) __attribute__((always_inline))
 	{
 		const int idx = chunk * 64 + lane;
 		bool maybe = false;
-		if (chunk < nchunks && idx < a.P)
+		if (chunk < c1 && idx < a.P)
 		{
 			if (PACKED) maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * cur.sc[0], cur.hl, wn2);
 			else if (!FOV && a.raw)
@@ -674,60 +646,76 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 				maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * (smax * smax) * 1.00001f, cur.hl, wn2);
 			}
 			else maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
-#ifdef FR_PROJ_MASKED_RADII
-			if (!maybe) a.radii[idx] = 0; // the survivors' radii are written by k_bin
-#else
 			a.radii[idx] = 0; // whole lines (a store with the survivors masked out is a partial-line write); k_bin, which runs
 			                  // after this kernel, writes the radius of every survivor
-#endif
 			// auxiliary.h:156-160: the reference traps on a near-culled point of a cloud declared prefiltered
 			if (a.prefiltered && !maybe && (vm[2] * cur.p[0] + vm[6] * cur.p[1] + vm[10] * cur.p[2] + vm[14]) <= 0.2f) atomicOr(a.geom.slab_ctr, 1u);
 		}
 		const unsigned long long m = __ballot(maybe);
 		if (maybe)
 		{
-			const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-			list[n + rank] = (uint32_t)idx;
+			const uint32_t slot = row_base + nrow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			a.geom.vis_seg[slot] = (uint32_t)idx;
 			if (ROWS)
 			{
-				float4 *row = a.geom.crow + 3 * (size_t)(row_base + nrow + rank);
+				float4 *row = a.geom.crow + 3 * (size_t)slot;
 				row[0] = make_float4(cur.p[0], cur.p[1], cur.p[2], cur.sc[0]);
 				row[1] = make_float4(cur.sc[1], cur.sc[2], cur.q.x, cur.q.y);
 				row[2] = make_float4(cur.q.z, cur.q.w, cur.hl, __uint_as_float((uint32_t)idx));
 			}
 		}
-		n += (uint32_t)__popcll(m);
 		nrow += (uint32_t)__popcll(m);
-		if (n > FR_PROJ_WLIST - 64) flush();
 	};
 	// FR_PROJ_DEPTH chunks in flight per wave, each in its own register set that is refilled in place
 	RawGaussian R[DEPTH];
 #pragma unroll
-	for (int d = 0; d < DEPTH; d++) R[d] = fetch(min(wave_gid + d * nwaves, nchunks - 1));
-	for (int base = wave_gid; base < nchunks; base += DEPTH * nwaves)
+	for (int d = 0; d < DEPTH; d++) R[d] = fetch(min(c0 + d, nchunks - 1));
+	for (int base = c0; base < c1; base += DEPTH)
 	{
 #pragma unroll
 		for (int d = 0; d < DEPTH; d++)
 		{
-			step(R[d], base + d * nwaves);
-			R[d] = fetch(min(base + (d + DEPTH) * nwaves, nchunks - 1));
+			step(R[d], base + d);
+			R[d] = fetch(min(base + d + DEPTH, nchunks - 1));
 		}
 	}
-	// The leftovers go out with ONE atomic per workgroup: all waves finish at about the same time, and one atomic per
-	// wave (4096 - 8192 of them on the same counter, ~11 ns each) was a 45 - 90 us queue at the end of the kernel.
-	__shared__ uint32_t s_left[FR_PROJ_THREADS / 64], s_left_base;
-	if (lane == 0) s_left[threadIdx.x >> 6] = n;
+	if (lane == 0) a.geom.proj_counts[wave_gid] = nrow;
+}
+
+// Strings the regions the cull pass's waves left behind into ONE list in index order: vis_list[item] = Gaussian index,
+// vis_src[item] = the slot of its candidate row (foveated variants), slab_ctr[1] = their number. A workgroup serves
+// FR_COMPACT_WAVES consecutive waves of k_project; it sums the counts of all waves before them itself (at most 8192 numbers).
+#define FR_COMPACT_WAVES 16
+__global__ void __launch_bounds__(256) k_compact(const GeomWS g, int nwaves, int cpw)
+{
+	__shared__ uint32_t s_red[4], s_cnt[FR_COMPACT_WAVES], s_base[FR_COMPACT_WAVES + 1];
+	const int tid = threadIdx.x;
+	const int w0 = (int)blockIdx.x * FR_COMPACT_WAVES;
+	uint32_t part = 0;
+	for (int j = tid; j < w0; j += 256) part += g.proj_counts[j];
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off);
+	if ((tid & 63) == 0) s_red[tid >> 6] = part;
+	if (tid < FR_COMPACT_WAVES) s_cnt[tid] = w0 + tid < nwaves ? g.proj_counts[w0 + tid] : 0u;
 	__syncthreads();
-	if (threadIdx.x == 0)
+	if (tid == 0)
 	{
-		uint32_t total = 0;
-		for (int w = 0; w < FR_PROJ_THREADS / 64; w++) total += s_left[w];
-		s_left_base = total ? atomicAdd(a.geom.slab_ctr + 1, total) : 0u;
+		uint32_t run = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+		for (int w = 0; w < FR_COMPACT_WAVES; w++) { s_base[w] = run; run += s_cnt[w]; }
+		s_base[FR_COMPACT_WAVES] = run;
+		if (w0 + FR_COMPACT_WAVES >= nwaves) g.slab_ctr[1] = run; // the last workgroup knows the total
 	}
 	__syncthreads();
-	uint32_t out = s_left_base;
-	for (int w = 0; w < (int)(threadIdx.x >> 6); w++) out += s_left[w];
-	copy_out(out);
+	// one k_project wave's survivors per wave here (a handful of 64-entry rounds each)
+	for (int w = tid >> 6; w < FR_COMPACT_WAVES; w += 4)
+	{
+		const uint32_t n = s_cnt[w], base = s_base[w], slot0 = (uint32_t)(w0 + w) * (uint32_t)cpw * 64u;
+		for (uint32_t k = tid & 63; k < n; k += 64)
+		{
+			g.vis_list[base + k] = g.vis_seg[slot0 + k];
+			if (g.vis_src != nullptr) g.vis_src[base + k] = slot0 + k;
+		}
+	}
 }
 
 // Stage 2 (RS rasterizer_impl.cu:70-146, RF :264-383 + :490-530): for every survivor, count the tiles it
@@ -932,7 +920,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			const int lo = f2i(lowest);
 			int hi = f2i(highest);
 			if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
-			a.geom.lrange[idx] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
+			a.geom.lrange[item] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
 			// all four levels' DC colours (12 floats) and opacities are fetched with the SH coefficients: one round trip
 			f4u dc0, dc1, dc2, opl;
 			float rest[3];
@@ -962,17 +950,18 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 					v.y = fmaxf(FR_SH_C0 * dcs[3 * l + 1] + rest[1], 0.0f);
 					v.z = fmaxf(FR_SH_C0 * dcs[3 * l + 2] + rest[2], 0.0f);
 					v.w = ops[l];
-					a.geom.lvl[(size_t)idx * FR_FOV_LEVELS + l] = v;
+					a.geom.lvl[(size_t)item * FR_FOV_LEVELS + l] = v;
 				}
 			}
 		}
-		float4 *rec = a.geom.rec + 3 * (size_t)idx;
+		// the item's record (dense: consecutive lanes write consecutive 48-byte rows)
+		float4 *rec = a.geom.rec + 3 * (size_t)item;
 		if (LEVELCOL) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
 		else rec[1] = make_float4(conic_c, opacity, rgb[0], rgb[1]);
-		// third part: item = where the backward pass keeps this Gaussian's sums; the shared-model foveated variant (no
-		// backward, no clamp bits needed) carries the Gaussian's highest level there instead
-		if (FOV && !LEVELCOL) rec[2] = make_float4(rgb[2], depth, hl, 0.0f);
-		else rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(item));
+		// third part: the Gaussian's index (the statistics of the training variants and the gradients are per Gaussian); the
+		// shared-model foveated variant (no backward, no clamp bits needed) carries the Gaussian's highest level in the clamp slot
+		if (FOV && !LEVELCOL) rec[2] = make_float4(rgb[2], depth, hl, __int_as_float(idx));
+		else rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(idx));
 	};
 #ifdef FR_BIN_TIMERS
 	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0;
@@ -1097,7 +1086,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		a.radii[idx] = pr.alive ? pr.radius : 0;
 		if (pr.alive)
 		{
-			a.geom.rec[3 * (size_t)idx] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b); // first third of the record
+			a.geom.rec[3 * (size_t)item] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b); // first third of the record
 			r1.x = pr.conic_c; r2.y = pr.depth;
 		}
 	}
@@ -1370,7 +1359,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		tnum = alive ? __float_as_uint(w3.x) : 0u;
 		hl = w3.y;
 	}
-	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
+	// the instance's payload is the ITEM (position in vis_list): the per-item records are dense, and items are in index order,
+	// so the per-tile sort by (depth bits, item) gives the reference's stable order
+	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)item;
 	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_bin's level test, no box test (single-tile splat)
 	if (in_place) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
 	{
@@ -1389,7 +1380,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			const float4 oev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
 			const float2 oel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
 			const Obb ob = make_obb(bcast_f(cx, L), bcast_f(cy, L), oev, oel);
-			const uint64_t opay = ((uint64_t)(uint32_t)bcast_i((int)depth_bits, L) << 32) | (uint32_t)bcast_i(idx, L);
+			const uint64_t opay = ((uint64_t)(uint32_t)bcast_i((int)depth_bits, L) << 32) | (uint32_t)(slab * 64 + L);
 			walk_uniform(ox0, oy0, ow, (uint32_t)bcast_i((int)tnum, L), ob, bcast_f(hl, L) + 1, opay, 0u, 64u);
 		}
 		const uint32_t my_n = (alive && !in_place && !big && !deferred) ? tnum : 0u;
@@ -1407,7 +1398,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			const int ox0 = __shfl(x0, owner), oy0 = __shfl(y0, owner), ow = max(__shfl(x1, owner) - ox0, 1);
 			const int x = ox0 + (int)(local % (uint32_t)ow), y = oy0 + (int)(local / (uint32_t)ow);
 			const int ti = y * a.gx + x;
-			const uint64_t opay = ((uint64_t)(uint32_t)__shfl((int)depth_bits, owner) << 32) | (uint32_t)__shfl(idx, owner);
+			const uint64_t opay = ((uint64_t)(uint32_t)__shfl((int)depth_bits, owner) << 32) | (uint32_t)(slab * 64 + owner);
 			bool pass = valid;
 			if (CULL)
 			{
@@ -1459,7 +1450,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
 		const Obb ob = make_obb(w0.x, w0.y, make_float4(w0.z, w0.w, w1.x, w1.y), make_float2(w1.z, w1.w));
 		const uint32_t xy = __float_as_uint(w2.z);
-		const uint64_t opay = ((uint64_t)__float_as_uint(w2.y) << 32) | (__float_as_uint(w2.x) & 0x3fffffffu);
+		const uint64_t opay = ((uint64_t)__float_as_uint(w2.y) << 32) | (uint32_t)s_gidx[g];
 		walk_uniform((int)(xy & 0xffffu), (int)(xy >> 16), (int)__float_as_uint(w2.w), __float_as_uint(w3.x), ob, w3.y + 1, opay,
 			(uint32_t)(threadIdx.x & ~63u), (uint32_t)FR_EMIT_THREADS);
 	}
@@ -1643,7 +1634,12 @@ int launch_project(FwdCtx &c)
 		default: LAUNCH_PROJ(FR_VARIANT_PCHECK_OBB); break;
 		}
 #undef LAUNCH_PROJ
-		return check_launch("project", c.stream, a->debug);
+		int rc = check_launch("project", c.stream, a->debug);
+		if (rc) return rc;
+		const int nwaves = (int)pgrid.x * (FR_PROJ_THREADS / 64);
+		hipLaunchKernelGGL(k_compact, dim3((nwaves + FR_COMPACT_WAVES - 1) / FR_COMPACT_WAVES), dim3(256), 0, c.stream, c.geom, nwaves,
+			proj_chunks_per_wave(a->P, nwaves));
+		return check_launch("compact", c.stream, a->debug);
 	}
 }
 

@@ -94,7 +94,8 @@ __device__ __forceinline__ void blend2(Px2 &s, bool in_x, bool in_y, v2f e, floa
 struct RenderArgs {
 	int W, H, gx;
 	const uint2 *ranges;
-	const uint32_t *point_list;
+	const uint32_t *point_list; // per-tile sorted lists of ITEMS (positions in vis_list): rec / lvl are per item
+	const uint32_t *vis_list;   // item -> Gaussian index (the training variants' statistics are per Gaussian)
 	const float4 *rec;
 	const float4 *lvl;      // RF
 	const float *tile_lv;   // RF float[5][T]
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 	for (int k = 0; k < (LWMC ? PPL : 1); k++) { best_w[k] = 0.0f; best_id[k] = 0; }
 
 	// prefetch registers
-	uint32_t pid = 0;
+	uint32_t pid = 0, pgid = 0; // item, and (statistics) its Gaussian index
 	float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
 	float p2 = 0.f;
 	if (st < n)
@@ -187,6 +188,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		pid = a.point_list[range.x + st];
 		const float4 *r = a.rec + 3 * (size_t)pid;
 		p0 = r[0]; p1 = r[1]; p2 = r[2].x;
+		if (NEEDID) pgid = a.vis_list[pid];
 	}
 	bool counting = false; // FETCHCNT: this wave owns the counts of the current 256-entry round
 	for (int base = 0; base < n; base += 64)
@@ -216,17 +218,17 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		}
 		else if (wave_done) break;
 		const bool staged = base + st < n;
-		if (FETCHCNT && counting && staged) atomicAdd(&a.gaussians_count[pid], 1);
+		if (FETCHCNT && counting && staged) atomicAdd(&a.gaussians_count[pgid], 1);
 		if (FETCHCNT && wave_done)
 		{
 			// this band is finished but owns the round: only its remaining counts are due
-			if (base + 64 + st < n) pid = a.point_list[range.x + base + 64 + st];
+			if (base + 64 + st < n) pgid = a.vis_list[a.point_list[range.x + base + 64 + st]];
 			continue;
 		}
 		if (staged)
 		{
 			s0[st] = p0; s1[st] = p1; s2[st] = p2;
-			if (NEEDID) sid[st] = (int)pid;
+			if (NEEDID) sid[st] = (int)pgid;
 		}
 		unsigned long long reach_own;
 		{
@@ -241,6 +243,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			pid = a.point_list[range.x + base + 64 + st];
 			const float4 *r = a.rec + 3 * (size_t)pid;
 			p0 = r[0]; p1 = r[1]; p2 = r[2].x;
+			if (NEEDID) pgid = a.vis_list[pid];
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // lanes read entries other lanes staged
 		__builtin_amdgcn_wave_barrier();
@@ -837,7 +840,7 @@ int launch_render(FwdCtx &c)
 	const fr_forward_args *a = c.a;
 	RenderArgs r;
 	r.W = a->W; r.H = a->H; r.gx = c.gx;
-	r.ranges = c.img.ranges; r.point_list = c.bin.point_list; r.rec = c.geom.rec; r.lvl = c.geom.lvl;
+	r.ranges = c.img.ranges; r.point_list = c.bin.point_list; r.vis_list = c.geom.vis_list; r.rec = c.geom.rec; r.lvl = c.geom.lvl;
 	r.tile_lv = c.img.tile_lv; r.tile_order = c.img.tile_order; r.T = c.T; r.bg = a->background; r.out_color = a->out_color;
 	r.final_T = c.img.final_T; r.n_contrib = c.img.n_contrib;
 	r.gaussians_count = a->gaussians_count; r.contributions = a->contributions; r.loss_map = a->loss_map;

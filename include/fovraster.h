@@ -22,11 +22,11 @@
  * the three workspaces are obtained through the caller's resize callbacks, exactly like the
  * reference's geometry/binning/image buffers, and must be kept alive by the caller for
  * fr_backward. All work is enqueued on `stream` (a hipStream_t). fr_forward returns num_rendered like the
- * reference, so it waits ONCE for that count (a 32-byte block the tile scan writes into pinned host memory) -- but not
- * for the frame: from the second frame of a kind (variant, P, W, H) on, the kernels behind the count are already
- * enqueued when the host starts waiting (they are sized by the previous frame's count plus a quarter and read the real
- * counts from device memory; a frame that does not fit is replayed), so the GPU never idles at that point and the
- * call returns while the frame is still being sorted and blended. fr_backward never synchronises.
+ * reference, so it waits ONCE for that count (a 32-byte block the tile scan writes into pinned host memory, polled) --
+ * but not for the frame. With FR_LAUNCH_AHEAD=1 in the environment the kernels behind the count are enqueued before
+ * that wait from the second frame of a kind (variant, P, W, H) on (sized by the previous frame's count plus a quarter,
+ * reading the real counts from device memory; a frame that does not fit is replayed): the call then returns ~0.35 ms
+ * earlier, at 1.3 % more GPU time per frame. fr_backward never synchronises.
  * All functions return 0 on success or a negative FR_ERR_* code; fr_last_error() gives the message
  * (thread-local).
  */
@@ -254,27 +254,31 @@ size_t fr_geometry_bytes(int32_t variant, int32_t P);
 size_t fr_image_bytes(int32_t variant, int32_t W, int32_t H);
 size_t fr_binning_bytes(int32_t variant, int64_t num_instances);
 
-/* Introspection for tests: copies of internal per-tile / per-instance state out of the workspaces.
- * ranges: uint32 [T,2]; point_list: uint32 [num_rendered] (device pointers into the workspaces). */
+/* Introspection for tests: device pointers to internal per-tile / per-instance state inside the workspaces.
+ * ranges: uint32 [T,2]. point_list: uint32 [num_rendered], the per-tile depth-sorted lists -- of ITEMS: an item is a
+ * position in the library's list of the Gaussians that survive its cull pass, which is in increasing Gaussian index
+ * (fr_geometry_vis_list), so vis_list[point_list[i]] is the reference's point_list entry and the order is the
+ * reference's. Everything the library keeps per candidate Gaussian (records, level colours, level ranges, walk records)
+ * is indexed by item: dense rows instead of rows scattered over all P Gaussians. */
 const uint32_t *fr_image_ranges(int32_t variant, int32_t W, int32_t H, const char *image);
 const uint32_t *fr_binning_point_list(int32_t variant, int64_t num_instances, const char *binning);
 const float *fr_image_final_T(int32_t variant, int32_t W, int32_t H, const char *image);
 const uint32_t *fr_image_n_contrib(int32_t variant, int32_t W, int32_t H, const char *image);
-/* per-Gaussian records float[P][12] = (x, y, conic a, conic b | conic c, opacity, r, g | b, depth, clamp bits, -);
- * valid for Gaussians with radii > 0 (RF: the second third holds (conic c, highest level, -, -)) */
+/* per-item records float[.][12] = (x, y, conic a, conic b | conic c, opacity, r, g | b, depth, clamp bits, Gaussian index);
+ * valid for items whose Gaussian has radii > 0 (RF: the second third holds (conic c, highest level, -, -)) */
 const float *fr_geometry_records(int32_t variant, int32_t P, const char *geometry);
 /* RF: device pointer to float[5][T] = levels, tile_min, grad_x, grad_y, blending(0/1 as float) */
 const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image);
-/* the Gaussians that survived projection, in the (unordered) order the binning kernels list them: uint32 [count], with
- * count = *fr_geometry_vis_count (a device word) */
+/* the Gaussians that survived the cull pass, in increasing index: uint32 [count], with count = *fr_geometry_vis_count
+ * (a device word); "item" i everywhere else means position i of this list */
 const uint32_t *fr_geometry_vis_list(int32_t variant, int32_t P, const char *geometry);
 const uint32_t *fr_geometry_vis_count(int32_t variant, int32_t P, const char *geometry);
-/* walk record of vis_list entry i: float[16] = (centre x, y, OBB axis 1 x, y | axis 2 x, y, half length 1, 2 |
+/* walk record of item i: float[16] = (centre x, y, OBB axis 1 x, y | axis 2 x, y, half length 1, 2 |
  * id + flags << 30, depth bits, clipped rectangle x0 + y0 << 16, its width | tiles, highest level, -, -)
  * -- what the reference keeps as eigen_vecs / eigen_lengths (RS forward.cu:244-265) */
 const float *fr_geometry_walk_records(int32_t variant, int32_t P, const char *geometry);
-/* RF: per-Gaussian per-level (r, g, b, opacity) float[P][4][4] (compute_fov_colors, RF rasterizer_impl.cu:490-530; only
- * the levels of the Gaussian's level range are written) and the packed level ranges uint32 [P] = lo | hi << 8 */
+/* RF: per-item per-level (r, g, b, opacity) float[.][4][4] (compute_fov_colors, RF rasterizer_impl.cu:490-530; only
+ * the levels of the Gaussian's level range are written) and the packed level ranges uint32 [.] = lo | hi << 8 */
 const float *fr_geometry_level_colours(int32_t P, const char *geometry);
 const uint32_t *fr_geometry_level_ranges(int32_t P, const char *geometry);
 

@@ -27,6 +27,12 @@ def _view(buf, ptr, count, dtype):
     return buf[off:off + nbytes].view(dtype)
 
 
+def vis_list_of(lib, vid, P, geom):
+    """The library's list of cull survivors (Gaussian indices, increasing) as an int64 device tensor."""
+    n = int(_view(geom, lib.fr_geometry_vis_count(vid, P, geom.data_ptr()), 1, torch.int32).item())
+    return _view(geom, lib.fr_geometry_vis_list(vid, P, geom.data_ptr()), n, torch.int32).long()
+
+
 def hip_forward(variant, scene, cam, dev="cuda:0", debug=True, packed=False):
     """-> dict shaped like oracle.forward()'s (the subset the HIP library keeps).
     packed: also hand the model over in the packed static-model layout (needs scales + rotations + 16 SH coefficients)."""
@@ -51,14 +57,20 @@ def hip_forward(variant, scene, cam, dev="cuda:0", debug=True, packed=False):
     out = {"num_rendered": num_rendered, "color": color.cpu().numpy(), "radii": radii.cpu().numpy(),
            "_tensors": tens, "_rs": rs, "_buffers": (geom, binb, img), "_radii_t": radii,
            "_lease": res[-1]}  # the workspace set stays reserved while this dict lives
-    if img.numel() == 0:  # P == 0: the library returns before touching any workspace
+    if img.numel() == 0 or tens["means3D"].shape[0] == 0:  # P == 0: the library returns before touching any workspace
         out["ranges"], out["point_list"] = np.zeros((T, 2), np.uint32), np.zeros(0, np.uint32)
         return out
     rptr = lib.fr_image_ranges(vid, W, H, img.data_ptr())
     out["ranges"] = _view(img, rptr, 2 * T, torch.int32).cpu().numpy().astype(np.uint32).reshape(T, 2)
+    P = tens["means3D"].shape[0]
+    vis = vis_list_of(lib, vid, P, geom)
+    out["vis_list"] = vis.cpu().numpy().astype(np.uint32)
     if num_rendered > 0:
+        # the library's per-tile lists hold ITEMS (positions in its index-ordered list of cull survivors, vis_list): the
+        # reference's point_list is their Gaussian indices
         pptr = lib.fr_binning_point_list(vid, num_rendered, binb.data_ptr())
-        out["point_list"] = _view(binb, pptr, num_rendered, torch.int32).cpu().numpy().astype(np.uint32)
+        items = _view(binb, pptr, num_rendered, torch.int32).long()
+        out["point_list"] = vis[items].cpu().numpy().astype(np.uint32)
     else:
         out["point_list"] = np.zeros(0, np.uint32)
     if variant in ("original", "pcheck_obb_sum", "pcheck_obb_max", "pcheck_obb_loss_weighted_max_count"):

@@ -37,6 +37,16 @@ FULL_WIN = (0, 0, GX, GY)
 WHOLE = os.environ.get("FOVRASTER_WHOLE_FRAME", "1" if (os.cpu_count() or 1) >= 64 else "0") == "1"
 
 
+def gaussian_lists(lib, vid, P, D, geom, binb):
+    """The per-tile sorted lists as GAUSSIAN indices (the reference's point_list): the library's lists hold positions in its
+    index-ordered list of cull survivors."""
+    from tests.gpu_helpers import vis_list_of
+    vis = vis_list_of(lib, vid, P, geom)
+    ptr = lib.fr_binning_point_list(vid, D, binb.data_ptr())
+    off = ptr - binb.data_ptr()
+    return vis[binb[off:off + 4 * D].view(torch.int32).long()].to(torch.int32)
+
+
 class S6M:
     """The bench scene, built once per session: CPU cloud (oracle inputs) + device tensors (rasterizer inputs)."""
 
@@ -100,7 +110,7 @@ class S6M:
             return buf[off:off + 4 * count].view(dtype)
         out = dict(num_rendered=D, color=color, radii=radii, buffers=(geom, binb, img), lease=res[-1], res=res)
         out["ranges"] = view(img, self.lib.fr_image_ranges(vid, W, H, img.data_ptr()), 2 * T, torch.int32).view(T, 2).long()
-        out["point_list"] = view(binb, self.lib.fr_binning_point_list(vid, D, binb.data_ptr()), D, torch.int32)
+        out["point_list"] = gaussian_lists(self.lib, vid, self.xyz.shape[0], D, geom, binb)
         if variant == "pcheck_obb_sum":
             out["final_T"] = view(img, self.lib.fr_image_final_T(vid, W, H, img.data_ptr()), W * H, torch.float32).view(H, W)
             out["n_contrib"] = view(img, self.lib.fr_image_n_contrib(vid, W, H, img.data_ptr()), W * H, torch.int32).view(H, W)
@@ -208,7 +218,7 @@ def _native_lists(s6m, vid, res):
     view = lambda buf, ptr, count, dtype: buf[ptr - buf.data_ptr():ptr - buf.data_ptr() + 4 * count].view(dtype)
     return dict(num_rendered=D, color=color, radii=radii,
                 ranges=view(img, s6m.lib.fr_image_ranges(vid, W, H, img.data_ptr()), 2 * T, torch.int32).view(T, 2).long(),
-                point_list=view(binb, s6m.lib.fr_binning_point_list(vid, D, binb.data_ptr()), D, torch.int32))
+                point_list=gaussian_lists(s6m.lib, vid, s6m.xyz.shape[0], D, geom, binb))
 
 
 def test_shared_model_baseline_full_size(s6m):

@@ -515,8 +515,12 @@ def test_full_size_properties(variant):
         off = ptr - buf.data_ptr()
         return buf[off:off + 4 * count].view(dtype)
     ranges = view(img, lib.fr_image_ranges(vid, W, H, img.data_ptr()), 2 * T, torch.int32).view(T, 2).long()
-    plist = view(binb, lib.fr_binning_point_list(vid, D, binb.data_ptr()), D, torch.int32).long()
-    rec = view(geom, lib.fr_geometry_records(vid, xyz.shape[0], geom.data_ptr()), 12 * xyz.shape[0], torch.float32).view(-1, 12)
+    from tests.gpu_helpers import vis_list_of
+    vis = vis_list_of(lib, vid, xyz.shape[0], geom)
+    assert bool((vis[1:] > vis[:-1]).all()), "the list of cull survivors is in index order"
+    items = view(binb, lib.fr_binning_point_list(vid, D, binb.data_ptr()), D, torch.int32).long()  # positions in that list
+    plist = vis[items]
+    rec = view(geom, lib.fr_geometry_records(vid, xyz.shape[0], geom.data_ptr()), 12 * xyz.shape[0], torch.float32).view(-1, 12)  # per item
     # ranges: non-empty tiles tile [0, D) exactly once
     n = ranges[:, 1] - ranges[:, 0]
     assert int(n.sum()) == D and int(n.min()) >= 0
@@ -530,7 +534,8 @@ def test_full_size_properties(variant):
     seen[plist] = True
     assert bool((seen == (radii > 0)).all())
     # per-tile order: key = (depth bits, index) strictly increasing inside every tile
-    depth_bits = rec[plist, 9].contiguous().view(torch.int32).long()
+    depth_bits = rec[items, 9].contiguous().view(torch.int32).long()
+    assert bool((rec[items, 11].contiguous().view(torch.int32).long() == plist).all()), "a record carries its Gaussian's index"
     key = depth_bits * (1 << 32) + plist
     tile_of = torch.repeat_interleave(torch.arange(T, device=dev), n)  # entries are laid out tile by tile in range order?
     start = torch.zeros(D, dtype=torch.bool, device=dev)
@@ -544,7 +549,7 @@ def test_full_size_properties(variant):
         r2 = run(vid)
         torch.cuda.synchronize()
     assert r2[0] == D and torch.equal(r2[1], img1)
-    plist2 = view(r2[4], lib.fr_binning_point_list(vid, D, r2[4].data_ptr()), D, torch.int32).long()
+    plist2 = vis_list_of(lib, vid, xyz.shape[0], r2[3])[view(r2[4], lib.fr_binning_point_list(vid, D, r2[4].data_ptr()), D, torch.int32).long()]
     assert torch.equal(plist2, pl1)
     if variant == "pcheck_obb":
         with torch.no_grad():
@@ -642,8 +647,12 @@ def test_fov_level_colours_match_oracle(gaze):
         def view(ptr, count, dtype):
             off = ptr - geom.data_ptr()
             return geom[off:off + 4 * count].view(dtype)
-        lvl = view(lib.fr_geometry_level_colours(P, geom.data_ptr()), 16 * P, torch.float32).view(P, 4, 4).cpu().numpy()
-        lr = view(lib.fr_geometry_level_ranges(P, geom.data_ptr()), P, torch.int32).cpu().numpy()
+        # both are kept per ITEM (position in the list of cull survivors): spread them out by Gaussian index
+        vl = got["vis_list"].astype(np.int64)
+        lvl = np.full((P, 4, 4), np.nan, np.float32)
+        lvl[vl] = view(lib.fr_geometry_level_colours(P, geom.data_ptr()), 16 * P, torch.float32).view(P, 4, 4).cpu().numpy()[:len(vl)]
+        lr = np.zeros(P, np.int32)
+        lr[vl] = view(lib.fr_geometry_level_ranges(P, geom.data_ptr()), P, torch.int32).cpu().numpy()[:len(vl)]
         vis = want["radii"] > 0
         assert vis.sum() > 1000
         np.testing.assert_array_equal((lr & 0xff)[vis], want["level_ranges"][vis, 0])
@@ -784,9 +793,9 @@ def test_prefiltered_violation_is_reported():
 
 
 @pytest.mark.parametrize("variant", ("pcheck_obb", "fov_pcheck_obb", "pcheck_obb_sum"))
-def test_frames_launched_ahead_of_their_instance_count(variant):
-    """fr_forward launches binning / sort / blend of the second and later frames of a kind before the instance count has
-    reached the host (include/fovraster.h). Same frame three ways: launched after the count (first call), ahead of it
+def test_frames_launched_ahead_of_their_instance_count(variant, monkeypatch):
+    """With FR_LAUNCH_AHEAD=1 fr_forward launches binning / sort / blend of the second and later frames of a kind before the
+    instance count has reached the host (include/fovraster.h). Same frame three ways: launched after the count (first call), ahead of it
     (second call), and ahead of it with a workspace that turns out too small (a frame with > 1.25x the instances right
     after a small one: replayed) -- lists and image identical to the oracle's each time."""
     _need_gpu()
@@ -794,6 +803,7 @@ def test_frames_launched_ahead_of_their_instance_count(variant):
     from fov3dgs_amd import _native
     scene, cam = small_case(variant, P=5003, seed=19, width=408, height=232)  # a (P, W, H) no other test uses: no guess yet
     want = orc.forward(variant, scene, cam)
+    monkeypatch.setenv("FR_LAUNCH_AHEAD", "1")
     s0 = _native.speculation_stats()
     runs = [hip_forward(variant, scene, cam, debug=False) for _ in range(3)]
     s1 = _native.speculation_stats()
@@ -822,3 +832,10 @@ def test_frames_launched_ahead_of_their_instance_count(variant):
     again = hip_forward(variant, scene, cam, debug=False)
     np.testing.assert_array_equal(again["point_list"], want["point_list"])
     np.testing.assert_array_equal(again["color"], runs[1]["color"])
+    # without the switch every frame is launched after its count
+    monkeypatch.delenv("FR_LAUNCH_AHEAD")
+    s3 = _native.speculation_stats()
+    plain = hip_forward(variant, scene, cam, debug=False)
+    s4 = _native.speculation_stats()
+    assert (s4[0] - s3[0], s4[2] - s3[2]) == (0, 1)
+    np.testing.assert_array_equal(plain["color"], runs[1]["color"])
