@@ -169,15 +169,15 @@ int fr_forward(fr_forward_args *a)
 		FR_HIP(hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, fill_stream));
 	}
 	if (fill_ax) (void)hipEventRecord(fill_ax->join2, fill_ax->s2);
-	// small clears in front of the first kernel: the level boxes (RF: k_tile_levels raises them with atomicMax; it clears the
-	// slab counters itself) or the slab counters; the per-tile counters only on the global-atomics path of huge tile grids
-	// (with LDS histograms every one of them is written by the column scan before it is read)
-	if (c.img.hist == nullptr)
-		FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
-	else if (is_fov(a->variant))
-		FR_HIP(hipMemsetAsync(c.img.lv_bbox, 0, 5 * FR_LV_BBOX_STRIDE * sizeof(uint32_t), stream));
+	// small clears in front of the first kernel: the per-tile instance counters (k_bin's workgroups add their shares to them;
+	// the global-atomics path of huge tile grids counts in them directly) and, next to them, the level boxes (RF:
+	// k_tile_levels raises them with atomicMax; it clears the slab counters itself)
+	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
 	if (!is_fov(a->variant)) // RF: k_tile_levels clears them
 		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
+	static thread_local uint32_t frame_seq = 0; // this call's tag: the totals block's sequence word
+	if (++frame_seq == 0) frame_seq = 1;
+	c.totals_seq = frame_seq;
 	mark(FR_STAGE_TILE_LEVELS);
 	if (is_fov(a->variant)) { rc = launch_tile_levels(c); if (rc) return rc; }
 	mark(FR_STAGE_PROJECT);
@@ -206,10 +206,7 @@ int fr_forward(fr_forward_args *a)
 		(void)hipGetLastError();
 	}
 	uint32_t *const pinned = pn.host, *const pinned_dev = pn.dev;
-	static thread_local uint32_t frame_seq = 0;
-	if (++frame_seq == 0) frame_seq = 1;
 	c.totals_host_dev = pinned_dev;
-	c.totals_seq = frame_seq;
 	mark(FR_STAGE_TILE_SCAN);
 	rc = launch_tile_scan(c); if (rc) return rc;
 

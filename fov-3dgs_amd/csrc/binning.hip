@@ -348,9 +348,16 @@ __global__ void __launch_bounds__(THREADS) k_tile_msort_chunks(const uint2 *chun
 // 1024-key sorts that spread over the whole chip. Keys are streamed from global memory twice (histogram,
 // scatter); LDS holds only the histogram.
 #define FR_SPLIT_REGS 16 // keys per thread held in registers by k_split_long (lists up to 16384 entries)
+#define FR_SPLIT_LDS_KEYS 8192 // keys staged in LDS per round of its scatter
+// The regrouped keys of a list of up to FR_SPLIT_REGS x 1024 entries go through LDS (s_keys: dynamic shared memory,
+// FR_SPLIT_LDS_KEYS slots): the scatter by depth bucket happens there and the list leaves the workgroup as one coalesced copy. Scattered
+// straight to global memory, every 8-byte store was a partial-sector write of its own -- ~11 cycles of the CU's memory
+// pipeline each (tools/scratch/gather_rate.hip), 50 us for the longest list of a 1080p frame, which one workgroup = one CU
+// handles alone: the kernel's whole duration.
 __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const uint32_t *tile_order, const uint64_t *entries,
 	uint64_t *entries2, uint2 *chunks, uint32_t *totals, SpecLimits lim, int direct)
 {
+	extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
 	__shared__ uint32_t s_hist[FR_SORT_FINE_BUCKETS];      // counts -> exclusive offsets -> scatter cursors
 	__shared__ uint32_t s_start[FR_SORT_FINE_BUCKETS + 1]; // compacted chunk starts
 	__shared__ uint32_t s_wave[16], s_wave2[16];
@@ -363,6 +370,12 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 	// covers a grid sized ahead of the counts that came out too small
 	for (uint32_t blk = blockIdx.x; blk < pl.nlong; blk += gridDim.x)
 	{
+#ifdef FR_SPLIT_TIMERS
+	const uint64_t tm0 = wall_clock64(); uint64_t tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0, tm5 = 0;
+#define TMS(x) x = wall_clock64()
+#else
+#define TMS(x)
+#endif
 	const uint2 rg = ranges[tile_order[blk]];
 	const uint32_t n = rg.y - rg.x;
 	if (n >= pl.split_min)
@@ -392,7 +405,9 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 	}
 	else
 		for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(src[i] >> 32))], 1u);
+	TMS(tm1);
 	__syncthreads();
+	TMS(tm2);
 	// 3. exclusive scan of the 2048 counts (two consecutive buckets per thread)
 	const uint32_t c0 = s_hist[2 * tid], c1 = s_hist[2 * tid + 1];
 	uint32_t sc = c0 + c1;
@@ -423,15 +438,30 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 	uint32_t pos = foff + fs - mine;
 	if (f0) s_start[pos++] = e0;
 	if (f1) s_start[pos] = e1;
+	TMS(tm3);
 	if (tid == 0) { s_start[nchunks] = n; s_slot = atomicAdd(chunk_ctr, nchunks); }
 	__syncthreads();
+	TMS(tm4);
 	for (uint32_t k = tid; k < nchunks; k += 1024) chunks[s_slot + k] = make_uint2(rg.x + s_start[k], rg.x + s_start[k + 1]);
 	// 5. scatter (the offsets become cursors)
 	if (in_regs)
 	{
+		// (FR_SPLIT_LDS_KEYS slots: two workgroups per CU; a longer list goes through them in rounds)
+		uint32_t pos[FR_SPLIT_REGS];
 #pragma unroll
 		for (int k = 0; k < FR_SPLIT_REGS; k++)
-			if (tid + 1024u * k < n) dst[atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(kreg[k] >> 32))], 1u)] = kreg[k];
+			pos[k] = tid + 1024u * k < n ? atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(kreg[k] >> 32))], 1u) : 0xffffffffu;
+		for (uint32_t base = 0; base < n; base += FR_SPLIT_LDS_KEYS)
+		{
+#pragma unroll
+			for (int k = 0; k < FR_SPLIT_REGS; k++)
+				if (pos[k] - base < (uint32_t)FR_SPLIT_LDS_KEYS) s_keys[pos[k] - base] = kreg[k];
+			__syncthreads();
+			const uint32_t m = min((uint32_t)FR_SPLIT_LDS_KEYS, n - base);
+			for (uint32_t i = tid; i < m; i += 1024) dst[base + i] = s_keys[i];
+			__syncthreads();
+		}
+		TMS(tm5);
 	}
 	else
 		for (uint32_t i = tid; i < n; i += 1024)
@@ -440,6 +470,15 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 			dst[atomicAdd(&s_hist[FR_DEPTH_BUCKET((uint32_t)(key >> 32))], 1u)] = key;
 		}
 #undef FR_DEPTH_BUCKET
+#ifdef FR_SPLIT_TIMERS
+	if (tid == 0)
+	{
+		// developer build (tools/split_stats.py): per-list phase times in the tail of the chunk table
+		uint32_t *d = (uint32_t *)(chunks + FR_SORT_MAX_CHUNKS(lim.capacity)) - 8 * (blk + 1);
+		d[0] = n; d[1] = (uint32_t)(tm1 - tm0); d[2] = (uint32_t)(tm2 - tm0); d[3] = (uint32_t)(tm3 - tm0); d[4] = (uint32_t)(tm4 - tm0); d[5] = (uint32_t)(tm5 - tm0);
+		d[6] = (uint32_t)(wall_clock64() - tm0); d[7] = (uint32_t)(tm0 & 0xffffff);
+	}
+#endif
 	}
 	__syncthreads(); // the next list reuses the histogram
 	}
@@ -503,7 +542,10 @@ int launch_tile_sort(FwdCtx &c)
 	}
 	if (nlong > 0)
 	{
-		hipLaunchKernelGGL(k_split_long, dim3(nlong), dim3(1024), 0, c.stream, rg, ord, c.bin.entries, c.bin.entries2, c.bin.chunks, totals, lim, direct ? 1 : 0);
+		static const hipError_t lds_ok = hipFuncSetAttribute((const void *)k_split_long, hipFuncAttributeMaxDynamicSharedMemorySize, FR_SPLIT_LDS_KEYS * (int)sizeof(uint64_t));
+		if (lds_ok != hipSuccess) { set_error("hipFuncSetAttribute(k_split_long): %s", hipGetErrorString(lds_ok)); return FR_ERR_HIP; }
+		hipLaunchKernelGGL(k_split_long, dim3(nlong), dim3(1024), FR_SPLIT_LDS_KEYS * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries, c.bin.entries2, c.bin.chunks,
+			totals, lim, direct ? 1 : 0);
 		const size_t max_chunks = FR_SORT_MAX_CHUNKS(c.capacity);
 		hipLaunchKernelGGL((k_tile_msort_chunks<256, 8>), dim3((unsigned)max_chunks), dim3(256), 2304 * sizeof(uint64_t), c.stream,
 			c.bin.chunks, c.bin.entries2, c.bin.point_list, totals, lim);

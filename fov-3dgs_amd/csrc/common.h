@@ -48,7 +48,7 @@ __host__ __device__ constexpr inline bool is_fov(int v) { return v == FR_VARIANT
 __host__ __device__ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // Geometry workspace. Everything per CANDIDATE is indexed by the candidate's position in vis_list ("item"), the list of
-// Gaussians that survive the cull pass IN INCREASING GAUSSIAN INDEX (k_project + k_compact): the binning kernel's outputs
+// Gaussians that survive the cull pass IN INCREASING GAUSSIAN INDEX (k_project): the binning kernel's outputs
 // are then dense rows written by consecutive lanes, and the blend kernels gather from a few tens of MB instead of from
 // 48-byte rows spread 12 % dense over P of them. (Measured on MI355X, tools/scratch/gather_rate.hip: a store instruction
 // whose 64 lanes hit 64 different lines costs a CU ~11 cycles per lane, a load ~3; round 2's per-Gaussian-index records
@@ -72,13 +72,13 @@ struct GeomWS {
 	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8 per item
 	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {prefiltered violation flag, number of entries in vis_list, ...}; k_bin's eight slab pull
 	                    // counters live at [32 * (1 + r)], one 128-byte line each
-	uint32_t *vis_list; // [P]  indices of the Gaussians that survive the cull pass, increasing (k_compact)
+	uint32_t *vis_list; // [P]  indices of the Gaussians that survive the cull pass, increasing
 	uint32_t *vis_seg;  // [P + FR_CROW_PAD] the same indices as k_project's waves leave them: wave w of the cull pass owns the slots
 	                    //      from w * (its chunks) * 64 on and fills them in the order it meets its survivors (its chunks are consecutive)
 	uint32_t *proj_counts; // [FR_PROJ_MAX_WAVES] survivors of every wave of the cull pass
 	float4 *crow;       // [3 (P + FR_CROW_PAD)] foveated variants' candidate rows (xyz, scale | scale.yz, rotation.xy | rotation.zw, highest
 	                    //      level, index), same slots as vis_seg ...
-	uint32_t *vis_src;  // [P]  ... and the slot of item i (k_bin reads one row instead of four gathers)
+	uint32_t *vis_src;  // [P]  (unused)
 	int32_t *slab_next;   // [ceil(P / 64)] per-wave chains of the 64-entry vis_list slabs k_bin's waves pulled ...
 	int32_t *wave_head;   // [FR_BIN_BLOCKS * FR_BIN_THREADS / 64] ... and the last slab of every wave (-1: none)
 	size_t bytes;
@@ -403,6 +403,7 @@ struct FwdCtx {
 	// the frame has more instances than the binning workspace holds, so they can be launched BEFORE the host knows the
 	// counts (fr_forward): counts_known = 0 -> grids are sized by upper bounds, heavy* / n_items above are not valid.
 	int counts_known;
+	int proj_waves, proj_cpw; // the cull pass's grid in waves and the consecutive chunks each wave took
 	int hint_heavy4, hint_heavy8; // counts not known: the class counts of the previous frame of this kind (sort plan, grid sizes)
 	int64_t capacity;   // instances the binning workspace was carved for
 	int64_t items_cap;  // blend work items the blend grid has workgroups for (a frame with more is replayed)

@@ -287,6 +287,7 @@ struct PreArgs {
 	int write_cov3D; // keep the 3D covariances for the backward pass (training variants only)
 	int raw;         // scales / rotations / opacities are raw parameters: activate on the fly (fr_forward_args.raw_activations)
 	int prefiltered; // fr_forward_args.prefiltered: a Gaussian behind the near plane is an error (slab_ctr[0] reports it)
+	int proj_waves, proj_cpw; // the cull pass's grid in waves and the chunks each of them took (k_bin finds the regions from them)
 };
 
 // Projection of one Gaussian: everything up to the tile rectangle.
@@ -562,7 +563,7 @@ __device__ __forceinline__ unsigned long long seg_mask(int a, int b)
 // leaves its survivors' indices (and, foveated variants, their input rows) in a region of its own, in the order it meets
 // them -- no counter, no atomics, no LDS staging (round 2 appended to one list through a device-wide counter: one atomic per
 // ~450 survivors, a 45 us queue of flushes at the end of the kernel before those were batched per workgroup) -- and
-// k_compact strings the regions together.
+// leaves its count; k_bin strings the regions together.
 #ifndef FR_PROJ_THREADS
 #define FR_PROJ_THREADS 1024
 #endif
@@ -666,6 +667,9 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		}
 		nrow += (uint32_t)__popcll(m);
 	};
+#ifdef FR_PROJ_TIMERS
+	const uint64_t tm0 = wall_clock64(); uint64_t tm_first = 0;
+#endif
 	// FR_PROJ_DEPTH chunks in flight per wave, each in its own register set that is refilled in place
 	RawGaussian R[DEPTH];
 #pragma unroll
@@ -676,46 +680,26 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		for (int d = 0; d < DEPTH; d++)
 		{
 			step(R[d], base + d);
+#ifdef FR_PROJ_TIMERS
+			if (tm_first == 0) tm_first = wall_clock64();
+#endif
 			R[d] = fetch(min(base + d + DEPTH, nchunks - 1));
 		}
 	}
+	// the wave's number of survivors: k_bin strings the regions together (it scans these counts at its start and finds the
+	// region of every item from the running sums -- no pass of its own over the survivors, no counter, no waiting. Tried: a
+	// kernel that copies the regions into one list (11 us of launch and dependent round trips); the copy at the end of this
+	// kernel with every workgroup adding up the counts of those in front of it (the polling of the workgroups that finish
+	// first halves the memory bandwidth of those still streaming: 74 -> 157 us).
 	if (lane == 0) a.geom.proj_counts[wave_gid] = nrow;
-}
-
-// Strings the regions the cull pass's waves left behind into ONE list in index order: vis_list[item] = Gaussian index,
-// vis_src[item] = the slot of its candidate row (foveated variants), slab_ctr[1] = their number. A workgroup serves
-// FR_COMPACT_WAVES consecutive waves of k_project; it sums the counts of all waves before them itself (at most 8192 numbers).
-#define FR_COMPACT_WAVES 16
-__global__ void __launch_bounds__(256) k_compact(const GeomWS g, int nwaves, int cpw)
-{
-	__shared__ uint32_t s_red[4], s_cnt[FR_COMPACT_WAVES], s_base[FR_COMPACT_WAVES + 1];
-	const int tid = threadIdx.x;
-	const int w0 = (int)blockIdx.x * FR_COMPACT_WAVES;
-	uint32_t part = 0;
-	for (int j = tid; j < w0; j += 256) part += g.proj_counts[j];
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off);
-	if ((tid & 63) == 0) s_red[tid >> 6] = part;
-	if (tid < FR_COMPACT_WAVES) s_cnt[tid] = w0 + tid < nwaves ? g.proj_counts[w0 + tid] : 0u;
-	__syncthreads();
-	if (tid == 0)
+#ifdef FR_PROJ_TIMERS
+	if (lane == 0)
 	{
-		uint32_t run = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-		for (int w = 0; w < FR_COMPACT_WAVES; w++) { s_base[w] = run; run += s_cnt[w]; }
-		s_base[FR_COMPACT_WAVES] = run;
-		if (w0 + FR_COMPACT_WAVES >= nwaves) g.slab_ctr[1] = run; // the last workgroup knows the total
+		// developer build (tools/proj_stats.py): per-wave (start, first chunk done, end) in ns / 10, in the unused covariance rows
+		float *d = a.geom.cov3D + (size_t)wave_gid * 4;
+		d[0] = (float)(tm0 & 0xffffff); d[1] = (float)(tm_first - tm0); d[2] = (float)(wall_clock64() - tm0); d[3] = (float)(c1 - c0);
 	}
-	__syncthreads();
-	// one k_project wave's survivors per wave here (a handful of 64-entry rounds each)
-	for (int w = tid >> 6; w < FR_COMPACT_WAVES; w += 4)
-	{
-		const uint32_t n = s_cnt[w], base = s_base[w], slot0 = (uint32_t)(w0 + w) * (uint32_t)cpw * 64u;
-		for (uint32_t k = tid & 63; k < n; k += 64)
-		{
-			g.vis_list[base + k] = g.vis_seg[slot0 + k];
-			if (g.vis_src != nullptr) g.vis_src[base + k] = slot0 + k;
-		}
-	}
+#endif
 }
 
 // Stage 2 (RS rasterizer_impl.cu:70-146, RF :264-383 + :490-530): for every survivor, count the tiles it
@@ -788,8 +772,36 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		cam_vm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.viewmatrix[i])));
 		cam_pm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.projmatrix[i])));
 	}
-	const int V = (int)a.geom.slab_ctr[1]; // entries of vis_list
+	// ---- the survivors of the cull pass: item i lives in the region of the wave whose running count covers i ----
+	// every workgroup scans the (at most 8192) per-wave counts into LDS; a slab then finds its first wave by binary search
+	// and its lanes step on from there (a region holds ~170 survivors: a slab spans one or two)
+	uint32_t *s_wbase = lds_hist + (LDSH ? a.T : 0) + (ldst ? a.T + (a.T + 31) / 32 : 0); // [proj_waves + 1] exclusive running counts
+	{
+		__shared__ uint32_t s_part[FR_BIN_THREADS / 64];
+		const int per = (a.proj_waves + FR_BIN_THREADS - 1) / FR_BIN_THREADS; // consecutive waves per thread
+		const int w0 = (int)threadIdx.x * per, w1 = min(a.proj_waves, w0 + per);
+		uint32_t mine = 0;
+		for (int w = w0; w < w1; w++) mine += a.geom.proj_counts[w];
+		uint32_t sc = wave_incl_scan_u32(mine, lane);
+		if (lane == 63) s_part[threadIdx.x >> 6] = sc;
+		__syncthreads();
+		uint32_t off = 0;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += s_part[w];
+		uint32_t run = off + sc - mine;
+		for (int w = w0; w < w1; w++) { s_wbase[w] = run; run += a.geom.proj_counts[w]; }
+		if (w1 == a.proj_waves && w0 < w1) s_wbase[a.proj_waves] = run;
+		if (a.proj_waves == 0 && threadIdx.x == 0) s_wbase[0] = 0;
+		__syncthreads();
+	}
+	const int V = (int)s_wbase[a.proj_waves]; // entries of vis_list
+	if (blockIdx.x == 0 && threadIdx.x == 0) a.geom.slab_ctr[1] = (uint32_t)V; // for the kernels that follow
 	const int nslabs = (V + 63) / 64;
+	// slot (in vis_seg / crow) of item i; `w` = a wave at or before the item's (from the slab's binary search)
+	auto slot_of = [&](const int item, int w) __attribute__((always_inline))
+	{
+		while ((uint32_t)item >= s_wbase[w + 1]) w++;
+		return (uint32_t)w * (uint32_t)a.proj_cpw * 64u + ((uint32_t)item - s_wbase[w]);
+	};
 	const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
 	const int nwaves = (int)gridDim.x * (FR_BIN_THREADS / 64);
 	int region = (int)blockIdx.x & 7;
@@ -1000,6 +1012,14 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	tm_n++;
 #endif
 	const int item = slab * 64 + lane;
+	// the wave whose region holds the slab's first item: largest w with s_wbase[w] <= 64 * slab (uniform search)
+	int slab_wave = 0;
+	{
+		int lo = 0, hi = a.proj_waves; // s_wbase[lo] <= first < s_wbase[hi] (first < V = s_wbase[proj_waves])
+		const uint32_t first = (uint32_t)slab * 64u;
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wbase[mid] <= first) lo = mid; else hi = mid; }
+		slab_wave = lo;
+	}
 	int idx = 0;
 	Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0; pr.pix_x = pr.pix_y = 0.f;
 	float4 r1 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
@@ -1015,10 +1035,11 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	{
 		// the candidate's full projection (covariance chain, conic, radius: forward.cu:155-262), its OBB axes and
 		// the rectangle to walk; candidates that turn out to reach no tile get radius 0, like every culled Gaussian
-		if (!CROW) idx = (int)a.geom.vis_list[item];
+		const uint32_t slot = slot_of(item, slab_wave);
+		if (!CROW) idx = (int)a.geom.vis_seg[slot];
 		if (CROW)
 		{
-			const float4 *cr = a.geom.crow + 3 * (size_t)a.geom.vis_src[item];
+			const float4 *cr = a.geom.crow + 3 * (size_t)slot;
 			const float4 g0 = cr[0], g1 = cr[1], g2 = cr[2];
 			w.p[0] = g0.x; w.p[1] = g0.y; w.p[2] = g0.z;
 			w.sc[0] = g0.w; w.sc[1] = g1.x; w.sc[2] = g1.y;
@@ -1084,6 +1105,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			pr.alive = wr.tnum != 0;
 		}
 		a.radii[idx] = pr.alive ? pr.radius : 0;
+		a.geom.vis_list[item] = (uint32_t)idx; // the list in index order, for the kernels that go from item to Gaussian
 		if (pr.alive)
 		{
 			a.geom.rec[3 * (size_t)item] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b); // first third of the record
@@ -1245,9 +1267,24 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 #endif
 	if (LDSH)
 	{
+		// The workgroup's share of every tile's bucket: its histogram is ADDED to the tile's global counter, and what the
+		// counter held before is where the share starts inside the bucket (k_emit's cursors). One returning atomic per
+		// (workgroup, tile it touched) -- ~0.8 M per 1080p frame, issued in bulk at the end of workgroups that finish at
+		// different times -- instead of storing all 256 x 8160 histogram rows and scanning them column by column in a kernel
+		// of its own (k_hist_colscan, 12.5 us of a frame, most of it launch and latency). The order of the shares inside a
+		// bucket is whatever order the atomics arrive in; the per-tile sort does not care.
 		__syncthreads();
 		uint32_t *out = a.hist + (size_t)blockIdx.x * a.T;
-		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) out[t] = lds_hist[t];
+		for (int t0 = threadIdx.x; t0 < a.T; t0 += 4 * FR_BIN_THREADS)
+		{
+			uint32_t h[4], o[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) { const int t = t0 + k * FR_BIN_THREADS; h[k] = t < a.T ? lds_hist[t] : 0u; }
+#pragma unroll
+			for (int k = 0; k < 4; k++) o[k] = h[k] ? atomicAdd(&a.tile_count[t0 + k * FR_BIN_THREADS], h[k]) : 0u;
+#pragma unroll
+			for (int k = 0; k < 4; k++) { const int t = t0 + k * FR_BIN_THREADS; if (t < a.T && h[k]) out[t] = o[k]; }
+		}
 	}
 }
 #undef BUMP_TILE
@@ -1299,6 +1336,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	}
 	if (LDSH)
 	{
+		// (pre[t] is only defined for the tiles this workgroup counted instances in -- the only cursors it will use)
 		const uint32_t *pre = a.hist + (size_t)blockIdx.x * a.T;
 		for (int t = threadIdx.x; t < a.T; t += FR_EMIT_THREADS) lds_cur[t] = a.ranges[t].x + pre[t];
 	}
@@ -1457,40 +1495,6 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 }
 #undef NEXT_SLOT
 
-// Column scan of the per-workgroup histograms: hist[b][t] becomes the exclusive prefix over b, the
-// tile's total goes to tile_count[t]. A workgroup owns FR_CS_TILES consecutive tiles (a full cache line per
-// histogram row); FR_CS_GROUPS row groups walk B / FR_CS_GROUPS rows each (two passes), which keeps that many
-// times more loads in flight than one thread per tile walking all B rows.
-#ifndef FR_CS_TILES
-#define FR_CS_TILES 16 // (8: 34 us, 16: 24.5 us, 32: 28 us, 64: 52 us at 512 x 8160)
-#endif
-#define FR_CS_GROUPS (256 / FR_CS_TILES)
-__global__ void __launch_bounds__(256) k_hist_colscan(int T, int B, uint32_t *hist, uint32_t *tile_count)
-{
-	__shared__ uint32_t s_part[FR_CS_GROUPS][FR_CS_TILES + 1];
-	const int c = threadIdx.x % FR_CS_TILES, g = threadIdx.x / FR_CS_TILES;
-	const int t = blockIdx.x * FR_CS_TILES + c;
-	const int R = (B + FR_CS_GROUPS - 1) / FR_CS_GROUPS;
-	const int r0 = g * R, r1 = min(B, r0 + R);
-	uint32_t sum = 0;
-	if (t < T)
-		for (int r = r0; r < r1; r++) sum += hist[(size_t)r * T + t];
-	s_part[g][c] = sum;
-	__syncthreads();
-	uint32_t run = 0;
-	for (int k = 0; k < g; k++) run += s_part[k][c];
-	if (t < T)
-	{
-		for (int r = r0; r < r1; r++)
-		{
-			const uint32_t v = hist[(size_t)r * T + t];
-			hist[(size_t)r * T + t] = run;
-			run += v;
-		}
-		if (g == FR_CS_GROUPS - 1) tile_count[t] = run;
-	}
-}
-
 __global__ void k_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present)
 {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1594,6 +1598,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 	p.radii = a->radii; p.geom = c.geom; p.tile_count = c.img.tile_count; p.hist = c.img.hist; p.raw = a->raw_activations;
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
 	p.prefiltered = a->prefiltered;
+	p.proj_waves = c.proj_waves; p.proj_cpw = c.proj_cpw;
 	return p;
 }
 
@@ -1625,6 +1630,9 @@ int launch_project(FwdCtx &c)
 		const int pchunks = (a->P + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS;
 		const int pmax = resident[slot] < FR_PROJ_MAX_WAVES / (FR_PROJ_THREADS / 64) ? resident[slot] : FR_PROJ_MAX_WAVES / (FR_PROJ_THREADS / 64);
 		const dim3 pgrid(pchunks < pmax ? pchunks : pmax), pblock(FR_PROJ_THREADS);
+		c.proj_waves = (int)pgrid.x * (FR_PROJ_THREADS / 64);
+		c.proj_cpw = proj_chunks_per_wave(a->P, c.proj_waves);
+		p.proj_waves = c.proj_waves; p.proj_cpw = c.proj_cpw;
 #define LAUNCH_PROJ(V) do { if (packed) hipLaunchKernelGGL((k_project<V, true>), pgrid, pblock, 0, c.stream, p); \
 	else hipLaunchKernelGGL((k_project<V>), pgrid, pblock, 0, c.stream, p); } while (0)
 		switch (vslot)
@@ -1634,12 +1642,7 @@ int launch_project(FwdCtx &c)
 		default: LAUNCH_PROJ(FR_VARIANT_PCHECK_OBB); break;
 		}
 #undef LAUNCH_PROJ
-		int rc = check_launch("project", c.stream, a->debug);
-		if (rc) return rc;
-		const int nwaves = (int)pgrid.x * (FR_PROJ_THREADS / 64);
-		hipLaunchKernelGGL(k_compact, dim3((nwaves + FR_COMPACT_WAVES - 1) / FR_COMPACT_WAVES), dim3(256), 0, c.stream, c.geom, nwaves,
-			proj_chunks_per_wave(a->P, nwaves));
-		return check_launch("compact", c.stream, a->debug);
+		return check_launch("project", c.stream, a->debug);
 	}
 }
 
@@ -1653,7 +1656,8 @@ int launch_bin(FwdCtx &c)
 	const dim3 block(FR_BIN_THREADS);
 	// LDS per workgroup: tile histogram (+ RF: tile_min and blend bits when two workgroups still fit a CU)
 	p.lds_tiles = (is_fov(a->variant) && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
-	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
+	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0) +
+		(size_t)(c.proj_waves + 1) * sizeof(uint32_t); // + the running counts of the cull pass's waves
 	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the
 	// ordinary path 5 %); it needs both packed tensors and the LDS histogram path. Otherwise, when k_project stored the
 	// candidates' rows (foveated variants, unpacked cull pass, scales + rotations given), the kernel that reads those.
@@ -1687,7 +1691,7 @@ int launch_bin(FwdCtx &c)
 #define LAUNCH_PRE(V) do { if (packed) lrc = launch((const void *)k_bin<V, true, true>, k_bin<V, true, true>, lds); \
 	else if (crow) lrc = launch((const void *)k_bin<V, true, false, true>, k_bin<V, true, false, true>, lds); \
 	else if (ldsh) lrc = launch((const void *)k_bin<V, true>, k_bin<V, true>, lds); \
-	else lrc = launch((const void *)k_bin<V, false>, k_bin<V, false>, 0); } while (0)
+	else lrc = launch((const void *)k_bin<V, false>, k_bin<V, false>, lds); } while (0)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
@@ -1696,17 +1700,14 @@ int launch_bin(FwdCtx &c)
 	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: // (no packed instantiation: validate_forward refuses the packed tensors)
 		if (crow) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true, false, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true, false, true>, lds);
 		else if (ldsh) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, lds);
-		else lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, 0);
+		else lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, lds);
 		break;
 	default: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
 	}
 #undef LAUNCH_PRE
 	if (lrc) return lrc;
 	c.bin_wgs = nblk;
-	int rc = check_launch("preprocess", c.stream, a->debug);
-	if (rc || !ldsh) return rc;
-	hipLaunchKernelGGL(k_hist_colscan, dim3((c.T + FR_CS_TILES - 1) / FR_CS_TILES), dim3(256), 0, c.stream, c.T, nblk, c.img.hist, c.img.tile_count);
-	return check_launch("hist_colscan", c.stream, a->debug);
+	return check_launch("preprocess", c.stream, a->debug);
 }
 
 int launch_emit(FwdCtx &c)

@@ -2,7 +2,7 @@
 # usage: tools/kstats.sh [stage_bench args]  -> per-kernel average durations (us) of the fr:: kernels
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is unset)}"
 rm -rf /tmp/ks1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks1 -o k -- python3 tools/stage_bench.py "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks1 -o k -- python3 tools/frames.py "$@" > /dev/null 2>&1
 python3 - <<PY
 import csv
 for r in csv.DictReader(open("/tmp/ks1/k_kernel_stats.csv")):
