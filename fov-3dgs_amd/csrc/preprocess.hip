@@ -764,6 +764,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// wave_head): k_emit must replay the same slab -> workgroup assignment because its bucket offsets are
 	// per workgroup.
 	__shared__ int s_own[FR_BIN_THREADS];
+	__shared__ float4 s_orec[4 * FR_BIN_THREADS]; // the pair loop's 64-byte row per lane (see there)
 	// camera matrices in scalar registers (see k_project)
 	float cam_vm[16], cam_pm[16];
 #pragma unroll
@@ -889,6 +890,14 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		const bool be_blend, const float conic_c, const float depth, const float *pos, const ColourPre &cp_in, const bool have_cp_in) __attribute__((always_inline))
 	{
 		if (count == 0) { a.radii[idx] = 0; return; } // culled everywhere (RS rasterizer_impl.cu:141-145)
+#ifdef FR_BIN_NO_COLOUR
+		{ // experiment: the kernel without its colour fetch / evaluation / level rows (images are wrong)
+			float4 *rec = a.geom.rec + 3 * (size_t)item;
+			rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f); rec[2] = make_float4(0.0f, depth, 0.0f, __int_as_float(idx));
+			if (LEVELCOL) a.geom.lrange[item] = (uint32_t)f2i(lowest) | ((uint32_t)f2i(highest) << 8) | (be_blend ? 0x10000u : 0u);
+			return;
+		}
+#endif
 		ColourPre cp = cp_in;
 		if (!have_cp_in && rows_ok) prefetch_colour(idx, cp);
 		const bool have_cp = have_cp_in || rows_ok;
@@ -976,51 +985,112 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		else rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(idx));
 	};
 #ifdef FR_BIN_TIMERS
-	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0;
+	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0, tm_bsteps = 0;
 #define TM_BEGIN() tm_x = wall_clock64()
 #define TM_END(acc) do { const uint64_t now_ = wall_clock64(); acc += now_ - tm_x; tm_x = now_; } while (0)
 #else
 #define TM_BEGIN()
 #define TM_END(acc)
 #endif
-	for (int sstat = wave_gid; ; sstat += nwaves)
+	// ---- the slab loop, one slab AHEAD: the next slab is asked for while this one is projected, and its candidates' input
+	// rows are in flight while this one's tiles are walked. Per slab a wave otherwise waits, one after the other, for the
+	// returning atomic of the pull (~2 us under load), the running-count search, and the dependent row loads: the SQ
+	// counters of the round-2 kernel have its waves parked on s_waitcnt 57 % of the time at 1.76 waves per SIMD. (Round 2
+	// found pulling ahead slower -- a wave stuck in a heavy slab sits on one another could take -- when nothing was
+	// fetched ahead with it.)
+	struct SlabIn { int idx; RawGaussian w; };
+	// inputs of slab `sl` (raw: the activations of fr_forward_args.raw_activations are applied where they are used)
+	auto load_inputs = [&](const int sl, SlabIn &in) __attribute__((always_inline))
 	{
-	TM_BEGIN();
-	int slab = sstat;
-	if (LDSH)
+		in.idx = 0; in.w.p[0] = in.w.p[1] = in.w.p[2] = 0.f; in.w.sc[0] = in.w.sc[1] = in.w.sc[2] = 0.f; in.w.q = make_float4(0, 0, 0, 0); in.w.hl = 0.f;
+		const int it = sl * 64 + lane;
+		// the wave whose region holds the slab's first item: largest w with s_wbase[w] <= 64 * slab (uniform search)
+		int lo = 0, hi = a.proj_waves; // s_wbase[lo] <= first < s_wbase[hi] (first < V = s_wbase[proj_waves])
+		const uint32_t first = (uint32_t)sl * 64u;
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wbase[mid] <= first) lo = mid; else hi = mid; }
+		if (it < V)
+		{
+			const uint32_t slot = slot_of(it, lo);
+			if (CROW)
+			{
+				const float4 *cr = a.geom.crow + 3 * (size_t)slot;
+				const float4 g0 = cr[0], g1 = cr[1], g2 = cr[2];
+				in.w.p[0] = g0.x; in.w.p[1] = g0.y; in.w.p[2] = g0.z;
+				in.w.sc[0] = g0.w; in.w.sc[1] = g1.x; in.w.sc[2] = g1.y;
+				in.w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
+				in.w.hl = g2.z;
+				in.idx = (int)__float_as_uint(g2.w);
+				return;
+			}
+			const int idx = (int)a.geom.vis_seg[slot];
+			in.idx = idx;
+			if (PACKED)
+			{
+				// one 64-byte row instead of four or five mostly-unused cache lines
+				const float4 *pg = (const float4 *)a.packed_geom + 4 * (size_t)idx;
+				const float4 g0 = pg[0], g1 = pg[1], g2 = pg[2];
+				in.w.p[0] = g0.x; in.w.p[1] = g0.y; in.w.p[2] = g0.z;
+				in.w.sc[0] = g0.w; in.w.sc[1] = g1.x; in.w.sc[2] = g1.y;
+				in.w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
+				in.w.hl = g2.z;
+			}
+			else
+			{
+#pragma unroll
+				for (int i = 0; i < 3; i++) in.w.p[i] = a.means3D[3 * (size_t)idx + i];
+				if (a.cov3D_precomp == nullptr)
+				{
+#pragma unroll
+					for (int i = 0; i < 3; i++) in.w.sc[i] = a.scales[3 * (size_t)idx + i];
+					in.w.q = ((const float4 *)a.rotations)[idx];
+				}
+				if (FOV) in.w.hl = a.highest_levels[idx];
+			}
+		}
+	};
+	// Pulling a slab (LDSH): a returning atomic on this wave's region counter, then the others if that one is dry. issue_pull
+	// only sends the first atomic; finish_pull waits for it (and does the rare rest). Static order otherwise.
+	int pend_li = 0, pend_r = 0, static_next = wave_gid;
+	auto issue_pull = [&]() __attribute__((always_inline))
 	{
+		if (LDSH) { pend_r = region; if (lane == 0) pend_li = (int)atomicAdd(a.geom.slab_ctr + 32 * (1 + region), 1u); }
+	};
+	auto finish_pull = [&]() __attribute__((always_inline))
+	{
+		if (!LDSH) { const int sl = static_next; static_next += nwaves; return sl < nslabs ? sl : -1; }
 		int got = -1;
 		if (lane == 0)
 		{
-			for (int tries = 0; tries < 8 && got < 0; tries++)
+			if (pend_li < ((nslabs - pend_r + 7) >> 3)) got = pend_li * 8 + pend_r;
+			for (int tries = 1; tries < 8 && got < 0; tries++)
 			{
-				const int r = (region + tries) & 7;
+				const int r = (pend_r + tries) & 7;
 				const int nr = (nslabs - r + 7) >> 3;
-				uint32_t *ctr = a.geom.slab_ctr + 32 * (1 + r);
-				const int li = (int)atomicAdd(ctr, 1u);
+				const int li = (int)atomicAdd(a.geom.slab_ctr + 32 * (1 + r), 1u);
 				if (li < nr) { got = li * 8 + r; region = r; }
 			}
 		}
-		slab = __builtin_amdgcn_readfirstlane(got);
-		if (slab < 0) break;
+		return __builtin_amdgcn_readfirstlane(got);
+	};
+	TM_BEGIN();
+	issue_pull();
+	int slab = finish_pull();
+	SlabIn in_cur;
+	if (slab >= 0) load_inputs(slab, in_cur);
+	while (slab >= 0)
+	{
+	if (LDSH)
+	{
 		if (lane == 0) a.geom.slab_next[slab] = chain;
 		chain = slab;
 	}
-	else if (slab >= nslabs) break;
+	issue_pull(); // the next slab: its number is back by the time this one is projected
 	TM_END(tm_s);
 #ifdef FR_BIN_TIMERS
 	tm_n++;
 #endif
 	const int item = slab * 64 + lane;
-	// the wave whose region holds the slab's first item: largest w with s_wbase[w] <= 64 * slab (uniform search)
-	int slab_wave = 0;
-	{
-		int lo = 0, hi = a.proj_waves; // s_wbase[lo] <= first < s_wbase[hi] (first < V = s_wbase[proj_waves])
-		const uint32_t first = (uint32_t)slab * 64u;
-		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wbase[mid] <= first) lo = mid; else hi = mid; }
-		slab_wave = lo;
-	}
-	int idx = 0;
+	int idx = in_cur.idx;
 	Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0; pr.pix_x = pr.pix_y = 0.f;
 	float4 r1 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
 	uint32_t count = 0;
@@ -1028,56 +1098,27 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	float2 el = make_float2(0, 0);
 	float hl = 0, lowest = 0, highest = 0;
 	bool be_blend = false, boxtest = false;
-	RawGaussian w; w.p[0] = w.p[1] = w.p[2] = 0.f; w.sc[0] = w.sc[1] = w.sc[2] = 0.f; w.q = make_float4(0, 0, 0, 0);
+	RawGaussian w = in_cur.w;
 	float inv_qnorm = 1.0f;
 	ColourPre cp;
+	int next_slab = -1;
+	SlabIn in_next;
 	if (item < V)
 	{
 		// the candidate's full projection (covariance chain, conic, radius: forward.cu:155-262), its OBB axes and
 		// the rectangle to walk; candidates that turn out to reach no tile get radius 0, like every culled Gaussian
-		const uint32_t slot = slot_of(item, slab_wave);
-		if (!CROW) idx = (int)a.geom.vis_seg[slot];
-		if (CROW)
-		{
-			const float4 *cr = a.geom.crow + 3 * (size_t)slot;
-			const float4 g0 = cr[0], g1 = cr[1], g2 = cr[2];
-			w.p[0] = g0.x; w.p[1] = g0.y; w.p[2] = g0.z;
-			w.sc[0] = g0.w; w.sc[1] = g1.x; w.sc[2] = g1.y;
-			w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
-			if (FOV) { hl = g2.z; lowest = hl; }
-			idx = (int)__float_as_uint(g2.w);
-		}
-		else if (PACKED)
-		{
-			// one 64-byte row instead of four or five mostly-unused cache lines
-			const float4 *pg = (const float4 *)a.packed_geom + 4 * (size_t)idx;
-			const float4 g0 = pg[0], g1 = pg[1], g2 = pg[2];
-			w.p[0] = g0.x; w.p[1] = g0.y; w.p[2] = g0.z;
-			w.sc[0] = g0.w; w.sc[1] = g1.x; w.sc[2] = g1.y;
-			w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
-			if (FOV) { hl = g2.z; lowest = hl; }
-		}
-		else
+		if (FOV) { hl = w.hl; lowest = hl; }
+		if (!CROW && !PACKED && !FOV && a.raw && a.cov3D_precomp == nullptr)
 		{
 #pragma unroll
-			for (int i = 0; i < 3; i++) w.p[i] = a.means3D[3 * (size_t)idx + i];
-			if (a.cov3D_precomp == nullptr)
-			{
-#pragma unroll
-				for (int i = 0; i < 3; i++) w.sc[i] = a.scales[3 * (size_t)idx + i];
-				w.q = ((const float4 *)a.rotations)[idx];
-				if (!FOV && a.raw)
-				{
-#pragma unroll
-					for (int i = 0; i < 3; i++) w.sc[i] = act_scale(w.sc[i]);
-					w.q = act_rotation(w.q, &inv_qnorm);
-				}
-			}
-			if (FOV) { hl = a.highest_levels[idx]; lowest = hl; }
+			for (int i = 0; i < 3; i++) w.sc[i] = act_scale(w.sc[i]);
+			w.q = act_rotation(w.q, &inv_qnorm);
 		}
 		// the colour rows are asked for NOW and evaluated after the walk (finish): their round trip and the lines they pull
 		// run under the projection and the tile walk
+#ifndef FR_BIN_NO_COLOUR
 		if (pre_ok) prefetch_colour(idx, cp);
+#endif
 		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q, a.write_cov3D ? (float4 *)a.geom.cov3D + 4 * (size_t)item : nullptr);
 		if (a.write_cov3D)
 		{
@@ -1112,6 +1153,10 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			r1.x = pr.conic_c; r2.y = pr.depth;
 		}
 	}
+
+	// the next slab's number is back: its candidates' rows are on their way while this slab's tiles are walked
+	next_slab = finish_pull();
+	if (next_slab >= 0) load_inputs(next_slab, in_next);
 
 	// ---- count the tiles this splat really lands in (and bump the per-tile counters) ----
 	// single-tile splats need no box test (RS rasterizer_impl.cu:99-102); handle them in place
@@ -1165,8 +1210,27 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 #ifdef FR_BIN_TIMERS
-		tm_steps += (int)((total + 63) / 64);
+		tm_steps += (int)((total + 63) / 64); tm_bsteps += (int)((total + 63) / 64);
+		TM_END(tm_sh); // (time of the big walks + deferral + scan: the balanced loop is what remains of tm_p)
 #endif
+		// Every lane leaves what a pair of its splat needs in a 64-byte LDS row (the corner extremes of its box included:
+		// make_obb once per splat, not once per pair); a pair then reads its OWNER's row -- four LDS reads, most of them
+		// broadcasts -- instead of pulling thirteen registers through ds_bpermute, divides by the rectangle's width with a
+		// reciprocal, and evaluates the box test without branches. (A step of this loop was ~150 vector + ~80 scalar
+		// instructions and took 1800 cycles at the kernel's 2 waves per SIMD: a third of k_bin.)
+		float4 *orec = s_orec + 4 * (threadIdx.x & ~63);
+		if (total != 0)
+		{
+			const Obb ob = make_obb(pr.pix_x, pr.pix_y, ev, el);
+			float4 *mine = orec + 4 * lane;
+			mine[0] = make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y);
+			mine[1] = make_float4(ev.z, ev.w, el.x, el.y);
+			mine[2] = make_float4(ob.vxmin, ob.vxmax, ob.vymin, ob.vymax);
+			mine[3] = make_float4(__uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)), __int_as_float(max(pr.x1 - pr.x0, 1)), __uint_as_float(excl), hl + 1);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
 		for (uint32_t k = 0; k < total; k += 64)
 		{
 			const uint32_t j = k + lane;
@@ -1174,30 +1238,47 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			const int seg_a = (int)max((long long)excl - (long long)k, 0ll);
 			const int seg_b = (int)min((long long)incl - (long long)k, 64ll);
 			const int owner = max(pair_owner_scan(s_own + (threadIdx.x & ~63), lane, seg_a, seg_b), 0);
-			const uint32_t local = (valid ? j : total - 1) - (uint32_t)__shfl((int)excl, owner);
-			const int ox0 = __shfl(pr.x0, owner), oy0 = __shfl(pr.y0, owner), ow = max(__shfl(pr.x1, owner) - ox0, 1);
-			const int x = ox0 + (int)(local % (uint32_t)ow), y = oy0 + (int)(local / (uint32_t)ow);
+			const float4 *orow = orec + 4 * owner;
+			const float4 o3 = orow[3];
+			const uint32_t oxy = __float_as_uint(o3.x);
+			const int ow = __float_as_int(o3.y);
+			const uint32_t local = (valid ? j : total - 1) - __float_as_uint(o3.z);
+			// local / ow and local % ow for local < 2^23 (a splat of this loop has fewer than 64 tiles)
+			int qy = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)ow));
+			int rx = (int)local - qy * ow;
+			if (rx < 0) { qy--; rx += ow; } else if (rx >= ow) { qy++; rx -= ow; }
+			const int x = (int)(oxy & 0xffffu) + rx, y = (int)(oxy >> 16) + qy;
 			const int ti = y * a.gx + x;
 			bool pass = valid;
 			uint32_t m = 0;
 			if (CULL)
 			{
-				const float4 oev = make_float4(__shfl(ev.x, owner), __shfl(ev.y, owner), __shfl(ev.z, owner), __shfl(ev.w, owner));
-				const float2 oel = make_float2(__shfl(el.x, owner), __shfl(el.y, owner));
-				const float ocx = __shfl(pr.pix_x, owner), ocy = __shfl(pr.pix_y, owner);
+				const float4 o0 = orow[0], o1 = orow[1], o2 = orow[2];
 				float level = 0.f;
 				if (FOV)
 				{
-					const float ohl = __shfl(hl, owner);
-					level = valid ? TILE_MIN(ti) : 0.f;
-					pass = pass && (level < (ohl + 1));
+					level = TILE_MIN(valid ? ti : 0);
+					pass = pass && (level < o3.w);
 				}
-				if (pass)
 				{
-					const Obb ob = make_obb(ocx, ocy, oev, oel);
-					pass = obb_hits_tile(ob, x, y);
+					// obb_hits_tile() without its early returns (same expressions, same comparisons: a NaN fails no test)
+					const float tpx = (float)x * (float)FR_TILE + (float)FR_TILE / 2.0f, tpy = (float)y * (float)FR_TILE + (float)FR_TILE / 2.0f;
+					const bool cx_ok = !((o2.y - tpx) < -8.0f || (o2.x - tpx) > 8.0f);
+					const bool cy_ok = !((o2.w - tpy) < -8.0f || (o2.z - tpy) > 8.0f);
+					const float xp = tpx + 8.0f - o0.x, xm = tpx - 8.0f - o0.x, yp = tpy + 8.0f - o0.y, ym = tpy - 8.0f - o0.y;
+					const float a1p = xp * o0.z, a1m = xm * o0.z, b1p = yp * o0.w, b1m = ym * o0.w;
+					const float mn1 = fminf(a1p, a1m) + fminf(b1p, b1m), mx1 = fmaxf(a1p, a1m) + fmaxf(b1p, b1m);
+					const bool e1_ok = !(o1.z < mn1 || -o1.z > mx1);
+					const float a2p = xp * o1.x, a2m = xm * o1.x, b2p = yp * o1.y, b2m = ym * o1.y;
+					const float mn2 = fminf(a2p, a2m) + fminf(b2p, b2m), mx2 = fmaxf(a2p, a2m) + fmaxf(b2p, b2m);
+					const bool e2_ok = !(o1.w < mn2 || -o1.w > mx2);
+					pass = pass && cx_ok && cy_ok && e1_ok && e2_ok;
 				}
-				if (FOV && pass) m = (1u << min(max(f2i(level), 0), 3)) | (TILE_BLENDS(ti) ? 16u : 0u);
+				if (FOV)
+				{
+					const uint32_t mm = (1u << min(max(f2i(level), 0), 3)) | (TILE_BLENDS(valid ? ti : 0) ? 16u : 0u);
+					m = pass ? mm : 0u;
+				}
 			}
 			if (pass) BUMP_TILE(ti);
 			// hand the results back to the owners: my pairs of this step are lanes [seg_a, seg_b)
@@ -1209,6 +1290,12 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 				for (int bit = 0; bit < 5; bit++)
 					if (__ballot((m >> bit) & 1u) & mine) lvmask |= 1u << bit;
 			}
+		}
+		if (total != 0)
+		{
+			// the rows are rewritten by the next slab: everyone is done reading
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 		}
 		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
 		TM_END(tm_p);
@@ -1226,6 +1313,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 	}
 	TM_END(tm_c);
+	slab = next_slab;
+	in_cur = in_next;
 	} // slab loop
 #ifdef FR_BIN_TIMERS
 	const uint64_t tm_loop_end = wall_clock64();
@@ -1262,7 +1351,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	{
 		float *d = a.geom.cov3D + (size_t)wave_gid * 8;
 		d[0] = (float)(wall_clock64() - tm0); d[1] = (float)(tm_loop_end - tm0); d[2] = (float)tm_l; d[3] = (float)tm_p; d[4] = (float)tm_c;
-		d[5] = (float)tm_n; d[6] = (float)(tm0 & 0xffffffull); d[7] = (float)tm_steps;
+		d[5] = (float)tm_n + 1024.0f * (float)tm_bsteps; d[6] = (float)tm_sh; d[7] = (float)tm_steps;
 	}
 #endif
 	if (LDSH)
@@ -1570,8 +1659,9 @@ int launch_pack_colour(int P, const float *shs, const float *shs_rest, const flo
 // ---- launchers -------------------------------------------------------------------------------
 // bytes of the RF tile table in LDS: tile_min floats + one blend bit per tile
 static inline size_t lds_tile_table_bytes(int T) { return (size_t)T * sizeof(float) + (size_t)((T + 31) / 32) * sizeof(uint32_t); }
-#define FR_LDS_TILE_TABLE_BUDGET (140u * 1024u) // one workgroup of k_bin / k_emit per CU (160 KiB) with its static LDS: every
-                                                 // tile grid that gets LDS histograms (<= 16384 tiles) also gets the LDS tile table
+#define FR_LDS_TILE_TABLE_BUDGET (104u * 1024u) // one workgroup of k_bin / k_emit per CU (160 KiB) beside its static LDS (36 KiB:
+                                                 // the pair loop's rows) and the cull pass's running counts (<= 16 KiB): tile grids
+                                                 // up to ~13 000 tiles get the LDS tile table beside their LDS histogram
 
 int launch_tile_levels(FwdCtx &c)
 {
@@ -1673,7 +1763,7 @@ int launch_bin(FwdCtx &c)
 		for (int i = 0; i < ncache; i++) if (cache[i].fn == fn && cache[i].dyn == dyn) wgs = cache[i].wgs;
 		if (wgs == 0)
 		{
-			if (dyn > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+			if (dyn > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
 			{ set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(hipGetLastError())); return FR_ERR_HIP; }
 			int per_cu = 0, dev = 0;
 			hipDeviceProp_t prop;

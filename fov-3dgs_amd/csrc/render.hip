@@ -57,6 +57,26 @@ __device__ __forceinline__ v2f power2(v2f dy, float C, float adx2, float bdx)
 	return __builtin_elementwise_fma((v2f){ -0.5f, -0.5f }, s, nb);
 }
 
+// q = -power = 0.5 (A dx^2 + C dy^2) + B dx dy for two rows at once. Negation commutes with rounding, so -q is bit for bit
+// the power of power2(); what the blend needs of it is exp(-q) and the support test 0 <= q <= 4.5 (power > 0 and
+// power < -4.5 are skipped, RS forward.cu:376-380), and on the BIT PATTERN that test is ONE unsigned comparison: a
+// negative q (power > 0) has its sign bit set, i.e. is a huge unsigned number, and non-negative floats order like their
+// bits. q is +0 where the reference's power is -0 or +0 (0.5 s is +0, and +0 + -0 = +0), which it does not skip either.
+// (A NaN has all exponent bits set and fails the test; the reference lets a NaN power through to a NaN alpha: garbage in
+// both cases, for a conic that is no conic.)
+__device__ __forceinline__ v2f qform2(v2f dy, float C, float adx2, float bdx)
+{
+	const v2f cdy = C * dy;
+	const v2f s = __builtin_elementwise_fma(cdy, dy, (v2f){ adx2, adx2 });
+	return __builtin_elementwise_fma((v2f){ 0.5f, 0.5f }, s, bdx * dy);
+}
+__device__ __forceinline__ bool in_support(float q) { return __float_as_uint(q) <= 0x40900000u; } // 0 <= q <= 4.5
+__device__ __forceinline__ v2f exp_neg_pair(v2f q)
+{
+	const v2f t = q * -1.4426950408889634f;
+	return (v2f){ __builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y) };
+}
+
 // Two pixels (rows) of a lane: transmittance (negated once the pixel is finished) and colour sums.
 struct Px2 { v2f T, C0, C1, C2; };
 __device__ __forceinline__ v2f exp2_pair(v2f p)
@@ -267,10 +287,11 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 #pragma unroll
 			for (int h = 0; h < HP; h++)
 			{
-				const v2f pw = power2(g0.y - pyp[h], g1.x, adx2, bdx);
-				t.inx[h] = valid && !(pw.x > 0.0f) && !(CUTOFF && pw.x < -4.5f);
-				t.iny[h] = valid && !(pw.y > 0.0f) && !(CUTOFF && pw.y < -4.5f);
-				t.e[h] = exp2_pair(pw);
+				// (forward.cu:349-351: power > 0 is skipped; RS :376-380 also power < -4.5 -- one comparison on q's bits, see qform2)
+				const v2f q = qform2(g0.y - pyp[h], g1.x, adx2, bdx);
+				t.inx[h] = valid && (CUTOFF ? in_support(q.x) : __float_as_int(q.x) >= 0);
+				t.iny[h] = valid && (CUTOFF ? in_support(q.y) : __float_as_int(q.y) >= 0);
+				t.e[h] = exp_neg_pair(q);
 			}
 			t.col = make_float4(g1.z, g1.w, s2[j], g1.y); // r, g, b, opacity
 			return t;
@@ -393,8 +414,9 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 {
 	static_assert(PPL == 2, "work items encode two bands per tile");
 	constexpr int HP = PPL / 2;
+	// three rows of 16 bytes per staged entry, all with the same stride: one address register serves the three reads
 	__shared__ float4 s0[64];   // x, y, A, B
-	__shared__ float2 s1[64];   // C, highest_level
+	__shared__ float4 s1[64];   // C, highest_level, -, -
 	__shared__ float4 sl1[64];  // this wave's level: r, g, b, opacity
 
 	const int lane = threadIdx.x;
@@ -473,7 +495,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 			tm_sync += wall_clock64() - tq0;
 #endif
 			const bool staged = base + lane < n;
-			if (staged) { s0[lane] = p0; s1[lane] = p1; sl1[lane] = pl1; }
+			if (staged) { s0[lane] = p0; s1[lane] = make_float4(p1.x, p1.y, 0.0f, 0.0f); sl1[lane] = pl1; }
 			unsigned long long reach_mask;
 			{
 				// alpha < 1/255 everywhere (forward.cu:563) <=> power < -ln(255 opacity): tighter than -4.5 for faint splats
@@ -503,18 +525,18 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 			{
 				Ent t;
 				const float4 g0 = s0[j];
-				const float2 g1 = s1[j];
+				const float g1x = s1[j].x;
 				const float dx = g0.x - pxf;
 				const float adx2 = (g0.z * dx) * dx;
 				const float bdx = g0.w * dx;
 #pragma unroll
 				for (int h = 0; h < HP; h++)
 				{
-					const v2f pw = power2(g0.y - pyp[h], g1.x, adx2, bdx);
+					const v2f q = qform2(g0.y - pyp[h], g1x, adx2, bdx);
 					// in the splat's support: RF forward.cu:556-560 (power > 0 and power < -4.5 are skipped)
-					t.inx[h] = valid && !(pw.x > 0.0f || pw.x < -4.5f);
-					t.iny[h] = valid && !(pw.y > 0.0f || pw.y < -4.5f);
-					t.e[h] = exp2_pair(pw);
+					t.inx[h] = valid && in_support(q.x);
+					t.iny[h] = valid && in_support(q.y);
+					t.e[h] = exp_neg_pair(q);
 				}
 				t.c1 = sl1[j];
 				return t;

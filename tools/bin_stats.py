@@ -27,13 +27,16 @@ geom = r[3]
 P = xyz.shape[0]
 off = ((P * 48 + 255) // 256) * 256
 dbg = geom[off:off + 512 * 8 * 8 * 4].view(torch.float32).view(512 * 8, 8).cpu().numpy()
+dbg = dbg[:256 * 8]  # one workgroup per CU
 tot, sched, load, pairs, col, pulled = [dbg[:, i] * (10 if i < 5 else 1) for i in range(6)]
+bsteps = np.floor(pulled / 1024); pulled = pulled - 1024 * bsteps
+bigt = dbg[:, 6] * 10
 print("waves", len(tot), "wave total us: mean %.0f max %.0f" % (tot.mean() / 1e3, tot.max() / 1e3))
 print("  slab loop end: mean %.1f p99 %.1f max %.1f us" % (sched.mean() / 1e3, np.percentile(sched, 99) / 1e3, sched.max() / 1e3))
 for name, v in ( ("load", load), ("pairs", pairs), ("colour+write", col)):
     print("  %-14s mean %.1f us  frac %.2f" % (name, v.mean() / 1e3, v.sum() / tot.sum()))
 print("slabs per wave mean %.2f max %d" % (pulled.mean(), pulled.max()))
-st = dbg[:, 6]; st = (st - st.min()) * 10 / 1e3
+st = np.zeros(len(tot))
 print("wave start us pct 10/50/90/99:", np.percentile(st, [10, 50, 90, 99]).round(1), " workgroups starting after 20 us:", int((st.reshape(-1, 8)[:, 0] > 20).sum()))
 print("end time us pct 10/50/90:", np.percentile(st + tot / 1e3, [10, 50, 90]).round(1))
 print("wave total pct 50/90/99: %s" % np.percentile(tot / 1e3, [50, 90, 99]).round(0))
@@ -42,9 +45,6 @@ print("pair steps per wave mean %.1f max %d total %.2fM pairs<=%.1fM; us/step %.
 w = int(np.argmax(tot))
 print("slowest wave: tot %.0f sched %.0f load %.0f pairs %.0f colour %.0f us, slabs %d steps %d" % (tot[w] / 1e3, sched[w] / 1e3, load[w] / 1e3, pairs[w] / 1e3, col[w] / 1e3, pulled[w], steps[w]))
 
-wg_start = st.reshape(-1, 8).min(1); wg_end = (st + tot / 1e3).reshape(-1, 8).max(1); wg_slabs = pulled.reshape(-1, 8).sum(1)
-h, e = np.histogram(wg_start, bins=[0, 1, 5, 20, 40, 60, 80, 100, 120, 140, 160, 180, 250])
-print("workgroup start histogram (us):", list(zip(e[:-1].astype(int), h)))
-order = np.argsort(wg_start)
-for q in (0, 100, 255, 256, 300, 350, 400, 450, 511):
-    i = order[q]; print("  wg rank %3d id %3d start %6.1f end %6.1f slabs %3d" % (q, i, wg_start[i], wg_end[i], wg_slabs[i]))
+
+print("big walks + scan: mean %.1f us per wave (%.1f steps: %.2f us/step); balanced loop: %.1f us (%.1f steps: %.2f us/step)" % (
+    bigt.mean() / 1e3, (steps - bsteps).mean(), bigt.sum() / 1e3 / max((steps - bsteps).sum(), 1), (pairs - bigt).mean() / 1e3, bsteps.mean(), (pairs - bigt).sum() / 1e3 / max(bsteps.sum(), 1)))
