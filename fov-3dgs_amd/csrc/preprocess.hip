@@ -886,14 +886,17 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// cp_in: the colour inputs fetched at the head of the slab if have_cp, else they are fetched here (giant splats; storage
 	// with fewer than 16 coefficients takes the generic path). (A value + a flag: a pointer that may be null, or a choice
 	// between two structs by reference, sends the whole struct through scratch memory.)
+	// the rows finish() makes for an item: the last two thirds of its record and (RF) its four level rows. The caller
+	// stores them: a slab's 64 items through LDS as whole kilobytes (see the slab loop), a giant splat's directly.
+	struct OutRows { float4 rec1, rec2, lvl[FR_FOV_LEVELS]; };
 	auto finish = [&](const int idx, const int item, const uint32_t count, const float hl, const float lowest, const float highest,
-		const bool be_blend, const float conic_c, const float depth, const float *pos, const ColourPre &cp_in, const bool have_cp_in) __attribute__((always_inline))
+		const bool be_blend, const float conic_c, const float depth, const float *pos, const ColourPre &cp_in, const bool have_cp_in,
+		OutRows &o) __attribute__((always_inline))
 	{
 		if (count == 0) { a.radii[idx] = 0; return; } // culled everywhere (RS rasterizer_impl.cu:141-145)
 #ifdef FR_BIN_NO_COLOUR
 		{ // experiment: the kernel without its colour fetch / evaluation / level rows (images are wrong)
-			float4 *rec = a.geom.rec + 3 * (size_t)item;
-			rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f); rec[2] = make_float4(0.0f, depth, 0.0f, __int_as_float(idx));
+			o.rec1 = make_float4(conic_c, hl, 0.0f, 0.0f); o.rec2 = make_float4(0.0f, depth, 0.0f, __int_as_float(idx));
 			if (LEVELCOL) a.geom.lrange[item] = (uint32_t)f2i(lowest) | ((uint32_t)f2i(highest) << 8) | (be_blend ? 0x10000u : 0u);
 			return;
 		}
@@ -971,18 +974,17 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 					v.y = fmaxf(FR_SH_C0 * dcs[3 * l + 1] + rest[1], 0.0f);
 					v.z = fmaxf(FR_SH_C0 * dcs[3 * l + 2] + rest[2], 0.0f);
 					v.w = ops[l];
-					a.geom.lvl[(size_t)item * FR_FOV_LEVELS + l] = v;
+					o.lvl[l] = v;
 				}
 			}
 		}
-		// the item's record (dense: consecutive lanes write consecutive 48-byte rows)
-		float4 *rec = a.geom.rec + 3 * (size_t)item;
-		if (LEVELCOL) rec[1] = make_float4(conic_c, hl, 0.0f, 0.0f);
-		else rec[1] = make_float4(conic_c, opacity, rgb[0], rgb[1]);
+		// the item's record
+		if (LEVELCOL) o.rec1 = make_float4(conic_c, hl, 0.0f, 0.0f);
+		else o.rec1 = make_float4(conic_c, opacity, rgb[0], rgb[1]);
 		// third part: the Gaussian's index (the statistics of the training variants and the gradients are per Gaussian); the
 		// shared-model foveated variant (no backward, no clamp bits needed) carries the Gaussian's highest level in the clamp slot
-		if (FOV && !LEVELCOL) rec[2] = make_float4(rgb[2], depth, hl, __int_as_float(idx));
-		else rec[2] = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(idx));
+		if (FOV && !LEVELCOL) o.rec2 = make_float4(rgb[2], depth, hl, __int_as_float(idx));
+		else o.rec2 = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(idx));
 	};
 #ifdef FR_BIN_TIMERS
 	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0, tm_bsteps = 0;
@@ -1092,7 +1094,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	const int item = slab * 64 + lane;
 	int idx = in_cur.idx;
 	Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0; pr.pix_x = pr.pix_y = 0.f;
-	float4 r1 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
+	float4 r1 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0), rec0 = make_float4(0, 0, 0, 0);
 	uint32_t count = 0;
 	float4 ev = make_float4(0, 0, 0, 0);
 	float2 el = make_float2(0, 0);
@@ -1149,7 +1151,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		a.geom.vis_list[item] = (uint32_t)idx; // the list in index order, for the kernels that go from item to Gaussian
 		if (pr.alive)
 		{
-			a.geom.rec[3 * (size_t)item] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b); // first third of the record
+			rec0 = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b); // first third of the record
 			r1.x = pr.conic_c; r2.y = pr.depth;
 		}
 	}
@@ -1299,17 +1301,44 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
 		TM_END(tm_p);
-		if (pr.alive && !deferred) finish(idx, item, count, hl, lowest, highest, be_blend, r1.x, r2.y, w.p, cp, pre_ok);
-		// walk record for k_emit (and for the giant phase below), in list order: coalesced 64-byte rows
-		if (item < V)
+		OutRows o;
+		o.rec1 = o.rec2 = make_float4(0, 0, 0, 0);
+#pragma unroll
+		for (int l = 0; l < FR_FOV_LEVELS; l++) o.lvl[l] = make_float4(0, 0, 0, 0);
+		if (pr.alive && !deferred) finish(idx, item, count, hl, lowest, highest, be_blend, r1.x, r2.y, w.p, cp, pre_ok, o);
+		// ---- the slab's rows leave through LDS: the walk records for k_emit (and for the giant phase below), the records,
+		// (RF) the level rows. Stored by the lane that made them, a row's 16-byte pieces lie 48 or 64 bytes apart between
+		// lanes: every store instruction then touches 24-32 cache lines, which costs the CU's memory pipeline ~3 cycles per
+		// lane -- eleven such instructions per slab were a quarter of the kernel. Transposed through the wave's LDS rows,
+		// a store instruction writes one contiguous kilobyte. (Rows of candidates without instances are zeros nobody reads;
+		// a giant splat's are written again by the giant phase, behind the workgroup barrier.)
 		{
+			float4 *st = orec;
 			const uint32_t flags = ((pr.alive && (deferred || count != 0)) ? 1u : 0u) | (boxtest ? 2u : 0u);
-			float4 *wr = a.geom.wrec + 4 * (size_t)item;
-			wr[0] = make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y);
-			wr[1] = make_float4(ev.z, ev.w, el.x, el.y);
-			wr[2] = make_float4(__uint_as_float((uint32_t)idx | (flags << 30)), pr.depth, __uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)),
-				__uint_as_float((uint32_t)(pr.x1 - pr.x0)));
-			wr[3] = make_float4(__uint_as_float(pr.tnum), hl, 0.0f, 0.0f);
+			auto stage = [&](const float4 *rows, const int n, float4 *dst_base) __attribute__((always_inline))
+			{
+				// rows[0..n) of this lane -> LDS at [n * lane + i]; piece c of the slab's n * 64 then goes to dst_base[n * 64 * slab + c]
+				for (int i = 0; i < n; i++) st[n * lane + i] = rows[i];
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const size_t g0 = (size_t)n * 64 * (size_t)slab, gend = (size_t)n * (size_t)V;
+				for (int i = 0; i < n; i++)
+				{
+					const size_t g = g0 + (size_t)(i * 64 + lane);
+					if (g < gend) dst_base[g] = st[i * 64 + lane];
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			};
+			const float4 wr[4] = { make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y), make_float4(ev.z, ev.w, el.x, el.y),
+				make_float4(__uint_as_float((uint32_t)idx | (flags << 30)), pr.depth, __uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)),
+					__uint_as_float((uint32_t)(pr.x1 - pr.x0))),
+				make_float4(__uint_as_float(pr.tnum), hl, 0.0f, 0.0f) };
+			stage(wr, 4, a.geom.wrec);
+			const float4 rr[3] = { rec0, o.rec1, o.rec2 };
+			stage(rr, 3, a.geom.rec);
+			if (LEVELCOL) stage(o.lvl, 4, a.geom.lvl);
 		}
 	}
 	TM_END(tm_c);
@@ -1344,7 +1373,20 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		bool be_blend = false;
 		if (FOV && gcount != 0) range_from_mask(s_gmask[threadIdx.x], lowest, highest, be_blend);
 		ColourPre none = {};
-		finish(gi, s_gitem[threadIdx.x], gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y, nullptr, none, false);
+		OutRows o;
+		o.rec1 = o.rec2 = make_float4(0, 0, 0, 0);
+#pragma unroll
+		for (int l = 0; l < FR_FOV_LEVELS; l++) o.lvl[l] = make_float4(0, 0, 0, 0);
+		const int gitem = s_gitem[threadIdx.x];
+		finish(gi, gitem, gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y, nullptr, none, false, o);
+		if (gcount != 0)
+		{
+			// (the first third of the record went out with the slab)
+			a.geom.rec[3 * (size_t)gitem + 1] = o.rec1; a.geom.rec[3 * (size_t)gitem + 2] = o.rec2;
+			if (LEVELCOL)
+#pragma unroll
+				for (int l = 0; l < FR_FOV_LEVELS; l++) a.geom.lvl[(size_t)gitem * FR_FOV_LEVELS + l] = o.lvl[l];
+		}
 	}
 #ifdef FR_BIN_TIMERS
 	if (lane == 0)
