@@ -378,9 +378,9 @@ __device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, co
 
 // The reference's per-Gaussian projection (forward.cu:155-262): near plane, 3D covariance, EWA 2D covariance,
 // conic, radius, tile rectangle. sc / q: raw scales and rotation (unused with cov3D_precomp).
-// stash: where to leave (xyz | raw scale | rotation | 3D covariance) for the backward pass, or null.
+// stash[4]: receives (xyz | raw scale | rotation | 3D covariance) for the backward pass if want_stash (the caller's registers).
 __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, const float *vm, const float *pm, int idx, const float p[3], const float sc[3], float4 q,
-	float4 *stash)
+	float4 *stash, const bool want_stash)
 {
 	Proj r; r.alive = false; r.tnum = 0; r.radius = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0;
 	r.pix_x = r.pix_y = r.depth = r.conic_a = r.conic_b = r.conic_c = r.cov0 = r.cov1 = r.lambda1 = r.lambda2 = 0.f;
@@ -433,7 +433,7 @@ __device__ __forceinline__ Proj project_gaussian(const PreArgs &a, const float *
 		const M3 Sg = m3_mul(m3_t(Mm), Mm);
 		cov3D[0] = Sg.c[0][0]; cov3D[1] = Sg.c[0][1]; cov3D[2] = Sg.c[0][2];
 		cov3D[3] = Sg.c[1][1]; cov3D[4] = Sg.c[1][2]; cov3D[5] = Sg.c[2][2];
-		if (stash != nullptr)
+		if (want_stash)
 		{
 			stash[0] = make_float4(p[0], p[1], p[2], sc[0]);
 			stash[1] = make_float4(sc[1], sc[2], q.x, q.y);
@@ -1000,7 +1000,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// counters of the round-2 kernel have its waves parked on s_waitcnt 57 % of the time at 1.76 waves per SIMD. (Round 2
 	// found pulling ahead slower -- a wave stuck in a heavy slab sits on one another could take -- when nothing was
 	// fetched ahead with it.)
-	struct SlabIn { int idx; RawGaussian w; };
+	struct SlabIn { int idx; RawGaussian w; float4 raw[3]; };
 	// inputs of slab `sl` (raw: the activations of fr_forward_args.raw_activations are applied where they are used)
 	auto load_inputs = [&](const int sl, SlabIn &in) __attribute__((always_inline))
 	{
@@ -1010,20 +1010,23 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		int lo = 0, hi = a.proj_waves; // s_wbase[lo] <= first < s_wbase[hi] (first < V = s_wbase[proj_waves])
 		const uint32_t first = (uint32_t)sl * 64u;
 		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wbase[mid] <= first) lo = mid; else hi = mid; }
+		if (CROW)
+		{
+			// the slab's 64 candidate rows (48 bytes each) as 192 pieces of 16 bytes, consecutive lanes taking consecutive
+			// pieces: three loads of (nearly) contiguous kilobytes instead of three whose lanes lie 48 bytes apart; the rows
+			// are put together again through LDS when the slab is processed (unpack_rows)
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+			{
+				const int c = i * 64 + lane, it_c = sl * 64 + c / 3;
+				in.raw[i] = make_float4(0, 0, 0, 0);
+				if (it_c < V) in.raw[i] = a.geom.crow[3 * (size_t)slot_of(it_c, lo) + (c % 3)];
+			}
+			return;
+		}
 		if (it < V)
 		{
 			const uint32_t slot = slot_of(it, lo);
-			if (CROW)
-			{
-				const float4 *cr = a.geom.crow + 3 * (size_t)slot;
-				const float4 g0 = cr[0], g1 = cr[1], g2 = cr[2];
-				in.w.p[0] = g0.x; in.w.p[1] = g0.y; in.w.p[2] = g0.z;
-				in.w.sc[0] = g0.w; in.w.sc[1] = g1.x; in.w.sc[2] = g1.y;
-				in.w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
-				in.w.hl = g2.z;
-				in.idx = (int)__float_as_uint(g2.w);
-				return;
-			}
 			const int idx = (int)a.geom.vis_seg[slot];
 			in.idx = idx;
 			if (PACKED)
@@ -1092,9 +1095,28 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	tm_n++;
 #endif
 	const int item = slab * 64 + lane;
+	if (CROW)
+	{
+		// the candidate rows fetched as pieces: through the wave's LDS rows, every lane picks up its own 48 bytes
+		float4 *st = s_orec + 4 * (threadIdx.x & ~63);
+#pragma unroll
+		for (int i = 0; i < 3; i++) st[i * 64 + lane] = in_cur.raw[i];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const float4 g0 = st[3 * lane], g1 = st[3 * lane + 1], g2 = st[3 * lane + 2];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		in_cur.w.p[0] = g0.x; in_cur.w.p[1] = g0.y; in_cur.w.p[2] = g0.z;
+		in_cur.w.sc[0] = g0.w; in_cur.w.sc[1] = g1.x; in_cur.w.sc[2] = g1.y;
+		in_cur.w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
+		in_cur.w.hl = g2.z;
+		in_cur.idx = (int)__float_as_uint(g2.w);
+	}
 	int idx = in_cur.idx;
 	Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0; pr.pix_x = pr.pix_y = 0.f;
 	float4 r1 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0), rec0 = make_float4(0, 0, 0, 0);
+	float4 stash_rows[4] = { rec0, rec0, rec0, rec0 }; // training variants: the item's row for the backward pass
 	uint32_t count = 0;
 	float4 ev = make_float4(0, 0, 0, 0);
 	float2 el = make_float2(0, 0);
@@ -1121,15 +1143,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 #ifndef FR_BIN_NO_COLOUR
 		if (pre_ok) prefetch_colour(idx, cp);
 #endif
-		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q, a.write_cov3D ? (float4 *)a.geom.cov3D + 4 * (size_t)item : nullptr);
-		if (a.write_cov3D)
-		{
-			// the backward pass adds into this entry's row of gradient sums: cleared here, in list order (coalesced);
-			// the last quarter is not summed into: it carries 1 / |raw quaternion| to the backward pass (raw parameters)
-			float4 *ac = a.geom.acc + 4 * (size_t)item;
-			ac[0] = ac[1] = ac[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-			ac[3] = make_float4(inv_qnorm, 0.f, 0.f, 0.f);
-		}
+		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q, stash_rows, a.write_cov3D != 0);
 		if (pr.alive)
 		{
 			if (CULL && pr.tnum > 1)
@@ -1339,6 +1353,14 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			const float4 rr[3] = { rec0, o.rec1, o.rec2 };
 			stage(rr, 3, a.geom.rec);
 			if (LEVELCOL) stage(o.lvl, 4, a.geom.lvl);
+			if (a.write_cov3D)
+			{
+				// training variants: the item's inputs and 3D covariance for the backward pass, and its row of gradient sums,
+				// cleared here; the last quarter of that row is not summed into: it carries 1 / |raw quaternion| (raw parameters)
+				stage(stash_rows, 4, (float4 *)a.geom.cov3D);
+				const float4 ac[4] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(inv_qnorm, 0.f, 0.f, 0.f) };
+				stage(ac, 4, a.geom.acc);
+			}
 		}
 	}
 	TM_END(tm_c);

@@ -82,7 +82,9 @@ def check_grad(got, want, name, rtol=1e-4, outlier_frac=GRAD_OUTLIERS, row_scale
     st = grad_stats(got, want, rtol=rtol, row_scale=row_scale)
     parity_report.record("grad", f"{_where()} {name}", rtol=rtol, frac_allowed=outlier_frac, gross_allowed=gross_frac, **st)
     assert np.isfinite(got).all(), name
-    assert st["frac_bad"] <= outlier_frac, f"{name}: {st['frac_bad']:.2e} of the rows outside {rtol:g} relative (max |diff| {st['max_abs']:.3e})"
+    # (a tensor with a few hundred rows may hold three such rows whatever the fraction says)
+    assert st["frac_bad"] <= max(outlier_frac, 3.5 / max(st["rows_with_gradient"], 1)), \
+        f"{name}: {st['frac_bad']:.2e} of the rows outside {rtol:g} relative (max |diff| {st['max_abs']:.3e})"
     assert st["frac_gross"] <= max(gross_frac, 1.5 / max(st["rows_with_gradient"], 1)), f"{name}: {st['frac_gross']:.2e} of the rows outside {100 * rtol:g} relative"
     assert st["one_minus_cosine"] <= cosine, f"{name}: 1 - cosine = {st['one_minus_cosine']:.3e}"
     assert st["rel_l2"] <= rel_l2, f"{name}: relative L2 error {st['rel_l2']:.3e}"
