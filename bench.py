@@ -45,7 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GAZES = [(0.25 * i, 0.25 * j) for i in range(1, 4) for j in range(1, 4)]  # render_compose_gazes_fps.py:26
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def parse_args(argv=None):
@@ -451,6 +451,38 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
             frame(syn.lissajous_gaze(10 + i, 90), None)
         torch.cuda.synchronize()
         extra["moving_gaze_fps"] = round(90 / (time.perf_counter() - t1), 2)
+        # --- a workload of the SHAPE of the reference's one published number (fov3dgs/fps/ours-Q-9gazes/bicycle.txt:242: 702 FPS on
+        # an unstated NVIDIA GPU): 1237 x 822, 1 161 358 Gaussians with the level counts of pnum/ours-Q/bicycle.txt:1-4 (the same
+        # level fractions as the S-6M cloud), nine gazes, the reference's protocol. Synthetic cloud, other hardware: context only.
+        from fov3dgs_amd.gaussian_renderer_fov import render as render_fov_small
+        small_cpu = syn.scene_bicycle_scale(P=1_161_358, seed=1)
+        fov_small = [t.to(dev) for t in syn.foveation_layers(small_cpu, seed=2)]
+        small = small_cpu.to(dev)
+
+        class _Frozen:
+            pass
+        ps = _Frozen()
+        ps.get_xyz, ps.get_scaling = small.get_xyz.detach(), small.get_scaling.detach().contiguous()
+        ps.get_rotation, ps.get_opacity = small.get_rotation.detach().contiguous(), small.get_opacity.detach().contiguous()
+        ps.get_rest_features, ps.active_sh_degree = small.get_rest_features.detach().contiguous(), small.active_sh_degree
+        cam_s = syn.camera_ring(0, 8, 1237, 822).to(dev)
+        fps_all = []
+        for gaze in GAZES:
+            kw = dict(alpha=0.05, gazeArray=gaze, blending=True, highest_levels=fov_small[0], shs_dcs=fov_small[1], opacities=fov_small[2])
+            for _ in range(10):
+                render_fov_small(cam_s, ps, bg, starter=starter, ender=ender, **kw)
+                torch.cuda.synchronize()
+            ms = 0.0
+            for _ in range(5):
+                render_fov_small(cam_s, ps, bg, starter=starter, ender=ender, **kw)
+                torch.cuda.synchronize()
+                ms += starter.elapsed_time(ender)
+            fps_all.append(5 / (ms / 1000))
+        extra["reference_shaped_fps"] = round(float(np.mean(fps_all)), 1)
+        extra["reference_shaped_note"] = ("1237x822, 1 161 358 Gaussians (level fractions of pnum/ours-Q/bicycle.txt), nine gazes, 10 warm-ups + 5 renders "
+                                          "each, events around the rasterizer: the shape of the reference's published 702 FPS (fps/ours-Q-9gazes/"
+                                          "bicycle.txt:242, unstated NVIDIA GPU, the real bicycle model) -- synthetic cloud, other hardware: context only")
+        del small, small_cpu, fov_small, ps
         # --- non-foveated forward (config 2)
         for _ in range(3):
             render_plain(cam, pc, Pipe(), bg, cuda_type="pcheck_obb")

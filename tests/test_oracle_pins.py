@@ -74,6 +74,51 @@ def test_tile_levels_match_odak_pooling_map():
         np.testing.assert_allclose(lv, lv64, atol=2e-4)
 
 
+def test_tile_levels_match_odak_at_the_bench_gazes():
+    """The nine gazes of the FPS protocol (render_compose_gazes_fps.py:26) and two off-screen ones at 1920x1080: the
+    oracle's level of EVERY tile against odak's pooling-size map (tests/golden/make_golden_r3.py)."""
+    g = _g("ref_pooling_gazes.npz")
+    W, H = [int(x) for x in g["size"]]
+    inside = g["inside"].reshape(-1)
+    for gi, gaze in enumerate(g["gazes"]):
+        cam = dict(image_width=W, image_height=H, tanfovx=1.0, tanfovy=1.0, bg=np.zeros(3), viewmatrix=np.eye(4), projmatrix=np.eye(4),
+                   campos=np.zeros(3), sh_degree=3, gaze=(float(gaze[0]), float(gaze[1])), alpha=float(g["alpha"]))
+        lv = orc.tile_levels(cam)["tile_levels"]
+        want = _ps2level(g[f"ps{gi}"].astype(np.float64).reshape(-1))
+        # (odak samples linspace(-0.5, 0.5, W), the rasterizer (x + 8) / W: a few 1e-3 of a level apart)
+        np.testing.assert_allclose(lv[inside], want[inside], atol=4e-3, err_msg=f"gaze {gaze}")
+        assert len(np.unique(np.floor(lv[inside]))) >= (4 if 0 <= gaze[0] <= 1 and 0 <= gaze[1] <= 1 else 1)
+
+
+def test_sh_colour_on_the_axes_and_at_the_bench_camera():
+    """eval_sh for view directions on / a hair off the coordinate axes (where degree-2 and degree-3 terms cancel or vanish)
+    and for the bench camera's real view directions."""
+    g = _g("ref_sh_axes.npz")
+    cam = dict(image_width=16, image_height=16, tanfovx=1.0, tanfovy=1.0, bg=np.zeros(3), viewmatrix=np.eye(4),
+               projmatrix=np.eye(4), campos=g["campos"], sh_degree=3)
+    n_axes = int(g["n_axes"])
+    for deg in range(4):
+        cam["sh_degree"] = deg
+        scene = dict(means3D=g["pos"], opacities=np.ones((len(g["pos"]), 1)), shs=g["sh"])
+        got = orc.sh_colors(scene, cam)
+        np.testing.assert_allclose(got[:n_axes], g[f"rgb_deg{deg}"][:n_axes], rtol=0, atol=3e-5, err_msg=f"degree {deg}: axis directions")
+        np.testing.assert_allclose(got[n_axes:], g[f"rgb_deg{deg}"][n_axes:], rtol=0, atol=3e-5, err_msg=f"degree {deg}: bench directions")
+        got_r = orc.sh_colors(dict(scene, shs=g["sh"][:, 1:, :]), cam, rest=True)
+        np.testing.assert_allclose(got_r + 0.28209479177387814 * g["sh"][:, 0, :], g[f"rgb_deg{deg}"], atol=3e-5)
+
+
+def test_ring_cameras_match_reference_graphics_utils():
+    """The eight cameras of the bench's ring (config 5: one per GPU) against getWorld2View2 / getProjectionMatrix."""
+    g = _g("ref_camera_ring.npz")
+    for i in range(8):
+        cam = syn.camera_ring(i, 8)
+        np.testing.assert_allclose([cam.FoVx, cam.FoVy], g[f"fov{i}"], rtol=1e-12)
+        np.testing.assert_allclose(cam.world_view_transform.numpy(), g[f"wvt{i}"], atol=1e-6)
+        np.testing.assert_allclose(cam.projection_matrix.numpy(), g[f"proj{i}"], atol=1e-6)
+        np.testing.assert_allclose(cam.full_proj_transform.numpy(), g[f"full{i}"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(cam.camera_center.numpy(), g[f"center{i}"], atol=1e-5)
+
+
 # ---------- (b) identities ----------
 def test_cov3d_is_R_S2_Rt():
     from scipy.spatial.transform import Rotation
