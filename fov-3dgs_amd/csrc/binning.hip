@@ -12,109 +12,16 @@
 // one 8-byte read and one 4-byte write per instance. The sort key is (depth bits << 32 | id),
 // which reproduces the order a stable sort of the reference's keys emitted in index order gives.
 #include "common.h"
+#include "tile_scan.h"
 #include <cstdlib>
 
 namespace fr {
 
-// Single workgroup: exclusive scan of tile_count[T] -> ranges, reset the counters to serve as
-// emission cursors, publish {total, max}.
-// Also lays out the blend kernel's work items (render_items): one per wave that has something to do -- two bands per
-// tile, and for the RF two-level tiles (blend flag in tile_blend, null otherwise) one such pair per level state --
-// in the same longest-list-first order, so that the persistent blend waves pull the costliest items first and no
-// workgroup is launched just to find out that its tile has a single level.
-__global__ void __launch_bounds__(1024) k_tile_scan(int T, uint32_t *tile_count, uint2 *ranges, uint32_t *totals, uint32_t *tile_order,
-	uint32_t *totals_host, uint32_t seq, const float *tile_blend, uint32_t *render_items, const uint32_t *prefilter_flag)
+constexpr int FR_TILE_SCAN_THREADS = 512;
+__global__ void __launch_bounds__(FR_TILE_SCAN_THREADS) k_tile_scan(const TileScanArgs ts)
 {
-	__shared__ uint32_t bucket[34];
-	__shared__ uint32_t ibucket[34];
-	__shared__ uint32_t wave_sum[16];
-	__shared__ uint32_t carry_s;
-	__shared__ uint32_t wave_max[16];
-	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-	if (tid == 0) carry_s = 0;
-	if (tid < 34) { bucket[tid] = 0; ibucket[tid] = 0; }
-	uint32_t vmax = 0;
-	__syncthreads();
-	// one pass: every thread owns a contiguous run of `per` tiles (8 at 1080p), sums it, the 1024 sums are scanned
-	// once (wave scan + 16 wave totals), then the thread walks its run again to write the ranges
-	const int per = (T + 1023) / 1024;
-	const int t0 = tid * per, t1 = min(T, t0 + per);
-	uint32_t mine = 0;
-	for (int i = t0; i < t1; i++)
-	{
-		const uint32_t v = tile_count[i];
-		mine += v;
-		vmax = max(vmax, v);
-		atomicAdd(&bucket[v ? 32 - __clz((int)v) : 0], 1u); // bucket b: 2^(b-1) <= v < 2^b
-		atomicAdd(&ibucket[v ? 32 - __clz((int)v) : 0], (tile_blend && tile_blend[i] != 0.0f) ? 4u : 2u);
-	}
-	uint32_t s = mine; // inclusive scan inside the wave
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1)
-	{
-		const uint32_t n = __shfl_up(s, off);
-		if (lane >= off) s += n;
-	}
-	if (lane == 63) wave_sum[wid] = s;
-	__syncthreads();
-	uint32_t wave_off = 0, block_total = 0;
-#pragma unroll
-	for (int w = 0; w < 16; w++) { if (w < wid) wave_off += wave_sum[w]; block_total += wave_sum[w]; }
-	uint32_t run = wave_off + s - mine;
-	for (int i = t0; i < t1; i++)
-	{
-		const uint32_t v = tile_count[i];
-		ranges[i] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u); // empty tiles stay (0,0) like the reference's memset
-		run += v;
-	}
-	if (tid == 0) carry_s = block_total;
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor(vmax, off));
-	if (lane == 0) wave_max[wid] = vmax;
-	__syncthreads();
-	if (tid == 0)
-	{
-		uint32_t m = 0;
-		for (int w = 0; w < 16; w++) m = max(m, wave_max[w]);
-		// bucket b holds lists with 2^(b-1) <= n < 2^b: n >= 2048 <=> b >= 12, 512 <= n < 2048 <=> b in {10, 11}
-		uint32_t h4 = 0;
-		for (int b = 12; b <= 32; b++) h4 += bucket[b];
-		const uint32_t h8 = h4 - bucket[12]; // lists with >= 4096 entries
-		totals[0] = carry_s; totals[1] = m; totals[2] = h4; totals[3] = bucket[10] + bucket[11]; totals[6] = h8;
-		totals[4] = 0; // chunk counter of k_split_long
-		const uint32_t pf = *prefilter_flag; // k_project: a Gaussian behind the near plane although `prefiltered` was set
-		totals[7] = pf;
-		uint32_t nitems = 0;
-		for (int b = 32; b >= 0; b--) { const uint32_t c = ibucket[b]; ibucket[b] = nitems; nitems += c; }
-		totals[5] = nitems;
-		// the host sizes the binning buffer from these: written straight into its pinned memory (no copy command)
-		// and followed by this frame's sequence number, which the host polls for (it then prepares the next launches
-		// while this kernel finishes)
-		if (totals_host)
-		{
-			totals_host[0] = carry_s; totals_host[1] = m; totals_host[2] = h4; totals_host[3] = bucket[10] + bucket[11];
-			totals_host[5] = nitems; totals_host[6] = h8; totals_host[7] = pf;
-			__threadfence_system();
-			__hip_atomic_store(&totals_host[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-		// bucket start offsets, longest lists first
-		uint32_t run = 0;
-		for (int b = 32; b >= 0; b--) { const uint32_t c = bucket[b]; bucket[b] = run; run += c; }
-	}
-	__syncthreads();
-	// longest-processing-time-first order for the per-tile kernels (sort, blend): a frame's critical
-	// path is its longest tile list, so those workgroups must start first. tile_count doubles as the
-	// emission cursor in the global-atomics fallback and is reset here.
-	for (int i = tid; i < T; i += 1024)
-	{
-		const uint32_t v = tile_count[i];
-		tile_order[atomicAdd(&bucket[v ? 32 - __clz((int)v) : 0], 1u)] = (uint32_t)i;
-		tile_count[i] = 0;
-		const uint32_t two = (tile_blend && tile_blend[i] != 0.0f) ? 1u : 0u;
-		uint32_t *it = render_items + atomicAdd(&ibucket[v ? 32 - __clz((int)v) : 0], two ? 4u : 2u);
-		it[0] = (uint32_t)i << 3 | two << 2; it[1] = (uint32_t)i << 3 | two << 2 | 1u;
-		if (two) { it[2] = (uint32_t)i << 3 | 4u | 2u; it[3] = (uint32_t)i << 3 | 4u | 2u | 1u; }
-	}
+	if (ts.T <= FR_SCAN_MAX_TILES) tile_scan_body<FR_TILE_SCAN_THREADS>(ts);
+	else tile_scan_atomics<FR_TILE_SCAN_THREADS>(ts);
 }
 
 // All-ascending bitonic network (first step of each merge mirrors the partner index), so that
@@ -484,11 +391,19 @@ __global__ void __launch_bounds__(1024) k_split_long(const uint2 *ranges, const 
 	}
 }
 
+TileScanArgs make_tile_scan_args(FwdCtx &c)
+{
+	TileScanArgs ts;
+	ts.T = c.T; ts.tile_count = c.img.tile_count; ts.ranges = c.img.ranges; ts.totals = c.img.totals; ts.tile_order = c.img.tile_order;
+	ts.totals_host = c.totals_host_dev; ts.seq = c.totals_seq;
+	ts.tile_blend = c.fov_split ? c.img.tile_lv + 4 * (size_t)c.T : (const float *)nullptr;
+	ts.render_items = c.img.render_items; ts.prefilter_flag = c.geom.slab_ctr;
+	return ts;
+}
+
 int launch_tile_scan(FwdCtx &c)
 {
-	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c.stream, c.T, c.img.tile_count, c.img.ranges, c.img.totals, c.img.tile_order,
-		c.totals_host_dev, c.totals_seq, c.fov_split ? c.img.tile_lv + 4 * (size_t)c.T : (const float *)nullptr, c.img.render_items,
-		c.geom.slab_ctr);
+	hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(FR_TILE_SCAN_THREADS), 0, c.stream, make_tile_scan_args(c));
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 

@@ -247,6 +247,23 @@ def test_huge_tile_grid_uses_global_counter_path(variant):
         np.testing.assert_array_equal(pk[k], got[k], err_msg="packed " + k)
 
 
+def test_8k_tile_grid_beyond_the_packed_tile_scan():
+    """7680x4320 -> 129 600 tiles: above the 65 535 tiles the tile scan's packed 16-bit positions hold (it takes its
+    LDS-atomics form there; tile_scan.h), and above every LDS table of the binning kernels."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    cloud = syn.scene_1k(P=1500, seed=12)
+    cloud._scaling += 0.5
+    cam = syn.camera_1k(7680, 4320, 70.0)
+    scene, cd = scene_dict(cloud, "pcheck_obb", None), cam_dict(cam, gaze=(0.6, 0.4))
+    want = orc.forward("pcheck_obb", scene, cd)
+    got = hip_forward("pcheck_obb", scene, cd)
+    assert got["num_rendered"] == want["num_rendered"]
+    np.testing.assert_array_equal(got["ranges"], want["ranges"])
+    np.testing.assert_array_equal(got["point_list"], want["point_list"])
+    check_image(got["color"], want["color"])
+
+
 def test_autograd_module_end_to_end():
     """render() entry point + autograd: grads reach the raw parameters and match the oracle chain."""
     _need_gpu()
