@@ -58,3 +58,15 @@ for fr in frames:
     print("  corr(list length, dur) %.2f corr(blended, dur) %.2f" % (np.corrcoef(n[live], dur[live])[0, 1], np.corrcoef(proc[live], dur[live])[0, 1]))
     print("  blended per wave: p50 %d p90 %d p99 %d max %d; two-level waves: %d, their share of wave time %.2f" % (
         *np.percentile(proc[live], [50, 90, 99, 100]).astype(int), int((two[live] == 1).sum()), dur[two == 1].sum() / dur.sum()))
+    # how far into its tile's list did a wave get (staged batches x 64)? -> what a lazy sort would have to have ready
+    tile_id = info & 0xffff
+    reach = np.minimum(batches.astype(np.int64) * 64, n)
+    per_tile_reach = np.zeros(T, np.int64); np.maximum.at(per_tile_reach, tile_id[live], reach[live])
+    per_tile_n = np.zeros(T, np.int64); np.maximum.at(per_tile_n, tile_id[live], n[live])
+    for lo, hi in ((1, 513), (513, 2048), (2048, 4096), (4096, 1 << 30)):
+        m = (per_tile_n >= lo) & (per_tile_n < hi)
+        if m.any():
+            r = per_tile_reach[m]
+            print("  lists [%d,%d): %5d tiles, %8d entries, reached %8d (%.3f); reach p50 %d p90 %d p99 %d max %d; tiles reaching > 960: %d, > 1920: %d" % (
+                lo, hi, int(m.sum()), int(per_tile_n[m].sum()), int(r.sum()), r.sum() / per_tile_n[m].sum(), *np.percentile(r, [50, 90, 99, 100]).astype(int),
+                int((r > 960).sum()), int((r > 1920).sum())))
