@@ -22,11 +22,7 @@
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop
 #define FR_GIANT_MAX 64         // giant splats a workgroup can set aside (more: handled like big ones)
-#define FR_SORT_SPLIT_LOG2 11       // (4096 / 8192 / 1024 measured slower)
-#define FR_SORT_SPLIT_MIN (1 << FR_SORT_SPLIT_LOG2) // tile lists with at least this many entries are split by depth before sorting
-#ifndef FR_SORT_DIRECT_TILES
-#define FR_SORT_DIRECT_TILES 1024   // this many lists of 2048..4095 entries: sort that class directly (see launch_tile_sort)
-#endif
+#define FR_SORT_SPLIT_MIN 16384      // tile lists with at least this many entries do not fit one workgroup's LDS: split by depth before sorting
 #define FR_SORT_CHUNK_TARGET 960    // ... into chunks of about this many entries (just under the 1024-key sort size)
 #define FR_SORT_FINE_BUCKETS 2048   // depth buckets of the split
 // chunks are cut at multiples of the target in the running count, so a list of n entries yields at most
@@ -125,7 +121,7 @@ struct ImageWS {
 	uint2 *ranges;        // [T]
 	uint32_t *tile_count; // [T]  instance counter, then emission cursor
 	uint32_t *lv_bbox;    // [5][FR_LV_BBOX_STRIDE] RF: box of the tiles with tile_min < k as {gx - x0, gy - y0, x1, y1} (0 = empty), k = 0..4
-	uint32_t *totals;     // [8]  {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, #blend items, #tiles with >= 4096, prefiltered violation}
+	uint32_t *totals;     // [16] {num_instances, max per tile, #tiles with >= 2048, #tiles with 512..2047, #sort chunks, #blend items, #tiles with >= 4096, prefiltered violation, #tiles with >= 8192, #tiles with >= 16384}
 	uint32_t *render_items; // [4T] blend work items, longest lists first: tile << 3 | band | level state << 1 | two-level << 2 (k_tile_scan)
 	uint32_t *tile_order; // [T]  tile ids by descending list length (power-of-two buckets): longest first
 	float *tile_lv;       // RF [5][T]: level, tile_min, grad_x, grad_y, blending
@@ -147,7 +143,7 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.ranges = (uint2 *)(base + off); off = align_up(off + T * sizeof(uint2));
 	s.tile_count = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.lv_bbox = (uint32_t *)(base + off); off = align_up(off + 5 * FR_LV_BBOX_STRIDE * sizeof(uint32_t));
-	s.totals = (uint32_t *)(base + off); off = align_up(off + 8 * sizeof(uint32_t));
+	s.totals = (uint32_t *)(base + off); off = align_up(off + 16 * sizeof(uint32_t));
 	s.render_items = (uint32_t *)(base + off); off = align_up(off + 4 * T * sizeof(uint32_t));
 	s.tile_order = (uint32_t *)(base + off); off = align_up(off + T * sizeof(uint32_t));
 	s.tile_lv = nullptr;

@@ -36,11 +36,12 @@ __device__ __forceinline__ int scan_bin(const uint32_t v) { return v ? min(32 - 
 
 // What tid 0 publishes once the counts are in: device totals + the host's pinned copy + the sequence number.
 __device__ __forceinline__ void publish_totals(const TileScanArgs &ts, const uint32_t total, const uint32_t longest, const uint32_t h4,
-                                               const uint32_t h8, const uint32_t mid, const uint32_t nitems)
+                                               const uint32_t h8, const uint32_t mid, const uint32_t nitems, const uint32_t h16, const uint32_t h32)
 {
 	uint32_t *const totals = ts.totals; uint32_t *const totals_host = ts.totals_host;
 	totals[0] = total; totals[1] = longest; totals[2] = h4; totals[3] = mid; totals[6] = h8;
 	totals[4] = 0; // chunk counter of k_split_long
+	totals[8] = h16; totals[9] = h32; // lists with >= 8192 / >= 16384 entries (the sort kernels find their classes from these)
 	const uint32_t pf = *ts.prefilter_flag; // k_project: a Gaussian behind the near plane although `prefiltered` was set
 	totals[7] = pf;
 	totals[5] = nitems;
@@ -190,7 +191,9 @@ __device__ __forceinline__ void tile_scan_body(const TileScanArgs &ts)
 		const uint32_t before11 = hist[(FR_SCAN_BINS - 1 - 11) * THREADS] & 0xffffu; // lists with >= 2048 entries
 		const uint32_t before12 = hist[(FR_SCAN_BINS - 1 - 12) * THREADS] & 0xffffu; // ... >= 4096
 		const uint32_t before9 = hist[(FR_SCAN_BINS - 1 - 9) * THREADS] & 0xffffu;   // ... >= 512
-		publish_totals(ts, carry, longest, before11, before12, before9 - before11, 2u * ((htotal & 0xffffu) + (htotal >> 16)));
+		const uint32_t before13 = hist[(FR_SCAN_BINS - 1 - 13) * THREADS] & 0xffffu; // ... >= 8192
+		const uint32_t before14 = hist[(FR_SCAN_BINS - 1 - 14) * THREADS] & 0xffffu; // ... >= 16384
+		publish_totals(ts, carry, longest, before11, before12, before9 - before11, 2u * ((htotal & 0xffffu) + (htotal >> 16)), before13, before14);
 	}
 	TMS(tm5);
 	// longest-processing-time-first order for the per-tile kernels (sort, blend): a frame's critical
@@ -312,10 +315,13 @@ __device__ __forceinline__ void tile_scan_atomics(const TileScanArgs &ts)
 		uint32_t h4 = 0;
 		for (int b = 12; b < FR_SCAN_BINS; b++) h4 += bucket[b];
 		const uint32_t h8 = h4 - bucket[12], mid = bucket[10] + bucket[11];
+		uint32_t h16 = 0, h32 = 0;
+		for (int b = 14; b < FR_SCAN_BINS; b++) h16 += bucket[b];
+		for (int b = 15; b < FR_SCAN_BINS; b++) h32 += bucket[b];
 		uint32_t nitems = 0, run2 = 0;
 		for (int b = FR_SCAN_BINS - 1; b >= 0; b--) { const uint32_t c = ibucket[b]; ibucket[b] = nitems; nitems += c; }
 		for (int b = FR_SCAN_BINS - 1; b >= 0; b--) { const uint32_t c = bucket[b]; bucket[b] = run2; run2 += c; }
-		publish_totals(ts, block_total, longest, h4, h8, mid, nitems);
+		publish_totals(ts, block_total, longest, h4, h8, mid, nitems, h16, h32);
 	}
 	__syncthreads();
 	for (int i = t0; i < t1; i++)

@@ -186,15 +186,21 @@ def test_edge_cases():
     check_image(got["color"], want["color"])
 
 
-@pytest.mark.parametrize("P", (700, 3000, 9000, 18000))
-def test_tile_sort_size_classes(P):
-    """Every size class of the per-tile sort: <=512 (one wave), <=2048, <=8192, <=16384 entries in LDS,
-    and the in-place global-memory network beyond that."""
+@pytest.mark.parametrize("depths", ("spread", "walls"))
+@pytest.mark.parametrize("P", (400, 700, 3000, 6000, 9000, 18000, 24000))
+def test_tile_sort_size_classes(P, depths):
+    """Every size class of the per-tile sort -- <= 512 entries (one wave), 513..2047, 2048..4095, 4096..8191, 8192..16383: the
+    whole list in LDS (interpolation sort: bucket by depth, then odd-even rounds inside the buckets) -- and the lists beyond
+    that, regrouped by depth into chunks first. "walls": the depths take 7 values only, thousands of entries share a
+    bucket, the sort falls back to the merge passes (and the regrouping to the global-memory network) and the order is
+    decided by the Gaussian index alone."""
     _need_gpu()
     from tests.gpu_helpers import hip_forward
     cloud = syn.scene_1k(P=P, seed=9)
     cloud._xyz[:, :2] *= 0.02      # pile everything onto a few tiles
     cloud._opacity -= 3.5          # faint, so nothing saturates early
+    if depths == "walls":
+        cloud._xyz[:, 2] = torch.round(cloud._xyz[:, 2] * 3.0) / 3.0  # identity camera: view depth = z
     cam = syn.camera_1k(64, 64)
     scene, cd = scene_dict(cloud, "original"), cam_dict(cam)
     want = orc.forward("original", scene, cd)
