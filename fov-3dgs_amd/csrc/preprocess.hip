@@ -723,6 +723,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	static_assert(!(PACKED && FOV && !LEVELCOL), "the shared-model foveated variant has no packed layout");
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
 	const int lane = threadIdx.x & 63;
+#ifdef FR_BIN_TIMERS
+	const uint64_t tm_entry = wall_clock64();
+#endif
 	// RF: every pair step looks its tile's level (and, if kept, its blend flag) up; from global memory those
 	// were two dependent ~1 us round trips in a loop that a near-camera splat runs a hundred times. When they
 	// fit beside the histogram, the workgroup keeps tile_min (float) and the blend flags (one bit) in LDS.
@@ -731,17 +734,47 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	const bool ldst = FOV && a.lds_tiles;
 	if (ldst)
 	{
+		// The tables are copied SIXTEEN loads at a time: written as `lds[t] = g[t]` loops, every iteration waited for its own load
+		// (16 + 16 + 16 round trips of ~0.6 us: a 10 us prologue on every CU before any work).
 		const float *gmin = a.tile_lv + a.T, *gbl = a.tile_lv + 4 * (size_t)a.T;
-		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_tmin[t] = gmin[t];
-		for (int w = threadIdx.x; w * 32 < a.T; w += FR_BIN_THREADS)
+		for (int t0 = threadIdx.x; t0 < a.T; t0 += 16 * FR_BIN_THREADS)
 		{
-			uint32_t bits = 0;
-			for (int b = 0; b < 32 && w * 32 + b < a.T; b++) bits |= (gbl[w * 32 + b] != 0.0f ? 1u : 0u) << b;
-			lds_blend[w] = bits;
+			float v[16];
+#pragma unroll
+			for (int k = 0; k < 16; k++) v[k] = gmin[min(t0 + k * FR_BIN_THREADS, a.T - 1)];
+#pragma unroll
+			for (int k = 0; k < 16; k++) if (t0 + k * FR_BIN_THREADS < a.T) lds_tmin[t0 + k * FR_BIN_THREADS] = v[k];
+		}
+		// the blend flags as bits: 64 consecutive flags per wave and load, packed by a ballot
+		const int nwords = (a.T + 31) / 32;
+		for (int base0 = (int)(threadIdx.x & ~63u); base0 < a.T; base0 += 16 * FR_BIN_THREADS)
+		{
+			float v[16];
+#pragma unroll
+			for (int k = 0; k < 16; k++) v[k] = gbl[min(base0 + k * FR_BIN_THREADS + lane, a.T - 1)];
+#pragma unroll
+			for (int k = 0; k < 16; k++)
+			{
+				const int base = base0 + k * FR_BIN_THREADS;
+				const unsigned long long m = __ballot(base + lane < a.T && v[k] != 0.0f);
+				if (base < a.T && lane == 0) lds_blend[base >> 5] = (uint32_t)m;
+				if (base < a.T && lane == 1 && (base >> 5) + 1 < nwords) lds_blend[(base >> 5) + 1] = (uint32_t)(m >> 32);
+			}
 		}
 	}
 	if (LDSH)
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
+	// the cull pass's per-wave counts (scanned below), loaded with the tables: ONE round trip of cold global loads at the head
+	// of the kernel instead of one per step
+	uint32_t *s_wbase = lds_hist + (LDSH ? a.T : 0) + (ldst ? a.T + (a.T + 31) / 32 : 0); // [proj_waves + 1] exclusive running counts
+	for (int w0 = threadIdx.x; w0 < a.proj_waves; w0 += 16 * FR_BIN_THREADS)
+	{
+		uint32_t v[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) v[k] = a.geom.proj_counts[min(w0 + k * FR_BIN_THREADS, a.proj_waves - 1)];
+#pragma unroll
+		for (int k = 0; k < 16; k++) if (w0 + k * FR_BIN_THREADS < a.proj_waves) s_wbase[w0 + k * FR_BIN_THREADS] = v[k];
+	}
 	// "giant" splats (FR_GIANT_TNUM+ tiles, up to the whole frame = 128 wave steps) are set aside here and walked
 	// by ALL waves of the workgroup after the slab loop: left to the wave that met them they were the kernel's
 	// critical path
@@ -751,7 +784,13 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	__shared__ uint32_t s_ng;
 	if (threadIdx.x < FR_GIANT_MAX) { s_gcount[threadIdx.x] = 0; s_gmask[threadIdx.x] = 0; }
 	if (threadIdx.x == 0) s_ng = 0;
+#ifdef FR_BIN_TIMERS
+	const uint64_t tm_pa = wall_clock64();
+#endif
 	__syncthreads();
+#ifdef FR_BIN_TIMERS
+	const uint64_t tm_pb = wall_clock64();
+#endif
 #define TILE_MIN(ti) (ldst ? lds_tmin[(ti)] : tile_min[(ti)])
 #define TILE_BLENDS(ti) (ldst ? ((lds_blend[(ti) >> 5] >> ((ti) & 31)) & 1u) != 0u : tile_bl[(ti)] != 0.0f)
 	// Work unit = a "slab" of 64 consecutive vis_list entries, handled by ONE wave; there is no workgroup
@@ -776,24 +815,28 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// ---- the survivors of the cull pass: item i lives in the region of the wave whose running count covers i ----
 	// every workgroup scans the (at most 8192) per-wave counts into LDS; a slab then finds its first wave by binary search
 	// and its lanes step on from there (a region holds ~170 survivors: a slab spans one or two)
-	uint32_t *s_wbase = lds_hist + (LDSH ? a.T : 0) + (ldst ? a.T + (a.T + 31) / 32 : 0); // [proj_waves + 1] exclusive running counts
 	{
 		__shared__ uint32_t s_part[FR_BIN_THREADS / 64];
+		// (the counts come in coalesced and are scanned in place: a thread's run of consecutive counts read straight from global
+		// memory is 16 loads whose lanes lie 64 bytes apart, twice)
 		const int per = (a.proj_waves + FR_BIN_THREADS - 1) / FR_BIN_THREADS; // consecutive waves per thread
 		const int w0 = (int)threadIdx.x * per, w1 = min(a.proj_waves, w0 + per);
 		uint32_t mine = 0;
-		for (int w = w0; w < w1; w++) mine += a.geom.proj_counts[w];
+		for (int w = w0; w < w1; w++) mine += s_wbase[w];
 		uint32_t sc = wave_incl_scan_u32(mine, lane);
 		if (lane == 63) s_part[threadIdx.x >> 6] = sc;
 		__syncthreads();
 		uint32_t off = 0;
 		for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += s_part[w];
 		uint32_t run = off + sc - mine;
-		for (int w = w0; w < w1; w++) { s_wbase[w] = run; run += a.geom.proj_counts[w]; }
+		for (int w = w0; w < w1; w++) { const uint32_t cw = s_wbase[w]; s_wbase[w] = run; run += cw; }
 		if (w1 == a.proj_waves && w0 < w1) s_wbase[a.proj_waves] = run;
 		if (a.proj_waves == 0 && threadIdx.x == 0) s_wbase[0] = 0;
 		__syncthreads();
 	}
+#ifdef FR_BIN_TIMERS
+	const uint64_t tm_pc = wall_clock64();
+#endif
 	const int V = (int)s_wbase[a.proj_waves]; // entries of vis_list
 	if (blockIdx.x == 0 && threadIdx.x == 0) a.geom.slab_ctr[1] = (uint32_t)V; // for the kernels that follow
 	const int nslabs = (V + 63) / 64;
@@ -1439,6 +1482,12 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			for (int k = 0; k < 4; k++) { const int t = t0 + k * FR_BIN_THREADS; if (t < a.T && h[k]) out[t] = o[k]; }
 		}
 	}
+#ifdef FR_BIN_TIMERS
+	__syncthreads();
+	if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)
+		printf("k_bin wg %d (10 ns ticks): prologue %d (issue %d first barrier %d scan %d rest %d) slab loop + giants %d flush %d\n", (int)blockIdx.x, (int)(tm0 - tm_entry),
+			(int)(tm_pa - tm_entry), (int)(tm_pb - tm_pa), (int)(tm_pc - tm_pb), (int)(tm0 - tm_pc), (int)(tm_loop_end - tm0), (int)(wall_clock64() - tm_loop_end));
+#endif
 }
 #undef BUMP_TILE
 #undef TILE_MIN
@@ -1485,13 +1534,27 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	if (ldst)
 	{
 		const float *gmin = a.tile_lv + a.T;
-		for (int t = threadIdx.x; t < a.T; t += FR_EMIT_THREADS) lds_tmin[t] = gmin[t];
+		for (int t0 = threadIdx.x; t0 < a.T; t0 += 16 * FR_EMIT_THREADS) // (sixteen loads at a time, see k_bin)
+		{
+			float v[16];
+#pragma unroll
+			for (int k = 0; k < 16; k++) v[k] = gmin[min(t0 + k * FR_EMIT_THREADS, a.T - 1)];
+#pragma unroll
+			for (int k = 0; k < 16; k++) if (t0 + k * FR_EMIT_THREADS < a.T) lds_tmin[t0 + k * FR_EMIT_THREADS] = v[k];
+		}
 	}
 	if (LDSH)
 	{
 		// (pre[t] is only defined for the tiles this workgroup counted instances in -- the only cursors it will use)
 		const uint32_t *pre = a.hist + (size_t)blockIdx.x * a.T;
-		for (int t = threadIdx.x; t < a.T; t += FR_EMIT_THREADS) lds_cur[t] = a.ranges[t].x + pre[t];
+		for (int t0 = threadIdx.x; t0 < a.T; t0 += 16 * FR_EMIT_THREADS)
+		{
+			uint32_t st[16], pr[16];
+#pragma unroll
+			for (int k = 0; k < 16; k++) { const int t = min(t0 + k * FR_EMIT_THREADS, a.T - 1); st[k] = a.ranges[t].x; pr[k] = pre[t]; }
+#pragma unroll
+			for (int k = 0; k < 16; k++) if (t0 + k * FR_EMIT_THREADS < a.T) lds_cur[t0 + k * FR_EMIT_THREADS] = st[k] + pr[k];
+		}
 	}
 	__syncthreads();
 	__shared__ int s_own[FR_EMIT_THREADS];
