@@ -221,8 +221,9 @@ __device__ __forceinline__ void get_rect_f(float px, float py, float r, int gx, 
 // boxtest: the splat's FULL rectangle has more than one tile, i.e. the reference applies the OBB test.
 struct WalkRect { int x0, y0, x1, y1; uint32_t tnum; bool boxtest; };
 template <bool CULL, bool FOV>
+// lv_box_stride: uint4 rows between two level boxes (the global table has one 128-byte line per box; k_bin keeps a dense LDS copy)
 __device__ __forceinline__ WalkRect walk_rect(float px, float py, int radius, int gx, int gy, float4 ev, float2 el,
-	float hl, const uint32_t *__restrict__ lv_bbox)
+	float hl, const uint4 *__restrict__ lv_boxes, const int lv_box_stride = FR_LV_BBOX_STRIDE / 4)
 {
 	WalkRect w;
 	get_rect(px, py, radius, gx, gy, w.x0, w.y0, w.x1, w.y1);
@@ -247,7 +248,7 @@ __device__ __forceinline__ WalkRect walk_rect(float px, float py, int radius, in
 	if (FOV)
 	{
 		const int k = (int)fminf(fmaxf(ceilf(hl + 1.0f), 0.0f), 4.0f); // NaN -> 0: nothing passes `level < NaN`
-		const uint4 b = *(const uint4 *)(lv_bbox + k * FR_LV_BBOX_STRIDE);
+		const uint4 b = lv_boxes[k * lv_box_stride];
 		w.x0 = max(w.x0, gx - (int)b.x); w.y0 = max(w.y0, gy - (int)b.y);
 		w.x1 = min(w.x1, (int)b.z); w.y1 = min(w.y1, (int)b.w);
 	}

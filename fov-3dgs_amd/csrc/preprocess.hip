@@ -782,6 +782,10 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	__shared__ float2 s_gcd[FR_GIANT_MAX]; // conic c, depth of the deferred splat
 	__shared__ uint32_t s_gcount[FR_GIANT_MAX], s_gmask[FR_GIANT_MAX];
 	__shared__ uint32_t s_ng;
+	// RF: the five level boxes every candidate's walk rectangle is clipped to (walk_rect): from LDS, not one dependent global
+	// load per candidate in the middle of its projection
+	__shared__ uint4 s_lvbox[5];
+	if (FOV && threadIdx.x < 5) s_lvbox[threadIdx.x] = *(const uint4 *)(a.lv_bbox + threadIdx.x * FR_LV_BBOX_STRIDE);
 	if (threadIdx.x < FR_GIANT_MAX) { s_gcount[threadIdx.x] = 0; s_gmask[threadIdx.x] = 0; }
 	if (threadIdx.x == 0) s_ng = 0;
 #ifdef FR_BIN_TIMERS
@@ -1125,6 +1129,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	int slab = finish_pull();
 	SlabIn in_cur;
 	if (slab >= 0) load_inputs(slab, in_cur);
+	issue_pull(); // the second slab's number
 	while (slab >= 0)
 	{
 	if (LDSH)
@@ -1132,7 +1137,6 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		if (lane == 0) a.geom.slab_next[slab] = chain;
 		chain = slab;
 	}
-	issue_pull(); // the next slab: its number is back by the time this one is projected
 	TM_END(tm_s);
 #ifdef FR_BIN_TIMERS
 	tm_n++;
@@ -1200,7 +1204,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 				ev = make_float4(e1x, e1y, e2x, e2y);
 				el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
 			}
-			const WalkRect wr = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, hl, a.lv_bbox);
+			const WalkRect wr = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, hl, s_lvbox, 1);
 			pr.x0 = wr.x0; pr.y0 = wr.y0; pr.x1 = wr.x1; pr.y1 = wr.y1; pr.tnum = wr.tnum; boxtest = wr.boxtest;
 			pr.alive = wr.tnum != 0;
 		}
@@ -1357,6 +1361,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			__builtin_amdgcn_wave_barrier();
 		}
 		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
+		// the slab after the next is asked for HERE, in front of this slab's row stores: a returning atomic queued behind those
+		// eleven kilobyte stores came back ~1.7 us after the projection of the next slab wanted it
+		issue_pull();
 		TM_END(tm_p);
 		OutRows o;
 		o.rec1 = o.rec2 = make_float4(0, 0, 0, 0);
