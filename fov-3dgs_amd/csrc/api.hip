@@ -227,9 +227,9 @@ int fr_forward(fr_forward_args *a)
 	const char *ahead_env = getenv("FR_LAUNCH_AHEAD"); // (read per call: tests switch it)
 	const bool speculate = same_kind && gs.capacity > 0 && pinned && !a->debug && ahead_env != nullptr && ahead_env[0] == '1';
 	const int64_t items_max = (int64_t)(c.fov_split ? 4 : 2) * c.T; // two bands per tile, twice that for an RF two-level tile
-	auto rest_of_frame = [&](int64_t capacity, bool known) -> int
+	auto rest_of_frame = [&](int64_t capacity, bool known, char *have = nullptr) -> int
 	{
-		char *bptr = a->binning_resize(a->resize_user[1], carve_bin(capacity, nullptr, c.T).bytes);
+		char *bptr = have ? have : a->binning_resize(a->resize_user[1], carve_bin(capacity, nullptr, c.T).bytes);
 		if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }
 		c.bin = carve_bin(capacity, bptr, c.T);
 		c.capacity = capacity; c.counts_known = known ? 1 : 0; c.hint_heavy4 = gs.heavy4; c.hint_heavy8 = gs.heavy8;
@@ -246,6 +246,14 @@ int fr_forward(fr_forward_args *a)
 		return r;
 	};
 	if (speculate) { rc = rest_of_frame(gs.capacity, false); if (rc) return rc; }
+
+	// The binning workspace is asked for BEFORE the count is in -- sized like the largest frame of this kind so far plus a
+	// quarter -- while the GPU is still binning: the callback (the caller's allocator, a Python function behind ctypes in the
+	// reference-shaped host code) is then off the critical path between the tile scan and k_emit. A frame that does not fit
+	// asks again with its real size.
+	char *early_bin = nullptr;
+	const int64_t early_cap = (same_kind && !speculate && !a->debug) ? gs.capacity : 0;
+	if (early_cap > 0) early_bin = a->binning_resize(a->resize_user[1], carve_bin(early_cap, nullptr, c.T).bytes);
 
 	uint32_t totals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	if (!pinned) FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
@@ -293,6 +301,7 @@ int fr_forward(fr_forward_args *a)
 	if (fits) return FR_OK; // the frame is already on its way
 	// first frame of its kind, a debug call, or the speculative launch found the workspace too small (its kernels left
 	// without touching anything): the stage with the known counts
+	if (early_bin && (int64_t)totals[0] <= early_cap) return rest_of_frame(early_cap, true, early_bin);
 	return rest_of_frame(speculate ? gs.capacity : (int64_t)totals[0], true);
 }
 
