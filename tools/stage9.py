@@ -22,6 +22,23 @@ dev = torch.device("cuda", 0)
 cloud = syn.scene_bicycle_scale(P=6_000_000, seed=1)
 fov = [t.to(dev) for t in syn.foveation_layers(cloud, seed=2)]
 cloud = cloud.to(dev)
+if os.environ.get("FR_MODEL_ORDER") == "morton":
+    # experiment: the model's Gaussians in Morton order of their positions (consecutive Gaussians are neighbours in space)
+    with torch.no_grad():
+        q = cloud._xyz
+        lo, hi = q.min(0).values, q.max(0).values
+        g = ((q - lo) / (hi - lo + 1e-9) * 1023.0).long().clamp(0, 1023)
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            v = (v | (v << 2)) & 0x09249249
+            return v
+        code = spread(g[:, 0]) | (spread(g[:, 1]) << 1) | (spread(g[:, 2]) << 2)
+        perm = torch.argsort(code)
+        for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+            setattr(cloud, name, getattr(cloud, name)[perm].contiguous())
+        fov = [t[perm].contiguous() for t in fov]
 cam = syn.camera_ring(0, 8).to(dev)
 W, H = cam.image_width, cam.image_height
 with torch.no_grad():
