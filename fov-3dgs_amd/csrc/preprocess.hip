@@ -85,38 +85,35 @@ __device__ float tile_level(int tx, int ty, int W, int H, float gaze_x, float ga
 // One thread per tile: level of the tile and of its 4 neighbours, finite-difference gradients, conservative tile minimum and the
 // two-level-blend flag. out = float[5][T]: level, tile_min, grad_x, grad_y, blending.
 // lv_bbox[k] (zeroed by the caller): bounding box of the tiles with tile_min < k, see walk_rect().
-// A workgroup owns a 16 x 16 patch of tiles: every level is evaluated once (plus the patch's one-tile halo) and
-// shared through LDS -- the level function (acos, tan, three sqrt) is ~500 instructions.
+// A workgroup owns a 14 x 14 patch of tiles: every level is evaluated once (plus the patch's one-tile halo: 16 x 16 threads,
+// one level each) and shared through LDS -- the level function (acos, tan, three sqrt) is ~500 instructions.
 // mmfr_level >= 0: the multi-model baseline's map for that level (mmfr rasterizer_impl.cu:246-262,277-304): tile_min is
 // clamped at 0 and kept in row 0 (the blend kernel's value); row 1, which the level filter of the binning kernels and
 // the level boxes read, becomes 0 for the tiles this level renders (tile_min in (level - 0.5, level + 1)) and 5 for the
 // skipped ones -- with highest_levels == 0 the filter `row 1 < highest_level + 1` is then exactly "not skipped".
+#define FR_LV_PATCH 14 // tiles per side a workgroup of k_tile_levels owns (+ a one-tile halo = its 16 x 16 threads)
 __global__ void __launch_bounds__(256) k_tile_levels(int T, int gx, int gy, int W, int H, float gaze_x, float gaze_y, float alpha, float *out,
 	uint32_t *lv_bbox, uint32_t *slab_ctr, float mmfr_level)
 {
 	// the counters of the two kernels that follow are cleared here (one fill command less at the head of the frame)
 	if (blockIdx.x == 0)
 		for (int i = threadIdx.x; i < FR_SLAB_CTR_WORDS; i += 256) slab_ctr[i] = 0;
-	__shared__ float s_lv[18][18]; // [y + 1][x + 1]; -1 = outside the grid
-	const int pxn = (gx + 15) / 16;
+	// A workgroup's 16 x 16 threads evaluate ONE level each: the 14 x 14 tiles it owns and their one-tile halo (the level
+	// function is a ~500-instruction dependent chain: a 16 x 16 patch whose first 64 threads also did the halo had a critical
+	// path of two of them).
+	__shared__ float s_lv[16][16]; // [y][x] of the haloed patch; -1 = outside the grid
+	const int pxn = (gx + FR_LV_PATCH - 1) / FR_LV_PATCH;
 	const int bx = (int)blockIdx.x % pxn, by = (int)blockIdx.x / pxn;
 	const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-	const int tx = bx * 16 + lx, ty = by * 16 + ly;
-	const bool live = tx < gx && ty < gy;
+	const int tx = bx * FR_LV_PATCH + lx - 1, ty = by * FR_LV_PATCH + ly - 1;
+	const bool in_grid = tx >= 0 && tx < gx && ty >= 0 && ty < gy;
+	const bool live = in_grid && lx >= 1 && lx <= FR_LV_PATCH && ly >= 1 && ly <= FR_LV_PATCH; // a tile this workgroup owns
 	const int idx = ty * gx + tx;
-	s_lv[ly + 1][lx + 1] = live ? tile_level(tx, ty, W, H, gaze_x, gaze_y, alpha) : -1.0f;
-	if (threadIdx.x < 64)
-	{
-		// halo: side 0 = left column, 1 = right column, 2 = row above, 3 = row below
-		const int side = threadIdx.x >> 4, k = threadIdx.x & 15;
-		const int hx = side == 0 ? -1 : (side == 1 ? 16 : k), hy = side == 2 ? -1 : (side == 3 ? 16 : k);
-		const int gxx = bx * 16 + hx, gyy = by * 16 + hy;
-		const bool in = gxx >= 0 && gxx < gx && gyy >= 0 && gyy < gy;
-		s_lv[hy + 1][hx + 1] = in ? tile_level(gxx, gyy, W, H, gaze_x, gaze_y, alpha) : -1.0f;
-	}
+	s_lv[ly][lx] = in_grid ? tile_level(tx, ty, W, H, gaze_x, gaze_y, alpha) : -1.0f;
 	__syncthreads();
-	const float lf = s_lv[ly + 1][lx + 1];
-	const float right = s_lv[ly + 1][lx + 2], left = s_lv[ly + 1][lx], up = s_lv[ly + 2][lx + 1], down = s_lv[ly][lx + 1];
+	const float lf = s_lv[ly][lx];
+	const int xl = max(lx - 1, 0), xr = min(lx + 1, 15), yd = max(ly - 1, 0), yu = min(ly + 1, 15); // (only owned tiles use them)
+	const float right = s_lv[ly][xr], left = s_lv[ly][xl], up = s_lv[yu][lx], down = s_lv[yd][lx];
 	float gxv = 0, gyv = 0;
 	if (right != -1 && left != -1) gxv = (right - left) / 2.0f;
 	else if (right != -1) gxv = right - lf;
@@ -1800,7 +1797,7 @@ static inline size_t lds_tile_table_bytes(int T) { return (size_t)T * sizeof(flo
 int launch_tile_levels(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
-	hipLaunchKernelGGL(k_tile_levels, dim3(((c.gx + 15) / 16) * ((c.gy + 15) / 16)), dim3(256), 0, c.stream,
+	hipLaunchKernelGGL(k_tile_levels, dim3(((c.gx + FR_LV_PATCH - 1) / FR_LV_PATCH) * ((c.gy + FR_LV_PATCH - 1) / FR_LV_PATCH)), dim3(256), 0, c.stream,
 		c.T, c.gx, c.gy, a->W, a->H, a->gaze_x, a->gaze_y, a->alpha, c.img.tile_lv, c.img.lv_bbox, c.geom.slab_ctr,
 		a->variant == FR_VARIANT_MMFR_PCHECK_OBB ? a->cur_level : -1.0f);
 	return check_launch("tile_levels", c.stream, a->debug);
