@@ -25,17 +25,22 @@ __global__ void __launch_bounds__(FR_TILE_SCAN_THREADS) k_tile_scan(const TileSc
 	else tile_scan_atomics<FR_TILE_SCAN_THREADS>(ts);
 }
 
-// One tile list per workgroup (ranges[tile_order[block]]): the lists with n_lo < n < n_hi that fit the kernel's LDS.
-template <int THREADS, int ITEMS>
+// The two classes of short lists, one workgroup per list: the lists of 512..2047 entries (the tile scan's bins 10 and 11:
+// tile_order[h4 .. h4 + mid), h4 = totals[2], mid = totals[3]) when !SHORTEST, the lists of <= 511 entries (the rest of
+// tile_order, empty tiles included) when SHORTEST.
+template <int THREADS, int ITEMS, bool SHORTEST>
 __global__ void __launch_bounds__(THREADS) k_tile_msort(const uint2 *ranges, const uint32_t *tile_order, uint64_t *entries,
-	uint32_t *point_list, int n_lo, int n_hi, const uint32_t *totals, SpecLimits lim)
+	uint32_t *point_list, int T, const uint32_t *totals, SpecLimits lim)
 {
 	extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
 	if (!frame_fits(totals, lim)) return;
-	const uint2 rg = ranges[tile_order[blockIdx.x]];
-	const int n = (int)(rg.y - rg.x);
-	if (n <= n_lo || n >= n_hi) return; // another kernel sorts this list
-	msort_list<THREADS, ITEMS, false>(rg, entries, point_list, sk);
+	const uint32_t lo = totals[2] + (SHORTEST ? totals[3] : 0u), hi = SHORTEST ? (uint32_t)T : totals[2] + totals[3];
+	for (uint32_t b = lo + blockIdx.x; b < hi; b += gridDim.x)
+	{
+		const uint2 rg = ranges[tile_order[b]];
+		if (rg.y != rg.x) msort_list<THREADS, ITEMS, false>(rg, entries, point_list, sk);
+		__syncthreads(); // the next list reuses the LDS keys
+	}
 }
 
 // The classes of longer lists, each sorted WHOLE in LDS by one workgroup: tile_order[totals[lo_word] .. totals[hi_word]) -- the
@@ -137,7 +142,6 @@ AuxStream *aux_stream()
 // from the counts in device memory and loops if its grid came out too small.
 int launch_tile_sort(FwdCtx &c)
 {
-	const dim3 grid(c.T);
 	const uint2 *rg = c.img.ranges;
 	const uint32_t *ord = c.img.tile_order;
 	uint32_t *totals = c.img.totals;
@@ -189,12 +193,15 @@ int launch_tile_sort(FwdCtx &c)
 	if (h4 - (known ? h8 : 0) > 0)
 		hipLaunchKernelGGL((k_tile_msort_direct<512, 8>), dim3(h4 - (known ? h8 : 0)), dim3(512), 4608 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries,
 			c.bin.point_list, totals, lim, 6, 2);
-	// (class boundaries: the 513..2047 class reads n_lo = 512)
-	if (!known || c.a->max_tile_instances > 512)
-		hipLaunchKernelGGL((k_tile_msort<256, 8>), grid, dim3(256), 2304 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
-			512, 2048, totals, lim);
-	hipLaunchKernelGGL((k_tile_msort<64, 8>), grid, dim3(64), 576 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
-		0, 513, totals, lim);
+	// (one workgroup per list of the class: a grid over all T tiles started 16 000 workgroups per frame only to find out that
+	// the list belongs to another kernel)
+	const int nmid = known ? c.heavy2 : c.T, nshort = known ? c.T - c.heavy4 - c.heavy2 : c.T;
+	if (nmid > 0)
+		hipLaunchKernelGGL((k_tile_msort<256, 8, false>), dim3(nmid), dim3(256), 2304 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+			c.T, totals, lim);
+	if (nshort > 0)
+		hipLaunchKernelGGL((k_tile_msort<64, 8, true>), dim3(nshort), dim3(64), 576 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
+			c.T, totals, lim);
 	if (ax)
 	{
 		(void)hipEventRecord(ax->join, ax->s);
