@@ -862,3 +862,31 @@ def test_frames_launched_ahead_of_their_instance_count(variant, monkeypatch):
     s4 = _native.speculation_stats()
     assert (s4[0] - s3[0], s4[2] - s3[2]) == (0, 1)
     np.testing.assert_array_equal(plain["color"], runs[1]["color"])
+
+
+@pytest.mark.parametrize("variant", ("fov_pcheck_obb", "pcheck_obb_sum"))
+def test_binning_workspace_requested_before_the_count(variant):
+    """From the second frame of a kind (variant, P, W, H) on, fr_forward asks for the binning workspace BEFORE the instance
+    count is in, sized like the largest frame of the kind so far plus a quarter (csrc/api.hip). Small frame (first call: sized
+    exactly), small frame again (early request fits), a frame with > 1.6x the instances (early request too small: asked
+    again), the small frame in the now oversized workspace -- lists and images as the oracle's each time, and the backward
+    pass of the training variant finds its lists in a workspace laid out for more instances than the frame has."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward, hip_backward
+    scene, cam = small_case(variant, P=4801, seed=23, width=424, height=248)  # a (P, W, H) no other test uses
+    big = dict(cam, scale_modifier=2.5)
+    want, want_big = orc.forward(variant, scene, cam), orc.forward(variant, scene, big)
+    assert want_big["num_rendered"] > 1.6 * want["num_rendered"]
+    for cd, w in ((cam, want), (cam, want), (big, want_big), (cam, want)):
+        got = hip_forward(variant, scene, cd, debug=False)
+        assert got["num_rendered"] == w["num_rendered"]
+        np.testing.assert_array_equal(got["ranges"], w["ranges"])
+        np.testing.assert_array_equal(got["point_list"], w["point_list"])
+        check_image(got["color"], w["color"], name=variant + " early workspace request")
+    if variant == "pcheck_obb_sum":
+        rng = np.random.default_rng(5)
+        dL = rng.standard_normal(want["color"].shape).astype(np.float32)
+        g = hip_backward(variant, got, dL)
+        wb = orc.backward(variant, scene, cam, want, dL)
+        for k in ("dL_dmean3D", "dL_dopacity", "dL_dscale", "dL_drot", "dL_dsh"):
+            check_grad(g[k].reshape(wb[k].shape), wb[k], k + " (oversized binning workspace)")
