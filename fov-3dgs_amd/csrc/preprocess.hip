@@ -609,6 +609,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	// read the last Gaussian; without scales / rotations the unused values come from the cov3D_precomp array.
 	const float *sc_src = have_sr ? a.scales : a.cov3D_precomp;
 	const float *q_src = have_sr ? a.rotations : a.cov3D_precomp;
+	bool odd_level = false; // RF: a highest level other than 0, 1, 2, 3 went by (see step)
 	auto fetch = [&](const int chunk) __attribute__((always_inline))
 	{
 		const size_t i = (size_t)min(chunk * 64 + lane, a.P - 1);
@@ -631,6 +632,9 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	{
 		const int idx = chunk * 64 + lane;
 		bool maybe = false;
+		// RF: the binning kernels filter tiles by `tile level < highest level + 1` from a 4-bit-per-tile LDS table, which is exact
+		// for highest levels 0, 1, 2, 3 (what a model holds); anything else sends them to the tiles' float levels in global memory
+		if (FOV && chunk < c1 && idx < a.P && !(cur.hl == 0.0f || cur.hl == 1.0f || cur.hl == 2.0f || cur.hl == 3.0f)) odd_level = true;
 		if (chunk < c1 && idx < a.P)
 		{
 			if (PACKED) maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * cur.sc[0], cur.hl, wn2);
@@ -689,6 +693,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	// kernel with every workgroup adding up the counts of those in front of it (the polling of the workgroups that finish
 	// first halves the memory bandwidth of those still streaming: 74 -> 157 us).
 	if (lane == 0) a.geom.proj_counts[wave_gid] = nrow;
+	if (FOV && __any(odd_level) && lane == 0) atomicOr(a.geom.slab_ctr + 3, 1u);
 #ifdef FR_PROJ_TIMERS
 	if (lane == 0)
 	{
@@ -726,36 +731,30 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// RF: every pair step looks its tile's level (and, if kept, its blend flag) up; from global memory those
 	// were two dependent ~1 us round trips in a loop that a near-camera splat runs a hundred times. When they
 	// fit beside the histogram, the workgroup keeps tile_min (float) and the blend flags (one bit) in LDS.
-	float *lds_tmin = (float *)(lds_hist + (LDSH ? a.T : 0));
-	uint32_t *lds_blend = (uint32_t *)(lds_tmin + a.T);
-	const bool ldst = FOV && a.lds_tiles;
-	if (ldst)
+	uint32_t *lds_tab = lds_hist + (LDSH ? a.T : 0);
+	const int tab_words = (a.T + 7) / 8;
+	// (the table answers `tile level < highest level + 1` only for highest levels 0..3: k_project says if it saw another)
+	const bool ldst = FOV && a.lds_tiles && a.geom.slab_ctr[3] == 0u;
+	if (FOV && a.lds_tiles)
 	{
-		// The tables are copied SIXTEEN loads at a time: written as `lds[t] = g[t]` loops, every iteration waited for its own load
-		// (16 + 16 + 16 round trips of ~0.6 us: a 10 us prologue on every CU before any work).
+		// Four bits per tile: min(max(int(tile_min), 0), 7) and the blend flag in bit 3 -- all the walks ask of a tile (the filter
+		// compares tile_min with an INTEGER, the level ranges take int(tile_min)): 4 KiB instead of 33 KiB of floats and bits for a
+		// 1080p frame, and a 1440p frame's table fits beside its histogram. Sixteen loads at a time (written as a plain copy loop
+		// every iteration waited for its own load: a 10 us prologue on every CU before any work); eight lanes pack a word.
 		const float *gmin = a.tile_lv + a.T, *gbl = a.tile_lv + 4 * (size_t)a.T;
 		for (int t0 = threadIdx.x; t0 < a.T; t0 += 16 * FR_BIN_THREADS)
 		{
-			float v[16];
+			float v[16], f[16];
 #pragma unroll
-			for (int k = 0; k < 16; k++) v[k] = gmin[min(t0 + k * FR_BIN_THREADS, a.T - 1)];
-#pragma unroll
-			for (int k = 0; k < 16; k++) if (t0 + k * FR_BIN_THREADS < a.T) lds_tmin[t0 + k * FR_BIN_THREADS] = v[k];
-		}
-		// the blend flags as bits: 64 consecutive flags per wave and load, packed by a ballot
-		const int nwords = (a.T + 31) / 32;
-		for (int base0 = (int)(threadIdx.x & ~63u); base0 < a.T; base0 += 16 * FR_BIN_THREADS)
-		{
-			float v[16];
-#pragma unroll
-			for (int k = 0; k < 16; k++) v[k] = gbl[min(base0 + k * FR_BIN_THREADS + lane, a.T - 1)];
+			for (int k = 0; k < 16; k++) { const int t = min(t0 + k * FR_BIN_THREADS, a.T - 1); v[k] = gmin[t]; f[k] = gbl[t]; }
 #pragma unroll
 			for (int k = 0; k < 16; k++)
 			{
-				const int base = base0 + k * FR_BIN_THREADS;
-				const unsigned long long m = __ballot(base + lane < a.T && v[k] != 0.0f);
-				if (base < a.T && lane == 0) lds_blend[base >> 5] = (uint32_t)m;
-				if (base < a.T && lane == 1 && (base >> 5) + 1 < nwords) lds_blend[(base >> 5) + 1] = (uint32_t)(m >> 32);
+				const int t = t0 + k * FR_BIN_THREADS;
+				uint32_t nib = t < a.T ? ((uint32_t)min(max(f2i(v[k]), 0), 7) | (f[k] != 0.0f ? 8u : 0u)) : 0u;
+				nib <<= 4 * (lane & 7);
+				nib |= (uint32_t)__shfl_xor((int)nib, 1); nib |= (uint32_t)__shfl_xor((int)nib, 2); nib |= (uint32_t)__shfl_xor((int)nib, 4);
+				if ((lane & 7) == 0 && (t >> 3) < tab_words) lds_tab[t >> 3] = nib;
 			}
 		}
 	}
@@ -763,7 +762,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
 	// the cull pass's per-wave counts (scanned below), loaded with the tables: ONE round trip of cold global loads at the head
 	// of the kernel instead of one per step
-	uint32_t *s_wbase = lds_hist + (LDSH ? a.T : 0) + (ldst ? a.T + (a.T + 31) / 32 : 0); // [proj_waves + 1] exclusive running counts
+	uint32_t *s_wbase = lds_hist + (LDSH ? a.T : 0) + ((FOV && a.lds_tiles) ? tab_words : 0); // [proj_waves + 1] exclusive running counts
 	for (int w0 = threadIdx.x; w0 < a.proj_waves; w0 += 16 * FR_BIN_THREADS)
 	{
 		uint32_t v[16];
@@ -792,8 +791,13 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 #ifdef FR_BIN_TIMERS
 	const uint64_t tm_pb = wall_clock64();
 #endif
-#define TILE_MIN(ti) (ldst ? lds_tmin[(ti)] : tile_min[(ti)])
-#define TILE_BLENDS(ti) (ldst ? ((lds_blend[(ti) >> 5] >> ((ti) & 31)) & 1u) != 0u : tile_bl[(ti)] != 0.0f)
+	// tile ti against a splat whose filter bound is olim = highest level + 1: does the tile pass, and its level bits
+	// (1 << min(max(int(tile_min), 0), 3), | 16 if it blends two levels) -- from the 4-bit table, or from the floats
+#define TILE_FILTER(ti, olim, pass_out, bits_out) do { \
+		if (ldst) { const uint32_t nb_ = (lds_tab[(ti) >> 3] >> (4 * ((ti) & 7))) & 15u; \
+			pass_out = (float)(nb_ & 7u) < (olim); bits_out = (1u << min(nb_ & 7u, 3u)) | ((nb_ & 8u) << 1); } \
+		else { const float lv_ = tile_min[(ti)]; pass_out = lv_ < (olim); \
+			bits_out = pass_out ? ((1u << min(max(f2i(lv_), 0), 3)) | (tile_bl[(ti)] != 0.0f ? 16u : 0u)) : 0u; } } while (0)
 	// Work unit = a "slab" of 64 consecutive vis_list entries, handled by ONE wave; there is no workgroup
 	// barrier inside the loop (a few near-camera splats make some slabs 100x more expensive than others,
 	// and waiting for the slowest wave of a workgroup at every slab cost a quarter of the kernel).
@@ -872,10 +876,10 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			uint32_t m = 0;
 			if (CULL)
 			{
-				float level = 0.f;
-				if (FOV) { level = TILE_MIN(ti); pass = pass && (level < olim); }
+				uint32_t lb = 0;
+				if (FOV) { bool lp; TILE_FILTER(ti, olim, lp, lb); pass = pass && lp; }
 				pass = pass && obb_hits_tile(ob, x, y);
-				if (FOV && pass) m = (1u << min(max(f2i(level), 0), 3)) | (TILE_BLENDS(ti) ? 16u : 0u);
+				if (FOV && pass) m = lb;
 			}
 			if (pass) BUMP_TILE(ti);
 			cnt += (uint32_t)__popcll(__ballot(pass));
@@ -1227,9 +1231,10 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		const int ti = pr.y0 * a.gx + pr.x0;
 		if (FOV)
 		{
-			const float level = TILE_MIN(ti);
-			keep = level < (hl + 1);
-			if (keep) { lowest = level; highest = level; be_blend = TILE_BLENDS(ti); }
+			uint32_t lb;
+			TILE_FILTER(ti, hl + 1, keep, lb);
+			// (int(lowest) / int(highest) are all that is used of them: the level's integer part stands for the level)
+			if (keep) { const float level = (float)(31 - __clz((int)(lb & 15u))); lowest = level; highest = level; be_blend = (lb & 16u) != 0u; }
 		}
 		if (keep) { BUMP_TILE(ti); count = 1; }
 	}
@@ -1314,11 +1319,12 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			if (CULL)
 			{
 				const float4 o0 = orow[0], o1 = orow[1], o2 = orow[2];
-				float level = 0.f;
+				uint32_t lb = 0;
 				if (FOV)
 				{
-					level = TILE_MIN(valid ? ti : 0);
-					pass = pass && (level < o3.w);
+					bool lp;
+					TILE_FILTER(valid ? ti : 0, o3.w, lp, lb);
+					pass = pass && lp;
 				}
 				{
 					// obb_hits_tile() without its early returns (same expressions, same comparisons: a NaN fails no test)
@@ -1334,11 +1340,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 					const bool e2_ok = !(o1.w < mn2 || -o1.w > mx2);
 					pass = pass && cx_ok && cy_ok && e1_ok && e2_ok;
 				}
-				if (FOV)
-				{
-					const uint32_t mm = (1u << min(max(f2i(level), 0), 3)) | (TILE_BLENDS(valid ? ti : 0) ? 16u : 0u);
-					m = pass ? mm : 0u;
-				}
+				if (FOV) m = pass ? lb : 0u;
 			}
 			if (pass) BUMP_TILE(ti);
 			// hand the results back to the owners: my pairs of this step are lanes [seg_a, seg_b)
@@ -1494,8 +1496,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 #endif
 }
 #undef BUMP_TILE
-#undef TILE_MIN
-#undef TILE_BLENDS
+#undef TILE_FILTER
 
 // One thread per Gaussian: re-walk the rect, repeat the cull test and append (depth,id) to the
 // tile's bucket through the tile cursor. Order inside a bucket is arbitrary; the per-tile sort
@@ -1533,8 +1534,11 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	// small nothing is emitted, the host replays the stage with a larger one
 	if (a.totals[0] > a.capacity || a.totals[5] > a.items_cap) return;
 	const int lane = threadIdx.x & 63;
-	float *lds_tmin = (float *)(lds_cur + (LDSH ? a.T : 0)); // RF: tile_min staged in LDS, as in k_bin
-	const bool ldst = FOV && a.lds_tiles;
+	// RF: the tiles' levels as k_bin keeps them: four bits per tile, min(max(int(tile_min), 0), 7) (the filter compares
+	// with an integer; exact for highest levels 0..3, k_project says if it saw another: then the floats in global memory)
+	uint32_t *lds_tab = lds_cur + (LDSH ? a.T : 0);
+	const int tab_words = (a.T + 7) / 8;
+	const bool ldst = FOV && a.lds_tiles && a.geom.slab_ctr[3] == 0u;
 	if (ldst)
 	{
 		const float *gmin = a.tile_lv + a.T;
@@ -1544,9 +1548,17 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 #pragma unroll
 			for (int k = 0; k < 16; k++) v[k] = gmin[min(t0 + k * FR_EMIT_THREADS, a.T - 1)];
 #pragma unroll
-			for (int k = 0; k < 16; k++) if (t0 + k * FR_EMIT_THREADS < a.T) lds_tmin[t0 + k * FR_EMIT_THREADS] = v[k];
+			for (int k = 0; k < 16; k++)
+			{
+				const int t = t0 + k * FR_EMIT_THREADS;
+				uint32_t nib = t < a.T ? (uint32_t)min(max(f2i(v[k]), 0), 7) : 0u;
+				nib <<= 4 * (lane & 7);
+				nib |= (uint32_t)__shfl_xor((int)nib, 1); nib |= (uint32_t)__shfl_xor((int)nib, 2); nib |= (uint32_t)__shfl_xor((int)nib, 4);
+				if ((lane & 7) == 0 && (t >> 3) < tab_words) lds_tab[t >> 3] = nib;
+			}
 		}
 	}
+#define TILE_PASSES(ti, olim) (ldst ? (float)((lds_tab[(ti) >> 3] >> (4 * ((ti) & 7))) & 7u) < (olim) : tile_min[(ti)] < (olim))
 	if (LDSH)
 	{
 		// (pre[t] is only defined for the tiles this workgroup counted instances in -- the only cursors it will use)
@@ -1583,7 +1595,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			bool pass = valid;
 			if (CULL)
 			{
-				if (FOV) pass = pass && ((ldst ? lds_tmin[ti] : tile_min[ti]) < olim);
+				if (FOV) pass = pass && TILE_PASSES(ti, olim);
 				pass = pass && obb_hits_tile(ob, x, y);
 			}
 			if (pass) a.entries[NEXT_SLOT(ti)] = opay;
@@ -1666,7 +1678,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 				if (FOV)
 				{
 					const float ohl = __shfl(hl, owner);
-					pass = pass && ((ldst ? lds_tmin[valid ? ti : 0] : tile_min[valid ? ti : 0]) < (ohl + 1));
+					pass = pass && TILE_PASSES(valid ? ti : 0, ohl + 1);
 				}
 				if (pass)
 				{
@@ -1714,6 +1726,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	}
 }
 #undef NEXT_SLOT
+#undef TILE_PASSES
 
 __global__ void k_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present)
 {
@@ -1789,7 +1802,7 @@ int launch_pack_colour(int P, const float *shs, const float *shs_rest, const flo
 
 // ---- launchers -------------------------------------------------------------------------------
 // bytes of the RF tile table in LDS: tile_min floats + one blend bit per tile
-static inline size_t lds_tile_table_bytes(int T) { return (size_t)T * sizeof(float) + (size_t)((T + 31) / 32) * sizeof(uint32_t); }
+static inline size_t lds_tile_table_bytes(int T) { return (size_t)((T + 7) / 8) * sizeof(uint32_t); } // four bits per tile
 #define FR_LDS_TILE_TABLE_BUDGET (104u * 1024u) // one workgroup of k_bin / k_emit per CU (160 KiB) beside its static LDS (36 KiB:
                                                  // the pair loop's rows) and the cull pass's running counts (<= 16 KiB): tile grids
                                                  // up to ~13 000 tiles get the LDS tile table beside their LDS histogram

@@ -890,3 +890,32 @@ def test_binning_workspace_requested_before_the_count(variant):
         wb = orc.backward(variant, scene, cam, want, dL)
         for k in ("dL_dmean3D", "dL_dopacity", "dL_dscale", "dL_drot", "dL_dsh"):
             check_grad(g[k].reshape(wb[k].shape), wb[k], k + " (oversized binning workspace)")
+
+
+@pytest.mark.parametrize("variant", ("fov_pcheck_obb", "naive_pcheck_obb"))
+@pytest.mark.parametrize("levels", ("fractional", "out_of_range"))
+def test_level_filter_with_unusual_highest_levels(variant, levels):
+    """The binning kernels answer `tile level < highest level + 1` from a 4-bit-per-tile table (the integer part of the tile's
+    level), which is exact for the highest levels a model holds: 0, 1, 2, 3. The cull pass flags any other value and the
+    frame then filters on the tiles' float levels: highest levels such as 1.5 or 4 / 7 must give the oracle's lists too."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    scene, cam = small_case("fov_pcheck_obb", P=2600, seed=31, width=400, height=304)
+    if variant == "naive_pcheck_obb":  # the shared-model baseline: plain colours + the foveated model's highest levels
+        plain, _ = small_case("pcheck_obb", P=2600, seed=31, width=400, height=304)
+        scene = dict(plain, highest_levels=scene["highest_levels"])
+    hl = np.array(scene["highest_levels"], dtype=np.float32, copy=True)
+    rng = np.random.default_rng(3)
+    pick = rng.random(hl.shape) < 0.3
+    hl[pick] = (hl[pick] + rng.choice([0.5, 0.25, 0.75], size=int(pick.sum())).astype(np.float32)) if levels == "fractional" \
+        else rng.choice([4.0, 7.0], size=int(pick.sum())).astype(np.float32)
+    scene = dict(scene, highest_levels=hl)
+    want = orc.forward(variant, scene, cam)
+    assert want["num_rendered"] > 5000
+    for packed in ((False, True) if variant == "fov_pcheck_obb" else (False,)):
+        got = hip_forward(variant, scene, cam, packed=packed)
+        assert got["num_rendered"] == want["num_rendered"]
+        np.testing.assert_array_equal(got["radii"], want["radii"])
+        np.testing.assert_array_equal(got["ranges"], want["ranges"])
+        np.testing.assert_array_equal(got["point_list"], want["point_list"])
+        check_image(got["color"], want["color"], name=f"{variant} {levels} highest levels packed={packed}")
