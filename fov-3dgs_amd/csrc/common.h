@@ -18,7 +18,9 @@
 #define FR_BIN_BLOCKS 512
 #define FR_PROJ_MAX_WAVES 8192                 // k_project's grid is capped to this many waves ...
 #define FR_CROW_PAD (64 * FR_PROJ_MAX_WAVES)     // ... each of which may leave its last chunk's worth of row slots unused
-#define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram up to 64 KiB
+#define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram of 32-bit counts up to 64 KiB
+#define FR_LDS_HIST16_MAX_TILES 34816 // ... of 16-bit counts (two tiles per word) beyond that: a 4K frame has 32 400 tiles
+#define FR_HIST16_MAX_SLABS 127       // slabs a wave of k_bin takes at most then: 8 waves x 127 x 64 items < 65 536 per workgroup
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop
 #define FR_GIANT_MAX 64         // giant splats a workgroup can set aside (more: handled like big ones)
@@ -149,7 +151,7 @@ __host__ __device__ inline ImageWS carve_image(int variant, int W, int H, char *
 	s.tile_lv = nullptr;
 	if (is_fov(variant)) { s.tile_lv = (float *)(base + off); off = align_up(off + 5 * T * sizeof(float)); }
 	s.hist = nullptr;
-	if (T <= FR_LDS_HIST_MAX_TILES) { s.hist = (uint32_t *)(base + off); off = align_up(off + (size_t)FR_BIN_BLOCKS * T * sizeof(uint32_t)); }
+	if (T <= FR_LDS_HIST16_MAX_TILES) { s.hist = (uint32_t *)(base + off); off = align_up(off + (size_t)FR_BIN_BLOCKS * T * sizeof(uint32_t)); }
 	s.bytes = off + 256;
 	return s;
 }
@@ -393,6 +395,7 @@ struct FwdCtx {
 	int gx, gy, T;
 	int fov_split;      // RF: the two level states of a two-level tile go to different waves (out_color was zero-filled)
 	int bin_wgs;        // workgroups k_bin ran with (k_emit replays the same number)
+	int hist_mode;      // k_bin / k_emit: 0 = global tile counters, 1 = LDS histogram of 32-bit counts, 2 = of 16-bit counts (launch_bin decides)
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
 	int heavy8;         // tiles with >= 4096 instances
 	int n_items;        // entries of ImageWS::render_items

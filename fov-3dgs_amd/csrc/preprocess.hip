@@ -709,12 +709,15 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 // its record. Persistent workgroups of FR_BIN_THREADS threads, work handed out per wave (see below).
 // LDSH: the counters are an LDS-private histogram (T <= 16 Ki tiles) written once per workgroup to
 // hist[block][tile] -- no global atomics at all; otherwise (huge tile grids) global atomics on tile_count.
-#define BUMP_TILE(ti) do { if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
+// LDSH == 2: 16-bit counts, two tiles per word (tile grids of more than 16 Ki tiles: 4K frames); a workgroup then bins fewer
+// than 65 536 items (FR_HIST16_MAX_SLABS per wave), so no count can overflow.
+#define BUMP_TILE(ti) do { if (LDSH == 2) atomicAdd(&lds_hist[(ti) >> 1], 1u << (16 * ((ti) & 1))); \
+	else if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
 #ifndef FR_BIN_PREFETCH
 #define FR_BIN_PREFETCH 1 // colour rows fetched at the head of a slab (0: after the walk, as round 2 did)
 #endif
 // CROW: the candidate's inputs come as the row k_project stored (GeomWS::crow via vis_src).
-template <int VARIANT, bool LDSH, bool PACKED = false, bool CROW = false>
+template <int VARIANT, int LDSH, bool PACKED = false, bool CROW = false>
 __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 {
 	static_assert(!(PACKED && CROW), "the packed model layout has its own rows");
@@ -731,7 +734,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// RF: every pair step looks its tile's level (and, if kept, its blend flag) up; from global memory those
 	// were two dependent ~1 us round trips in a loop that a near-camera splat runs a hundred times. When they
 	// fit beside the histogram, the workgroup keeps tile_min (float) and the blend flags (one bit) in LDS.
-	uint32_t *lds_tab = lds_hist + (LDSH ? a.T : 0);
+	const int hist_words = LDSH == 2 ? (a.T + 1) / 2 : (LDSH ? a.T : 0);
+	uint32_t *lds_tab = lds_hist + hist_words;
 	const int tab_words = (a.T + 7) / 8;
 	// (the table answers `tile level < highest level + 1` only for highest levels 0..3: k_project says if it saw another)
 	const bool ldst = FOV && a.lds_tiles && a.geom.slab_ctr[3] == 0u;
@@ -759,10 +763,10 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 	}
 	if (LDSH)
-		for (int t = threadIdx.x; t < a.T; t += FR_BIN_THREADS) lds_hist[t] = 0;
+		for (int t = threadIdx.x; t < hist_words; t += FR_BIN_THREADS) lds_hist[t] = 0;
 	// the cull pass's per-wave counts (scanned below), loaded with the tables: ONE round trip of cold global loads at the head
 	// of the kernel instead of one per step
-	uint32_t *s_wbase = lds_hist + (LDSH ? a.T : 0) + ((FOV && a.lds_tiles) ? tab_words : 0); // [proj_waves + 1] exclusive running counts
+	uint32_t *s_wbase = lds_hist + hist_words + ((FOV && a.lds_tiles) ? tab_words : 0); // [proj_waves + 1] exclusive running counts
 	for (int w0 = threadIdx.x; w0 < a.proj_waves; w0 += 16 * FR_BIN_THREADS)
 	{
 		uint32_t v[16];
@@ -1103,7 +1107,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	};
 	// Pulling a slab (LDSH): a returning atomic on this wave's region counter, then the others if that one is dry. issue_pull
 	// only sends the first atomic; finish_pull waits for it (and does the rare rest). Static order otherwise.
-	int pend_li = 0, pend_r = 0, static_next = wave_gid;
+	int pend_li = 0, pend_r = 0, static_next = wave_gid, pulled = 0;
 	auto issue_pull = [&]() __attribute__((always_inline))
 	{
 		if (LDSH) { pend_r = region; if (lane == 0) pend_li = (int)atomicAdd(a.geom.slab_ctr + 32 * (1 + region), 1u); }
@@ -1111,6 +1115,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	auto finish_pull = [&]() __attribute__((always_inline))
 	{
 		if (!LDSH) { const int sl = static_next; static_next += nwaves; return sl < nslabs ? sl : -1; }
+		if (LDSH == 2 && pulled >= FR_HIST16_MAX_SLABS) return -1; // (16-bit counts: the other workgroups take the rest)
+		pulled++;
 		int got = -1;
 		if (lane == 0)
 		{
@@ -1481,7 +1487,11 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		{
 			uint32_t h[4], o[4];
 #pragma unroll
-			for (int k = 0; k < 4; k++) { const int t = t0 + k * FR_BIN_THREADS; h[k] = t < a.T ? lds_hist[t] : 0u; }
+			for (int k = 0; k < 4; k++)
+			{
+				const int t = t0 + k * FR_BIN_THREADS;
+				h[k] = t < a.T ? (LDSH == 2 ? (lds_hist[t >> 1] >> (16 * (t & 1))) & 0xffffu : lds_hist[t]) : 0u;
+			}
 #pragma unroll
 			for (int k = 0; k < 4; k++) o[k] = h[k] ? atomicAdd(&a.tile_count[t0 + k * FR_BIN_THREADS], h[k]) : 0u;
 #pragma unroll
@@ -1523,8 +1533,11 @@ struct EmitArgs {
 #define FR_EMIT_SHARE 2
 #endif
 #define FR_EMIT_THREADS (FR_BIN_THREADS * FR_EMIT_SHARE)
-#define NEXT_SLOT(ti) (LDSH ? atomicAdd(&lds_cur[(ti)], 1u) : a.ranges[(ti)].x + atomicAdd(&a.cursor[(ti)], 1u))
-template <int VARIANT, bool LDSH>
+// LDSH == 2 (see k_bin): the LDS cursors are 16-bit offsets inside the workgroup's share, two tiles per word; where the share
+// starts comes from global memory with every entry
+#define NEXT_SLOT(ti) (LDSH == 2 ? a.ranges[(ti)].x + pre_row[(ti)] + ((atomicAdd(&lds_cur[(ti) >> 1], 1u << (16 * ((ti) & 1))) >> (16 * ((ti) & 1))) & 0xffffu) \
+	: LDSH ? atomicAdd(&lds_cur[(ti)], 1u) : a.ranges[(ti)].x + atomicAdd(&a.cursor[(ti)], 1u))
+template <int VARIANT, int LDSH>
 __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 {
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
@@ -1536,7 +1549,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	const int lane = threadIdx.x & 63;
 	// RF: the tiles' levels as k_bin keeps them: four bits per tile, min(max(int(tile_min), 0), 7) (the filter compares
 	// with an integer; exact for highest levels 0..3, k_project says if it saw another: then the floats in global memory)
-	uint32_t *lds_tab = lds_cur + (LDSH ? a.T : 0);
+	const int cur_words = LDSH == 2 ? (a.T + 1) / 2 : (LDSH ? a.T : 0);
+	const uint32_t *const pre_row = a.hist + (LDSH ? (size_t)blockIdx.x * a.T : 0); // where this workgroup's share of every tile's bucket starts
+	uint32_t *lds_tab = lds_cur + cur_words;
 	const int tab_words = (a.T + 7) / 8;
 	const bool ldst = FOV && a.lds_tiles && a.geom.slab_ctr[3] == 0u;
 	if (ldst)
@@ -1559,10 +1574,12 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		}
 	}
 #define TILE_PASSES(ti, olim) (ldst ? (float)((lds_tab[(ti) >> 3] >> (4 * ((ti) & 7))) & 7u) < (olim) : tile_min[(ti)] < (olim))
-	if (LDSH)
+	if (LDSH == 2)
+		for (int t = threadIdx.x; t < cur_words; t += FR_EMIT_THREADS) lds_cur[t] = 0;
+	else if (LDSH)
 	{
 		// (pre[t] is only defined for the tiles this workgroup counted instances in -- the only cursors it will use)
-		const uint32_t *pre = a.hist + (size_t)blockIdx.x * a.T;
+		const uint32_t *pre = pre_row;
 		for (int t0 = threadIdx.x; t0 < a.T; t0 += 16 * FR_EMIT_THREADS)
 		{
 			uint32_t st[16], pr[16];
@@ -1803,10 +1820,6 @@ int launch_pack_colour(int P, const float *shs, const float *shs_rest, const flo
 // ---- launchers -------------------------------------------------------------------------------
 // bytes of the RF tile table in LDS: tile_min floats + one blend bit per tile
 static inline size_t lds_tile_table_bytes(int T) { return (size_t)((T + 7) / 8) * sizeof(uint32_t); } // four bits per tile
-#define FR_LDS_TILE_TABLE_BUDGET (104u * 1024u) // one workgroup of k_bin / k_emit per CU (160 KiB) beside its static LDS (36 KiB:
-                                                 // the pair loop's rows) and the cull pass's running counts (<= 16 KiB): tile grids
-                                                 // up to ~13 000 tiles get the LDS tile table beside their LDS histogram
-
 int launch_tile_levels(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
@@ -1885,17 +1898,31 @@ int launch_bin(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	PreArgs p = make_pre_args(c);
-	const bool ldsh = c.img.hist != nullptr;
 	int nblk = bin_blocks(a->P);
 	const dim3 block(FR_BIN_THREADS);
-	// LDS per workgroup: tile histogram (+ RF: tile_min and blend bits when two workgroups still fit a CU)
-	p.lds_tiles = (is_fov(a->variant) && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
-	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0) +
+	// Where the tiles are counted: an LDS histogram per workgroup of 32-bit counts (grids up to 16 Ki tiles), of 16-bit counts
+	// (up to 34 816 tiles: a workgroup then takes fewer than 65 536 items, so at least one workgroup per CU must cover all
+	// P Gaussians), or global counters.
+	static thread_local int cus = 0;
+	if (cus == 0)
+	{
+		int dev = 0; hipDeviceProp_t prop;
+		cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
+		(void)hipGetLastError();
+	}
+	const int64_t wgs_lo = nblk < cus ? nblk : cus;
+	c.hist_mode = c.img.hist == nullptr ? 0 : (c.T <= FR_LDS_HIST_MAX_TILES ? 1 :
+		(wgs_lo * (FR_BIN_THREADS / 64) * FR_HIST16_MAX_SLABS * 64 >= (int64_t)a->P ? 2 : 0));
+	const bool ldsh = c.hist_mode != 0;
+	// LDS per workgroup: tile histogram (+ RF: the 4-bit tile table)
+	p.lds_tiles = (is_fov(a->variant) && ldsh) ? 1 : 0;
+	const size_t hist_bytes = c.hist_mode == 2 ? (size_t)((c.T + 1) / 2) * sizeof(uint32_t) : (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0);
+	const size_t lds = hist_bytes + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0) +
 		(size_t)(c.proj_waves + 1) * sizeof(uint32_t); // + the running counts of the cull pass's waves
 	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the
 	// ordinary path 5 %); it needs both packed tensors and the LDS histogram path. Otherwise, when k_project stored the
 	// candidates' rows (foveated variants, unpacked cull pass, scales + rotations given), the kernel that reads those.
-	const bool packed = ldsh && a->packed_geom && a->packed_colour;
+	const bool packed = c.hist_mode == 1 && a->packed_geom && a->packed_colour;
 	const bool crow = ldsh && !packed && is_fov(a->variant) && a->packed_cull == nullptr && a->cov3D_precomp == nullptr;
 	// Never more workgroups than the device keeps resident: the slabs are handed out dynamically, so workgroups of a
 	// second round start when the first ones are done, find the counters empty and only cost their LDS set-up, an
@@ -1922,19 +1949,24 @@ int launch_bin(FwdCtx &c)
 		return FR_OK;
 	};
 	int lrc = FR_OK;
-#define LAUNCH_PRE(V) do { if (packed) lrc = launch((const void *)k_bin<V, true, true>, k_bin<V, true, true>, lds); \
-	else if (crow) lrc = launch((const void *)k_bin<V, true, false, true>, k_bin<V, true, false, true>, lds); \
-	else if (ldsh) lrc = launch((const void *)k_bin<V, true>, k_bin<V, true>, lds); \
-	else lrc = launch((const void *)k_bin<V, false>, k_bin<V, false>, lds); } while (0)
+#define LAUNCH_PRE(V) do { if (packed) lrc = launch((const void *)k_bin<V, 1, true>, k_bin<V, 1, true>, lds); \
+	else if (crow && c.hist_mode == 2) lrc = launch((const void *)k_bin<V, 2, false, true>, k_bin<V, 2, false, true>, lds); \
+	else if (crow) lrc = launch((const void *)k_bin<V, 1, false, true>, k_bin<V, 1, false, true>, lds); \
+	else if (c.hist_mode == 2) lrc = launch((const void *)k_bin<V, 2>, k_bin<V, 2>, lds); \
+	else if (ldsh) lrc = launch((const void *)k_bin<V, 1>, k_bin<V, 1>, lds); \
+	else lrc = launch((const void *)k_bin<V, 0>, k_bin<V, 0>, lds); } while (0)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
 	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_PRE(FR_VARIANT_FOV_PCHECK_OBB); break;
 	case FR_VARIANT_MMFR_PCHECK_OBB:      // plain colours + the level filter (on the skip key, see k_tile_levels): the same kernel
-	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: // (no packed instantiation: validate_forward refuses the packed tensors)
-		if (crow) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true, false, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true, false, true>, lds);
-		else if (ldsh) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, true>, lds);
-		else lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false>, lds);
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB:
+		// (no packed instantiation: validate_forward refuses the packed tensors)
+		if (crow && c.hist_mode == 2) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 2, false, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 2, false, true>, lds);
+		else if (crow) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 1, false, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 1, false, true>, lds);
+		else if (c.hist_mode == 2) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 2>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 2>, lds);
+		else if (ldsh) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 1>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 1>, lds);
+		else lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 0>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 0>, lds);
 		break;
 	default: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
 	}
@@ -1952,18 +1984,24 @@ int launch_emit(FwdCtx &c)
 	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.lv_bbox = c.img.lv_bbox; e.ranges = c.img.ranges;
 	e.cursor = c.img.tile_count; e.entries = c.bin.entries; e.hist = c.img.hist;
 	e.totals = c.img.totals; e.capacity = (uint32_t)c.capacity; e.items_cap = (uint32_t)c.items_cap;
-	const bool ldsh = c.img.hist != nullptr;
+	const bool ldsh = c.hist_mode != 0; // (as k_bin counted: launch_bin)
 	const dim3 grid(c.bin_wgs), block(FR_EMIT_THREADS);
-	e.lds_tiles = (is_fov(a->variant) && ldsh && lds_tile_table_bytes(c.T) + (size_t)c.T * 4 <= FR_LDS_TILE_TABLE_BUDGET) ? 1 : 0;
-	const size_t lds = (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0) + (e.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
+	e.lds_tiles = (is_fov(a->variant) && ldsh) ? 1 : 0;
+	const size_t lds = (c.hist_mode == 2 ? (size_t)((c.T + 1) / 2) * sizeof(uint32_t) : (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0)) +
+		(e.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
 	if (lds > 64u * 1024u)
 	{
-		static const hipError_t once = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, true>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+		static const hipError_t once = [&]() {
+			const hipError_t e1 = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+			const hipError_t e2 = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+			const hipError_t e3 = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_PCHECK_OBB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+			const hipError_t e4 = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_ORIGINAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+			return e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4)); }();
 		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_emit): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
 	}
-#define LAUNCH_EMIT(V) do { if (ldsh) hipLaunchKernelGGL((k_emit<V, true>), grid, block, lds, c.stream, e); \
-	else hipLaunchKernelGGL((k_emit<V, false>), grid, block, 0, c.stream, e); } while (0)
+#define LAUNCH_EMIT(V) do { if (c.hist_mode == 2) hipLaunchKernelGGL((k_emit<V, 2>), grid, block, lds, c.stream, e); \
+	else if (ldsh) hipLaunchKernelGGL((k_emit<V, 1>), grid, block, lds, c.stream, e); \
+	else hipLaunchKernelGGL((k_emit<V, 0>), grid, block, 0, c.stream, e); } while (0)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_EMIT(FR_VARIANT_ORIGINAL); break;
