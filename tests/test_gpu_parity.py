@@ -232,8 +232,8 @@ def test_1440p_tile_grid_keeps_tables_in_lds():
 
 @pytest.mark.parametrize("variant", ("pcheck_obb", "fov_pcheck_obb"))
 def test_huge_tile_grid_uses_global_counter_path(variant):
-    """More than 16384 tiles (4096x2160 -> 34560): the per-workgroup LDS histograms do not fit and the
-    binning kernels fall back to global per-tile counters / cursors."""
+    """More than 16384 tiles (4096x2160 -> 34560): the per-workgroup LDS histograms / cursors hold 16-bit counts, two tiles
+    per word (up to 34816 tiles; the 8K test below is on global per-tile counters / cursors)."""
     _need_gpu()
     from tests.gpu_helpers import hip_forward
     cloud = syn.scene_1k(P=1500, seed=12)
