@@ -7,7 +7,7 @@ Tolerances (fp32 path; BASELINE north_star: per-pixel match within 1e-4, gradien
     within an ulp of a threshold may flip; each flip moves a pixel by at most ~alpha x colour x T: <= 1.1e-2 at the -4.5
     cutoff (0.99 e^-4.5), <= 3.9e-3 at alpha < 1/255. Whole 1080p frames (6.2 M values, ~10^10 (pixel, Gaussian) pairs)
     do hold a handful of such pairs: `hard` is that bound, not a measured maximum; `frac` is what keeps the image tight.
-    The measured fraction and maximum of every comparison are kept in tests/parity_report.json.
+    The measured fraction and maximum of every comparison are kept in tests/parity_report_gpu.json.
   * gradients: RELATIVE, row by row. A row is one Gaussian's slice of the tensor ([3] of dL_dmean3D, [16,3] of dL_dsh,
     a scalar of dL_dopacity ...): ||got_i - want_i||_2 <= rtol * ||want_i||_2 + floor_i on all but `outlier_frac` of the
     rows that carry a gradient. There is no floor tied to the tensor's LARGEST entry (round 2 had 1e-5 * max|want|,
@@ -17,7 +17,7 @@ Tolerances (fp32 path; BASELINE north_star: per-pixel match within 1e-4, gradien
         defined order in the reference either (the oracle sums in double), and a row whose terms cancel carries the
         rounding of its largest summand, not of its result.
     Two budgets: at most GRAD_OUTLIERS (3e-3) of the rows outside rtol and at most GRAD_GROSS (2e-4) outside 100 rtol.
-    Measured on the whole S-6M frame (131 k Gaussians with a gradient, tests/parity_report.json): the median row agrees
+    Measured on the whole S-6M frame (131 k Gaussians with a gradient, tests/parity_report_gpu.json): the median row agrees
     to 6e-7, 99 % of the rows to 3e-6 ... 2.5e-5, and 2e-4 ... 1.7e-3 of them (dL_dopacity the most) lie outside 1e-4.
     Those rows are not threshold flips alone: the backward pass recovers T by dividing T_final by (1 - alpha) down a
     list of up to thousands of entries (backward.cu:503-507; a rounding drift of ~1e-5 at the front of a long list, in
@@ -33,7 +33,7 @@ import numpy as np
 
 from tests import parity_report
 
-# Bounds a few times above the worst case measured over the whole GPU suite (tests/parity_report.json):
+# Bounds a few times above the worst case measured over the whole GPU suite (tests/parity_report_gpu.json):
 IMAGE_FRAC = 1e-6   # share of pixels allowed above 1e-4
 IMAGE_HARD = 1.5e-2 # ... and how far those may be off: one flipped (pixel, Gaussian) pair at the support cutoff
 GRAD_OUTLIERS = 3e-3  # share of gradient rows allowed outside rtol (cancelling rows, threshold flips)

@@ -33,6 +33,12 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_runtest_setup(item):
+    # comparisons recorded by a test marked `gpu` go to the GPU report, all others to the CPU one (tests/parity_report.py)
+    from tests import parity_report
+    parity_report.current_test_is_gpu = "gpu" in item.keywords
+
+
 def pytest_sessionfinish(session, exitstatus):
     try:
         from tests import parity_report

@@ -3,7 +3,7 @@
 Tolerances (fp32 path; BASELINE north_star: per-pixel match within 1e-4):
   * integer / index outputs (radii, instance count, per-tile ranges, sorted id lists): bit-exact;
   * images and gradients: tests/checks.py (every comparison's measured maximum and outlier fraction is kept in
-    tests/parity_report.json).
+    tests/parity_report_gpu.json).
 """
 import math
 import os
@@ -25,7 +25,7 @@ def _need_gpu():
         pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
 
 
-from tests.checks import check_grad, check_image  # noqa: E402  (record what they measure: tests/parity_report.json)
+from tests.checks import check_grad, check_image  # noqa: E402  (record what they measure: tests/parity_report_gpu.json)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
