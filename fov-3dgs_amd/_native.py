@@ -8,12 +8,14 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfovraster_hip.so")
-ABI_VERSION = 6
+# (FOVRASTER_LIB: an experiment build of the library, tools/ab_build.sh -- never a different implementation: same ABI check)
+LIB_PATH = os.environ.get("FOVRASTER_LIB") or os.path.join(HERE, "libfovraster_hip.so")
+ABI_VERSION = 7
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
 VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC, VARIANT_NAIVE_FOV_PCHECK_OBB, VARIANT_MMFR_PCHECK_OBB = 4, 5, 6, 7
 STAGES = ("tile_levels", "project", "bin", "tile_scan", "emit", "tile_sort", "render")
+NUM_STAGE_EVENTS = len(STAGES) + 1
 VARIANT_IDS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3, "pcheck_obb_max": 4,
                "pcheck_obb_loss_weighted_max_count": 5, "naive_pcheck_obb": 6, "mmfr_pcheck_obb": 7}
 
@@ -68,7 +70,7 @@ EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destr
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
            "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records",
            "fr_geometry_vis_list", "fr_geometry_vis_count", "fr_geometry_walk_records", "fr_geometry_level_colours",
-           "fr_geometry_level_ranges", "fr_speculation_stats")
+           "fr_geometry_level_ranges", "fr_forward_begin", "fr_forward_finish")
 
 _lib = None
 
@@ -146,8 +148,10 @@ def load():
         getattr(lib, n).restype = C.c_void_p
     lib.fr_image_tile_levels.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
     lib.fr_image_tile_levels.restype = C.c_void_p
-    lib.fr_speculation_stats.argtypes = [C.POINTER(C.c_int64)]
-    lib.fr_speculation_stats.restype = None
+    lib.fr_forward_begin.argtypes = [C.POINTER(ForwardArgs), C.POINTER(C.c_void_p)]
+    lib.fr_forward_begin.restype = C.c_int
+    lib.fr_forward_finish.argtypes = [C.c_void_p]
+    lib.fr_forward_finish.restype = C.c_int
     if lib.fr_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"fovraster: ABI version mismatch ({lib.fr_abi_version()} != {ABI_VERSION})")
     _lib = lib
@@ -156,10 +160,3 @@ def load():
 
 def last_error():
     return load().fr_last_error().decode("utf-8", "replace")
-
-
-def speculation_stats():
-    """-> (frames launched ahead of their instance count, of those replayed, frames launched after the count) of this thread."""
-    out = (C.c_int64 * 3)()
-    load().fr_speculation_stats(out)
-    return tuple(int(x) for x in out)

@@ -5,11 +5,11 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <new>
 
 namespace fr {
 
 static thread_local char g_err[512] = "";
-static thread_local int64_t g_spec_stats[3] = { 0, 0, 0 }; // frames launched ahead of their counts / of those replayed / launched after them
 
 void set_error(const char *fmt, ...)
 {
@@ -104,7 +104,6 @@ int fr_event_elapsed_ms(void *start, void *stop, float *ms)
 	return FR_OK;
 }
 const char *fr_last_error(void) { return g_err; }
-void fr_speculation_stats(int64_t out[3]) { for (int i = 0; i < 3; i++) out[i] = g_spec_stats[i]; }
 
 size_t fr_geometry_bytes(int32_t variant, int32_t P) { return carve_geom(variant, (size_t)P, nullptr).bytes; }
 size_t fr_image_bytes(int32_t variant, int32_t W, int32_t H) { return carve_image(variant, W, H, nullptr).bytes; }
@@ -122,23 +121,90 @@ const float *fr_geometry_level_colours(int32_t P, const char *geometry) { return
 const uint32_t *fr_geometry_level_ranges(int32_t P, const char *geometry) { return carve_geom(FR_VARIANT_FOV_PCHECK_OBB, (size_t)P, (char *)geometry).lrange; }
 const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image) { return carve_image(FR_VARIANT_FOV_PCHECK_OBB, W, H, (char *)image).tile_lv; }
 
-int fr_forward(fr_forward_args *a)
+// ---- the forward call ---------------------------------------------------------------------------
+// A frame is enqueued in two halves around its ONE host synchronisation (the instance count, which sizes the binning
+// workspace -- the reference synchronises twice for it, rasterizer_impl.cu:281 and RS :401,422):
+//   fr_forward_begin    workspaces (geometry, image), fills, tile levels, cull pass, projection, tile counts, tile scan
+//   fr_forward_finish   waits for the count, binning workspace, emission, per-tile sort, colours, blend
+// fr_forward is begin + finish. A host that keeps TWO frames in flight (two streams, two workspace sets) calls
+// begin(n + 1) before finish(n): the latency-bound head of one frame then runs beside the sort and the blend of the other.
+} // extern "C"
+
+namespace fr {
+
+// 64 bytes of pinned, device-mapped host memory per frame in flight: k_tile_scan writes the frame's totals and its sequence
+// number there, the host polls (a copy command after the kernel costs ~10 us more of an idle GPU). A small pool per host
+// thread; the device address of mapped host memory belongs to the device that was current when it was asked for.
+struct PinnedBlock { uint32_t *host = nullptr, *dev = nullptr; int device = -1; bool busy = false; };
+static PinnedBlock *take_pinned(int device)
 {
+	static thread_local PinnedBlock pool[16];
+	PinnedBlock *spare = nullptr;
+	for (PinnedBlock &b : pool)
+	{
+		if (!b.busy && b.host && b.device == device) { b.busy = true; return &b; }
+		if (!b.busy && !spare && (!b.host || b.device != device)) spare = &b;
+	}
+	if (!spare) return nullptr; // sixteen frames in flight in one thread: the frame falls back to a copy + stream wait
+	if (spare->host) (void)hipHostFree(spare->host);
+	spare->host = spare->dev = nullptr; spare->device = device;
+	void *h = nullptr, *d = nullptr;
+	if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess)
+	{ spare->host = (uint32_t *)h; spare->dev = (uint32_t *)d; for (int i = 0; i < 16; i++) spare->host[i] = 0; }
+	else if (h) (void)hipHostFree(h);
+	(void)hipGetLastError();
+	if (!spare->host) return nullptr;
+	spare->busy = true;
+	return spare;
+}
+
+// what the next frame of a kind (variant, P, W, H) asks its binning workspace for before its count is in
+struct Guess { int32_t variant = -1, P = 0, W = 0, H = 0; int64_t capacity = 0; };
+static Guess &guess_for(int variant) { static thread_local Guess guesses[8]; return guesses[variant & 7]; }
+
+} // namespace fr
+
+struct fr_frame
+{
+	fr_forward_args *a = nullptr;
+	FwdCtx c;
+	AuxStream *ax = nullptr;       // the frame's helper streams (null: everything on the launch stream)
+	bool aux_pending = false;      // work on ax->s2 that the launch stream has not waited for yet
+	PinnedBlock *pin = nullptr;
+	bool empty = false;            // P == 0: nothing left to do
+	// every exit that abandons the frame joins the helper stream first: the caller may free or reuse out_color / the
+	// statistics arrays / the workspaces as soon as the call has returned
+	void join_aux() { if (aux_pending && ax) (void)hipStreamWaitEvent(c.stream, ax->join2, 0); aux_pending = false; }
+	~fr_frame() { join_aux(); if (pin) pin->busy = false; }
+};
+
+extern "C" {
+
+int fr_forward_begin(fr_forward_args *a, fr_frame **out)
+{
+	if (!out) { set_error("null frame handle"); return FR_ERR_INVALID; }
+	*out = nullptr;
 	int rc = validate_forward(a);
 	if (rc) return rc;
 	hipStream_t stream = (hipStream_t)a->stream;
 	a->num_rendered = 0;
 	a->max_tile_instances = 0;
+	fr_frame *f = new (std::nothrow) fr_frame;
+	if (!f) { set_error("out of host memory"); return FR_ERR_ALLOC; }
+	struct Guard { fr_frame *f; ~Guard() { delete f; } } guard = { f }; // (released at the end: an early return drops the frame)
+	f->a = a;
+	FwdCtx &c = f->c;
+	c.a = a; c.stream = stream;
 	if (a->P == 0)
 	{
 		// reference: RasterizeGaussiansCUDA returns the zero-initialised image when P == 0
 		FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, stream));
+		f->empty = true;
+		*out = f; guard.f = nullptr;
 		return FR_OK;
 	}
 	// optional per-stage timing: record the caller's events on the launch stream (no sync here)
 	auto mark = [&](int i) { if (a->stage_events && a->stage_events[i]) (void)hipEventRecord((hipEvent_t)a->stage_events[i], stream); };
-	FwdCtx c;
-	c.a = a; c.stream = stream;
 	c.gx = (a->W + FR_TILE - 1) / FR_TILE; c.gy = (a->H + FR_TILE - 1) / FR_TILE; c.T = c.gx * c.gy;
 	c.focal_y = a->H / (2.0f * a->tanfovy);
 	c.focal_x = a->W / (2.0f * a->tanfovx);
@@ -152,30 +218,38 @@ int fr_forward(fr_forward_args *a)
 	// RF: the two level states of a two-level tile are blended by different waves, which ADD their halves to the image
 	// (clearing only those tiles inside k_tile_levels tripled that kernel: 11 -> 32 us; the fill command is 6 us)
 	c.fov_split = a->variant == FR_VARIANT_FOV_PCHECK_OBB ? 1 : 0;
-	// The large fills of a frame -- the image (RF) and the training variants' two statistics arrays -- are only needed by the
-	// blend kernel at the END of the frame: they run on a helper stream beside the cull / binning kernels instead of in front
-	// of them (7 + 6 us at the head of a 1080p foveated frame), and the blend stage waits for them (rest_of_frame).
-	AuxStream *fill_ax = ((c.fov_split || has_stats(a->variant)) && !a->debug) ? aux_stream() : nullptr;
+	// The frame's helper stream (s2 of the pair that belongs to this thread and launch stream) carries the large fills -- the
+	// image (RF) and the training variants' two statistics arrays (7 + 6 us at the head of a 1080p foveated frame when they ran in
+	// front of it) -- beside the cull / binning kernels; only the blend kernel at the END of the frame needs them and waits
+	// (fr_forward_finish).
+	f->ax = !a->debug ? aux_stream(stream) : nullptr;
 	hipStream_t fill_stream = stream;
-	if (fill_ax)
+	if (f->ax && (c.fov_split || has_stats(a->variant)))
 	{
-		if (hipEventRecord(fill_ax->fork, stream) != hipSuccess || hipStreamWaitEvent(fill_ax->s2, fill_ax->fork, 0) != hipSuccess) { (void)hipGetLastError(); fill_ax = nullptr; }
-		else fill_stream = fill_ax->s2;
+		if (hipEventRecord(f->ax->fork, stream) != hipSuccess || hipStreamWaitEvent(f->ax->s2, f->ax->fork, 0) != hipSuccess) { (void)hipGetLastError(); f->ax = nullptr; }
+		else fill_stream = f->ax->s2;
 	}
-	if (c.fov_split) FR_HIP(hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, fill_stream));
+	auto fills_done = [&]() { if (fill_stream != stream && hipEventRecord(f->ax->join2, f->ax->s2) == hipSuccess) f->aux_pending = true; };
+	if (c.fov_split)
+	{
+		const hipError_t e = hipMemsetAsync(a->out_color, 0, sizeof(float) * 3 * (size_t)a->W * a->H, fill_stream);
+		fills_done();
+		if (e != hipSuccess) { set_error("hipMemsetAsync(out_color): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
+	}
 	if (has_stats(a->variant))
 	{
-		FR_HIP(hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, fill_stream));
-		FR_HIP(hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, fill_stream));
+		const hipError_t e1 = hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, fill_stream);
+		const hipError_t e2 = hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, fill_stream);
+		fills_done();
+		if (e1 != hipSuccess || e2 != hipSuccess) { set_error("hipMemsetAsync(statistics): %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return FR_ERR_HIP; }
 	}
-	if (fill_ax) (void)hipEventRecord(fill_ax->join2, fill_ax->s2);
-	// small clears in front of the first kernel: the per-tile instance counters (k_bin's workgroups add their shares to them;
+	// small clears in front of the first kernel: the per-tile instance counters (k_count's workgroups add their shares to them;
 	// the global-atomics path of huge tile grids counts in them directly) and, next to them, the level boxes (RF:
 	// k_tile_levels raises them with atomicMax; it clears the slab counters itself)
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
 	if (!is_fov(a->variant)) // RF: k_tile_levels clears them
 		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
-	static thread_local uint32_t frame_seq = 0; // this call's tag: the totals block's sequence word
+	static thread_local uint32_t frame_seq = 0; // this frame's tag: the totals block's sequence word
 	if (++frame_seq == 0) frame_seq = 1;
 	c.totals_seq = frame_seq;
 	mark(FR_STAGE_TILE_LEVELS);
@@ -183,101 +257,64 @@ int fr_forward(fr_forward_args *a)
 	mark(FR_STAGE_PROJECT);
 	rc = launch_project(c); if (rc) return rc;
 	mark(FR_STAGE_BIN);
-	rc = launch_bin(c); if (rc) return rc;
-	// the one host synchronisation of a frame: how many instances must the binning buffer hold. k_tile_scan writes
-	// the four numbers into pinned, device-mapped host memory of this thread (a copy command after the kernel
-	// costs ~10 us more of an idle GPU); pageable-copy fallback if that memory cannot be had.
-	// (one such block per host thread and device: the device address of mapped host memory belongs to the device
-	// that was current when it was asked for)
-	struct Pinned { uint32_t *host = nullptr, *dev = nullptr; int device = -1; };
-	static thread_local Pinned pinned_of[16];
+	rc = launch_geom(c); if (rc) return rc;
+	rc = launch_count(c); if (rc) return rc;
 	int cur_dev = 0;
 	(void)hipGetDevice(&cur_dev);
-	Pinned &pn = pinned_of[cur_dev & 15];
-	if (pn.device != cur_dev)
-	{
-		// (a slot is shared by devices 16 apart: whoever calls owns it, the previous owner's block is released)
-		if (pn.host) (void)hipHostFree(pn.host);
-		pn.host = pn.dev = nullptr;
-		pn.device = cur_dev;
-		void *h = nullptr, *d = nullptr;
-		if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess)
-		{ pn.host = (uint32_t *)h; pn.dev = (uint32_t *)d; for (int i = 0; i < 16; i++) pn.host[i] = 0; }
-		(void)hipGetLastError();
-	}
-	uint32_t *const pinned = pn.host, *const pinned_dev = pn.dev;
-	c.totals_host_dev = pinned_dev;
+	f->pin = a->debug ? nullptr : take_pinned(cur_dev);
+	c.totals_host_dev = f->pin ? f->pin->dev : nullptr;
 	mark(FR_STAGE_TILE_SCAN);
 	rc = launch_tile_scan(c); if (rc) return rc;
+	*out = f; guard.f = nullptr;
+	return FR_OK;
+}
 
+int fr_forward_finish(fr_frame *f)
+{
+	if (!f) { set_error("null frame"); return FR_ERR_INVALID; }
+	struct Guard { fr_frame *f; ~Guard() { delete f; } } guard = { f }; // the handle is released whatever happens
+	if (f->empty) return FR_OK;
+	fr_forward_args *a = f->a;
+	FwdCtx &c = f->c;
+	hipStream_t stream = c.stream;
+	auto mark = [&](int i) { if (a->stage_events && a->stage_events[i]) (void)hipEventRecord((hipEvent_t)a->stage_events[i], stream); };
 	// Everything behind the tile scan needs the frame's counts: the number of instances D (size of the binning workspace)
-	// and the sort / blend class counts. They are on their way to this thread's pinned block, which the host polls: the
+	// and the sort / blend class counts. They are on their way to the frame's pinned block, which the host polls: the
 	// numbers land a few microseconds before k_tile_scan retires, so the launches that follow reach the queue while it still
-	// runs and the GPU does not wait for the host (measured: the union of a frame's kernels covers all of it but ~20 us, none
-	// of them at this point). LAUNCH-AHEAD MODE (opt-in, FR_LAUNCH_AHEAD=1): when the caller's binning buffer of the
-	// previous frame of this kind was large enough, the rest of the frame is launched BEFORE the wait, sized by that frame
-	// -- the kernels read the counts from device memory and leave at once if the frame does not fit (frame_fits), in which
-	// case the stage is replayed -- so that the call returns ~0.35 ms earlier (a host with other work to do between frames).
-	// It does not make the GPU faster: the grids are bounds, the kernels find their work through one more indirection, and the
-	// same frames take 1.3 % longer (0.753 vs 0.743 ms, four alternations on one box), which is why it is not the default.
-	struct Guess { int32_t variant = -1, P = 0, W = 0, H = 0; int64_t capacity = 0, items_cap = 0; int heavy4 = 0, heavy8 = 0; };
-	static thread_local Guess guesses[8];
-	Guess &gs = guesses[a->variant & 7];
-	const bool same_kind = gs.variant == a->variant && gs.P == a->P && gs.W == a->W && gs.H == a->H;
-	const char *ahead_env = getenv("FR_LAUNCH_AHEAD"); // (read per call: tests switch it)
-	const bool speculate = same_kind && gs.capacity > 0 && pinned && !a->debug && ahead_env != nullptr && ahead_env[0] == '1';
-	const int64_t items_max = (int64_t)(c.fov_split ? 4 : 2) * c.T; // two bands per tile, twice that for an RF two-level tile
-	auto rest_of_frame = [&](int64_t capacity, bool known, char *have = nullptr) -> int
-	{
-		char *bptr = have ? have : a->binning_resize(a->resize_user[1], carve_bin(capacity, nullptr, c.T).bytes);
-		if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }
-		c.bin = carve_bin(capacity, bptr, c.T);
-		c.capacity = capacity; c.counts_known = known ? 1 : 0; c.hint_heavy4 = gs.heavy4; c.hint_heavy8 = gs.heavy8;
-		c.items_cap = known ? items_max : (gs.items_cap < items_max ? gs.items_cap : items_max);
-		mark(FR_STAGE_EMIT);
-		int r = FR_OK;
-		if (!known || a->num_rendered > 0) { r = launch_emit(c); if (r) return r; }
-		mark(FR_STAGE_TILE_SORT);
-		if (!known || a->num_rendered > 0) { r = launch_tile_sort(c); if (r) return r; }
-		mark(FR_STAGE_RENDER);
-		if (fill_ax) (void)hipStreamWaitEvent(stream, fill_ax->join2, 0); // the image / statistics fills of the frame's head
-		r = launch_render(c);
-		mark(FR_NUM_STAGES);
-		return r;
-	};
-	if (speculate) { rc = rest_of_frame(gs.capacity, false); if (rc) return rc; }
-
+	// runs and the GPU does not wait for the host.
 	// The binning workspace is asked for BEFORE the count is in -- sized like the largest frame of this kind so far plus a
 	// quarter -- while the GPU is still binning: the callback (the caller's allocator, a Python function behind ctypes in the
 	// reference-shaped host code) is then off the critical path between the tile scan and k_emit. A frame that does not fit
-	// asks again with its real size.
+	// asks again with its real size (the callback may therefore be called twice per frame; the last answer is the one in use).
+	Guess &gs = guess_for(a->variant);
+	const bool same_kind = gs.variant == a->variant && gs.P == a->P && gs.W == a->W && gs.H == a->H;
 	char *early_bin = nullptr;
-	const int64_t early_cap = (same_kind && !speculate && !a->debug) ? gs.capacity : 0;
+	const int64_t early_cap = (same_kind && !a->debug) ? gs.capacity : 0;
 	if (early_cap > 0) early_bin = a->binning_resize(a->resize_user[1], carve_bin(early_cap, nullptr, c.T).bytes);
 
 	uint32_t totals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	if (!pinned) FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
-	if (pinned && !a->debug)
+	uint32_t *const pinned = f->pin ? f->pin->host : nullptr;
+	if (!pinned)
+	{
+		FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
+		FR_HIP(hipStreamSynchronize(stream));
+	}
+	else
 	{
 		// poll the sequence word instead of sleeping on the stream: the numbers arrive a few microseconds before
 		// the kernel retires, and the wake-up latency of a stream wait is saved. The stream is queried now and then
 		// so that a failed launch cannot hang the caller.
 		const volatile uint32_t *v = pinned;
-		for (uint32_t spins = 1; __atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != frame_seq; spins++)
+		for (uint32_t spins = 1; __atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != c.totals_seq; spins++)
 			if ((spins & 0xffff) == 0)
 			{
 				const hipError_t q = hipStreamQuery(stream);
 				if (q == hipErrorNotReady) continue;
 				if (q != hipSuccess) { set_error("hip: %s", hipGetErrorString(q)); return FR_ERR_HIP; }
-				if (__atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != frame_seq) { set_error("tile scan did not publish its totals"); return FR_ERR_HIP; }
+				if (__atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != c.totals_seq) { set_error("tile scan did not publish its totals"); return FR_ERR_HIP; }
 			}
 		for (int i = 0; i < 4; i++) totals[i] = v[i];
 		totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7];
-	}
-	else
-	{
-		FR_HIP(hipStreamSynchronize(stream));
-		if (pinned) { const volatile uint32_t *v = pinned; for (int i = 0; i < 4; i++) totals[i] = v[i]; totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7]; }
 	}
 	// reference auxiliary.h:156-160: a point behind the near plane although the caller said the cloud was prefiltered
 	// (there: printf + __trap, which kills the context; here an error code)
@@ -288,21 +325,36 @@ int fr_forward(fr_forward_args *a)
 	a->max_tile_instances = (int32_t)totals[1];
 	c.heavy4 = (int)totals[2]; c.heavy2 = (int)totals[3];
 	c.n_items = (int)totals[5]; c.heavy8 = (int)totals[6];
-	// what the next frame of this kind will be launched with: a quarter of headroom over the largest frame seen
+	// what the next frame of this kind will ask for: a quarter of headroom over the largest frame seen
 	const int64_t want = (int64_t)totals[0] + (int64_t)totals[0] / 4 + 65536;
-	if (!same_kind) { gs.variant = a->variant; gs.P = a->P; gs.W = a->W; gs.H = a->H; gs.capacity = 0; gs.items_cap = 0; }
-	const bool fits = speculate && (int64_t)totals[0] <= gs.capacity && (int64_t)totals[5] <= (gs.items_cap < items_max ? gs.items_cap : items_max);
+	if (!same_kind) { gs.variant = a->variant; gs.P = a->P; gs.W = a->W; gs.H = a->H; gs.capacity = 0; }
 	if (want > gs.capacity) gs.capacity = want;
-	const int64_t want_items = (int64_t)totals[5] + (int64_t)totals[5] / 16 + 64; // (a moving gaze changes the two-level ring by a few per cent)
-	if (want_items > gs.items_cap) gs.items_cap = want_items;
-	gs.heavy4 = (int)totals[2]; gs.heavy8 = (int)totals[6];
-	g_spec_stats[speculate ? (fits ? 0 : 1) : 2]++;
-	if (speculate && !fits) g_spec_stats[0]++;
-	if (fits) return FR_OK; // the frame is already on its way
-	// first frame of its kind, a debug call, or the speculative launch found the workspace too small (its kernels left
-	// without touching anything): the stage with the known counts
-	if (early_bin && (int64_t)totals[0] <= early_cap) return rest_of_frame(early_cap, true, early_bin);
-	return rest_of_frame(speculate ? gs.capacity : (int64_t)totals[0], true);
+
+	const bool fits_early = early_bin && (int64_t)totals[0] <= early_cap;
+	const int64_t capacity = fits_early ? early_cap : (int64_t)totals[0];
+	char *bptr = fits_early ? early_bin : a->binning_resize(a->resize_user[1], carve_bin(capacity, nullptr, c.T).bytes);
+	if (!bptr) { set_error("binning resize callback returned null"); return FR_ERR_ALLOC; }
+	c.bin = carve_bin(capacity, bptr, c.T);
+	c.capacity = capacity;
+	c.items_cap = (int64_t)(c.fov_split ? 4 : 2) * c.T; // two bands per tile, twice that for an RF two-level tile
+	int rc = FR_OK;
+	mark(FR_STAGE_EMIT);
+	if (a->num_rendered > 0) { rc = launch_emit(c); if (rc) return rc; }
+	mark(FR_STAGE_TILE_SORT);
+	if (a->num_rendered > 0) { rc = launch_tile_sort(c); if (rc) return rc; }
+	mark(FR_STAGE_RENDER);
+	f->join_aux(); // the fills of the frame's head
+	rc = launch_render(c);
+	mark(FR_NUM_STAGES);
+	return rc;
+}
+
+int fr_forward(fr_forward_args *a)
+{
+	fr_frame *f = nullptr;
+	const int rc = fr_forward_begin(a, &f);
+	if (rc) return rc;
+	return fr_forward_finish(f);
 }
 
 int fr_pack_geom(int32_t P, const float *means3D, const float *scales, const float *rotations, const float *opacities,

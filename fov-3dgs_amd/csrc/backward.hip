@@ -575,7 +575,7 @@ int launch_backward(const fr_backward_args *a)
 			{ a->dL_dmean3D, 12 * P }, { a->dL_dmean2D, 12 * P }, { a->dL_dopacity, 4 * P }, { a->dL_dscale, 12 * P }, { a->dL_drot, 16 * P },
 			{ a->dL_dsh, 12 * m0 * P }, { a->dL_dsh_rest, have_sh && a->shs_rest ? 12 * ((size_t)a->M - 1) * P : 0 },
 			{ a->dL_dcolor, 12 * P }, { a->dL_dconic, 16 * P }, { a->dL_dcov3D, 24 * P } };
-		AuxStream *ax = (a->R > 0 && !a->debug) ? aux_stream() : nullptr;
+		AuxStream *ax = (a->R > 0 && !a->debug) ? aux_stream(stream) : nullptr;
 		hipStream_t fs = stream;
 		if (ax)
 		{

@@ -111,25 +111,40 @@ int launch_tile_scan(FwdCtx &c)
 	return check_launch("tile_scan", c.stream, c.a->debug);
 }
 
-// Helper stream of the calling host thread (per device), created on first use. The size classes of the per-tile
-// sort are independent kernels; the two classes with long lists hold a handful of tiles that each keep one CU busy
-// for 50-80 us, so the (many) short lists are sorted meanwhile on the helper stream (event fork / join).
-AuxStream *aux_stream()
+// Helper streams of the calling host thread, one pair per (device, launch stream), created on first use: two frames in flight on
+// two launch streams must not share them (frame n + 1's fills would queue behind frame n's colours). The size classes of the
+// per-tile sort are independent kernels; the classes with long lists hold a handful of tiles that each keep one CU busy
+// for 50-80 us, so the (many) short lists are sorted meanwhile on the helper stream `s` (event fork / join); `s2` carries a
+// frame's fills and its colour kernel (fr_forward_begin / _finish), `s` also the backward pass's gradient fills.
+AuxStream *aux_stream(hipStream_t main)
 {
 	static thread_local AuxStream cache[8];
+	static thread_local int next_victim = 0;
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-	AuxStream &a = cache[dev & 7];
-	if (a.device != dev)
+	for (AuxStream &a : cache) if (a.device == dev && a.main == main) return a.ok ? &a : nullptr;
+	AuxStream *slot = nullptr;
+	for (AuxStream &a : cache) if (a.device < 0) { slot = &a; break; }
+	if (!slot)
 	{
-		a.device = dev;
-		a.ok = hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) == hipSuccess &&
-			hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) == hipSuccess &&
-			hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess &&
-			hipEventCreateWithFlags(&a.join, hipEventDisableTiming) == hipSuccess &&
-			hipEventCreateWithFlags(&a.join2, hipEventDisableTiming) == hipSuccess;
-		(void)hipGetLastError();
+		// (more than eight launch streams in one thread: the oldest pair is recycled; its streams drain first)
+		slot = &cache[next_victim]; next_victim = (next_victim + 1) & 7;
+		if (slot->ok)
+		{
+			(void)hipStreamSynchronize(slot->s); (void)hipStreamSynchronize(slot->s2);
+			(void)hipStreamDestroy(slot->s); (void)hipStreamDestroy(slot->s2);
+			(void)hipEventDestroy(slot->fork); (void)hipEventDestroy(slot->fork2); (void)hipEventDestroy(slot->join); (void)hipEventDestroy(slot->join2);
+		}
 	}
+	AuxStream &a = *slot;
+	a.device = dev; a.main = main;
+	a.ok = hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) == hipSuccess &&
+		hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) == hipSuccess &&
+		hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess &&
+		hipEventCreateWithFlags(&a.fork2, hipEventDisableTiming) == hipSuccess &&
+		hipEventCreateWithFlags(&a.join, hipEventDisableTiming) == hipSuccess &&
+		hipEventCreateWithFlags(&a.join2, hipEventDisableTiming) == hipSuccess;
+	(void)hipGetLastError();
 	return a.ok ? &a : nullptr;
 }
 
@@ -137,9 +152,8 @@ AuxStream *aux_stream()
 //   <= 512 entries: one wave;  513..2047: 256 threads;  2048..4095: 512 threads;  4096..8191: 512 threads x 16 keys;
 //   8192..16383: 1024 threads x 16 keys (139 KiB of LDS);  longer: regrouped by depth into chunks first (k_split_long).
 // The classes are independent: the three of the long lists run on the launch stream, the two of the short lists meanwhile on
-// the helper stream (event fork / join). counts_known: the host has the tile scan's class counts; otherwise the stage is
-// launched ahead of them: the grids come from the previous frame of the kind (FwdCtx::hint_*), every kernel finds its lists
-// from the counts in device memory and loops if its grid came out too small.
+// the helper stream (event fork / join). Every kernel finds its lists from the tile scan's class counts in device memory (the
+// grids come from the host's copy of them) and loops if its grid came out too small.
 int launch_tile_sort(FwdCtx &c)
 {
 	const uint2 *rg = c.img.ranges;
@@ -147,13 +161,10 @@ int launch_tile_sort(FwdCtx &c)
 	uint32_t *totals = c.img.totals;
 	const SpecLimits lim = { (uint32_t)c.capacity, (uint32_t)c.items_cap };
 	static const bool serial = getenv("FR_SERIAL_SORT") != nullptr;
-	const bool known = c.counts_known != 0;
-	// grids ahead of the counts: a quarter more than last time (at least 64 workgroups)
-	auto ahead = [&](int n) { const int g = n + n / 4 + 64; return g < c.T ? g : c.T; };
-	const int h4 = known ? c.heavy4 : ahead(c.hint_heavy4), h8 = known ? c.heavy8 : ahead(c.hint_heavy8);
-	const int longest = known ? c.a->max_tile_instances : (1 << 30);
+	const int h4 = c.heavy4, h8 = c.heavy8;
+	const int longest = c.a->max_tile_instances;
 	// long lists exist: the short ones are sorted meanwhile on the helper stream
-	AuxStream *ax = (h4 > 0 && !serial && !c.a->debug) ? aux_stream() : nullptr;
+	AuxStream *ax = (h4 > 0 && !serial && !c.a->debug) ? aux_stream(c.stream) : nullptr;
 	// (measured on the S-6M frames, stage time: this split 88 us; the 2048..4095 class on the helper stream too 94; on a third
 	// stream 96; the 8192..16383 class -- a handful of workgroups that need a whole CU's LDS each -- on a third stream 95: the
 	// stage is bound by the sum of the work, not by a chain)
@@ -190,12 +201,12 @@ int launch_tile_sort(FwdCtx &c)
 		if (lds_ok != hipSuccess) { set_error("hipFuncSetAttribute(k_tile_msort_direct<512, 16>): %s", hipGetErrorString(lds_ok)); return FR_ERR_HIP; }
 		hipLaunchKernelGGL((k_tile_msort_direct<512, 16>), dim3(h8), dim3(512), lds, c.stream, rg, ord, c.bin.entries, c.bin.point_list, totals, lim, 8, 6);
 	}
-	if (h4 - (known ? h8 : 0) > 0)
-		hipLaunchKernelGGL((k_tile_msort_direct<512, 8>), dim3(h4 - (known ? h8 : 0)), dim3(512), 4608 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries,
+	if (h4 - h8 > 0)
+		hipLaunchKernelGGL((k_tile_msort_direct<512, 8>), dim3(h4 - h8), dim3(512), 4608 * sizeof(uint64_t), c.stream, rg, ord, c.bin.entries,
 			c.bin.point_list, totals, lim, 6, 2);
 	// (one workgroup per list of the class: a grid over all T tiles started 16 000 workgroups per frame only to find out that
 	// the list belongs to another kernel)
-	const int nmid = known ? c.heavy2 : c.T, nshort = known ? c.T - c.heavy4 - c.heavy2 : c.T;
+	const int nmid = c.heavy2, nshort = c.T - c.heavy4 - c.heavy2;
 	if (nmid > 0)
 		hipLaunchKernelGGL((k_tile_msort<256, 8, false>), dim3(nmid), dim3(256), 2304 * sizeof(uint64_t), small, rg, ord, c.bin.entries, c.bin.point_list,
 			c.T, totals, lim);

@@ -10,7 +10,8 @@
 #define FR_FOV_LEVELS 4       // RF auxiliary.h:26 fov_num
 #define FR_SORT_LDS_MAX 8192  // longest per-tile list sorted inside LDS (64 KiB of u64 keys)
 #ifndef FR_BIN_THREADS
-#define FR_BIN_THREADS 512    // workgroup size of k_bin (k_emit: FR_EMIT_SHARE times as many)
+#define FR_BIN_THREADS 1024   // workgroup size of k_count (k_emit: FR_EMIT_SHARE times as many): the tile walk is a chain of LDS round
+                              // trips, sixteen waves per CU hide what eight did not (k_count 120 -> ? us)
 #endif
 // persistent workgroups of the binning kernels: 2 per CU by LDS (up to 76 KiB each); k_bin's ~145 VGPRs let only one of
 // them run at a time (2 waves/SIMD), the other finds the slab counters empty -- 384-thread workgroups (3 waves/SIMD)
@@ -19,6 +20,7 @@
 #define FR_PROJ_MAX_WAVES 8192                 // k_project's grid is capped to this many waves ...
 #define FR_CROW_PAD (64 * FR_PROJ_MAX_WAVES)     // ... each of which may leave its last chunk's worth of row slots unused
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram of 32-bit counts up to 64 KiB
+#define FR_ITEM_NONE 0xffffffffu    // GeomWS::lrange of an item that lands in no tile
 #define FR_LDS_HIST16_MAX_TILES 34816 // ... of 16-bit counts (two tiles per word) beyond that: a 4K frame has 32 400 tiles
 #define FR_HIST16_MAX_SLABS 127       // slabs a wave of k_bin takes at most then: 8 waves x 127 x 64 items < 65 536 per workgroup
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
@@ -31,7 +33,7 @@
 // n / target + 1 of them, and there are at most D / FR_SORT_SPLIT_MIN long lists
 #define FR_SORT_MAX_CHUNKS(D) ((size_t)(D) / FR_SORT_CHUNK_TARGET + (size_t)(D) / FR_SORT_SPLIT_MIN + 16)
 #define FR_LV_BBOX_STRIDE 32  // words between the level boxes of ImageWS::lv_bbox (one 128-byte line each)
-#define FR_SLAB_CTR_WORDS 288 // header line + eight 128-byte counter lines
+#define FR_SLAB_CTR_WORDS 32  // one 128-byte line of frame counters (GeomWS::slab_ctr)
 
 namespace fr {
 
@@ -66,19 +68,19 @@ struct GeomWS {
 	float4 *wrec;       // [4P] walk record of item i at [4i..4i+3], written by k_bin for k_emit:
 	                    //      (cx, cy, e1x, e1y | e2x, e2y, len1, len2 | Gaussian index + flags << 30, depth bits, x0 + y0 << 16, width |
 	                    //      tiles, highest level, -, -); flags: 1 = lands in a tile, 2 = the OBB test applies
-	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity) of item i at [4i..4i+3]
-	uint32_t *lrange;   // [P]  RF packed level range lo | hi<<8 per item
-	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {prefiltered violation flag, number of entries in vis_list, ...}; k_bin's eight slab pull
-	                    // counters live at [32 * (1 + r)], one 128-byte line each
+	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity) of item i at [4i..4i+3] (k_count)
+	uint32_t *lrange;   // [P]  per item, written by k_count: 0xffffffff = the item lands in no tile (culled everywhere), else the packed
+	                    //      level range lo | hi<<8 (RF; 0 for the variants without levels)
+	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {prefiltered violation flag, number of entries in vis_list, workgroups of the cull pass that
+	                    // are done, odd highest level seen}
 	uint32_t *vis_list; // [P]  indices of the Gaussians that survive the cull pass, increasing
 	uint32_t *vis_seg;  // [P + FR_CROW_PAD] the same indices as k_project's waves leave them: wave w of the cull pass owns the slots
 	                    //      from w * (its chunks) * 64 on and fills them in the order it meets its survivors (its chunks are consecutive)
-	uint32_t *proj_counts; // [FR_PROJ_MAX_WAVES] survivors of every wave of the cull pass
+	uint32_t *proj_counts; // [FR_PROJ_MAX_WAVES] survivors of every wave of the cull pass ...
+	uint32_t *wbase;       // [FR_PROJ_MAX_WAVES + 1] ... and their exclusive running sums (the cull pass's last workgroup): the first ITEM of
+	                       // every wave's region; [waves] = the number of items
 	float4 *crow;       // [3 (P + FR_CROW_PAD)] foveated variants' candidate rows (xyz, scale | scale.yz, rotation.xy | rotation.zw, highest
 	                    //      level, index), same slots as vis_seg ...
-	uint32_t *vis_src;  // [P]  (unused)
-	int32_t *slab_next;   // [ceil(P / 64)] per-wave chains of the 64-entry vis_list slabs k_bin's waves pulled ...
-	int32_t *wave_head;   // [FR_BIN_BLOCKS * FR_BIN_THREADS / 64] ... and the last slab of every wave (-1: none)
 	size_t bytes;
 };
 __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
@@ -91,27 +93,19 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 	g.cov3D = (float *)(base + off); off = align_up(off + P * (keeps ? 16 : 6) * sizeof(float));
 	g.acc = nullptr;
 	if (keeps) { g.acc = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4)); }
-	g.lvl = nullptr; g.lrange = nullptr;
+	g.lvl = nullptr;
 	g.wrec = (float4 *)(base + off); off = align_up(off + P * 4 * sizeof(float4));
-	if (variant == FR_VARIANT_FOV_PCHECK_OBB)
-	{
-		g.lvl = (float4 *)(base + off); off = align_up(off + P * FR_FOV_LEVELS * sizeof(float4));
-		g.lrange = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
-	}
+	if (variant == FR_VARIANT_FOV_PCHECK_OBB) { g.lvl = (float4 *)(base + off); off = align_up(off + P * FR_FOV_LEVELS * sizeof(float4)); }
+	g.lrange = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
 	g.slab_ctr = (uint32_t *)(base + off); off = align_up(off + FR_SLAB_CTR_WORDS * sizeof(uint32_t));
 	g.vis_list = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
 	g.vis_seg = (uint32_t *)(base + off); off = align_up(off + (P + FR_CROW_PAD) * sizeof(uint32_t));
 	g.proj_counts = (uint32_t *)(base + off); off = align_up(off + FR_PROJ_MAX_WAVES * sizeof(uint32_t));
+	g.wbase = (uint32_t *)(base + off); off = align_up(off + (FR_PROJ_MAX_WAVES + 1) * sizeof(uint32_t));
 	// candidate rows: only the foveated variants' cull pass stores them (k_project's ROWS); 52 B per Gaussian the plain and
 	// training frames need not carry
-	g.crow = nullptr; g.vis_src = nullptr;
-	if (is_fov(variant))
-	{
-		g.crow = (float4 *)(base + off); off = align_up(off + (P + FR_CROW_PAD) * 3 * sizeof(float4));
-		g.vis_src = (uint32_t *)(base + off); off = align_up(off + P * sizeof(uint32_t));
-	}
-	g.slab_next = (int32_t *)(base + off); off = align_up(off + ((P + 63) / 64 + 1) * sizeof(int32_t));
-	g.wave_head = (int32_t *)(base + off); off = align_up(off + FR_BIN_BLOCKS * (FR_BIN_THREADS / 64) * sizeof(int32_t));
+	g.crow = nullptr;
+	if (is_fov(variant)) { g.crow = (float4 *)(base + off); off = align_up(off + (P + FR_CROW_PAD) * 3 * sizeof(float4)); }
 	g.bytes = off + 256;
 	return g;
 }
@@ -399,14 +393,9 @@ struct FwdCtx {
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
 	int heavy8;         // tiles with >= 4096 instances
 	int n_items;        // entries of ImageWS::render_items
-	// The kernels behind the tile scan read the frame's counts (ImageWS::totals) from device memory and leave at once when
-	// the frame has more instances than the binning workspace holds, so they can be launched BEFORE the host knows the
-	// counts (fr_forward): counts_known = 0 -> grids are sized by upper bounds, heavy* / n_items above are not valid.
-	int counts_known;
 	int proj_waves, proj_cpw; // the cull pass's grid in waves and the consecutive chunks each wave took
-	int hint_heavy4, hint_heavy8; // counts not known: the class counts of the previous frame of this kind (sort plan, grid sizes)
 	int64_t capacity;   // instances the binning workspace was carved for
-	int64_t items_cap;  // blend work items the blend grid has workgroups for (a frame with more is replayed)
+	int64_t items_cap;  // upper bound of the blend work items (the kernels' defensive bound checks)
 	uint32_t *totals_host_dev; // device address of the host's pinned copy of totals[4] (+ sequence word), or null
 	uint32_t totals_seq;       // this frame's sequence number for that word
 	float focal_x, focal_y;
@@ -414,8 +403,8 @@ struct FwdCtx {
 	ImageWS img;
 	BinWS bin;
 };
-struct AuxStream { int device = -1; hipStream_t s, s2; hipEvent_t fork, join, join2; bool ok = false; };
-AuxStream *aux_stream(); // helper streams of the calling host thread (binning.hip)
+struct AuxStream { int device = -1; hipStream_t main = nullptr, s, s2; hipEvent_t fork, fork2, join, join2; bool ok = false; };
+AuxStream *aux_stream(hipStream_t main); // helper streams of the calling host thread for work launched on `main` (binning.hip)
 int launch_tile_levels(FwdCtx &c);
 int launch_pack_geom(int P, const float *means3D, const float *scales, const float *rotations, const float *opacities, int levels,
 	const float *highest_levels, float *out, hipStream_t stream);
@@ -429,7 +418,8 @@ int launch_activate_forward(int P, const float *rs, const float *rq, const float
 int launch_activate_backward(int P, const float *rs, const float *rq, const float *ro, const float *gs, const float *gq, const float *go,
 	float *ds, float *dq, float *dop, hipStream_t stream);
 int launch_project(FwdCtx &c); // cull pass + the ordered compaction of its survivors
-int launch_bin(FwdCtx &c);
+int launch_geom(FwdCtx &c);   // full projection of the cull pass's survivors -> walk records, blend records
+int launch_count(FwdCtx &c);  // tile counts from the walk records + the colours of the items that landed somewhere
 int launch_tile_scan(FwdCtx &c);
 int launch_emit(FwdCtx &c);
 int launch_tile_sort(FwdCtx &c);

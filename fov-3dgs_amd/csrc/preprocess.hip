@@ -16,6 +16,7 @@
 // and re-evaluated in emit (no bitmap, no per-Gaussian scan); instances are bucketed by tile
 // at emission time through per-tile cursors, so no global 64-bit radix sort is needed.
 #include "common.h"
+#include <cstdlib>
 
 namespace fr {
 
@@ -692,8 +693,45 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	// kernel that copies the regions into one list (11 us of launch and dependent round trips); the copy at the end of this
 	// kernel with every workgroup adding up the counts of those in front of it (the polling of the workgroups that finish
 	// first halves the memory bandwidth of those still streaming: 74 -> 157 us).
-	if (lane == 0) a.geom.proj_counts[wave_gid] = nrow;
+	// The wave's count leaves as a RETURNING device-scope atomic: it is performed at the memory side once its value is back, so
+	// the workgroup can be counted as done without a release fence (an agent-scope fence writes the L2's dirty lines back --
+	// this kernel's radii and candidate rows -- once per wave: 80 -> 250 us).
+	if (lane == 0)
+	{
+		const uint32_t was = atomicExch(a.geom.proj_counts + wave_gid, nrow);
+		asm volatile("" :: "v"(was));
+	}
 	if (FOV && __any(odd_level) && lane == 0) atomicOr(a.geom.slab_ctr + 3, 1u);
+	// The LAST workgroup to get here turns the counts into running sums (wbase[w] = first item of wave w's region, wbase[waves] =
+	// slab_ctr[1] = the number of items): 8192 counts, eight per thread, ~2 us at the tail of a kernel whose workgroups finish
+	// within a few us of each other -- where every workgroup of round 3's binning kernel scanned them for itself in its prologue.
+	__shared__ uint32_t s_last, s_part[FR_PROJ_THREADS / 64];
+	__syncthreads();
+	if (threadIdx.x == 0) s_last = atomicAdd(a.geom.slab_ctr + 2, 1u) == gridDim.x - 1 ? 1u : 0u;
+	__syncthreads();
+	if (s_last)
+	{
+		// (the counts are read with device-scope atomic loads: they come from the memory side, not from this XCD's L2)
+		const int per = (nwaves + FR_PROJ_THREADS - 1) / FR_PROJ_THREADS; // consecutive waves per thread
+		const int w0 = (int)threadIdx.x * per, w1 = min(nwaves, w0 + per);
+		uint32_t cv[FR_PROJ_MAX_WAVES / FR_PROJ_THREADS], mine = 0;
+#pragma unroll
+		for (int k = 0; k < FR_PROJ_MAX_WAVES / FR_PROJ_THREADS; k++)
+		{
+			cv[k] = w0 + k < w1 ? __hip_atomic_load(a.geom.proj_counts + w0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+			mine += cv[k];
+		}
+		const uint32_t sc = wave_incl_scan_u32(mine, lane);
+		if (lane == 63) s_part[threadIdx.x >> 6] = sc;
+		__syncthreads();
+		uint32_t off = 0;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += s_part[w];
+		uint32_t run = off + sc - mine;
+#pragma unroll
+		for (int k = 0; k < FR_PROJ_MAX_WAVES / FR_PROJ_THREADS; k++)
+			if (w0 + k < w1) { a.geom.wbase[w0 + k] = run; run += cv[k]; }
+		if (w1 == nwaves && w0 < w1) { a.geom.wbase[nwaves] = run; a.geom.slab_ctr[1] = run; }
+	}
 #ifdef FR_PROJ_TIMERS
 	if (lane == 0)
 	{
@@ -704,36 +742,300 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 #endif
 }
 
-// Stage 2 (RS rasterizer_impl.cu:70-146, RF :264-383 + :490-530): for every survivor, count the tiles it
-// really lands in (OBB / foveal tests), bump the per-tile instance counters, evaluate its colour(s) and finish
-// its record. Persistent workgroups of FR_BIN_THREADS threads, work handed out per wave (see below).
-// LDSH: the counters are an LDS-private histogram (T <= 16 Ki tiles) written once per workgroup to
-// hist[block][tile] -- no global atomics at all; otherwise (huge tile grids) global atomics on tile_count.
-// LDSH == 2: 16-bit counts, two tiles per word (tile grids of more than 16 Ki tiles: 4K frames); a workgroup then bins fewer
-// than 65 536 items (FR_HIST16_MAX_SLABS per wave), so no count can overflow.
-#define BUMP_TILE(ti) do { if (LDSH == 2) atomicAdd(&lds_hist[(ti) >> 1], 1u << (16 * ((ti) & 1))); \
-	else if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
-#ifndef FR_BIN_PREFETCH
-#define FR_BIN_PREFETCH 1 // colour rows fetched at the head of a slab (0: after the walk, as round 2 did)
-#endif
-// CROW: the candidate's inputs come as the row k_project stored (GeomWS::crow via vis_src).
-template <int VARIANT, int LDSH, bool PACKED = false, bool CROW = false>
-__global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
+// ---- per-item rows through LDS ------------------------------------------------------------------
+// Everything the library keeps per candidate is a row of N float4 indexed by ITEM, and a wave works on 64 consecutive items:
+// its rows are one contiguous piece of memory, but a lane's own row lies 16 N bytes from its neighbour's, so a load or store
+// instruction of the lanes' own rows touches 24-32 cache lines (~3 cycles per lane of the CU's one address unit: eleven such
+// stores per slab were a quarter of round 2's binning kernel). Transposed through the wave's LDS rows an instruction moves one
+// contiguous kilobyte. st: the wave's staging area of >= 64 N float4; nitems: valid items of the wave (0..64).
+#define FR_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+template <int N>
+__device__ __forceinline__ void rows_store(const float4 (&rows)[N], float4 *st, float4 *dst, const int nitems, const int lane)
+{
+#pragma unroll
+	for (int i = 0; i < N; i++) st[N * lane + i] = rows[i];
+	FR_WAVE_LDS_SYNC();
+#pragma unroll
+	for (int i = 0; i < N; i++) { const int c = i * 64 + lane; if (c < N * nitems) dst[c] = st[c]; }
+	FR_WAVE_LDS_SYNC();
+}
+// the two halves of the load apart, so that a kernel can have the next slab's pieces in flight while it works on this one
+template <int N>
+__device__ __forceinline__ void rows_fetch(float4 (&piece)[N], const float4 *src, const int nitems, const int lane)
+{
+#pragma unroll
+	for (int i = 0; i < N; i++) { const int c = i * 64 + lane; piece[i] = c < N * nitems ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f); }
+}
+template <int N>
+__device__ __forceinline__ void rows_unpack(float4 (&rows)[N], const float4 (&piece)[N], float4 *st, const int lane)
+{
+#pragma unroll
+	for (int i = 0; i < N; i++) st[i * 64 + lane] = piece[i];
+	FR_WAVE_LDS_SYNC();
+#pragma unroll
+	for (int i = 0; i < N; i++) rows[i] = st[N * lane + i];
+	FR_WAVE_LDS_SYNC();
+}
+
+// Stage 2 (reference: the rest of preprocessCUDA, RS forward.cu:155-293 / RF :105-238): the full projection of every survivor
+// of the cull pass -- 3D covariance, EWA 2D covariance, conic, radius, OBB axes, the tile rectangle to walk -- one lane per
+// candidate, no tile walk and no LDS table, so that the per-item math (a ~600-instruction dependent chain per lane) runs at the
+// occupancy its registers allow instead of at the one workgroup per CU of the kernel that owns the tile histogram (round 3's
+// k_bin did both at 1.7 waves per SIMD). A WAVE takes the region of ONE wave of the cull pass: its survivors' inputs (the
+// candidate rows k_project stored, or gathers through vis_seg) are contiguous, and so are its items: wbase[w] .. + count.
+// Writes, per item: the walk record (k_count, k_emit), the blend record with the POSITION in its colour slots (k_colour replaces
+// it by the colour), (training) the backward pass's input row and the cleared gradient row; per Gaussian: the radius; vis_list.
+template <int VARIANT, bool PACKED = false, bool CROW = false>
+__global__ void __launch_bounds__(256) k_geom(const PreArgs a)
 {
 	static_assert(!(PACKED && CROW), "the packed model layout has its own rows");
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
+	constexpr bool FOV = is_fov(VARIANT);
+	constexpr bool LEVELCOL = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
+	__shared__ float4 s_st[4][4 * 64];
+	// RF: the five level boxes every candidate's walk rectangle is clipped to (walk_rect)
+	__shared__ uint4 s_lvbox[5];
+	if (FOV && threadIdx.x < 5) s_lvbox[threadIdx.x] = *(const uint4 *)(a.lv_bbox + threadIdx.x * FR_LV_BBOX_STRIDE);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+	const int w = (int)blockIdx.x * 4 + wv; // the wave of the cull pass whose survivors this wave takes
+	if (w >= a.proj_waves) return;          // (the waves of a workgroup are on their own from here: no workgroup barrier below)
+	const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.geom.proj_counts[w]);
+	if (cnt == 0) return;
+	const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.geom.wbase[w]);
+	const uint32_t row_base = (uint32_t)w * (uint32_t)a.proj_cpw * 64u;
+	float4 *const st = s_st[wv];
+	float cam_vm[16], cam_pm[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+	{
+		cam_vm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.viewmatrix[i])));
+		cam_pm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.projmatrix[i])));
+	}
+	const bool raw = !CROW && !PACKED && !FOV && a.raw && a.cov3D_precomp == nullptr;
+	for (uint32_t c = 0; c < cnt; c += 64)
+	{
+		const int nv = (int)min(64u, cnt - c);
+		const bool valid = lane < nv;
+		const uint32_t item = base + c + (uint32_t)lane;
+		RawGaussian g;
+		g.p[0] = g.p[1] = g.p[2] = 0.f; g.sc[0] = g.sc[1] = g.sc[2] = 0.f; g.q = make_float4(0, 0, 0, 0); g.hl = 0.f;
+		int idx = 0;
+		if (CROW)
+		{
+			float4 piece[3], r[3];
+			rows_fetch<3>(piece, a.geom.crow + 3 * (size_t)(row_base + c), nv, lane);
+			rows_unpack<3>(r, piece, st, lane);
+			g.p[0] = r[0].x; g.p[1] = r[0].y; g.p[2] = r[0].z;
+			g.sc[0] = r[0].w; g.sc[1] = r[1].x; g.sc[2] = r[1].y;
+			g.q = make_float4(r[1].z, r[1].w, r[2].x, r[2].y);
+			g.hl = r[2].z;
+			idx = (int)__float_as_uint(r[2].w);
+		}
+		else if (valid)
+		{
+			idx = (int)a.geom.vis_seg[row_base + c + (uint32_t)lane];
+			if (PACKED)
+			{
+				// one 64-byte row instead of four or five mostly-unused cache lines
+				const float4 *pg = (const float4 *)a.packed_geom + 4 * (size_t)idx;
+				const float4 g0 = pg[0], g1 = pg[1], g2 = pg[2];
+				g.p[0] = g0.x; g.p[1] = g0.y; g.p[2] = g0.z;
+				g.sc[0] = g0.w; g.sc[1] = g1.x; g.sc[2] = g1.y;
+				g.q = make_float4(g1.z, g1.w, g2.x, g2.y);
+				g.hl = g2.z;
+			}
+			else
+			{
+#pragma unroll
+				for (int i = 0; i < 3; i++) g.p[i] = a.means3D[3 * (size_t)idx + i];
+				if (a.cov3D_precomp == nullptr)
+				{
+#pragma unroll
+					for (int i = 0; i < 3; i++) g.sc[i] = a.scales[3 * (size_t)idx + i];
+					g.q = ((const float4 *)a.rotations)[idx];
+				}
+				if (FOV) g.hl = a.highest_levels[idx];
+			}
+		}
+		Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0;
+		pr.pix_x = pr.pix_y = pr.depth = pr.conic_a = pr.conic_b = pr.conic_c = 0.f;
+		float4 stash_rows[4] = { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) };
+		float4 ev = make_float4(0, 0, 0, 0);
+		float2 el = make_float2(0, 0);
+		bool boxtest = false;
+		float inv_qnorm = 1.0f;
+		if (valid)
+		{
+			if (raw)
+			{
+#pragma unroll
+				for (int i = 0; i < 3; i++) g.sc[i] = act_scale(g.sc[i]);
+				g.q = act_rotation(g.q, &inv_qnorm);
+			}
+			pr = project_gaussian(a, cam_vm, cam_pm, idx, g.p, g.sc, g.q, stash_rows, a.write_cov3D != 0);
+			if (pr.alive)
+			{
+				if (CULL && pr.tnum > 1)
+				{
+					// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
+					float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
+					const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
+					e1x *= n1; e1y *= n1;
+					const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
+					e2x *= n2; e2y *= n2;
+					ev = make_float4(e1x, e1y, e2x, e2y);
+					el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
+				}
+				const WalkRect wr = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, g.hl, s_lvbox, 1);
+				pr.x0 = wr.x0; pr.y0 = wr.y0; pr.x1 = wr.x1; pr.y1 = wr.y1; pr.tnum = wr.tnum; boxtest = wr.boxtest;
+				pr.alive = wr.tnum != 0;
+			}
+			// candidates that turn out to reach no tile get radius 0, like every culled Gaussian; k_count clears the radius of
+			// those whose tiles all fail the box / level tests (RS rasterizer_impl.cu:141-145)
+			a.radii[idx] = pr.alive ? pr.radius : 0;
+			a.geom.vis_list[item] = (uint32_t)idx; // the list in index order, for the kernels that go from item to Gaussian
+		}
+		const uint32_t flags = (pr.alive ? 1u : 0u) | (boxtest ? 2u : 0u);
+		const float4 wrow[4] = { make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y), make_float4(ev.z, ev.w, el.x, el.y),
+			make_float4(__uint_as_float((uint32_t)idx | (flags << 30)), pr.depth, __uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)),
+				__uint_as_float((uint32_t)(pr.x1 - pr.x0))),
+			make_float4(__uint_as_float(pr.tnum), g.hl, 0.0f, 0.0f) };
+		rows_store<4>(wrow, st, a.geom.wrec + 4 * (size_t)(base + c), nv, lane);
+		// the blend record; its colour slots carry the position until k_count has evaluated the colour (RF: the colours live in
+		// the level rows, the slots keep the position)
+		const float4 rrow[3] = { make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b),
+			make_float4(pr.conic_c, LEVELCOL ? g.hl : 0.0f, g.p[0], g.p[1]),
+			make_float4(g.p[2], pr.depth, (FOV && !LEVELCOL) ? g.hl : 0.0f, __int_as_float(idx)) };
+		rows_store<3>(rrow, st, a.geom.rec + 3 * (size_t)(base + c), nv, lane);
+		if (a.write_cov3D)
+		{
+			// training variants: the item's inputs and 3D covariance for the backward pass, and its row of gradient sums,
+			// cleared here; the last quarter of that row is not summed into: it carries 1 / |raw quaternion| (raw parameters)
+			rows_store<4>(stash_rows, st, (float4 *)a.geom.cov3D + 4 * (size_t)(base + c), nv, lane);
+			const float4 ac[4] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(inv_qnorm, 0.f, 0.f, 0.f) };
+			rows_store<4>(ac, st, a.geom.acc + 4 * (size_t)(base + c), nv, lane);
+		}
+	}
+}
+
+// The colour(s) of one item (forward.cu:20-71 computeColorFromSH; RF rasterizer_impl.cu:37-84, 490-530 compute_fov_colors), for
+// the items that landed in a tile only: the SH rows are the largest read of a frame (180-192 bytes per Gaussian, unaligned), and
+// a quarter of the candidates that were projected need none. r: the item's blend record as k_geom left it (position in the
+// colour slots); on return the record with opacity / colour / clamp bits (variants with one colour per Gaussian) or, RF, the
+// level rows lv[lo..hi] of the item's level range lr (the others stay zero: nobody reads them).
+template <int VARIANT, bool PACKED>
+__device__ __forceinline__ void colour_item(const PreArgs &a, const bool rows_ok, const uint32_t lr, float4 (&r)[3], float4 (&lv)[FR_FOV_LEVELS])
+{
+	constexpr bool FOV = is_fov(VARIANT);
+	constexpr bool LEVELCOL = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
+	const int idx = __float_as_int(r[2].w);
+	const float dirx = r[1].z - a.campos[0], diry = r[1].w - a.campos[1], dirz = r[2].x - a.campos[2];
+	const float *pcol = PACKED ? a.packed_colour + 64 * (size_t)idx : nullptr;
+	if (!LEVELCOL)
+	{
+		float rgb[3] = { 0, 0, 0 };
+		uint32_t clamp_bits = 0;
+		const float op_in = PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx];
+		if (a.colors_precomp == nullptr)
+		{
+			float c[3];
+			if (rows_ok)
+			{
+				ShRows sh;
+				if (PACKED) { sh_fetch<true>(pcol, sh); const float dc[3] = { pcol[45], pcol[46], pcol[47] }; sh_eval<true>(a.D, sh, dc, dirx, diry, dirz, c); }
+				else if (a.shs_rest != nullptr)
+				{
+					sh_fetch<true>(a.shs_rest + (size_t)idx * (a.M - 1) * 3, sh);
+					const float dc[3] = { a.shs[3 * (size_t)idx], a.shs[3 * (size_t)idx + 1], a.shs[3 * (size_t)idx + 2] };
+					sh_eval<true>(a.D, sh, dc, dirx, diry, dirz, c);
+				}
+				else { sh_fetch<false>(a.shs + (size_t)idx * a.M * 3, sh); sh_eval<false>(a.D, sh, nullptr, dirx, diry, dirz, c); }
+			}
+			else if (a.shs_rest != nullptr)
+				sh_colour<true>(a.D, (a.M - 1) * 3, a.shs_rest + (size_t)idx * (a.M - 1) * 3, a.shs + 3 * (size_t)idx, dirx, diry, dirz, c);
+			else
+				sh_colour<false>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, c);
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) { if (c[ch] < 0) clamp_bits |= 1u << ch; rgb[ch] = fmaxf(c[ch], 0.0f); }
+		}
+		else
+		{
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) rgb[ch] = a.colors_precomp[3 * (size_t)idx + ch];
+		}
+		const float opacity = (!PACKED && !FOV && a.raw) ? act_opacity(op_in) : op_in;
+		r[1] = make_float4(r[1].x, opacity, rgb[0], rgb[1]);
+		// third part: the Gaussian's index (the statistics of the training variants and the gradients are per Gaussian); the
+		// shared-model foveated variant (no backward, no clamp bits needed) carries the Gaussian's highest level in the clamp slot
+		r[2] = make_float4(rgb[2], r[2].y, FOV ? r[2].z : __uint_as_float(clamp_bits), r[2].w);
+	}
+	else
+	{
+		// RF rasterizer_impl.cu:490-530: per-level colours; all four levels' DC colours (12 floats) and opacities are fetched
+		// with the SH coefficients: one round trip
+		const f4u *dcp = (const f4u *)(PACKED ? pcol + 48 : a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
+		const f4u dc0 = dcp[0], dc1 = dcp[1], dc2 = dcp[2];
+		const f4u opl = *(const f4u *)(PACKED ? a.packed_geom + 16 * (size_t)idx + 12 : a.opacities + (size_t)idx * FR_FOV_LEVELS);
+		float rest[3];
+		if (rows_ok)
+		{
+			ShRows sh;
+			sh_fetch<true>(PACKED ? pcol : a.shs + (size_t)idx * a.M * 3, sh);
+			sh_eval<true>(a.D, sh, nullptr, dirx, diry, dirz, rest);
+		}
+		else sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, rest);
+		const float dcs[12] = { dc0.x, dc0.y, dc0.z, dc0.w, dc1.x, dc1.y, dc1.z, dc1.w, dc2.x, dc2.y, dc2.z, dc2.w };
+		const float ops[4] = { opl.x, opl.y, opl.z, opl.w };
+		static_assert(FR_FOV_LEVELS == 4, "level data is fetched as float4s");
+		const int lo = (int)(lr & 0xffu), hi = (int)((lr >> 8) & 0xffu);
+#pragma unroll
+		for (int l = 0; l < FR_FOV_LEVELS; l++)
+		{
+			if (l >= lo && l <= hi)
+			{
+				float4 v;
+				v.x = fmaxf(FR_SH_C0 * dcs[3 * l] + rest[0], 0.0f);
+				v.y = fmaxf(FR_SH_C0 * dcs[3 * l + 1] + rest[1], 0.0f);
+				v.z = fmaxf(FR_SH_C0 * dcs[3 * l + 2] + rest[2], 0.0f);
+				v.w = ops[l];
+				lv[l] = v;
+			}
+		}
+	}
+}
+
+// Stage 3 (RS rasterizer_impl.cu:70-146 OBB_test, RF :264-383 filter; + the colours, forward.cu:20-71 / RF rasterizer_impl.cu:
+// 490-530): count the tiles every item really lands in (OBB / foveal tests) from its walk record alone -- 64 bytes per item,
+// read as contiguous kilobytes -- into a per-workgroup LDS histogram; then, for the items that landed somewhere, the colour(s).
+// One persistent workgroup of FR_BIN_THREADS threads per CU; a wave takes the 64-item slabs wave, wave + waves, ... (STATIC: round
+// 3 handed the slabs out through eight atomic counters -- 15 000 returning atomics on eight addresses were 45 us of the
+// kernel, more than its tile walks; k_emit takes the same slabs, because its bucket offsets are per workgroup).
+// The tile walk is VALU / LDS work that leaves the memory system idle, the colours are the frame's largest scattered read and
+// no arithmetic to speak of: in one kernel, at sixteen waves per CU, one wave's colour round trip runs under the others' walks
+// (as a kernel of its own the colours took 94 us, beside another kernel on a second stream they only took its wave slots).
+// LDSH: the counters are an LDS-private histogram (T <= 16 Ki tiles) added once per workgroup to the tiles' global counters
+// (the returned values are the workgroup's starts inside the buckets: hist[block][tile]); otherwise (huge tile grids) global
+// atomics on tile_count.
+// LDSH == 2: 16-bit counts, two tiles per word (tile grids of more than 16 Ki tiles: 4K frames); a workgroup then bins fewer
+// than 65 536 items (launch_count admits the mode only when every wave's share of the slabs is below FR_HIST16_MAX_SLABS).
+// Per item it leaves GeomWS::lrange: FR_ITEM_NONE when no tile is left (k_emit skips the item; its radius is cleared), else
+// the level range of RF rasterizer_impl.cu:374-381; and the finished blend record / (RF) level rows.
+#define BUMP_TILE(ti) do { if (LDSH == 2) atomicAdd(&lds_hist[(ti) >> 1], 1u << (16 * ((ti) & 1))); \
+	else if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
+template <int VARIANT, int LDSH, bool PACKED = false>
+__global__ void __launch_bounds__(FR_BIN_THREADS) k_count(const PreArgs a)
+{
+	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = is_fov(VARIANT);                            // level map + level filter
-	constexpr bool LEVELCOL = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;  // per-level colours / opacities (RF); the shared-model
-	                                                                 // baseline has one colour per Gaussian like the plain variants
+	constexpr bool LEVELCOL = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;  // per-level colours / opacities (RF)
 	static_assert(!(PACKED && FOV && !LEVELCOL), "the shared-model foveated variant has no packed layout");
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
 	const int lane = threadIdx.x & 63;
-#ifdef FR_BIN_TIMERS
-	const uint64_t tm_entry = wall_clock64();
-#endif
 	// RF: every pair step looks its tile's level (and, if kept, its blend flag) up; from global memory those
 	// were two dependent ~1 us round trips in a loop that a near-camera splat runs a hundred times. When they
-	// fit beside the histogram, the workgroup keeps tile_min (float) and the blend flags (one bit) in LDS.
+	// fit beside the histogram, the workgroup keeps them in LDS.
 	const int hist_words = LDSH == 2 ? (a.T + 1) / 2 : (LDSH ? a.T : 0);
 	uint32_t *lds_tab = lds_hist + hist_words;
 	const int tab_words = (a.T + 7) / 8;
@@ -764,37 +1066,15 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	}
 	if (LDSH)
 		for (int t = threadIdx.x; t < hist_words; t += FR_BIN_THREADS) lds_hist[t] = 0;
-	// the cull pass's per-wave counts (scanned below), loaded with the tables: ONE round trip of cold global loads at the head
-	// of the kernel instead of one per step
-	uint32_t *s_wbase = lds_hist + hist_words + ((FOV && a.lds_tiles) ? tab_words : 0); // [proj_waves + 1] exclusive running counts
-	for (int w0 = threadIdx.x; w0 < a.proj_waves; w0 += 16 * FR_BIN_THREADS)
-	{
-		uint32_t v[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) v[k] = a.geom.proj_counts[min(w0 + k * FR_BIN_THREADS, a.proj_waves - 1)];
-#pragma unroll
-		for (int k = 0; k < 16; k++) if (w0 + k * FR_BIN_THREADS < a.proj_waves) s_wbase[w0 + k * FR_BIN_THREADS] = v[k];
-	}
 	// "giant" splats (FR_GIANT_TNUM+ tiles, up to the whole frame = 128 wave steps) are set aside here and walked
 	// by ALL waves of the workgroup after the slab loop: left to the wave that met them they were the kernel's
 	// critical path
-	__shared__ int s_gidx[FR_GIANT_MAX], s_gitem[FR_GIANT_MAX];
-	__shared__ float2 s_gcd[FR_GIANT_MAX]; // conic c, depth of the deferred splat
+	__shared__ int s_gitem[FR_GIANT_MAX];
 	__shared__ uint32_t s_gcount[FR_GIANT_MAX], s_gmask[FR_GIANT_MAX];
 	__shared__ uint32_t s_ng;
-	// RF: the five level boxes every candidate's walk rectangle is clipped to (walk_rect): from LDS, not one dependent global
-	// load per candidate in the middle of its projection
-	__shared__ uint4 s_lvbox[5];
-	if (FOV && threadIdx.x < 5) s_lvbox[threadIdx.x] = *(const uint4 *)(a.lv_bbox + threadIdx.x * FR_LV_BBOX_STRIDE);
 	if (threadIdx.x < FR_GIANT_MAX) { s_gcount[threadIdx.x] = 0; s_gmask[threadIdx.x] = 0; }
 	if (threadIdx.x == 0) s_ng = 0;
-#ifdef FR_BIN_TIMERS
-	const uint64_t tm_pa = wall_clock64();
-#endif
 	__syncthreads();
-#ifdef FR_BIN_TIMERS
-	const uint64_t tm_pb = wall_clock64();
-#endif
 	// tile ti against a splat whose filter bound is olim = highest level + 1: does the tile pass, and its level bits
 	// (1 << min(max(int(tile_min), 0), 3), | 16 if it blends two levels) -- from the 4-bit table, or from the floats
 #define TILE_FILTER(ti, olim, pass_out, bits_out) do { \
@@ -802,63 +1082,17 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			pass_out = (float)(nb_ & 7u) < (olim); bits_out = (1u << min(nb_ & 7u, 3u)) | ((nb_ & 8u) << 1); } \
 		else { const float lv_ = tile_min[(ti)]; pass_out = lv_ < (olim); \
 			bits_out = pass_out ? ((1u << min(max(f2i(lv_), 0), 3)) | (tile_bl[(ti)] != 0.0f ? 16u : 0u)) : 0u; } } while (0)
-	// Work unit = a "slab" of 64 consecutive vis_list entries, handled by ONE wave; there is no workgroup
+	// Work unit = a "slab" of 64 consecutive items, handled by ONE wave; there is no workgroup
 	// barrier inside the loop (a few near-camera splats make some slabs 100x more expensive than others,
 	// and waiting for the slowest wave of a workgroup at every slab cost a quarter of the kernel).
-	// LDSH: waves pull slabs dynamically from eight counters (slab s belongs to counter s % 8; a wave
-	// starts at its workgroup's counter and steals from the others when that one runs dry: one counter
-	// serves only ~90 pulls/us; no peeking at the counters with atomic loads -- those slowed every memory
-	// access of the kernel down by 2x). Every wave leaves the chain of slabs it pulled behind (slab_next,
-	// wave_head): k_emit must replay the same slab -> workgroup assignment because its bucket offsets are
-	// per workgroup.
-	__shared__ int s_own[FR_BIN_THREADS];
-	__shared__ float4 s_orec[4 * FR_BIN_THREADS]; // the pair loop's 64-byte row per lane (see there)
-	// camera matrices in scalar registers (see k_project)
-	float cam_vm[16], cam_pm[16];
-#pragma unroll
-	for (int i = 0; i < 16; i++)
-	{
-		cam_vm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.viewmatrix[i])));
-		cam_pm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.projmatrix[i])));
-	}
-	// ---- the survivors of the cull pass: item i lives in the region of the wave whose running count covers i ----
-	// every workgroup scans the (at most 8192) per-wave counts into LDS; a slab then finds its first wave by binary search
-	// and its lanes step on from there (a region holds ~170 survivors: a slab spans one or two)
-	{
-		__shared__ uint32_t s_part[FR_BIN_THREADS / 64];
-		// (the counts come in coalesced and are scanned in place: a thread's run of consecutive counts read straight from global
-		// memory is 16 loads whose lanes lie 64 bytes apart, twice)
-		const int per = (a.proj_waves + FR_BIN_THREADS - 1) / FR_BIN_THREADS; // consecutive waves per thread
-		const int w0 = (int)threadIdx.x * per, w1 = min(a.proj_waves, w0 + per);
-		uint32_t mine = 0;
-		for (int w = w0; w < w1; w++) mine += s_wbase[w];
-		uint32_t sc = wave_incl_scan_u32(mine, lane);
-		if (lane == 63) s_part[threadIdx.x >> 6] = sc;
-		__syncthreads();
-		uint32_t off = 0;
-		for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += s_part[w];
-		uint32_t run = off + sc - mine;
-		for (int w = w0; w < w1; w++) { const uint32_t cw = s_wbase[w]; s_wbase[w] = run; run += cw; }
-		if (w1 == a.proj_waves && w0 < w1) s_wbase[a.proj_waves] = run;
-		if (a.proj_waves == 0 && threadIdx.x == 0) s_wbase[0] = 0;
-		__syncthreads();
-	}
-#ifdef FR_BIN_TIMERS
-	const uint64_t tm_pc = wall_clock64();
-#endif
-	const int V = (int)s_wbase[a.proj_waves]; // entries of vis_list
-	if (blockIdx.x == 0 && threadIdx.x == 0) a.geom.slab_ctr[1] = (uint32_t)V; // for the kernels that follow
+	// (dynamic LDS behind the histogram and the table, 16-byte aligned: the waves' staging rows / the pair loop's 64-byte row per
+	// lane (see there), and the owner rows of pair_owner_scan)
+	float4 *const s_orec = (float4 *)(lds_hist + ((hist_words + ((FOV && a.lds_tiles) ? tab_words : 0) + 3) & ~3));
+	int *const s_own = (int *)(s_orec + 4 * FR_BIN_THREADS);
+	const int V = (int)a.geom.slab_ctr[1]; // entries of vis_list (the cull pass's last workgroup)
 	const int nslabs = (V + 63) / 64;
-	// slot (in vis_seg / crow) of item i; `w` = a wave at or before the item's (from the slab's binary search)
-	auto slot_of = [&](const int item, int w) __attribute__((always_inline))
-	{
-		while ((uint32_t)item >= s_wbase[w + 1]) w++;
-		return (uint32_t)w * (uint32_t)a.proj_cpw * 64u + ((uint32_t)item - s_wbase[w]);
-	};
 	const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
 	const int nwaves = (int)gridDim.x * (FR_BIN_THREADS / 64);
-	int region = (int)blockIdx.x & 7;
-	int chain = -1; // last slab this wave pulled
 	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
 	const float *tile_bl = FOV ? a.tile_lv + 4 * (size_t)a.T : nullptr;
 	// Wave-uniform walk of ONE splat's rectangle: lanes take tiles k0 + lane, k0 + lane + kstep, ... of the on
@@ -904,337 +1138,46 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		highest = fmaxf(highest, (float)hi_bit);
 		be_blend = (lvmask & 16u) != 0;
 	};
-	// Per-Gaussian epilogue once its tile count is known: radius of culled-everywhere splats, colour(s), final record.
-	// Colour inputs of a candidate, fetched at the head of its slab (see the slab loop): SH rows, and either the four
-	// levels' DC coefficients + opacities (RF) or coefficient 0 (split / packed storage) + the opacity.
-	struct ColourPre { ShRows sh; f4u dc0, dc1, dc2, opl; float dc[3]; float op; };
-	// (uniform) the usual storage -- SH coefficients given, all 16 allocated -- is what the early fetch handles
+	// what the item leaves behind: FR_ITEM_NONE or its level range (RF rasterizer_impl.cu:374-381)
+	auto range_word = [&](const uint32_t count, const float lowest, const float highest, const bool be_blend) __attribute__((always_inline))
+	{
+		if (count == 0) return FR_ITEM_NONE;
+		if (!FOV) return 0u;
+		const int lo = f2i(lowest);
+		int hi = f2i(highest);
+		if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
+		return (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
+	};
+	float4 *const orec = s_orec + 4 * (threadIdx.x & ~63);
+	// (uniform) the usual SH storage -- coefficients given, all 16 allocated -- is fetched as whole 16-byte pieces
 	const bool rows_ok = a.colors_precomp == nullptr &&
 		(PACKED || (LEVELCOL ? a.M * 3 >= 45 : (a.shs_rest != nullptr ? (a.M - 1) * 3 >= 45 : a.M * 3 >= 48)));
-	const bool pre_ok = FR_BIN_PREFETCH && rows_ok;
-	auto prefetch_colour = [&](const int idx, ColourPre &cp) __attribute__((always_inline))
+	for (int slab = wave_gid; slab < nslabs; slab += nwaves)
 	{
-		const float *pcol = PACKED ? a.packed_colour + 64 * (size_t)idx : nullptr;
-		if (LEVELCOL)
-		{
-			const f4u *dcp = (const f4u *)(PACKED ? pcol + 48 : a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
-			cp.dc0 = dcp[0]; cp.dc1 = dcp[1]; cp.dc2 = dcp[2];
-			cp.opl = *(const f4u *)(PACKED ? a.packed_geom + 16 * (size_t)idx + 12 : a.opacities + (size_t)idx * FR_FOV_LEVELS);
-			sh_fetch<true>(PACKED ? pcol : a.shs + (size_t)idx * a.M * 3, cp.sh);
-		}
-		else
-		{
-			cp.op = PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx];
-			if (PACKED) { sh_fetch<true>(pcol, cp.sh); cp.dc[0] = pcol[45]; cp.dc[1] = pcol[46]; cp.dc[2] = pcol[47]; }
-			else if (a.shs_rest != nullptr)
-			{
-				sh_fetch<true>(a.shs_rest + (size_t)idx * (a.M - 1) * 3, cp.sh);
-				cp.dc[0] = a.shs[3 * (size_t)idx]; cp.dc[1] = a.shs[3 * (size_t)idx + 1]; cp.dc[2] = a.shs[3 * (size_t)idx + 2];
-			}
-			else sh_fetch<false>(a.shs + (size_t)idx * a.M * 3, cp.sh);
-		}
-	};
-	// Per-Gaussian epilogue once its tile count is known: radius of culled-everywhere splats, colour(s), final record.
-	// cp_in: the colour inputs fetched at the head of the slab if have_cp, else they are fetched here (giant splats; storage
-	// with fewer than 16 coefficients takes the generic path). (A value + a flag: a pointer that may be null, or a choice
-	// between two structs by reference, sends the whole struct through scratch memory.)
-	// the rows finish() makes for an item: the last two thirds of its record and (RF) its four level rows. The caller
-	// stores them: a slab's 64 items through LDS as whole kilobytes (see the slab loop), a giant splat's directly.
-	struct OutRows { float4 rec1, rec2, lvl[FR_FOV_LEVELS]; };
-	auto finish = [&](const int idx, const int item, const uint32_t count, const float hl, const float lowest, const float highest,
-		const bool be_blend, const float conic_c, const float depth, const float *pos, const ColourPre &cp_in, const bool have_cp_in,
-		OutRows &o) __attribute__((always_inline))
-	{
-		if (count == 0) { a.radii[idx] = 0; return; } // culled everywhere (RS rasterizer_impl.cu:141-145)
-#ifdef FR_BIN_NO_COLOUR
-		{ // experiment: the kernel without its colour fetch / evaluation / level rows (images are wrong)
-			o.rec1 = make_float4(conic_c, hl, 0.0f, 0.0f); o.rec2 = make_float4(0.0f, depth, 0.0f, __int_as_float(idx));
-			if (LEVELCOL) a.geom.lrange[item] = (uint32_t)f2i(lowest) | ((uint32_t)f2i(highest) << 8) | (be_blend ? 0x10000u : 0u);
-			return;
-		}
-#endif
-		ColourPre cp = cp_in;
-		if (!have_cp_in && rows_ok) prefetch_colour(idx, cp);
-		const bool have_cp = have_cp_in || rows_ok;
-		float rgb[3] = { 0, 0, 0 };
-		uint32_t clamp_bits = 0;
-		// pos: the caller still holds the position (null: fetch it)
-		const float *mp = pos ? pos : (PACKED ? a.packed_geom + 16 * (size_t)idx : a.means3D + 3 * (size_t)idx);
-		const float dirx = mp[0] - a.campos[0], diry = mp[1] - a.campos[1], dirz = mp[2] - a.campos[2];
-		const float *pcol = PACKED ? a.packed_colour + 64 * (size_t)idx : nullptr;
-		float opacity = 0.0f;
-		if (!LEVELCOL)
-		{
-			if (a.colors_precomp == nullptr)
-			{
-				float c[3];
-				if (have_cp)
-				{
-					if (PACKED || a.shs_rest != nullptr) sh_eval<true>(a.D, cp.sh, cp.dc, dirx, diry, dirz, c);
-					else sh_eval<false>(a.D, cp.sh, nullptr, dirx, diry, dirz, c);
-				}
-				else if (PACKED)
-					sh_colour<true>(a.D, 45, pcol, pcol + 45, dirx, diry, dirz, c);
-				else if (a.shs_rest != nullptr)
-					sh_colour<true>(a.D, (a.M - 1) * 3, a.shs_rest + (size_t)idx * (a.M - 1) * 3, a.shs + 3 * (size_t)idx, dirx, diry, dirz, c);
-				else
-					sh_colour<false>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, c);
-#pragma unroll
-				for (int ch = 0; ch < 3; ch++) { if (c[ch] < 0) clamp_bits |= 1u << ch; rgb[ch] = fmaxf(c[ch], 0.0f); }
-			}
-			else
-			{
-#pragma unroll
-				for (int ch = 0; ch < 3; ch++) rgb[ch] = a.colors_precomp[3 * (size_t)idx + ch];
-			}
-			const float op_in = have_cp ? cp.op : (PACKED ? a.packed_geom[16 * (size_t)idx + 12] : a.opacities[idx]);
-			opacity = (!PACKED && !FOV && a.raw) ? act_opacity(op_in) : op_in;
-		}
-		else
-		{
-			// RF rasterizer_impl.cu:374-381 (level range) + :490-530 (per-level colours)
-			const int lo = f2i(lowest);
-			int hi = f2i(highest);
-			if (be_blend) hi = min(hi + 1, FR_FOV_LEVELS - 1);
-			a.geom.lrange[item] = (uint32_t)(lo & 0xff) | ((uint32_t)(hi & 0xff) << 8);
-			// all four levels' DC colours (12 floats) and opacities are fetched with the SH coefficients: one round trip
-			f4u dc0, dc1, dc2, opl;
-			float rest[3];
-			if (have_cp)
-			{
-				dc0 = cp.dc0; dc1 = cp.dc1; dc2 = cp.dc2; opl = cp.opl;
-				sh_eval<true>(a.D, cp.sh, nullptr, dirx, diry, dirz, rest);
-			}
-			else
-			{
-				const f4u *dcp = (const f4u *)(PACKED ? pcol + 48 : a.shs_dcs + (size_t)idx * 3 * FR_FOV_LEVELS);
-				dc0 = dcp[0]; dc1 = dcp[1]; dc2 = dcp[2];
-				opl = *(const f4u *)(PACKED ? a.packed_geom + 16 * (size_t)idx + 12 : a.opacities + (size_t)idx * FR_FOV_LEVELS);
-				if (PACKED) sh_colour<true>(a.D, 45, pcol, nullptr, dirx, diry, dirz, rest);
-				else sh_colour<true>(a.D, a.M * 3, a.shs + (size_t)idx * a.M * 3, nullptr, dirx, diry, dirz, rest);
-			}
-			const float dcs[12] = { dc0.x, dc0.y, dc0.z, dc0.w, dc1.x, dc1.y, dc1.z, dc1.w, dc2.x, dc2.y, dc2.z, dc2.w };
-			const float ops[4] = { opl.x, opl.y, opl.z, opl.w };
-			static_assert(FR_FOV_LEVELS == 4, "level data is fetched as float4s");
-#pragma unroll
-			for (int l = 0; l < FR_FOV_LEVELS; l++)
-			{
-				if (l >= lo && l <= hi)
-				{
-					float4 v;
-					v.x = fmaxf(FR_SH_C0 * dcs[3 * l] + rest[0], 0.0f);
-					v.y = fmaxf(FR_SH_C0 * dcs[3 * l + 1] + rest[1], 0.0f);
-					v.z = fmaxf(FR_SH_C0 * dcs[3 * l + 2] + rest[2], 0.0f);
-					v.w = ops[l];
-					o.lvl[l] = v;
-				}
-			}
-		}
-		// the item's record
-		if (LEVELCOL) o.rec1 = make_float4(conic_c, hl, 0.0f, 0.0f);
-		else o.rec1 = make_float4(conic_c, opacity, rgb[0], rgb[1]);
-		// third part: the Gaussian's index (the statistics of the training variants and the gradients are per Gaussian); the
-		// shared-model foveated variant (no backward, no clamp bits needed) carries the Gaussian's highest level in the clamp slot
-		if (FOV && !LEVELCOL) o.rec2 = make_float4(rgb[2], depth, hl, __int_as_float(idx));
-		else o.rec2 = make_float4(rgb[2], depth, __uint_as_float(clamp_bits), __int_as_float(idx));
-	};
-#ifdef FR_BIN_TIMERS
-	const uint64_t tm0 = wall_clock64(); uint64_t tm_s = 0, tm_l = 0, tm_p = 0, tm_c = 0, tm_sh = 0, tm_x; int tm_n = 0, tm_steps = 0, tm_bsteps = 0;
-#define TM_BEGIN() tm_x = wall_clock64()
-#define TM_END(acc) do { const uint64_t now_ = wall_clock64(); acc += now_ - tm_x; tm_x = now_; } while (0)
-#else
-#define TM_BEGIN()
-#define TM_END(acc)
-#endif
-	// ---- the slab loop, one slab AHEAD: the next slab is asked for while this one is projected, and its candidates' input
-	// rows are in flight while this one's tiles are walked. Per slab a wave otherwise waits, one after the other, for the
-	// returning atomic of the pull (~2 us under load), the running-count search, and the dependent row loads: the SQ
-	// counters of the round-2 kernel have its waves parked on s_waitcnt 57 % of the time at 1.76 waves per SIMD. (Round 2
-	// found pulling ahead slower -- a wave stuck in a heavy slab sits on one another could take -- when nothing was
-	// fetched ahead with it.)
-	struct SlabIn { int idx; RawGaussian w; float4 raw[3]; };
-	// inputs of slab `sl` (raw: the activations of fr_forward_args.raw_activations are applied where they are used)
-	auto load_inputs = [&](const int sl, SlabIn &in) __attribute__((always_inline))
-	{
-		in.idx = 0; in.w.p[0] = in.w.p[1] = in.w.p[2] = 0.f; in.w.sc[0] = in.w.sc[1] = in.w.sc[2] = 0.f; in.w.q = make_float4(0, 0, 0, 0); in.w.hl = 0.f;
-		const int it = sl * 64 + lane;
-		// the wave whose region holds the slab's first item: largest w with s_wbase[w] <= 64 * slab (uniform search)
-		int lo = 0, hi = a.proj_waves; // s_wbase[lo] <= first < s_wbase[hi] (first < V = s_wbase[proj_waves])
-		const uint32_t first = (uint32_t)sl * 64u;
-		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wbase[mid] <= first) lo = mid; else hi = mid; }
-		if (CROW)
-		{
-			// the slab's 64 candidate rows (48 bytes each) as 192 pieces of 16 bytes, consecutive lanes taking consecutive
-			// pieces: three loads of (nearly) contiguous kilobytes instead of three whose lanes lie 48 bytes apart; the rows
-			// are put together again through LDS when the slab is processed (unpack_rows)
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-			{
-				const int c = i * 64 + lane, it_c = sl * 64 + c / 3;
-				in.raw[i] = make_float4(0, 0, 0, 0);
-				if (it_c < V) in.raw[i] = a.geom.crow[3 * (size_t)slot_of(it_c, lo) + (c % 3)];
-			}
-			return;
-		}
-		if (it < V)
-		{
-			const uint32_t slot = slot_of(it, lo);
-			const int idx = (int)a.geom.vis_seg[slot];
-			in.idx = idx;
-			if (PACKED)
-			{
-				// one 64-byte row instead of four or five mostly-unused cache lines
-				const float4 *pg = (const float4 *)a.packed_geom + 4 * (size_t)idx;
-				const float4 g0 = pg[0], g1 = pg[1], g2 = pg[2];
-				in.w.p[0] = g0.x; in.w.p[1] = g0.y; in.w.p[2] = g0.z;
-				in.w.sc[0] = g0.w; in.w.sc[1] = g1.x; in.w.sc[2] = g1.y;
-				in.w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
-				in.w.hl = g2.z;
-			}
-			else
-			{
-#pragma unroll
-				for (int i = 0; i < 3; i++) in.w.p[i] = a.means3D[3 * (size_t)idx + i];
-				if (a.cov3D_precomp == nullptr)
-				{
-#pragma unroll
-					for (int i = 0; i < 3; i++) in.w.sc[i] = a.scales[3 * (size_t)idx + i];
-					in.w.q = ((const float4 *)a.rotations)[idx];
-				}
-				if (FOV) in.w.hl = a.highest_levels[idx];
-			}
-		}
-	};
-	// Pulling a slab (LDSH): a returning atomic on this wave's region counter, then the others if that one is dry. issue_pull
-	// only sends the first atomic; finish_pull waits for it (and does the rare rest). Static order otherwise.
-	int pend_li = 0, pend_r = 0, static_next = wave_gid, pulled = 0;
-	auto issue_pull = [&]() __attribute__((always_inline))
-	{
-		if (LDSH) { pend_r = region; if (lane == 0) pend_li = (int)atomicAdd(a.geom.slab_ctr + 32 * (1 + region), 1u); }
-	};
-	auto finish_pull = [&]() __attribute__((always_inline))
-	{
-		if (!LDSH) { const int sl = static_next; static_next += nwaves; return sl < nslabs ? sl : -1; }
-		if (LDSH == 2 && pulled >= FR_HIST16_MAX_SLABS) return -1; // (16-bit counts: the other workgroups take the rest)
-		pulled++;
-		int got = -1;
-		if (lane == 0)
-		{
-			if (pend_li < ((nslabs - pend_r + 7) >> 3)) got = pend_li * 8 + pend_r;
-			for (int tries = 1; tries < 8 && got < 0; tries++)
-			{
-				const int r = (pend_r + tries) & 7;
-				const int nr = (nslabs - r + 7) >> 3;
-				const int li = (int)atomicAdd(a.geom.slab_ctr + 32 * (1 + r), 1u);
-				if (li < nr) { got = li * 8 + r; region = r; }
-			}
-		}
-		return __builtin_amdgcn_readfirstlane(got);
-	};
-	TM_BEGIN();
-	issue_pull();
-	int slab = finish_pull();
-	SlabIn in_cur;
-	if (slab >= 0) load_inputs(slab, in_cur);
-	issue_pull(); // the second slab's number
-	while (slab >= 0)
-	{
-	if (LDSH)
-	{
-		if (lane == 0) a.geom.slab_next[slab] = chain;
-		chain = slab;
-	}
-	TM_END(tm_s);
-#ifdef FR_BIN_TIMERS
-	tm_n++;
-#endif
+	const int nv = min(64, V - slab * 64);
+	float4 cur[4];
+	rows_fetch<4>(cur, a.geom.wrec + 4 * (size_t)slab * 64, nv, lane);
 	const int item = slab * 64 + lane;
-	if (CROW)
-	{
-		// the candidate rows fetched as pieces: through the wave's LDS rows, every lane picks up its own 48 bytes
-		float4 *st = s_orec + 4 * (threadIdx.x & ~63);
-#pragma unroll
-		for (int i = 0; i < 3; i++) st[i * 64 + lane] = in_cur.raw[i];
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		const float4 g0 = st[3 * lane], g1 = st[3 * lane + 1], g2 = st[3 * lane + 2];
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		in_cur.w.p[0] = g0.x; in_cur.w.p[1] = g0.y; in_cur.w.p[2] = g0.z;
-		in_cur.w.sc[0] = g0.w; in_cur.w.sc[1] = g1.x; in_cur.w.sc[2] = g1.y;
-		in_cur.w.q = make_float4(g1.z, g1.w, g2.x, g2.y);
-		in_cur.w.hl = g2.z;
-		in_cur.idx = (int)__float_as_uint(g2.w);
-	}
-	int idx = in_cur.idx;
-	Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0; pr.pix_x = pr.pix_y = 0.f;
-	float4 r1 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0), rec0 = make_float4(0, 0, 0, 0);
-	float4 stash_rows[4] = { rec0, rec0, rec0, rec0 }; // training variants: the item's row for the backward pass
+	float4 wr[4];
+	rows_unpack<4>(wr, cur, orec, lane);
+	const uint32_t idf = __float_as_uint(wr[2].x), xy = __float_as_uint(wr[2].z);
+	const int idx = (int)(idf & 0x3fffffffu);
+	const bool alive = item < V && ((idf >> 30) & 1u) != 0, boxtest = ((idf >> 31) & 1u) != 0;
+	const float4 ev = make_float4(wr[0].z, wr[0].w, wr[1].x, wr[1].y);
+	const float2 el = make_float2(wr[1].z, wr[1].w);
+	const int x0 = (int)(xy & 0xffffu), y0 = (int)(xy >> 16), ow0 = (int)__float_as_uint(wr[2].w);
+	const uint32_t tnum = alive ? __float_as_uint(wr[3].x) : 0u;
+	const float hl = wr[3].y;
 	uint32_t count = 0;
-	float4 ev = make_float4(0, 0, 0, 0);
-	float2 el = make_float2(0, 0);
-	float hl = 0, lowest = 0, highest = 0;
-	bool be_blend = false, boxtest = false;
-	RawGaussian w = in_cur.w;
-	float inv_qnorm = 1.0f;
-	ColourPre cp;
-	int next_slab = -1;
-	SlabIn in_next;
-	if (item < V)
-	{
-		// the candidate's full projection (covariance chain, conic, radius: forward.cu:155-262), its OBB axes and
-		// the rectangle to walk; candidates that turn out to reach no tile get radius 0, like every culled Gaussian
-		if (FOV) { hl = w.hl; lowest = hl; }
-		if (!CROW && !PACKED && !FOV && a.raw && a.cov3D_precomp == nullptr)
-		{
-#pragma unroll
-			for (int i = 0; i < 3; i++) w.sc[i] = act_scale(w.sc[i]);
-			w.q = act_rotation(w.q, &inv_qnorm);
-		}
-		// the colour rows are asked for NOW and evaluated after the walk (finish): their round trip and the lines they pull
-		// run under the projection and the tile walk
-#ifndef FR_BIN_NO_COLOUR
-		if (pre_ok) prefetch_colour(idx, cp);
-#endif
-		pr = project_gaussian(a, cam_vm, cam_pm, idx, w.p, w.sc, w.q, stash_rows, a.write_cov3D != 0);
-		if (pr.alive)
-		{
-			if (CULL && pr.tnum > 1)
-			{
-				// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
-				float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
-				const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
-				e1x *= n1; e1y *= n1;
-				const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
-				e2x *= n2; e2y *= n2;
-				ev = make_float4(e1x, e1y, e2x, e2y);
-				el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
-			}
-			const WalkRect wr = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, hl, s_lvbox, 1);
-			pr.x0 = wr.x0; pr.y0 = wr.y0; pr.x1 = wr.x1; pr.y1 = wr.y1; pr.tnum = wr.tnum; boxtest = wr.boxtest;
-			pr.alive = wr.tnum != 0;
-		}
-		a.radii[idx] = pr.alive ? pr.radius : 0;
-		a.geom.vis_list[item] = (uint32_t)idx; // the list in index order, for the kernels that go from item to Gaussian
-		if (pr.alive)
-		{
-			rec0 = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b); // first third of the record
-			r1.x = pr.conic_c; r2.y = pr.depth;
-		}
-	}
-
-	// the next slab's number is back: its candidates' rows are on their way while this slab's tiles are walked
-	next_slab = finish_pull();
-	if (next_slab >= 0) load_inputs(next_slab, in_next);
-
+	float lowest = hl, highest = 0;
+	bool be_blend = false;
 	// ---- count the tiles this splat really lands in (and bump the per-tile counters) ----
 	// single-tile splats need no box test (RS rasterizer_impl.cu:99-102); handle them in place
-	const bool in_place = pr.alive && pr.tnum == 1 && !boxtest;
+	const bool in_place = alive && tnum == 1 && !boxtest;
 	if (in_place)
 	{
 		bool keep = true;
-		const int ti = pr.y0 * a.gx + pr.x0;
+		const int ti = y0 * a.gx + x0;
 		if (FOV)
 		{
 			uint32_t lb;
@@ -1244,63 +1187,51 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		}
 		if (keep) { BUMP_TILE(ti); count = 1; }
 	}
-	TM_END(tm_l);
 	// everything else: wave-balanced pair loop
+	bool deferred = false;
 	{
 		uint32_t lvmask = 0; // FOV: bit l = some kept tile has int(level) == l; bit 4 = some kept tile blends
 		// Splats with at least a wave's worth of tiles are walked by the whole wave ONE AT A TIME: the owner is
 		// wave-uniform (scalar registers), so a step needs no owner search and no shuffles and is ~3x shorter
 		// than a step of the mixed loop below. A frame-filling splat is 128 such steps and sits on the
 		// kernel's critical path.
-		bool deferred = false;
-		if (pr.alive && !in_place && pr.tnum >= FR_GIANT_TNUM)
+		if (alive && !in_place && tnum >= FR_GIANT_TNUM)
 		{
 			const uint32_t slot = atomicAdd(&s_ng, 1u);
-			if (slot < FR_GIANT_MAX) { s_gidx[slot] = idx; s_gitem[slot] = item; s_gcd[slot] = make_float2(r1.x, r2.y); deferred = true; }
+			if (slot < FR_GIANT_MAX) { s_gitem[slot] = item; deferred = true; }
 		}
-		const bool big = pr.alive && !in_place && !deferred && pr.tnum >= FR_BIG_TNUM;
+		const bool big = alive && !in_place && !deferred && tnum >= FR_BIG_TNUM;
 		if (__ballot(big)) __builtin_amdgcn_s_setprio(3);
 		for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1)
 		{
 			const int L = __ffsll((long long)bigm) - 1;
-			const int ox0 = bcast_i(pr.x0, L), oy0 = bcast_i(pr.y0, L), ow = bcast_i(pr.x1, L) - ox0;
-			const uint32_t on = (uint32_t)bcast_i((int)pr.tnum, L);
+			const int ox0 = bcast_i(x0, L), oy0 = bcast_i(y0, L), ow = bcast_i(ow0, L);
+			const uint32_t on = (uint32_t)bcast_i((int)tnum, L);
 			const float4 oev = make_float4(bcast_f(ev.x, L), bcast_f(ev.y, L), bcast_f(ev.z, L), bcast_f(ev.w, L));
 			const float2 oel = make_float2(bcast_f(el.x, L), bcast_f(el.y, L));
-			const Obb ob = make_obb(bcast_f(pr.pix_x, L), bcast_f(pr.pix_y, L), oev, oel);
+			const Obb ob = make_obb(bcast_f(wr[0].x, L), bcast_f(wr[0].y, L), oev, oel);
 			uint32_t cnt = 0, bits = 0;
-#ifdef FR_BIN_TIMERS
-			tm_steps += (int)((on + 63) / 64);
-#endif
 			walk_uniform(ox0, oy0, ow, on, ob, bcast_f(hl, L) + 1, 0u, 64u, cnt, bits);
 			if (lane == L) { count = cnt; lvmask = bits; }
 		}
 		__builtin_amdgcn_s_setprio(0);
-		const uint32_t my_n = (pr.alive && !in_place && !big && !deferred) ? pr.tnum : 0u;
+		const uint32_t my_n = (alive && !in_place && !big && !deferred) ? tnum : 0u;
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-#ifdef FR_BIN_TIMERS
-		tm_steps += (int)((total + 63) / 64); tm_bsteps += (int)((total + 63) / 64);
-		TM_END(tm_sh); // (time of the big walks + deferral + scan: the balanced loop is what remains of tm_p)
-#endif
 		// Every lane leaves what a pair of its splat needs in a 64-byte LDS row (the corner extremes of its box included:
 		// make_obb once per splat, not once per pair); a pair then reads its OWNER's row -- four LDS reads, most of them
 		// broadcasts -- instead of pulling thirteen registers through ds_bpermute, divides by the rectangle's width with a
-		// reciprocal, and evaluates the box test without branches. (A step of this loop was ~150 vector + ~80 scalar
-		// instructions and took 1800 cycles at the kernel's 2 waves per SIMD: a third of k_bin.)
-		float4 *orec = s_orec + 4 * (threadIdx.x & ~63);
+		// reciprocal, and evaluates the box test without branches.
 		if (total != 0)
 		{
-			const Obb ob = make_obb(pr.pix_x, pr.pix_y, ev, el);
+			const Obb ob = make_obb(wr[0].x, wr[0].y, ev, el);
 			float4 *mine = orec + 4 * lane;
-			mine[0] = make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y);
-			mine[1] = make_float4(ev.z, ev.w, el.x, el.y);
+			mine[0] = wr[0];
+			mine[1] = wr[1];
 			mine[2] = make_float4(ob.vxmin, ob.vxmax, ob.vymin, ob.vymax);
-			mine[3] = make_float4(__uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)), __int_as_float(max(pr.x1 - pr.x0, 1)), __uint_as_float(excl), hl + 1);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			mine[3] = make_float4(__uint_as_float(xy), __int_as_float(max(ow0, 1)), __uint_as_float(excl), hl + 1);
+			FR_WAVE_LDS_SYNC();
 		}
 		for (uint32_t k = 0; k < total; k += 64)
 		{
@@ -1366,72 +1297,31 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			__builtin_amdgcn_wave_barrier();
 		}
 		if (FOV && (my_n != 0 || big) && count != 0) range_from_mask(lvmask, lowest, highest, be_blend);
-		// the slab after the next is asked for HERE, in front of this slab's row stores: a returning atomic queued behind those
-		// eleven kilobyte stores came back ~1.7 us after the projection of the next slab wanted it
-		issue_pull();
-		TM_END(tm_p);
-		OutRows o;
-		o.rec1 = o.rec2 = make_float4(0, 0, 0, 0);
-#pragma unroll
-		for (int l = 0; l < FR_FOV_LEVELS; l++) o.lvl[l] = make_float4(0, 0, 0, 0);
-		if (pr.alive && !deferred) finish(idx, item, count, hl, lowest, highest, be_blend, r1.x, r2.y, w.p, cp, pre_ok, o);
-		// ---- the slab's rows leave through LDS: the walk records for k_emit (and for the giant phase below), the records,
-		// (RF) the level rows. Stored by the lane that made them, a row's 16-byte pieces lie 48 or 64 bytes apart between
-		// lanes: every store instruction then touches 24-32 cache lines, which costs the CU's memory pipeline ~3 cycles per
-		// lane -- eleven such instructions per slab were a quarter of the kernel. Transposed through the wave's LDS rows,
-		// a store instruction writes one contiguous kilobyte. (Rows of candidates without instances are zeros nobody reads;
-		// a giant splat's are written again by the giant phase, behind the workgroup barrier.)
-		{
-			float4 *st = orec;
-			const uint32_t flags = ((pr.alive && (deferred || count != 0)) ? 1u : 0u) | (boxtest ? 2u : 0u);
-			auto stage = [&](const float4 *rows, const int n, float4 *dst_base) __attribute__((always_inline))
-			{
-				// rows[0..n) of this lane -> LDS at [n * lane + i]; piece c of the slab's n * 64 then goes to dst_base[n * 64 * slab + c]
-				for (int i = 0; i < n; i++) st[n * lane + i] = rows[i];
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				const size_t g0 = (size_t)n * 64 * (size_t)slab, gend = (size_t)n * (size_t)V;
-				for (int i = 0; i < n; i++)
-				{
-					const size_t g = g0 + (size_t)(i * 64 + lane);
-					if (g < gend) dst_base[g] = st[i * 64 + lane];
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-			};
-			const float4 wr[4] = { make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y), make_float4(ev.z, ev.w, el.x, el.y),
-				make_float4(__uint_as_float((uint32_t)idx | (flags << 30)), pr.depth, __uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)),
-					__uint_as_float((uint32_t)(pr.x1 - pr.x0))),
-				make_float4(__uint_as_float(pr.tnum), hl, 0.0f, 0.0f) };
-			stage(wr, 4, a.geom.wrec);
-			const float4 rr[3] = { rec0, o.rec1, o.rec2 };
-			stage(rr, 3, a.geom.rec);
-			if (LEVELCOL) stage(o.lvl, 4, a.geom.lvl);
-			if (a.write_cov3D)
-			{
-				// training variants: the item's inputs and 3D covariance for the backward pass, and its row of gradient sums,
-				// cleared here; the last quarter of that row is not summed into: it carries 1 / |raw quaternion| (raw parameters)
-				stage(stash_rows, 4, (float4 *)a.geom.cov3D);
-				const float4 ac[4] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(inv_qnorm, 0.f, 0.f, 0.f) };
-				stage(ac, 4, a.geom.acc);
-			}
-		}
 	}
-	TM_END(tm_c);
-	slab = next_slab;
-	in_cur = in_next;
+	// what the item leaves: one dense word (a giant splat's is written after the workgroup has walked it); candidates whose
+	// tiles were all rejected lose their radius (RS rasterizer_impl.cu:141-145)
+	const uint32_t lr = (alive && !deferred) ? range_word(count, lowest, highest, be_blend) : FR_ITEM_NONE;
+	if (item < V && !deferred) a.geom.lrange[item] = lr;
+	if (alive && !deferred && count == 0) a.radii[idx] = 0;
+	// ---- the colours of the slab's items that landed in a tile; the blend record leaves with them (RF: the level rows) ----
+	if (__any(lr != FR_ITEM_NONE))
+	{
+		float4 piece[3], r[3], lv[FR_FOV_LEVELS];
+		rows_fetch<3>(piece, a.geom.rec + 3 * (size_t)slab * 64, nv, lane);
+		rows_unpack<3>(r, piece, orec, lane);
+#pragma unroll
+		for (int l = 0; l < FR_FOV_LEVELS; l++) lv[l] = make_float4(0, 0, 0, 0);
+		if (lr != FR_ITEM_NONE) colour_item<VARIANT, PACKED>(a, rows_ok, lr, r, lv);
+		if (LEVELCOL) rows_store<4>(lv, orec, a.geom.lvl + 4 * (size_t)slab * 64, nv, lane);
+		else rows_store<3>(r, orec, a.geom.rec + 3 * (size_t)slab * 64, nv, lane);
+	}
 	} // slab loop
-#ifdef FR_BIN_TIMERS
-	const uint64_t tm_loop_end = wall_clock64();
-#endif
-	if (LDSH && lane == 0) a.geom.wave_head[wave_gid] = chain;
 	// ---- giant splats: every wave of the workgroup takes every (FR_BIN_THREADS / 64)-th step ----
 	__syncthreads();
 	const int ng = min((int)s_ng, FR_GIANT_MAX);
 	for (int g = 0; g < ng; g++)
 	{
-		const float4 *wr = a.geom.wrec + 4 * (size_t)s_gitem[g]; // written above by the wave that set the splat aside
+		const float4 *wr = a.geom.wrec + 4 * (size_t)s_gitem[g];
 		const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
 		const Obb ob = make_obb(w0.x, w0.y, make_float4(w0.z, w0.w, w1.x, w1.y), make_float2(w1.z, w1.w));
 		const uint32_t xy = __float_as_uint(w2.z);
@@ -1443,36 +1333,31 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	__syncthreads();
 	if ((int)threadIdx.x < ng)
 	{
-		const int gi = s_gidx[threadIdx.x];
+		const int gitem = s_gitem[threadIdx.x];
 		const uint32_t gcount = s_gcount[threadIdx.x];
-		const float ghl = FOV ? (PACKED ? a.packed_geom[16 * (size_t)gi + 10] : a.highest_levels[gi]) : 0.0f;
-		float lowest = ghl, highest = 0.0f;
+		const float4 w2 = a.geom.wrec[4 * (size_t)gitem + 2], w3 = a.geom.wrec[4 * (size_t)gitem + 3];
+		float lowest = w3.y, highest = 0.0f;
 		bool be_blend = false;
 		if (FOV && gcount != 0) range_from_mask(s_gmask[threadIdx.x], lowest, highest, be_blend);
-		ColourPre none = {};
-		OutRows o;
-		o.rec1 = o.rec2 = make_float4(0, 0, 0, 0);
-#pragma unroll
-		for (int l = 0; l < FR_FOV_LEVELS; l++) o.lvl[l] = make_float4(0, 0, 0, 0);
-		const int gitem = s_gitem[threadIdx.x];
-		finish(gi, gitem, gcount, ghl, lowest, highest, be_blend, s_gcd[threadIdx.x].x, s_gcd[threadIdx.x].y, nullptr, none, false, o);
-		if (gcount != 0)
+		const uint32_t lr = range_word(gcount, lowest, highest, be_blend);
+		a.geom.lrange[gitem] = lr;
+		if (gcount == 0) a.radii[__float_as_uint(w2.x) & 0x3fffffffu] = 0;
+		else
 		{
-			// (the first third of the record went out with the slab)
-			a.geom.rec[3 * (size_t)gitem + 1] = o.rec1; a.geom.rec[3 * (size_t)gitem + 2] = o.rec2;
-			if (LEVELCOL)
+			float4 r[3], lv[FR_FOV_LEVELS];
 #pragma unroll
-				for (int l = 0; l < FR_FOV_LEVELS; l++) a.geom.lvl[(size_t)gitem * FR_FOV_LEVELS + l] = o.lvl[l];
+			for (int i = 0; i < 3; i++) r[i] = a.geom.rec[3 * (size_t)gitem + i];
+#pragma unroll
+			for (int l = 0; l < FR_FOV_LEVELS; l++) lv[l] = make_float4(0, 0, 0, 0);
+			colour_item<VARIANT, PACKED>(a, rows_ok, lr, r, lv);
+			if (LEVELCOL)
+			{
+#pragma unroll
+				for (int l = 0; l < FR_FOV_LEVELS; l++) a.geom.lvl[(size_t)gitem * FR_FOV_LEVELS + l] = lv[l];
+			}
+			else { a.geom.rec[3 * (size_t)gitem + 1] = r[1]; a.geom.rec[3 * (size_t)gitem + 2] = r[2]; }
 		}
 	}
-#ifdef FR_BIN_TIMERS
-	if (lane == 0)
-	{
-		float *d = a.geom.cov3D + (size_t)wave_gid * 8;
-		d[0] = (float)(wall_clock64() - tm0); d[1] = (float)(tm_loop_end - tm0); d[2] = (float)tm_l; d[3] = (float)tm_p; d[4] = (float)tm_c;
-		d[5] = (float)tm_n + 1024.0f * (float)tm_bsteps; d[6] = (float)tm_sh; d[7] = (float)tm_steps;
-	}
-#endif
 	if (LDSH)
 	{
 		// The workgroup's share of every tile's bucket: its histogram is ADDED to the tile's global counter, and what the
@@ -1498,12 +1383,6 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			for (int k = 0; k < 4; k++) { const int t = t0 + k * FR_BIN_THREADS; if (t < a.T && h[k]) out[t] = o[k]; }
 		}
 	}
-#ifdef FR_BIN_TIMERS
-	__syncthreads();
-	if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)
-		printf("k_bin wg %d (10 ns ticks): prologue %d (issue %d first barrier %d scan %d rest %d) slab loop + giants %d flush %d\n", (int)blockIdx.x, (int)(tm0 - tm_entry),
-			(int)(tm_pa - tm_entry), (int)(tm_pb - tm_pa), (int)(tm_pc - tm_pb), (int)(tm0 - tm_pc), (int)(tm_loop_end - tm0), (int)(wall_clock64() - tm_loop_end));
-#endif
 }
 #undef BUMP_TILE
 #undef TILE_FILTER
@@ -1529,10 +1408,7 @@ struct EmitArgs {
 };
 // LDSH: the workgroup's write cursor of every tile lives in LDS, initialised to
 // tile start + (instances of the same tile owned by lower-numbered workgroups).
-#ifndef FR_EMIT_SHARE
-#define FR_EMIT_SHARE 2
-#endif
-#define FR_EMIT_THREADS (FR_BIN_THREADS * FR_EMIT_SHARE)
+#define FR_EMIT_THREADS FR_BIN_THREADS // (the same waves take the same slabs in k_count and k_emit)
 // LDSH == 2 (see k_bin): the LDS cursors are 16-bit offsets inside the workgroup's share, two tiles per word; where the share
 // starts comes from global memory with every entry
 #define NEXT_SLOT(ti) (LDSH == 2 ? a.ranges[(ti)].x + pre_row[(ti)] + ((atomicAdd(&lds_cur[(ti) >> 1], 1u << (16 * ((ti) & 1))) >> (16 * ((ti) & 1))) & 0xffffu) \
@@ -1635,11 +1511,13 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	float2 el = make_float2(0, 0);
 	if (item < V)
 	{
+		// (what k_count found out about the item: one that landed in no tile is not walked again)
+		const uint32_t lr = a.geom.lrange[item];
 		const float4 *wr = a.geom.wrec + 4 * (size_t)item;
 		const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
 		const uint32_t idf = __float_as_uint(w2.x), xy = __float_as_uint(w2.z);
 		idx = (int)(idf & 0x3fffffffu);
-		alive = (idf >> 30) & 1u; boxtest = (idf >> 31) & 1u;
+		alive = lr != FR_ITEM_NONE && ((idf >> 30) & 1u) != 0; boxtest = (idf >> 31) & 1u;
 		cx = w0.x; cy = w0.y; ev = make_float4(w0.z, w0.w, w1.x, w1.y); el = make_float2(w1.z, w1.w);
 		depth_bits = __float_as_uint(w2.y);
 		x0 = (int)(xy & 0xffffu); y0 = (int)(xy >> 16); x1 = x0 + (int)__float_as_uint(w2.w);
@@ -1649,7 +1527,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	// the instance's payload is the ITEM (position in vis_list): the per-item records are dense, and items are in index order,
 	// so the per-tile sort by (depth bits, item) gives the reference's stable order
 	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)item;
-	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_bin's level test, no box test (single-tile splat)
+	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_count's level test, no box test (single-tile splat)
 	if (in_place) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
 	{
 		bool deferred = false;
@@ -1707,24 +1585,8 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		}
 	}
 	}; // process(slab)
-	if (LDSH)
 	{
-		// replay k_bin's slab -> wave assignment (the bucket offsets are per workgroup) by walking the
-		// chain that wave left behind
-		// FR_EMIT_SHARE waves share the chain one of k_bin's waves left (they take every FR_EMIT_SHARE-th slab of it): the
-		// kernel waits on memory 70 % of the time (a slab's scattered stores and the next slab's loads sit behind
-		// one in-order counter), more waves per SIMD is what hides that
-		const int w = (int)(threadIdx.x >> 6);
-		int slab = a.geom.wave_head[(int)blockIdx.x * (FR_BIN_THREADS / 64) + (w % (FR_BIN_THREADS / 64))];
-		for (int pos = 0; slab >= 0; pos++)
-		{
-			const int next = a.geom.slab_next[slab];
-			if (pos % FR_EMIT_SHARE == w / (FR_BIN_THREADS / 64)) process(slab);
-			slab = next;
-		}
-	}
-	else
-	{
+		// the slabs k_count's wave of the same number took (the bucket offsets are per workgroup): wave, wave + waves, ...
 		const int wave_gid = (int)blockIdx.x * (FR_EMIT_THREADS / 64) + (int)(threadIdx.x >> 6);
 		const int nwaves = (int)gridDim.x * (FR_EMIT_THREADS / 64);
 		for (int slab = wave_gid; slab < nslabs; slab += nwaves) process(slab);
@@ -1857,7 +1719,10 @@ int launch_project(FwdCtx &c)
 	{
 		// persistent waves: exactly as many workgroups as the device keeps resident (a second, partial round of
 		// workgroups would run on a half-empty chip)
-		static int resident[6] = { 0, 0, 0, 0, 0, 0 };
+		static thread_local int resident_of[8][6]; // per host thread and device (zero = not asked yet)
+		int cur_dev = 0;
+		(void)hipGetDevice(&cur_dev);
+		int *const resident = resident_of[cur_dev & 7];
 		const bool packed = a->packed_cull != nullptr;
 		const int vslot = a->variant == FR_VARIANT_ORIGINAL ? 0 : (is_fov(a->variant) ? 1 : 2); // the cull pass only knows "level box or not"
 		const int slot = vslot + (packed ? 3 : 0);
@@ -1893,16 +1758,46 @@ int launch_project(FwdCtx &c)
 	}
 }
 
-// stage "bin": tile counts (LDS histograms), colours, final records; then the column scan of the histograms
-int launch_bin(FwdCtx &c)
+// stage "bin", first half: the full projection of the cull pass's survivors (k_geom): one wave per wave of the cull pass
+int launch_geom(FwdCtx &c)
+{
+	const fr_forward_args *a = c.a;
+	PreArgs p = make_pre_args(c);
+	const dim3 grid((c.proj_waves + 3) / 4), block(256);
+	// the packed model layout and the candidate rows are compile-time variants of the kernel (run-time tests on the pointers
+	// cost the ordinary path 5 %): packed needs both packed tensors; the rows exist when k_project stored them (foveated
+	// variants, unpacked cull pass, scales + rotations given)
+	const bool packed = a->packed_geom && a->packed_colour;
+	const bool crow = !packed && is_fov(a->variant) && a->packed_cull == nullptr && a->cov3D_precomp == nullptr;
+#define LAUNCH_GEOM(V) do { if (packed) hipLaunchKernelGGL((k_geom<V, true, false>), grid, block, 0, c.stream, p); \
+	else if (crow) hipLaunchKernelGGL((k_geom<V, false, true>), grid, block, 0, c.stream, p); \
+	else hipLaunchKernelGGL((k_geom<V, false, false>), grid, block, 0, c.stream, p); } while (0)
+	switch (a->variant)
+	{
+	case FR_VARIANT_ORIGINAL: LAUNCH_GEOM(FR_VARIANT_ORIGINAL); break;
+	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_GEOM(FR_VARIANT_FOV_PCHECK_OBB); break;
+	case FR_VARIANT_MMFR_PCHECK_OBB:      // plain colours + the level filter (on the skip key, see k_tile_levels): the same kernels
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB:
+		// (no packed instantiation: validate_forward refuses the packed tensors)
+		if (crow) hipLaunchKernelGGL((k_geom<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false, true>), grid, block, 0, c.stream, p);
+		else hipLaunchKernelGGL((k_geom<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false, false>), grid, block, 0, c.stream, p);
+		break;
+	default: LAUNCH_GEOM(FR_VARIANT_PCHECK_OBB); break; // every other cull variant projects alike
+	}
+#undef LAUNCH_GEOM
+	return check_launch("geom", c.stream, a->debug);
+}
+
+// stage "bin", second half: tile counts (LDS histograms) from the walk records, and the colours (k_count)
+int launch_count(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	PreArgs p = make_pre_args(c);
 	int nblk = bin_blocks(a->P);
 	const dim3 block(FR_BIN_THREADS);
 	// Where the tiles are counted: an LDS histogram per workgroup of 32-bit counts (grids up to 16 Ki tiles), of 16-bit counts
-	// (up to 34 816 tiles: a workgroup then takes fewer than 65 536 items, so at least one workgroup per CU must cover all
-	// P Gaussians), or global counters.
+	// (up to 34 816 tiles: a workgroup then takes fewer than 65 536 items, so the resident workgroups must cover all
+	// P Gaussians with a margin for waves that finish early), or global counters.
 	static thread_local int cus = 0;
 	if (cus == 0)
 	{
@@ -1912,18 +1807,13 @@ int launch_bin(FwdCtx &c)
 	}
 	const int64_t wgs_lo = nblk < cus ? nblk : cus;
 	c.hist_mode = c.img.hist == nullptr ? 0 : (c.T <= FR_LDS_HIST_MAX_TILES ? 1 :
-		(wgs_lo * (FR_BIN_THREADS / 64) * FR_HIST16_MAX_SLABS * 64 >= (int64_t)a->P ? 2 : 0));
+		(wgs_lo * (FR_BIN_THREADS / 64) * (int64_t)(FR_HIST16_MAX_SLABS - 1) * 64 >= (int64_t)a->P ? 2 : 0)); // (wave w takes slabs w, w + waves, ...)
 	const bool ldsh = c.hist_mode != 0;
 	// LDS per workgroup: tile histogram (+ RF: the 4-bit tile table)
 	p.lds_tiles = (is_fov(a->variant) && ldsh) ? 1 : 0;
 	const size_t hist_bytes = c.hist_mode == 2 ? (size_t)((c.T + 1) / 2) * sizeof(uint32_t) : (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0);
-	const size_t lds = hist_bytes + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0) +
-		(size_t)(c.proj_waves + 1) * sizeof(uint32_t); // + the running counts of the cull pass's waves
-	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the
-	// ordinary path 5 %); it needs both packed tensors and the LDS histogram path. Otherwise, when k_project stored the
-	// candidates' rows (foveated variants, unpacked cull pass, scales + rotations given), the kernel that reads those.
-	const bool packed = c.hist_mode == 1 && a->packed_geom && a->packed_colour;
-	const bool crow = ldsh && !packed && is_fov(a->variant) && a->packed_cull == nullptr && a->cov3D_precomp == nullptr;
+	const size_t lds = ((hist_bytes + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0) + 15) & ~(size_t)15) +
+		(size_t)FR_BIN_THREADS * (4 * sizeof(float4) + sizeof(int)); // + the waves' staging / owner rows
 	// Never more workgroups than the device keeps resident: the slabs are handed out dynamically, so workgroups of a
 	// second round start when the first ones are done, find the counters empty and only cost their LDS set-up, an
 	// all-zero histogram row and the tail of the kernel (measured: 256 of 512 workgroups, 175 -> 211 us).
@@ -1935,13 +1825,16 @@ int launch_bin(FwdCtx &c)
 		if (wgs == 0)
 		{
 			if (dyn > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
-			{ set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(hipGetLastError())); return FR_ERR_HIP; }
+			{ set_error("hipFuncSetAttribute(k_count): %s", hipGetErrorString(hipGetLastError())); return FR_ERR_HIP; }
 			int per_cu = 0, dev = 0;
 			hipDeviceProp_t prop;
 			if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
 				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FR_BIN_THREADS, dyn) != hipSuccess || per_cu < 1)
 			{ per_cu = 1; prop.multiProcessorCount = 256; (void)hipGetLastError(); }
 			wgs = per_cu * prop.multiProcessorCount;
+			// one workgroup per CU: a second one on the CU doubles the histogram flushes (one returning atomic per workgroup and
+			// touched tile) and the table prologues for slabs that one workgroup's eight waves already cover
+			if (const char *e = getenv("FR_COUNT_WGS_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) wgs = v * prop.multiProcessorCount; }
 			if (ncache < 24) { cache[ncache].fn = fn; cache[ncache].dyn = dyn; cache[ncache].wgs = wgs; ncache++; }
 		}
 		nblk = nblk < wgs ? nblk : wgs;
@@ -1949,31 +1842,25 @@ int launch_bin(FwdCtx &c)
 		return FR_OK;
 	};
 	int lrc = FR_OK;
-#define LAUNCH_PRE(V) do { if (packed) lrc = launch((const void *)k_bin<V, 1, true>, k_bin<V, 1, true>, lds); \
-	else if (crow && c.hist_mode == 2) lrc = launch((const void *)k_bin<V, 2, false, true>, k_bin<V, 2, false, true>, lds); \
-	else if (crow) lrc = launch((const void *)k_bin<V, 1, false, true>, k_bin<V, 1, false, true>, lds); \
-	else if (c.hist_mode == 2) lrc = launch((const void *)k_bin<V, 2>, k_bin<V, 2>, lds); \
-	else if (ldsh) lrc = launch((const void *)k_bin<V, 1>, k_bin<V, 1>, lds); \
-	else lrc = launch((const void *)k_bin<V, 0>, k_bin<V, 0>, lds); } while (0)
+	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the ordinary path 5 %)
+	const bool packed = a->packed_geom && a->packed_colour;
+#define LAUNCH_COUNT_P(V, PK) do { if (c.hist_mode == 2) lrc = launch((const void *)k_count<V, 2, PK>, k_count<V, 2, PK>, lds); \
+	else if (ldsh) lrc = launch((const void *)k_count<V, 1, PK>, k_count<V, 1, PK>, lds); \
+	else lrc = launch((const void *)k_count<V, 0, PK>, k_count<V, 0, PK>, lds); } while (0)
+#define LAUNCH_COUNT(V) do { if (packed) LAUNCH_COUNT_P(V, true); else LAUNCH_COUNT_P(V, false); } while (0)
 	switch (a->variant)
 	{
-	case FR_VARIANT_ORIGINAL: LAUNCH_PRE(FR_VARIANT_ORIGINAL); break;
-	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_PRE(FR_VARIANT_FOV_PCHECK_OBB); break;
+	case FR_VARIANT_ORIGINAL: LAUNCH_COUNT(FR_VARIANT_ORIGINAL); break;
+	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_COUNT(FR_VARIANT_FOV_PCHECK_OBB); break;
 	case FR_VARIANT_MMFR_PCHECK_OBB:      // plain colours + the level filter (on the skip key, see k_tile_levels): the same kernel
-	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB:
-		// (no packed instantiation: validate_forward refuses the packed tensors)
-		if (crow && c.hist_mode == 2) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 2, false, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 2, false, true>, lds);
-		else if (crow) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 1, false, true>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 1, false, true>, lds);
-		else if (c.hist_mode == 2) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 2>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 2>, lds);
-		else if (ldsh) lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 1>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 1>, lds);
-		else lrc = launch((const void *)k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 0>, k_bin<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, 0>, lds);
-		break;
-	default: LAUNCH_PRE(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: LAUNCH_COUNT_P(FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false); break; // (no packed layout: validate_forward)
+	default: LAUNCH_COUNT(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
 	}
-#undef LAUNCH_PRE
+#undef LAUNCH_COUNT
+#undef LAUNCH_COUNT_P
 	if (lrc) return lrc;
 	c.bin_wgs = nblk;
-	return check_launch("preprocess", c.stream, a->debug);
+	return check_launch("count", c.stream, a->debug);
 }
 
 int launch_emit(FwdCtx &c)

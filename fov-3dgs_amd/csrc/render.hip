@@ -878,7 +878,7 @@ int launch_render(FwdCtx &c)
 	// on the device until the host has read the counts: the grid is then FwdCtx::items_cap (a little more than the previous
 	// frame of the kind had; surplus workgroups leave at once -- they sit at the END of the grid, behind all the work -- and
 	// a frame with more items than that is not blended but replayed, see frame_fits)
-	const unsigned n_items = (unsigned)(c.counts_known ? c.n_items : c.items_cap);
+	const unsigned n_items = (unsigned)c.n_items;
 #define FR_LAUNCH_RENDER(V, UNUSED_) hipLaunchKernelGGL((k_render<V, PPL>), dim3(n_items), dim3(64), 0, c.stream, r)
 	switch (a->variant)
 	{

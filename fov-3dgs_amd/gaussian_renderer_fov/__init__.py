@@ -5,7 +5,8 @@ import weakref
 import torch
 
 from ..diff_gaussian_rasterization_fov_pcheck_obb import GaussianRasterizationSettings, GaussianRasterizer
-from ..rasterizer import PackedModel, pack_model, zero_points_like
+from .. import _native
+from ..rasterizer import PackedModel, _forward_begin, pack_model, zero_points_like
 
 
 class _PackState:
@@ -113,3 +114,53 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, a
 
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}
+
+
+class PendingRender:
+    """A foveated frame between the two halves of its native call (render_begin): finish() -> the dict render() returns."""
+
+    def __init__(self, frame, points):
+        self._frame, self._points = frame, points
+
+    def finish(self):
+        res = self._frame.finish()
+        radii = res[2]
+        return {"render": res[1], "viewspace_points": self._points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def render_begin(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, alpha=None, gazeArray=None,
+                 blending=None, highest_levels=None, shs_dcs=None, opacities=None, packed=None, stream=None):
+    """Throughput mode (extension, inference only): enqueue the HEAD of a foveated frame -- tile levels, cull pass, projection,
+    tile counts, tile scan -- on `stream` (default: the current one) and return without waiting for its instance count;
+    PendingRender.finish() waits for the count and enqueues emission, sort, colours and blend. A host that alternates two
+    streams -- begin(n + 1) before finish(n) -- keeps two frames in flight: the latency-bound head of one runs beside the sort
+    and the blend of the other (csrc/api.hip). Every stream has its own workspaces; the image of a frame is valid once its
+    stream has reached the end of finish()'s work (synchronise the stream, or make the consumer's stream wait for it). Same
+    arguments and result as render()."""
+    with torch.no_grad(), torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(pc.get_xyz.device)):
+        xyz = pc.get_xyz
+        rs = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+            tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+            scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+            projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+            campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+        act = getattr(pc, "get_activated", None)
+        if act is not None:
+            scales, rotations, opacity = act
+            if opacities is not None:
+                opacity = opacities
+        else:
+            opacity = pc.get_opacity if opacities is None else opacities
+            scales, rotations = pc.get_scaling, pc.get_rotation
+        shs_rest = pc.get_rest_features
+        if isinstance(packed, str):
+            packed = _auto_packed(pc, xyz, scales, rotations, opacity, shs_rest, shs_dcs, highest_levels)
+        if gazeArray is None:
+            raise Exception("gazeArray is required by the foveated rasterizer")
+        gaze = gazeArray.detach().flatten().tolist() if isinstance(gazeArray, torch.Tensor) else list(gazeArray)
+        empty = torch.Tensor([])
+        frame = _forward_begin(_native.VARIANT_FOV_PCHECK_OBB, rs, xyz, shs_rest, empty, opacity, scales, rotations, empty,
+                               shs_dcs, highest_levels, (float(gaze[0]), float(gaze[1])), float(alpha), persistent=True,
+                               packed=packed)
+        return PendingRender(frame, zero_points_like(xyz))

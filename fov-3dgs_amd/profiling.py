@@ -1,6 +1,6 @@
 """Per-stage kernel timing with HIP events recorded by the C library on the launch stream.
 
-`StageTimer` hands the rasterizer one set of FR_NUM_STAGES + 1 events per forward call; nothing is
+`StageTimer` hands the rasterizer one set of FR_NUM_STAGE_EVENTS events per forward call; nothing is
 synchronised while the timed region runs. Durations are read afterwards (fr_event_elapsed_ms).
 Stage names: _native.STAGES. `stages` limits the events to the boundaries of the named stages: every event
 record is a command of its own on the stream (~3 us each on MI355X: eight of them are 3.5 % of a 0.72 ms frame), so a
@@ -14,11 +14,11 @@ from . import _native, rasterizer
 class StageTimer:
     def __init__(self, max_calls, stages=None):
         self.lib = _native.load()
-        self.n = len(_native.STAGES) + 1
+        self.n = _native.NUM_STAGE_EVENTS
         self.stages = tuple(_native.STAGES) if stages is None else tuple(stages)
         wanted = set()
         for name in self.stages:
-            i = _native.STAGES.index(name)
+            i = self._first(name)
             wanted.update((i, i + 1))
         self.sets = []
         for _ in range(max_calls):
@@ -27,6 +27,10 @@ class StageTimer:
                 arr[i] = self.lib.fr_event_create() if i in wanted else None
             self.sets.append(arr)
         self.used = 0
+
+    @staticmethod
+    def _first(name):
+        return _native.STAGES.index(name)
 
     def _next(self):
         if self.used >= len(self.sets):
@@ -49,7 +53,7 @@ class StageTimer:
         for arr in self.sets[:self.used]:
             d = {}
             for name in self.stages:
-                i = _native.STAGES.index(name)
+                i = self._first(name)
                 rc = self.lib.fr_event_elapsed_ms(arr[i], arr[i + 1], C.byref(ms))
                 d[name] = ms.value if rc == 0 else float("nan")
             out.append(d)

@@ -12,6 +12,7 @@ All tensors must live on a ROCm device; there is no CPU path. Output / workspace
 allocated here with torch (the C library never allocates device memory).
 """
 import ctypes as C
+import threading
 from typing import NamedTuple
 
 import torch
@@ -55,30 +56,32 @@ def _ptr(t):
 
 
 _small_copies = {}
+SMALL_COPY_CACHE = True  # set to False to copy the per-call camera tensors on every call
 
 
 def _f32_small(t, device):
     """_f32 for the per-call camera tensors (viewmatrix, projmatrix, campos, bg: a few floats each). The reference's cameras
     keep world_view_transform as a TRANSPOSED view (scene/cameras.py:54), so `.contiguous()` is a copy kernel on the stream
     at the head of every frame (~6 us of a 0.7 ms frame, twice); the copy is kept for as long as the caller hands over the
-    same tensor object with the same storage, strides and autograd version (writes through `.data` are not seen: clone the
-    tensor after such a write)."""
+    same tensor object with the same storage, strides and autograd version. Writes the version counter cannot see (`.data`
+    writes, raw-pointer kernels, DLPack / numpy aliases) are caught for CPU tensors by comparing the values (a few floats on
+    the host); for a device tensor clone it after such a write, or set SMALL_COPY_CACHE = False."""
     if t is None or t.numel() == 0:
         return None
     if t.device == device and t.dtype == torch.float32 and t.is_contiguous():
         return t
-    if t.numel() > 64:
+    if t.numel() > 64 or not SMALL_COPY_CACHE:
         return _f32(t, device)
     key = id(t)
     ent = _small_copies.get(key)
     sig = (t._version, t.data_ptr(), t.stride(), t.dtype, t.device)
-    if ent is not None and ent[0]() is t and ent[1] == sig:
+    if ent is not None and ent[0]() is t and ent[1] == sig and (t.is_cuda or torch.equal(ent[3], t)):
         return ent[2]
     c = _f32(t, device)
     if len(_small_copies) > 256:
         _small_copies.clear()
     import weakref
-    _small_copies[key] = (weakref.ref(t), sig, c)
+    _small_copies[key] = (weakref.ref(t), sig, c, None if t.is_cuda else t.detach().clone())
     return c
 
 
@@ -108,7 +111,9 @@ class _Workspaces:
     def _make(self, i):
         def resize(_user, nbytes):
             if self.buf[i].numel() < nbytes:
-                want = (int(nbytes) * 5 // 4 + _GRANULE - 1) // _GRANULE * _GRANULE
+                # (no headroom on top: the library asks for the binning workspace with a quarter of headroom over the largest
+                # frame of the kind itself, include/fovraster.h)
+                want = (int(nbytes) + _GRANULE - 1) // _GRANULE * _GRANULE
                 self.buf[i] = torch.empty(want, dtype=torch.uint8, device=self.device)
             return self.buf[i].data_ptr()
         return resize
@@ -133,16 +138,19 @@ class _Lease:
 
 
 def _workspaces_for(device, needs_graph):
-    """-> (workspaces, lease). A per-device persistent set for calls without an autograd graph; for training a
-    set from a small pool, leased until the graph is gone: allocating GBs of fresh buffers every step made the
-    caching allocator fall back to hipMalloc/hipFree every few steps (30-40 ms stalls)."""
+    """-> (workspaces, lease). Calls without an autograd graph use a persistent grow-only set per (device, current stream, host
+    thread) -- the C ABI is thread-compatible and two frames may be in flight on two streams (begin / finish), so neither two
+    threads nor two streams ever share buffers; a call is only valid until the next call on the same stream of the same
+    thread. For training a set from a small pool, leased until the graph is gone: allocating GBs of fresh buffers every step
+    made the caching allocator fall back to hipMalloc/hipFree every few steps (30-40 ms stalls)."""
     if needs_graph:
         idle = _pooled_ws.get(device)
         ws = idle.pop() if idle else _Workspaces(device)
         return ws, _Lease(ws)
-    ws = _persistent_ws.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
+    ws = _persistent_ws.get(key)
     if ws is None:
-        ws = _persistent_ws[device] = _Workspaces(device)
+        ws = _persistent_ws[key] = _Workspaces(device)
     return ws, None
 
 
@@ -210,16 +218,50 @@ def pack_model(means3D, scales, rotations, opacities, shs=None, shs_rest=None, s
 
 
 # Set by fov3dgs_amd.profiling.StageTimer while a timed region is active: a ctypes array of
-# FR_NUM_STAGES + 1 event handles that the next forward call records on its stream.
+# FR_NUM_STAGE_EVENTS event handles that the next forward call records on its streams.
 _stage_events_hook = None
 
 
-def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
-                    sh_rest=None, packed=None, cur_level=0.0, raw_activations=False):
-    """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease)
-    persistent=True: the workspaces are the per-device grow-only set (valid until the next call); otherwise they
-    stay reserved for as long as `lease` (the last element) is referenced."""
+class FrameInFlight:
+    """A forward call between its two halves (fr_forward_begin / fr_forward_finish, include/fovraster.h): the head of the
+    frame is on the stream, finish() waits for the instance count and enqueues the rest. Holds everything the native call
+    reads (argument struct, tensors, workspaces) alive until then."""
+
+    def __init__(self, lib, a, keep, color, radii, ws, lease, counts, contribs, handle, device, stream):
+        self.lib, self.a, self.keep, self.color, self.radii = lib, a, keep, color, radii
+        self.ws, self.lease, self.counts, self.contribs, self.handle = ws, lease, counts, contribs, handle
+        self.device, self.stream = device, stream
+
+    def finish(self):
+        """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease)"""
+        handle, self.handle = self.handle, None
+        if handle is None:
+            raise RuntimeError("fovraster: frame already finished")
+        # (the binning workspace callback allocates: on the frame's own stream, whatever stream the caller is on by now)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            rc = self.lib.fr_forward_finish(handle)
+        if rc != 0:
+            raise RuntimeError(f"fovraster forward failed ({rc}): {_native.last_error()}")
+        ws = self.ws
+        out = (int(self.a.num_rendered), self.color, self.radii, ws.buf[0], ws.buf[1], ws.buf[2])
+        if self.counts is not None:
+            out = out + (self.counts, self.contribs)
+        return out + (self.lease,)  # last element: keeps the workspace set reserved (None for the persistent set)
+
+    def __del__(self):
+        if getattr(self, "handle", None) is not None:  # abandoned between the halves: the library must release its handle
+            try:
+                self.lib.fr_forward_finish(self.handle)
+            except Exception:
+                pass
+
+
+def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                   shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
+                   sh_rest=None, packed=None, cur_level=0.0, raw_activations=False):
+    """First half of a forward call on the current stream -> FrameInFlight. persistent=True: the workspaces are the grow-only
+    set of this (device, stream, thread) (valid until the next call there); otherwise they stay reserved for as long as the
+    `lease` of the result is referenced."""
     lib = _native.load()
     _require_gpu(means3D)
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -238,7 +280,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
 
     with torch.cuda.device(dev):
         # both outputs are written in full by the kernels (every pixel by the blend, every radius by the cull pass
-        # or the binning kernel; the P == 0 path fills the image itself): no zero-fill kernels at the head of the frame
+        # or the projection kernel; the P == 0 path fills the image itself): no zero-fill kernels at the head of the frame
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         ws, lease = _workspaces_for(dev, not persistent)
@@ -255,7 +297,8 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         a.gaze_x, a.gaze_y, a.alpha = float(gaze[0]), float(gaze[1]), float(alpha)
         a.cur_level = float(cur_level)
         a.raw_activations = int(bool(raw_activations))
-        a.stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = torch.cuda.current_stream(dev)
+        a.stream = stream.cuda_stream
         put("background", rs.bg, small=True)
         put("means3D", means3D)
         put("colors_precomp", colors_precomp)
@@ -275,6 +318,7 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
             a.packed_geom = _ptr(packed.geom)
             a.packed_colour = _ptr(packed.colour)
             a.packed_cull = _ptr(packed.cull)
+            keep.append(packed)
         if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC):
             counts = torch.empty((P,), dtype=torch.int32, device=dev)      # zeroed by fr_forward itself
             contribs = torch.empty((P,), dtype=torch.float32, device=dev)
@@ -282,13 +326,17 @@ def _forward_native(variant, rs, means3D, sh, colors_precomp, opacities, scales,
         a.geometry_resize, a.binning_resize, a.image_resize = ws.cbs[0], ws.cbs[1], ws.cbs[2]
         if _stage_events_hook is not None:
             a.stage_events = _stage_events_hook()
-        rc = lib.fr_forward(C.byref(a))
+        handle = C.c_void_p()
+        rc = lib.fr_forward_begin(C.byref(a), C.byref(handle))
         if rc != 0:
             raise RuntimeError(f"fovraster forward failed ({rc}): {_native.last_error()}")
-    out = (int(a.num_rendered), color, radii, ws.buf[0], ws.buf[1], ws.buf[2])
-    if counts is not None:
-        out = out + (counts, contribs)
-    return out + (lease,)  # last element: keeps the workspace set reserved (None for the persistent set)
+    return FrameInFlight(lib, a, keep, color, radii, ws, lease, counts, contribs, handle, dev, stream)
+
+
+def _forward_native(*args, **kw):
+    """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease):
+    both halves of the forward call back to back (arguments: _forward_begin)."""
+    return _forward_begin(*args, **kw).finish()
 
 
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -21,12 +21,11 @@
  * stands for the reference's "empty tensor". The library never allocates or frees device memory:
  * the three workspaces are obtained through the caller's resize callbacks, exactly like the
  * reference's geometry/binning/image buffers, and must be kept alive by the caller for
- * fr_backward. All work is enqueued on `stream` (a hipStream_t). fr_forward returns num_rendered like the
- * reference, so it waits ONCE for that count (a 32-byte block the tile scan writes into pinned host memory, polled) --
- * but not for the frame. With FR_LAUNCH_AHEAD=1 in the environment the kernels behind the count are enqueued before
- * that wait from the second frame of a kind (variant, P, W, H) on (sized by the previous frame's count plus a quarter,
- * reading the real counts from device memory; a frame that does not fit is replayed): the call then returns ~0.35 ms
- * earlier, at 1.3 % more GPU time per frame. fr_backward never synchronises.
+ * fr_backward. All work is enqueued on `stream` (a hipStream_t) and on helper streams of the library that fork from / join
+ * into it. fr_forward returns num_rendered like the reference, so it waits ONCE for that count (a 32-byte block the tile
+ * scan writes into pinned host memory, polled) -- but not for the frame. fr_forward_begin / fr_forward_finish are the two
+ * halves of that call around the wait: a host that keeps two frames in flight (two streams, two workspace sets) runs the
+ * head of frame n + 1 beside the sort and the blend of frame n. fr_backward never synchronises.
  * All functions return 0 on success or a negative FR_ERR_* code; fr_last_error() gives the message
  * (thread-local).
  */
@@ -40,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 6
+#define FR_ABI_VERSION 7
 
 /* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
  * fov3dgs/gaussian_wrapper.py:11-23) */
@@ -122,8 +121,8 @@ typedef struct fr_forward_args {
 	/* result */
 	int32_t num_rendered;        /* out: number of (Gaussian,tile) instances after culling */
 	int32_t max_tile_instances;  /* out: longest per-tile list */
-	/* optional profiling: HOST pointer to FR_NUM_STAGES + 1 event handles made by fr_event_create(),
-	 * or NULL. Event i is recorded on `stream` just before stage i (FR_STAGE_* order), event
+	/* optional profiling: HOST pointer to FR_NUM_STAGES + 1 event handles made by fr_event_create() (any of
+	 * them may be NULL), or NULL. Event i is recorded on `stream` just before stage i (FR_STAGE_* order), event
 	 * FR_NUM_STAGES after the last one; nothing is synchronised. Read the stage durations later with
 	 * fr_event_elapsed_ms(ev[i], ev[i+1]). */
 	void **stage_events;
@@ -199,11 +198,6 @@ typedef struct fr_backward_args {
 
 int fr_abi_version(void);
 const char *fr_last_error(void);
-/* How the calling thread's fr_forward calls obtained their instance count (see fr_forward below): out[0] = frames whose
- * binning / sort / blend kernels were launched BEFORE the count reached the host (sized by the previous frame of the
- * same kind), out[1] = those of them that had to be replayed because the count exceeded that size, out[2] = frames
- * launched after the count (first frame of a kind, debug calls). For tests and tuning. */
-void fr_speculation_stats(int64_t out[3]);
 
 /* hipEvent wrappers so a host that only speaks the C ABI can time stages on the launch stream */
 void *fr_event_create(void);
@@ -211,6 +205,19 @@ void fr_event_destroy(void *event);
 int fr_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 
 int fr_forward(fr_forward_args *args);
+/* The same call in two halves (fr_forward == begin, then finish):
+ *   fr_forward_begin   validates, asks for the geometry and image workspaces, enqueues the head of the frame (fills, tile levels,
+ *                      cull pass, projection, tile counts, tile scan) and returns without waiting for anything; *frame is
+ *                      the handle of the frame in flight (NULL on error). `args` must stay alive and unchanged until
+ *                      fr_forward_finish(*frame) has returned, which must be called exactly once, by the same host thread.
+ *   fr_forward_finish  waits for the instance count (the frame's one host synchronisation), asks for the binning workspace
+ *                      (possibly twice: once sized like the largest frame of the kind so far, again if that was too small
+ *                      -- the last answer is the one in use), enqueues emission, sort, colours and blend, fills
+ *                      args->num_rendered / max_tile_instances and releases the handle (also when it fails).
+ * Frames in flight at the same time need their own stream and their own three workspaces each. */
+typedef struct fr_frame fr_frame;
+int fr_forward_begin(fr_forward_args *args, fr_frame **frame);
+int fr_forward_finish(fr_frame *frame);
 /* Fill fr_forward_args.packed_geom / packed_colour / packed_cull (device buffers of P*16 / P*64 / P*4 floats) from the tensors of the
  * same names; opacities is [P,levels] with levels = 1 or 4, highest_levels / shs_dcs may be NULL (not RF);
  * shs_rest NULL: shs is [P,16,3] (RF: [P,15,3] = coefficients 1..15 and shs_dcs given), else shs = [P,1,3]. */

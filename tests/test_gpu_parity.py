@@ -816,52 +816,50 @@ def test_prefiltered_violation_is_reported():
 
 
 @pytest.mark.parametrize("variant", ("pcheck_obb", "fov_pcheck_obb", "pcheck_obb_sum"))
-def test_frames_launched_ahead_of_their_instance_count(variant, monkeypatch):
-    """With FR_LAUNCH_AHEAD=1 fr_forward launches binning / sort / blend of the second and later frames of a kind before the
-    instance count has reached the host (include/fovraster.h). Same frame three ways: launched after the count (first call), ahead of it
-    (second call), and ahead of it with a workspace that turns out too small (a frame with > 1.25x the instances right
-    after a small one: replayed) -- lists and image identical to the oracle's each time."""
+def test_two_frames_in_flight(variant):
+    """fr_forward_begin / fr_forward_finish (include/fovraster.h): the head of frame B is enqueued on a second stream before
+    frame A's instance count has been waited for. Two different frames (two cameras' scale modifiers), interleaved
+    begin(A) begin(B) finish(A) finish(B), three rounds over the same two workspace sets: images, lists and statistics equal the
+    oracle's and the back-to-back calls' bit for bit."""
     _need_gpu()
-    from tests.gpu_helpers import hip_forward
-    from fov3dgs_amd import _native
-    scene, cam = small_case(variant, P=5003, seed=19, width=408, height=232)  # a (P, W, H) no other test uses: no guess yet
-    want = orc.forward(variant, scene, cam)
-    monkeypatch.setenv("FR_LAUNCH_AHEAD", "1")
-    s0 = _native.speculation_stats()
-    runs = [hip_forward(variant, scene, cam, debug=False) for _ in range(3)]
-    s1 = _native.speculation_stats()
-    assert (s1[0] - s0[0], s1[1] - s0[1], s1[2] - s0[2]) == (2, 0, 1), (s0, s1)
-    for got in runs:
-        assert got["num_rendered"] == want["num_rendered"]
-        np.testing.assert_array_equal(got["radii"], want["radii"])
-        np.testing.assert_array_equal(got["ranges"], want["ranges"])
-        np.testing.assert_array_equal(got["point_list"], want["point_list"])
-        check_image(got["color"], want["color"], name=variant + " launched ahead of its count")
-        if variant == "pcheck_obb_sum":
-            np.testing.assert_array_equal(got["gaussians_count"], want["gaussians_count"])
-    np.testing.assert_array_equal(runs[1]["color"], runs[2]["color"])
-    # a much heavier frame of the same kind: every splat 2.5x larger
-    big = dict(cam, scale_modifier=2.5)
-    want_big = orc.forward(variant, scene, big)
-    assert want_big["num_rendered"] > 1.6 * want["num_rendered"]
-    got_big = hip_forward(variant, scene, big, debug=False)
-    s2 = _native.speculation_stats()
-    assert (s2[0] - s1[0], s2[1] - s1[1], s2[2] - s1[2]) == (1, 1, 0), (s1, s2)
-    assert got_big["num_rendered"] == want_big["num_rendered"]
-    np.testing.assert_array_equal(got_big["ranges"], want_big["ranges"])
-    np.testing.assert_array_equal(got_big["point_list"], want_big["point_list"])
-    check_image(got_big["color"], want_big["color"], name=variant + " replayed after an undersized launch")
-    # ... and back to the small frame (the workspace is larger than needed now)
-    again = hip_forward(variant, scene, cam, debug=False)
-    np.testing.assert_array_equal(again["point_list"], want["point_list"])
-    np.testing.assert_array_equal(again["color"], runs[1]["color"])
-    # without the switch every frame is launched after its count
-    monkeypatch.delenv("FR_LAUNCH_AHEAD")
-    s3 = _native.speculation_stats()
-    plain = hip_forward(variant, scene, cam, debug=False)
-    s4 = _native.speculation_stats()
-    assert (s4[0] - s3[0], s4[2] - s3[2]) == (0, 1)
-    np.testing.assert_array_equal(plain["color"], runs[1]["color"])
+    from tests.gpu_helpers import VARIANT_IDS, _t, settings_from, hip_forward
+    from fov3dgs_amd.rasterizer import _forward_begin
+    scene, cam_a = small_case(variant, P=5003, seed=19, width=408, height=232)
+    cam_b = dict(cam_a, scale_modifier=1.7, gaze=(0.3, 0.6))
+    wants = [orc.forward(variant, scene, c) for c in (cam_a, cam_b)]
+    serial = [hip_forward(variant, scene, c, debug=False) for c in (cam_a, cam_b)]
+    dev = "cuda:0"
+    vid = VARIANT_IDS[variant]
+    tens = {k: _t(scene.get(k), dev) for k in ("means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
+                                                "cov3D_precomp", "shs_dcs", "highest_levels")}
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize()
+
+    def begin(cam, st):
+        rs = settings_from(cam, dev, debug=False)
+        with torch.cuda.stream(st):
+            return _forward_begin(vid, rs, tens["means3D"], tens["shs"], tens["colors_precomp"], tens["opacities"], tens["scales"],
+                                  tens["rotations"], tens["cov3D_precomp"], tens["shs_dcs"], tens["highest_levels"],
+                                  cam.get("gaze", (0.5, 0.5)), cam.get("alpha", 0.05), persistent=True)
+    for rnd in range(3):
+        fa = begin(cam_a, streams[0])
+        fb = begin(cam_b, streams[1])
+        ra, rb = fa.finish(), fb.finish()
+        torch.cuda.synchronize()
+        for res, want, ser, name in ((ra, wants[0], serial[0], "A"), (rb, wants[1], serial[1], "B")):
+            assert res[0] == want["num_rendered"]
+            np.testing.assert_array_equal(res[2].cpu().numpy(), want["radii"])
+            np.testing.assert_array_equal(res[1].cpu().numpy(), ser["color"])
+            check_image(res[1].cpu().numpy(), want["color"], name=f"{variant} frame {name} of two in flight")
+            if variant == "pcheck_obb_sum":
+                np.testing.assert_array_equal(res[6].cpu().numpy(), want["gaussians_count"])
+    # a frame abandoned between its halves releases its handle and leaves the streams usable
+    fa = begin(cam_a, streams[0])
+    del fa
+    torch.cuda.synchronize()
+    again = begin(cam_a, streams[0]).finish()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(again[1].cpu().numpy(), serial[0]["color"])
 
 
 @pytest.mark.parametrize("variant", ("fov_pcheck_obb", "pcheck_obb_sum"))
