@@ -20,6 +20,9 @@ in an untimed pass first) and around the blend stage are recorded; the other sta
 same frames (an event record is a command on the stream: all eight per frame cost 3.5 %).
 Besides `value` the line carries
   value_packed  the same frames with render(packed="auto") (static-model layout, bit-identical image; fovraster.h)
+  value_pipelined  the same frames, the reference's tensors, TWO frames in flight (render_begin / finish on two streams: the head
+                of frame n + 1 is enqueued before frame n's instance count is waited for; images bit-identical). Throughput
+                mode: `value` and the reference-protocol figures stay one frame at a time, as the reference times them.
   roofline      dominant kernel: algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak; `blend` =
                 the same for the blend kernel (+ VALU / occupancy figures of the committed SQ-counter pass);
                 `frame` = all stages' bytes / ms_per_step; `traffic` = PMC bytes of the committed profile if it was made
@@ -45,7 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GAZES = [(0.25 * i, 0.25 * j) for i in range(1, 4) for j in range(1, 4)]  # render_compose_gazes_fps.py:26
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def parse_args(argv=None):
@@ -63,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--packed-only", action="store_true", help="time only the packed-model frames (profiling passes)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="time only the headline frames (the reference's tensors, one frame at a time): no packed-layout and no "
+                         "two-frames-in-flight runs (profiling passes: one workload per kernel-stats file)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also collect every rank's frame on rank 0 (asynchronous RCCL gather overlapped with the next "
                          "frame). Off by default: the views are independent and the path has no exchange step.")
@@ -115,6 +121,48 @@ def lib_sha16():
     from fov3dgs_amd import _native
     with open(_native.LIB_PATH, "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def algorithmic_bytes(variant, n):
+    """SURVEY.md 8(d) per-unit figures x the units of one launch, per stage of this build, for the FOVEATED (RF) or a plain
+    (R0 / RS / RP) frame. n: P, Px, T, V_in (in front of the near plane), C (candidates: survivors of the conservative cull
+    pass), V (visible: radii > 0), D (instances), D_single / D_blend (instances in single- / two-level tiles).
+    RF (RF/cuda_rasterizer/forward.cu:105-238, rasterizer_impl.cu:264-383, 490-530) evaluates SH only for the Gaussians that
+    SURVIVE the filter and per level in their range; R0 / RS / RP (forward.cu:155-262) for every Gaussian inside the frustum:
+      project   12 B xyz read + 8 B radii / tiles_touched written per Gaussian; scale 12 + rotation 16 (+ RF highest level 4)
+                read per Gaussian in front of the camera
+      geom + count (the reference's preprocess / filter / compute_fov_colors; this build: k_geom = full projection, k_count = tile
+                counts + colours)
+                RF: the candidate's inputs handed on (48 B per candidate) and, per VISIBLE Gaussian, depth 4 + mean2D 8 + conic 12
+                + eigen axes 24 + walk record 64 written [geom]; 180 (rest SH) + 48 (level DCs) + 16 (level opacities) + 4
+                (highest level) read, level range 8 + four level rows 64 written [count]: 48 C + 432 V in all
+                plain: 48 (+ 24 eigen) written per visible Gaussian [geom]; opacity 4 + SH 192 read per Gaussian in front of the
+                camera (B_pre's 224 V_in less the 28 of project) [count]
+      emit      12 B per instance (key + value) + 44 B read per visible Gaussian;  tile_sort: 12 B per instance (this build moves
+                (depth, item) once per stage instead of a 6-pass radix sort);  tile_scan 16 T;  tile_levels 20 T
+      render    RF: 32 D_single + 52 D_blend + 12 Px;  plain: 40 D + 20 Px"""
+    fov = variant == "fov_pcheck_obb"
+    b = {"project": 20 * n["P"] + (32 if fov else 28) * n["V_in"],
+         "emit": 12 * n["D"] + 44 * n["V"], "tile_sort": 12 * n["D"], "tile_scan": 16 * n["T"], "tile_levels": 20 * n["T"] if fov else 0}
+    if fov:
+        b["geom"], b["count"] = 48 * n["C"] + 112 * n["V"], (248 + 72) * n["V"]
+        b["render"] = 32 * n["D_single"] + 52 * n["D_blend"] + 12 * n["Px"]
+    else:
+        b["geom"], b["count"] = (48 + 24) * n["V"], 196 * n["V_in"]
+        b["render"] = 40 * n["D"] + 20 * n["Px"]
+    return b
+
+
+def training_bytes(n, sh_coeffs=16):
+    """SURVEY.md 8(d) for the kernels of a training step beside the forward stages above (n as in algorithmic_bytes, plain frame):
+      render (RS)      40 D + 20 Px        R0/RS forward blend (RS/cuda_rasterizer/forward.cu:298-430)
+      render_bwd       40 D + 20 Px + 80 V (R0/cuda_rasterizer/backward.cu:399-557)
+      preprocess_bwd   276 V + 256 V       (backward.cu:144-396: inputs re-read, gradients written)
+      fill_zero        what RasterizeGaussiansBackwardCUDA's torch::zeros clear of the tensors this call returns
+                       (RS/rasterize_points.cu:171-179): dL_dmeans3D 12 + dL_dmeans2D 12 + dL_dopacity 4 + dL_dscales 12 +
+                       dL_drotations 16 + dL_dsh 12 M bytes per Gaussian"""
+    return {"render": 40 * n["D"] + 20 * n["Px"], "render_bwd": 40 * n["D"] + 20 * n["Px"] + 80 * n["V"],
+            "preprocess_bwd": 532 * n["V"], "fill_zero": (56 + 12 * sh_coeffs) * n["P"]}
 
 
 def main():
@@ -227,6 +275,36 @@ def main():
                 timer.close()
         return float(np.median(times)), [min(times), max(times)], {k: float(np.mean(v)) for k, v in per_stage.items()}
 
+    def timed_run_pipelined(depth=2):
+        """The same K frames per repeat with `depth` frames in flight (render_begin / finish, one stream per slot)."""
+        from fov3dgs_amd.gaussian_renderer_fov import render_begin
+        streams = [torch.cuda.Stream(dev) for _ in range(depth)]
+        kw = dict(alpha=0.05, blending=True, highest_levels=highest, shs_dcs=shs_dcs, opacities=opac)
+
+        def run(n):
+            pending = []
+            for i in range(n):
+                pending.append(render_begin(cam, pc, bg, gazeArray=GAZES[i % 9], stream=streams[i % depth], **kw))
+                if len(pending) == depth:
+                    pending.pop(0).finish()
+            for p_ in pending:
+                p_.finish()
+        torch.cuda.synchronize()
+        run(Wm)
+        times = []
+        for rep in range(max(1, args.repeats)):
+            barrier_sync()
+            t_start = time.perf_counter()
+            run(K)
+            barrier_sync()
+            el = time.perf_counter() - t_start
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                el = float(t.item())
+            times.append(el)
+        return float(np.median(times)), [min(times), max(times)]
+
     def stage_pass(packed, n=27):
         """Untimed: every stage's kernel time (all eight events per frame), mean over n frames of the nine gazes."""
         with torch.no_grad():
@@ -245,16 +323,20 @@ def main():
         for i in range(3):
             frame(GAZES[i % 9], "auto" if args.packed_only else None)
     pre = stage_pass("auto" if args.packed_only else None)
-    dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: pre[k])
+    dominant = max(("project", "geom", "count", "render", "tile_sort", "emit"), key=lambda k: pre[k])
     ev_stages = tuple(dict.fromkeys((dominant, "render")))
     if args.packed_only:
         elapsed_p, spread_p, timed_ms_p = timed_run("auto", ev_stages)
         elapsed, spread, timed_ms = elapsed_p, spread_p, timed_ms_p
     else:
         elapsed, spread, timed_ms = timed_run(None, ev_stages)        # the reference's tensor interface: the headline
-        elapsed_p, spread_p, timed_ms_p = timed_run("auto", ev_stages)  # static-model layout
+        if args.headline_only:
+            elapsed_p, spread_p, timed_ms_p = elapsed, spread, timed_ms
+        else:
+            elapsed_p, spread_p, timed_ms_p = timed_run("auto", ev_stages)  # static-model layout
+    elapsed_pl, spread_pl = (elapsed, spread) if (args.headline_only or args.packed_only) else timed_run_pipelined(2)
     mean_ms = stage_pass("auto" if args.packed_only else None)
-    mean_ms_p = stage_pass("auto")
+    mean_ms_p = mean_ms if args.headline_only else stage_pass("auto")
     multi = multi_gpu_extras(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync, frame, torch, np) if world > 1 else {}
     if rank != 0:
         return
@@ -271,7 +353,7 @@ def main():
             res = rz._forward_native(vid, rs, pc.get_xyz, pc.get_rest_features, torch.Tensor([]), opac, pc.get_scaling,
                                      pc.get_rotation, torch.Tensor([]), shs_dcs, highest, gaze, 0.05)
             torch.cuda.synchronize()
-            stats.append(frame_stats(torch, lib, vid, (res[0], res[2], res[5]), W, H, T))
+            stats.append(frame_stats(torch, lib, vid, (res[0], res[2], res[5]), W, H, T, geom=res[3], P=args.points))
         vm = cam.world_view_transform
         z = pc.get_xyz @ vm[:3, 2] + vm[3, 2]
         V_in = int((z > 0.2).sum().item())
@@ -279,20 +361,8 @@ def main():
     wts = np.array([len(range(g, K, 9)) for g in range(9)], dtype=np.float64)
     st = {k: float(np.sum([s[k] * w for s, w in zip(stats, wts)]) / wts.sum()) for k in stats[0]}
     P, Px = args.points, W * H
-    alg_bytes = {
-        # SURVEY.md 8(d) per-unit figures x units of one launch
-        # B_pre = 20 P + 224 V_in + 48 V (+24 V OBB axes), split over this build's two kernels: the cull pass streams
-        # xyz/scale/rotation and writes radii; binning projects the survivors, reads opacity + SH and writes the
-        # per-Gaussian record and the OBB axes
-        "project": 20 * P + 28 * V_in,
-        "bin": 196 * V_in + (48 + 24) * st["V"],
-        "render": 32 * st["D_single"] + 52 * st["D_blend"] + 12 * Px,
-        # this build's binning moves (depth,id) once per stage instead of a 6-pass radix sort
-        "emit": 12 * st["D"] + 44 * st["V"],
-        "tile_sort": 12 * st["D"],
-        "tile_scan": 16 * T,
-        "tile_levels": 20 * T,
-    }
+    counts = dict(st, P=P, Px=Px, T=T, V_in=V_in)
+    alg_bytes = algorithmic_bytes("fov_pcheck_obb", counts)  # the RF formulas: SH per VISIBLE Gaussian (see there)
     prof = load_profiles()
     # kernel durations of the roofline: the events recorded INSIDE the timed frames for the two stages that carry them
     # (measured_in says so), the untimed all-stage pass of the same frames for the rest
@@ -324,6 +394,24 @@ def main():
     if world == 1 and not args.no_extra:
         extra = extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H, W)
 
+    if "_train_counts" in extra:
+        n_tr, fwd_ms, bwd_ms = extra.pop("_train_counts"), extra.pop("_train_fwd_ms"), extra.pop("_train_bwd_ms")
+        tb = training_bytes(n_tr)
+        fb = algorithmic_bytes("pcheck_obb_sum", dict(n_tr, C=0, D_single=0, D_blend=0))
+        tr_ms = dict(fwd_ms, **bwd_ms)
+        kern = {"render": "k_render", "render_bwd": "k_render_bwd", "preprocess_bwd": "k_preprocess_bwd", "fill_zero": "k_fill_zero",
+                "project": "k_project", "geom": "k_geom", "count": "k_count", "emit": "k_emit", "tile_sort": "k_tile_msort*"}
+        rows = {}
+        for k_, byt in list(tb.items()) + [(k2, fb[k2]) for k2 in ("project", "geom", "count", "emit", "tile_sort")]:
+            ms_ = tr_ms[k_]
+            tr_b, tr_src = prof.traffic_train(kern[k_])
+            rows[k_] = dict(kernel=kern[k_], ms=round(ms_, 4), algorithmic_bytes=int(byt), achieved=round(byt / max(ms_, 1e-9) / 1e6, 1),
+                            frac=round(byt / max(ms_, 1e-9) / 1e6 / HBM_PEAK_GBS, 5), traffic=tr_b,
+                            frac_traffic=None if not tr_b else round(tr_b / max(ms_, 1e-9) / 1e6 / HBM_PEAK_GBS, 5))
+        roofline["train"] = dict(unit="GB/s", peak=HBM_PEAK_GBS, counts=n_tr, kernels=rows,
+                                 note="training step (pcheck_obb_sum, raw parameters, fused L1 + SSIM): median of 10 instrumented steps, HIP events "
+                                      "recorded by the library on the streams the kernels run on (fill_zero runs on the helper stream beside "
+                                      "render_bwd); bytes: training_bytes() / algorithmic_bytes() of the plain frame; traffic: " + str(prof.train_source()))
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         try:
@@ -338,10 +426,13 @@ def main():
         "repeats": max(1, args.repeats), "value_spread": [round(world * K / spread[1], 3), round(world * K / spread[0], 3)],
         "value_packed": round(world * K / elapsed_p, 3), "ms_per_step_packed": round(elapsed_p / K * 1e3, 4),
         "value_packed_spread": [round(world * K / spread_p[1], 3), round(world * K / spread_p[0], 3)],
+        "value_pipelined": round(world * K / elapsed_pl, 3), "ms_per_step_pipelined": round(elapsed_pl / K * 1e3, 4),
+        "value_pipelined_spread": [round(world * K / spread_pl[1], 3), round(world * K / spread_pl[0], 3)],
+        "pipeline_depth": 2,
         "config": {"workload": "S-6M bicycle-scale cloud, 4-layer foveated render (fov_pcheck_obb), the reference's 9 fixed gazes "
                                "(0.25 i, 0.25 j) in turn, one camera per GPU" + (", frames gathered on rank 0" if (world > 1 and args.gather) else ""),
                    "gaussians": P, "width": W, "height": H, "alpha": 0.05, "sh_degree": 3,
-                   "visible": int(st["V"]), "in_front": V_in, "instances": int(st["D"]),
+                   "visible": int(st["V"]), "candidates": int(st["C"]), "in_front": V_in, "instances": int(st["D"]),
                    "instances_blend_tiles": int(st["D_blend"]), "max_tile_list": int(max(s["max_list"] for s in stats)),
                    "model_layout": "value: the reference's tensor interface (render(packed=None)); value_packed: the static-model "
                                    "layout (packed_geom / packed_colour, made once, bit-identical image)",
@@ -355,9 +446,13 @@ def main():
     print(json.dumps(line), flush=True)
 
 
-def frame_stats(torch, lib, vid, out_state, W, H, T):
-    """V, D, D_single, D_blend of the last foveated forward call (reads the image workspace)."""
+def frame_stats(torch, lib, vid, out_state, W, H, T, geom=None, P=0):
+    """V, D, D_single, D_blend (and C, the cull pass's survivors) of the last foveated forward call (reads the workspaces)."""
     num_rendered, radii, img = out_state
+    cands = 0
+    if geom is not None:
+        off = lib.fr_geometry_vis_count(vid, P, geom.data_ptr()) - geom.data_ptr()
+        cands = int(geom[off:off + 4].view(torch.int32).item())
     rptr = lib.fr_image_ranges(vid, W, H, img.data_ptr())
     off = rptr - img.data_ptr()
     ranges = img[off:off + 8 * T].view(torch.int32).view(T, 2)
@@ -368,15 +463,16 @@ def frame_stats(torch, lib, vid, out_state, W, H, T):
     blend = lv[4] != 0
     d_blend = int(lens[blend].sum().item())
     d_all = int(lens.sum().item())
-    return dict(V=int((radii > 0).sum().item()), D=d_all, D_single=d_all - d_blend, D_blend=d_blend,
+    return dict(V=int((radii > 0).sum().item()), C=cands, D=d_all, D_single=d_all - d_blend, D_blend=d_blend,
                 max_list=int(lens.max().item()), blend_tiles=int(blend.sum().item()))
 
 
 class load_profiles:
     """The committed rocprofv3 summaries (profiles/<tag>_pmc.json, <tag>_render_sq.json). PMC bytes are only quoted when
     the profile was made with this very library build (sha of libfovraster_hip.so recorded by tools/make_profiles.sh)."""
-    STAGE_KERNELS = {"render": ["k_render_fov"], "project": ["k_project"], "bin": ["k_bin", "k_hist_colscan"],
-                     "tile_sort": ["k_tile_msort", "k_split_long"], "emit": ["k_emit"]}
+    STAGE_KERNELS = {"render": ["k_render_fov"], "project": ["k_project"], "geom": ["k_geom"], "count": ["k_count"],
+                     "tile_sort": ["k_tile_msort", "k_tile_msort_direct", "k_split_long", "k_tile_msort_chunks"], "emit": ["k_emit"],
+                     "tile_scan": ["k_tile_scan"], "tile_levels": ["k_tile_levels"]}
 
     def __init__(self):
         self.pmc = self.sq = None
@@ -398,11 +494,32 @@ class load_profiles:
         f_fetch = self.pmc.get("calibration", {}).get("fetch_factor", 2.0)
         f_write = self.pmc.get("calibration", {}).get("write_factor", 1.0)
         try:
-            b = sum(f_fetch * k[n]["FETCH_SIZE_KiB_per_frame"] + f_write * k[n]["WRITE_SIZE_KiB_per_frame"]
-                    for n in self.STAGE_KERNELS[stage] if n in k) * 1024
+            names = [n + "_packed" if (packed and n + "_packed" in k) else n for n in self.STAGE_KERNELS[stage]]
+            b = sum(f_fetch * k[n]["FETCH_SIZE_KiB_per_frame"] + f_write * k[n]["WRITE_SIZE_KiB_per_frame"] for n in names if n in k) * 1024
         except Exception:
             return None, src + ": kernel missing"
         return int(b), src + f"; bytes = {f_fetch} x FETCH_SIZE + {f_write} x WRITE_SIZE (factors calibrated on the k_pack_* launches of the same pass)"
+
+    def train_source(self):
+        if self.pmc is None or "train" not in self.pmc:
+            return "no training-step PMC pass in profiles/%s_pmc.json" % PROFILE_TAG
+        if self.pmc.get("lib_sha16") != self.sha:
+            return f"profiles/{PROFILE_TAG}_pmc.json was made with another build ({self.pmc.get('lib_sha16')}, this one is {self.sha}) -- not quoted"
+        return f"profiles/{PROFILE_TAG}_pmc.json [train] (lib {self.sha})"
+
+    def traffic_train(self, kernel):
+        """PMC bytes per launch of a kernel of the training step (the profile's `train` section: kernel names with their template
+        arguments), or None."""
+        if self.pmc is None or "train" not in self.pmc or self.pmc.get("lib_sha16") != self.sha:
+            return None, None
+        f_fetch = self.pmc.get("calibration", {}).get("fetch_factor", 2.0)
+        f_write = self.pmc.get("calibration", {}).get("write_factor", 1.0)
+        tot = 0.0
+        for name, e in self.pmc["train"].items():
+            base = name.split("<")[0]
+            if base == kernel or (kernel.endswith("*") and base.startswith(kernel[:-1])):
+                tot += (f_fetch * e.get("FETCH_SIZE_KiB_per_frame", 0) + f_write * e.get("WRITE_SIZE_KiB_per_frame", 0)) * 1024
+        return (int(tot) if tot else None), None
 
     def blend_sq(self):
         if self.sq is None:
@@ -523,6 +640,35 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
             extra["train_raw_fwd_ms"], extra["train_raw_loss_fwd_ms"], extra["train_raw_bwd_ms"], extra["train_raw_step_ms"] = med
         else:
             extra["train_fwd_ms"], extra["train_loss_fwd_ms"], extra["train_bwd_ms"], extra["train_step_ms"] = med
+    # --- roofline of the training step's kernels (BASELINE metric "fwd+bwd ms/iter; HBM GB/s"): a short instrumented loop of the
+    # raw-parameter step -- HIP events around the forward stages and around the backward pass's kernels, recorded by the library on
+    # the streams the kernels run on; algorithmic bytes: training_bytes(); PMC bytes: the committed profile of the training step
+    from fov3dgs_amd.profiling import BackwardTimer, StageTimer
+    from fov3dgs_amd import _native as _nat
+    tr.fuse_activations = True
+    n_inst = 12
+    ft, bt = StageTimer(n_inst), BackwardTimer(n_inst)
+    with ft, bt:
+        for it in range(n_inst):
+            for p in tr.parameters():
+                p.grad = None
+            o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
+            l1_ssim_loss(o["render"], target, 0.2).backward()
+    torch.cuda.synchronize()
+    fwd_ms = {k: float(np.median([r_[k] for r_ in ft.stage_ms()[2:]])) for k in _nat.STAGES}
+    bwd_ms = {k: float(np.median([r_[k] for r_ in bt.stage_ms()[2:]])) for k in ("render_bwd", "preprocess_bwd", "fill_zero")}
+    ft.close(); bt.close()
+    with torch.no_grad():
+        vmat = cam.world_view_transform
+        v_in = int(((tr.get_xyz @ vmat[:3, 2] + vmat[3, 2]) > 0.2).sum().item())
+        from fov3dgs_amd import rasterizer as rz_
+        rs_ = rz_.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0, cam.world_view_transform,
+                                                cam.full_proj_transform, 3, cam.camera_center, False, False)
+        d_tr = rz_._forward_native(_nat.VARIANT_PCHECK_OBB_SUM, rs_, pc.get_xyz, pc.get_features, torch.Tensor([]), pc.get_opacity,
+                                   pc.get_scaling, pc.get_rotation, torch.Tensor([]), persistent=True)[0]  # the frame's instances
+    n_tr = dict(P=int(tr.get_xyz.shape[0]), Px=H * W, T=((W + 15) // 16) * ((H + 15) // 16), V=int(o["visibility_filter"].sum().item()),
+                V_in=v_in, D=int(d_tr))
+    extra["_train_counts"], extra["_train_fwd_ms"], extra["_train_bwd_ms"] = n_tr, fwd_ms, bwd_ms
     extra["train_note"] = ("pcheck_obb_sum forward (incl. the model's activations: one fused pass over all P Gaussians each way; "
                            "train_raw_*: the model's raw parameters handed to the rasterizer, activations inside its kernels) / fused "
                            "L1+SSIM forward / backward of both (loss + rasterizer + activations), events on the stream, median of 50; "
@@ -609,6 +755,22 @@ def multi_gpu_extras(args, rank, world, dev, cloud, cam, bg, multiview, render_p
     algbw = nbytes / (co * 1e-3) / 1e9 if co > 0 else None
     out["gather_fps"] = round(world * K / el, 2)
     out["gather_note"] = f"{K} frames per rank, every frame's image gathered on rank 0 (asynchronous gather of the previous frame under the next one)"
+    # diagnosis for the first real multi-GPU run: what RCCL looks like from rank 0, the dense exchange tensor by tensor (the
+    # 1.15 GB dL_dsh all-reduce dominates), and the same sum as one flat reduce-scatter + all-gather
+    out["rccl"] = multiview.comm_info()
+    try:
+        for p_ in params:
+            p_.grad = torch.zeros_like(p_)
+        per_t = []
+        multiview.allreduce_gradients(params, per_tensor_ms=per_t)
+        tm = {}
+        multiview.allreduce_gradients_flat(params, timings=tm)
+        out["collective_breakdown"] = dict(per_tensor=[dict(MB=round(n_ * 4 / 1e6, 1), ms=round(ms_, 3)) for n_, ms_ in per_t],
+                                           flat_reduce_scatter_all_gather_ms={k_: round(v_, 3) for k_, v_ in tm.items()})
+        for p_ in params:
+            p_.grad = None
+    except Exception as e:  # (gloo on a shared GPU has no reduce_scatter_tensor: the headline must not die of a diagnosis)
+        out["collective_breakdown"] = f"failed: {e}"
     out["multiview_train"] = dict(fwd_bwd_ms=round(fb, 4), collective_ms=round(co, 4), backend=torch.distributed.get_backend(),
                                   collective=dict(info or {}, algbw_GBs=None if algbw is None else round(algbw, 2),
                                                   busbw_GBs=None if algbw is None else round(algbw * 2 * (world - 1) / world, 2)),

@@ -99,8 +99,11 @@ void fr_event_destroy(void *event) { if (event) (void)hipEventDestroy((hipEvent_
 int fr_event_elapsed_ms(void *start, void *stop, float *ms)
 {
 	if (!start || !stop || !ms) { set_error("null event"); return FR_ERR_INVALID; }
-	FR_HIP(hipEventSynchronize((hipEvent_t)stop));
-	FR_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+	// (an event that was never recorded is the caller's mistake, not a device fault: the error is reported here and not left
+	// behind as the runtime's sticky "last error" for whoever calls into HIP next)
+	hipError_t e = hipEventSynchronize((hipEvent_t)stop);
+	if (e == hipSuccess) e = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+	if (e != hipSuccess) { (void)hipGetLastError(); set_error("event timing: %s (was the event recorded?)", hipGetErrorString(e)); return FR_ERR_HIP; }
 	return FR_OK;
 }
 const char *fr_last_error(void) { return g_err; }
@@ -256,8 +259,9 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 	if (is_fov(a->variant)) { rc = launch_tile_levels(c); if (rc) return rc; }
 	mark(FR_STAGE_PROJECT);
 	rc = launch_project(c); if (rc) return rc;
-	mark(FR_STAGE_BIN);
+	mark(FR_STAGE_GEOM);
 	rc = launch_geom(c); if (rc) return rc;
+	mark(FR_STAGE_COUNT);
 	rc = launch_count(c); if (rc) return rc;
 	int cur_dev = 0;
 	(void)hipGetDevice(&cur_dev);

@@ -598,9 +598,17 @@ int launch_backward(const fr_backward_args *a)
 			}
 		if (fa.n)
 		{
+			// (optional events 3 / 4: around the fill kernel, on the stream it runs on)
+			if (a->stage_events && a->stage_events[3]) (void)hipEventRecord((hipEvent_t)a->stage_events[3], fs);
 			hipLaunchKernelGGL(k_fill_zero, dim3(FR_FILL_BLOCKS), dim3(256), 0, fs, fa);
 			const int rcf = check_launch("fill_zero", fs, a->debug);
-			if (rcf) return rcf;
+			if (a->stage_events && a->stage_events[4]) (void)hipEventRecord((hipEvent_t)a->stage_events[4], fs);
+			if (rcf)
+			{
+				// (whatever was enqueued on the helper stream is joined before the caller gets its tensors back)
+				if (ax) { (void)hipEventRecord(ax->join, ax->s); (void)hipStreamWaitEvent(stream, ax->join, 0); }
+				return rcf;
+			}
 		}
 		if (ax) (void)hipEventRecord(ax->join, ax->s); // waited for below, after k_render_bwd has been launched
 		if (a->R > 0)

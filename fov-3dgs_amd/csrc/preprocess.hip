@@ -263,6 +263,12 @@ __device__ __forceinline__ void sh_colour(int deg, int navail, const float *__re
 	for (int ch = 0; ch < 3; ch++) out[ch] = acc[ch] + 0.5f;
 }
 
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float *p)
+{
+	const nt_f4 v = __builtin_nontemporal_load((const nt_f4 *)p);
+	return make_float4(v.x, v.y, v.z, v.w);
+}
 // raw per-Gaussian inputs of the projection
 struct RawGaussian { float p[3], sc[3]; float4 q; float hl; };
 
@@ -623,10 +629,12 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		else
 		{
 #pragma unroll
-			for (int k = 0; k < 3; k++) { w.p[k] = a.means3D[3 * i + k]; w.sc[k] = sc_src[3 * i + k]; }
-			w.q = *(const float4 *)(q_src + 4 * i);
+			// (non-temporal: the cloud is read once per frame, 264 MB that would only push the rows the binning kernels come back
+			// to out of the caches: k_project 84 -> 79 us)
+			for (int k = 0; k < 3; k++) { w.p[k] = __builtin_nontemporal_load(a.means3D + 3 * i + k); w.sc[k] = __builtin_nontemporal_load(sc_src + 3 * i + k); }
+			w.q = nt_load4(q_src + 4 * i);
 		}
-		w.hl = FOV ? a.highest_levels[i] : 0.0f;
+		w.hl = FOV ? __builtin_nontemporal_load(a.highest_levels + i) : 0.0f;
 		return w;
 	};
 	auto step = [&](const RawGaussian &cur, const int chunk) __attribute__((always_inline))

@@ -64,7 +64,65 @@ def all_gather_images(image, async_op=False):
     return (work if async_op else None), flat.view((world,) + tuple(image.shape))
 
 
-def allreduce_gradients(params, visible=None, sparse_below=0.4, check_rows=False):
+def comm_info():
+    """What the process group looks like from this rank (for the bench line: was RCCL really running with N ranks?)."""
+    if not dist.is_initialized():
+        return dict(backend=None, world=1)
+    info = dict(backend=dist.get_backend(), world=dist.get_world_size(), rank=dist.get_rank(),
+                local_world=int(os.environ.get("LOCAL_WORLD_SIZE", str(dist.get_world_size()))),
+                device_count=torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    try:
+        v = torch.cuda.nccl.version()  # RCCL's version on ROCm
+        info["nccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        info["nccl_version"] = None
+    return info
+
+
+def allreduce_gradients_flat(params, timings=None):
+    """The dense gradient sum as ONE flat reduce-scatter + all-gather over a single buffer (the two halves of a ring all-reduce,
+    exposed: with N ranks every rank sums 1/N of the 1.42 GB and the halves run over all xGMI links at once) instead of one
+    all-reduce per tensor. Costs a pack and an unpack pass over the gradients (2 x 1.42 GB of HBM traffic at 6 M Gaussians,
+    ~0.5 ms); opt-in, for comparison with the per-tensor exchange on the 8-GPU node (single ring ~16 ms vs all
+    links ~3 ms). timings: optional dict that receives per-phase CUDA-event milliseconds (pack, reduce_scatter, all_gather, unpack)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(mode="none", bytes=0)
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return dict(mode="none", bytes=0)
+    world = dist.get_world_size()
+    n = sum(g.numel() for g in grads)
+    per = (n + world - 1) // world
+    flat = torch.zeros(per * world, dtype=grads[0].dtype, device=grads[0].device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if (timings is not None and flat.is_cuda) else None
+    if ev:
+        ev[0].record()
+    off = 0
+    for g in grads:
+        flat[off:off + g.numel()].copy_(g.reshape(-1))
+        off += g.numel()
+    if ev:
+        ev[1].record()
+    shard = torch.empty(per, dtype=flat.dtype, device=flat.device)
+    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+    if ev:
+        ev[2].record()
+    dist.all_gather_into_tensor(flat, shard)
+    if ev:
+        ev[3].record()
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+    if ev:
+        ev[4].record()
+        torch.cuda.synchronize()
+        for name, i in (("pack", 0), ("reduce_scatter", 1), ("all_gather", 2), ("unpack", 3)):
+            timings[name] = ev[i].elapsed_time(ev[i + 1])
+    return dict(mode="flat", bytes=n * flat.element_size())
+
+
+def allreduce_gradients(params, visible=None, sparse_below=0.4, check_rows=False, per_tensor_ms=None):
     """Sum the per-view gradients of the replicated parameters over all ranks. -> dict with what was exchanged.
 
     dense (default): every gradient tensor is all-reduced IN PLACE, all collectives in flight at once (no flat copy: the
@@ -79,7 +137,8 @@ def allreduce_gradients(params, visible=None, sparse_below=0.4, check_rows=False
     p.grad was cleared before the step and holds nothing but this view's rasterizer gradients. With gradient
     accumulation or a dense loss term (opacity / scale regularisers, a mask loss) rows outside the union would be left
     un-summed -- use the dense exchange (visible=None) there. check_rows=True verifies the precondition (one reduction
-    per tensor and a host sync: for tests and debugging)."""
+    per tensor and a host sync: for tests and debugging). per_tensor_ms: optional list that receives (numel, milliseconds) of
+    every tensor's all-reduce, issued one after the other and timed with CUDA events (diagnosis: which tensor dominates)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return dict(mode="none", bytes=0)
     grads = [p.grad for p in params if p.grad is not None]
@@ -110,6 +169,17 @@ def allreduce_gradients(params, visible=None, sparse_below=0.4, check_rows=False
                 g.reshape(P, w).index_copy_(0, idx, rows[:, off:off + w])
                 off += w
             return dict(mode="rows", rows=U, of=P, bytes=rows.numel() * rows.element_size() + P)
+    if per_tensor_ms is not None and grads[0].is_cuda:
+        evs = []
+        for g in grads:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            e1.record()
+            evs.append((g.numel(), e0, e1))
+        torch.cuda.synchronize()
+        per_tensor_ms.extend((n_, e0.elapsed_time(e1)) for n_, e0, e1 in evs)
+        return dict(mode="dense", bytes=sum(g.numel() * g.element_size() for g in grads))
     works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
     for w in works:
         w.wait()

@@ -65,3 +65,52 @@ class StageTimer:
                 if arr[i]:
                     self.lib.fr_event_destroy(arr[i])
         self.sets = []
+
+
+class BackwardTimer:
+    """The same for fr_backward calls: events around the tile pass (k_render_bwd), the per-Gaussian pass (k_preprocess_bwd) and,
+    on the helper stream it runs on, the zero fill of the gradient tensors. stage_ms() -> dicts render_bwd / preprocess_bwd /
+    fill_zero in milliseconds."""
+    NAMES = (("render_bwd", 0, 1), ("preprocess_bwd", 1, 2), ("fill_zero", 3, 4))
+
+    def __init__(self, max_calls):
+        self.lib = _native.load()
+        self.sets = []
+        for _ in range(max_calls):
+            arr = (C.c_void_p * 5)()
+            for i in range(5):
+                arr[i] = self.lib.fr_event_create()
+            self.sets.append(arr)
+        self.used = 0
+
+    def _next(self):
+        if self.used >= len(self.sets):
+            return None
+        arr = self.sets[self.used]
+        self.used += 1
+        return C.cast(arr, C.POINTER(C.c_void_p))
+
+    def __enter__(self):
+        rasterizer._bwd_events_hook = self._next
+        return self
+
+    def __exit__(self, *exc):
+        rasterizer._bwd_events_hook = None
+
+    def stage_ms(self):
+        out = []
+        ms = C.c_float()
+        for arr in self.sets[:self.used]:
+            d = {}
+            for name, i, j in self.NAMES:
+                rc = self.lib.fr_event_elapsed_ms(arr[i], arr[j], C.byref(ms))
+                d[name] = ms.value if rc == 0 else float("nan")
+            out.append(d)
+        return out
+
+    def close(self):
+        for arr in self.sets:
+            for i in range(5):
+                if arr[i]:
+                    self.lib.fr_event_destroy(arr[i])
+        self.sets = []

@@ -220,6 +220,7 @@ def pack_model(means3D, scales, rotations, opacities, shs=None, shs_rest=None, s
 # Set by fov3dgs_amd.profiling.StageTimer while a timed region is active: a ctypes array of
 # FR_NUM_STAGE_EVENTS event handles that the next forward call records on its streams.
 _stage_events_hook = None
+_bwd_events_hook = None  # the same for backward calls: 5 handles (fr_backward_args.stage_events)
 
 
 class FrameInFlight:
@@ -401,6 +402,8 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
             a.dL_dsh = dL_dsh.data_ptr() if M else None
             a.dL_dsh_rest = dL_dsh_rest.data_ptr() if dL_dsh_rest is not None else None
             a.dL_dscale, a.dL_drot = dL_dscales.data_ptr(), dL_drotations.data_ptr()
+            if _bwd_events_hook is not None:
+                a.stage_events = _bwd_events_hook()
             rc = lib.fr_backward(C.byref(a))
             if rc != 0:
                 raise RuntimeError(f"fovraster backward failed ({rc}): {_native.last_error()}")

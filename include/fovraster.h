@@ -157,8 +157,8 @@ typedef struct fr_forward_args {
 	int32_t raw_activations;
 } fr_forward_args;
 
-enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
-	FR_STAGE_TILE_SORT = 5, FR_STAGE_RENDER = 6, FR_NUM_STAGES = 7 };
+enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_GEOM = 2, FR_STAGE_COUNT = 3, FR_STAGE_TILE_SCAN = 4, FR_STAGE_EMIT = 5,
+	FR_STAGE_TILE_SORT = 6, FR_STAGE_RENDER = 7, FR_NUM_STAGES = 8 };
 
 typedef struct fr_backward_args {
 	int32_t variant;             /* ORIGINAL, PCHECK_OBB_SUM, PCHECK_OBB_MAX or PCHECK_OBB_LWMC */
@@ -189,7 +189,9 @@ typedef struct fr_backward_args {
 	float *dL_dsh;               /* [P,M,3] */
 	float *dL_dscale;            /* [P,3] */
 	float *dL_drot;              /* [P,4] */
-	void **stage_events;         /* optional: 3 event handles around render-backward and preprocess-backward */
+	void **stage_events;         /* optional: HOST pointer to 5 event handles (any may be NULL): [0] [1] [2] on `stream` before the
+	                              * tile pass (k_render_bwd), between it and the per-Gaussian pass (k_preprocess_bwd), and after that;
+	                              * [3] [4] around the zero fill of the gradient tensors, on the helper stream it runs on */
 	const float *shs_rest;       /* split SH input, see fr_forward_args.shs_rest ... */
 	float *dL_dsh_rest;          /* ... then dL_dsh is [P,1,3] and dL_dsh_rest [P,M-1,3] */
 	int32_t raw_activations;     /* as in the forward call: dL_dscale / dL_drot / dL_dopacity are then gradients w.r.t. the RAW

@@ -38,6 +38,17 @@ def _worker(rank, world, port, q):
         p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
     info = multiview.allreduce_gradients(params)
     assert info["mode"] == "dense" and info["bytes"] == (7 * 3 + 11) * 4
+    # the same sum as one flat reduce-scatter + all-gather
+    fl = [torch.nn.Parameter(torch.zeros(7, 3)), torch.nn.Parameter(torch.zeros(11)), torch.nn.Parameter(torch.zeros(5, 2, 2))]
+    for i, p in enumerate(fl):
+        p.grad = torch.arange(p.numel(), dtype=torch.float32).view_as(p) * (rank + 1) + i
+    info_f = multiview.allreduce_gradients_flat(fl)
+    assert info_f["mode"] == "flat" and info_f["bytes"] == (21 + 11 + 20) * 4
+    for i, p in enumerate(fl):
+        want = torch.arange(p.numel(), dtype=torch.float32).view_as(p) * sum(range(1, world + 1)) + i * world
+        assert torch.equal(p.grad, want)
+    ci = multiview.comm_info()
+    assert ci["backend"] == "gloo" and ci["world"] == world
     # row-sparse exchange: rank r's view touches rows {r, 5}; rows outside the union stay exactly zero everywhere
     sp = [torch.nn.Parameter(torch.zeros(40, 3)), torch.nn.Parameter(torch.zeros(40, 2, 2))]
     vis = torch.zeros(40, dtype=torch.bool)
