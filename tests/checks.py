@@ -1,7 +1,9 @@
 """Tolerance checks of the GPU parity tests. Every call records what it measured (tests/parity_report.py).
 
 Tolerances (fp32 path; BASELINE north_star: per-pixel match within 1e-4, gradients 1e-4 relative):
-  * image: |diff| <= 1e-4 on all but `frac` (1e-6) of the pixels and <= `hard` (1.5e-2) everywhere. The blend thresholds
+  * image: |diff| <= 1e-4 on all but `frac` (1e-6) of the pixels and <= `hard` (1.5e-2) everywhere; WHOLE FRAMES (tests/
+    test_full_size_parity.py) instead get a count budget: at most 8 of a 1080p frame's 6.2 M values beyond 1e-4, none beyond
+    what ONE flipped (pixel, Gaussian) pair at the support cutoff can do (0.99 e^-4.5 = 1.1e-2). The blend thresholds
     (alpha < 1/255, T < 1e-4, power < -4.5, power > 0) are discontinuous, and the HIP kernel uses the hardware exp2
     and fused multiply-adds while the oracle follows the reference's literal fp32 expression, so a pair that sits
     within an ulp of a threshold may flip; each flip moves a pixel by at most ~alpha x colour x T: <= 1.1e-2 at the -4.5
@@ -47,12 +49,24 @@ def _where():
     return os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1]
 
 
-def check_image(got, want, frac=IMAGE_FRAC, hard=IMAGE_HARD, name=""):
+FLIP_BOUND = 0.99 * float(np.exp(-4.5)) * 1.001  # one (pixel, Gaussian) pair flipped at the support cutoff: alpha <= 0.99 e^-4.5, colour, T <= 1
+
+
+def check_image(got, want, frac=IMAGE_FRAC, hard=IMAGE_HARD, name="", count=None):
+    """count: a COUNT budget instead of the fraction (whole 1080p frames: 6.2 M values): at most `count` values beyond 1e-4, each
+    no further off than one flipped (pixel, Gaussian) pair at the support cutoff can move a pixel (FLIP_BOUND = 0.99 e^-4.5 =
+    1.1e-2; measured: <= 3 values per frame, largest 4.9e-3)."""
     st = parity_report.image_stats(got, want)
-    parity_report.record("image", f"{_where()} {name}".strip(), frac_allowed=frac, hard_allowed=hard, **st)
+    if count is not None:
+        hard = FLIP_BOUND
+        st["count_gt_1e4"] = int(round(st["frac_gt_1e4"] * st["n"]))
+    parity_report.record("image", f"{_where()} {name}".strip(), frac_allowed=frac, hard_allowed=hard, count_allowed=count, **st)
     assert np.isfinite(got).all()
     assert st["max_abs"] <= hard, f"max image diff {st['max_abs']}"
-    assert st["frac_gt_1e4"] <= frac, f"{st['frac_gt_1e4']:.2e} of pixels differ by more than 1e-4"
+    if count is not None:
+        assert st["count_gt_1e4"] <= count, f"{st['count_gt_1e4']} values differ by more than 1e-4 (budget {count})"
+    else:
+        assert st["frac_gt_1e4"] <= frac, f"{st['frac_gt_1e4']:.2e} of pixels differ by more than 1e-4"
 
 
 def grad_stats(got, want, rtol=1e-4, row_scale=None, cancel=4e-6):

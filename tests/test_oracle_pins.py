@@ -364,3 +364,58 @@ def test_reference_arithmetic_noise_of_the_gradients():
         worst = max(worst, st["frac_bad"])
         assert st["one_minus_cosine"] < 1e-7 and st["row_rel_p50"] < 1e-5, (k, st)
     assert worst <= 3e-3, worst  # the fp32 reference arithmetic itself stays inside the budget the HIP path is held to
+
+
+# ---------- (e) an independent derivation of the gradients: torch.autograd through a naive PyTorch-CPU rasterizer ----------
+@pytest.mark.parametrize("variant", ("original", "pcheck_obb_sum"))
+def test_backward_matches_autograd_of_a_torch_rasterizer(variant):
+    """BASELINE config 1 (S-1k cloud, a naive PyTorch-CPU forward rasterizer: tests/torch_rasterizer.py; 128 x 128 here -- the
+    P x pixels tables of the autograd graph are 4 x smaller than at 256 x 256, which only the forward is run at, for its time):
+    its image equals the oracle's double-precision forward to the last digits the float-typed literals of the C source leave
+    (0.3f, 1e-7f, the SH constants: 3e-8), and torch.autograd through it gives the gradients of all six parameter tensors that
+    orc_backward (the line-by-line restatement of R0/cuda_rasterizer/backward.cu) computes -- a second, independent derivation
+    beside the finite-difference probes above. pcheck_obb_sum: the RS blend rule (power < -4.5 skipped,
+    RS forward.cu:376-380, backward.cu:495) on R0's tile rectangles: a cloud of small splats (one tile each, where RS applies no
+    box test, RS rasterizer_impl.cu:99-102), so that both rasterizers see the same lists."""
+    import time
+    from tests.torch_rasterizer import rasterize
+    cloud = syn.scene_1k(P=1000, seed=0)
+    if variant == "pcheck_obb_sum":
+        cloud._scaling -= 1.6  # sub-tile splats: rect of one tile, no OBB test in RS
+    cam = syn.camera_1k(128, 128)
+    scene = {k: v.astype(np.float64) for k, v in scene_dict(cloud, variant).items()}
+    cd = cam_dict(cam, bg=(0.2, 0.4, 0.1))
+    o = orc.forward(variant, scene, cd, dtype=np.float64)
+    if variant == "pcheck_obb_sum":
+        multi = (o["tiles_rect"] > 1) & (o["radii"] > 0)  # tiles_rect: tiles of the splat's rectangle before the box test
+        keep = ~multi  # the few splats that still straddle a tile boundary are left out (RS would box-test them)
+        scene = {k: v[keep] for k, v in scene.items()}
+        o = orc.forward(variant, scene, cd, dtype=np.float64)
+    assert (o["radii"] > 0).sum() > 400
+    t_fwd = None
+    if variant == "original":  # the baseline's forward time at config 1's size (no autograd graph)
+        cd256 = cam_dict(syn.camera_1k(256, 256), bg=(0.2, 0.4, 0.1))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            img256 = rasterize(*(torch.tensor(scene[k], dtype=torch.float64) for k in ("means3D", "scales", "rotations", "opacities", "shs")), cd256)
+            t_fwd = time.perf_counter() - t0
+        o256 = orc.forward(variant, scene, cd256, dtype=np.float64)
+        assert np.abs(img256.numpy() - o256["color"]).max() < 1e-6
+    params = {k: torch.tensor(scene[k], dtype=torch.float64, requires_grad=True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    img = rasterize(params["means3D"], params["scales"], params["rotations"], params["opacities"], params["shs"], cd,
+                    cutoff=variant != "original")
+    d = np.abs(img.detach().numpy() - o["color"])
+    assert d.max() < 1e-6, d.max()
+    rng = np.random.default_rng(3)
+    wpix = rng.normal(size=o["color"].shape)
+    (img * torch.tensor(wpix)).sum().backward()
+    g = orc.backward(variant, scene, cd, o, wpix, dtype=np.float64)
+    from tests import parity_report
+    for pname, gname in (("means3D", "dL_dmean3D"), ("scales", "dL_dscale"), ("rotations", "dL_drot"), ("opacities", "dL_dopacity"), ("shs", "dL_dsh")):
+        want, got = g[gname].reshape(scene[pname].shape), params[pname].grad.numpy()
+        scale = np.abs(want).max()
+        err = np.abs(got - want).max()
+        parity_report.record("autograd", f"{variant} {gname}: oracle backward vs torch.autograd", max_abs=float(err), ref_max=float(scale), n=int(want.size))
+        assert scale > 0 and err <= 1e-5 * max(1.0, scale), (pname, err, scale)  # (measured: 5e-8 original, 4e-6 on the sub-tile splats, whose covariance is mostly the 0.3f dilation)
+    if t_fwd is not None:
+        parity_report.record("cpu_torch_baseline", f"{variant}: naive PyTorch-CPU forward, S-1k @ 256x256", seconds=float(t_fwd), threads=int(torch.get_num_threads()))
