@@ -614,8 +614,11 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
     tr = cloud.requires_grad_(True)
     target = torch.rand(3, H, W, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    for fuse in (True, False):  # the model's raw parameters activated inside the kernels / by the fused activation pass
+    # the model's raw parameters activated inside the kernels / by the fused activation pass / raw parameters + ROW-SPARSE gradients
+    # (extension: the backward pass writes compact rows and autograd gets sparse tensors -- no 1.5 GB of zero fills)
+    for fuse, sparse in ((True, False), (False, False), (True, True)):
         tr.fuse_activations = fuse
+        tr.row_sparse_grads = sparse
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(55)]
         t1 = 0.0
         for it in range(55):
@@ -636,7 +639,9 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
         wall = (time.perf_counter() - t1) / 50 * 1e3
         rows = [(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])) for e in evs[5:]]
         med = [round(float(x), 3) for x in np.median(np.array(rows), axis=0)] + [round(wall, 3)]
-        if fuse:
+        if sparse:
+            extra["train_sparse_fwd_ms"], extra["train_sparse_loss_fwd_ms"], extra["train_sparse_bwd_ms"], extra["train_sparse_step_ms"] = med
+        elif fuse:
             extra["train_raw_fwd_ms"], extra["train_raw_loss_fwd_ms"], extra["train_raw_bwd_ms"], extra["train_raw_step_ms"] = med
         else:
             extra["train_fwd_ms"], extra["train_loss_fwd_ms"], extra["train_bwd_ms"], extra["train_step_ms"] = med
@@ -645,7 +650,7 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
     # the streams the kernels run on; algorithmic bytes: training_bytes(); PMC bytes: the committed profile of the training step
     from fov3dgs_amd.profiling import BackwardTimer, StageTimer
     from fov3dgs_amd import _native as _nat
-    tr.fuse_activations = True
+    tr.fuse_activations, tr.row_sparse_grads = True, False
     n_inst = 12
     ft, bt = StageTimer(n_inst), BackwardTimer(n_inst)
     with ft, bt:
@@ -669,8 +674,10 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
     n_tr = dict(P=int(tr.get_xyz.shape[0]), Px=H * W, T=((W + 15) // 16) * ((H + 15) // 16), V=int(o["visibility_filter"].sum().item()),
                 V_in=v_in, D=int(d_tr))
     extra["_train_counts"], extra["_train_fwd_ms"], extra["_train_bwd_ms"] = n_tr, fwd_ms, bwd_ms
+    tr.row_sparse_grads = False
     extra["train_note"] = ("pcheck_obb_sum forward (incl. the model's activations: one fused pass over all P Gaussians each way; "
-                           "train_raw_*: the model's raw parameters handed to the rasterizer, activations inside its kernels) / fused "
+                           "train_raw_*: the model's raw parameters handed to the rasterizer, activations inside its kernels; "
+                           "train_sparse_*: the same with row-sparse gradients, an extension -- the reference's contract is dense) / fused "
                            "L1+SSIM forward / backward of both (loss + rasterizer + activations), events on the stream, median of 50; "
                            "*_step_ms = wall clock of 50 back-to-back steps / 50")
     # the reference's formulation of the loss (five grouped conv2d's + elementwise ops + autograd) in torch on the same GPU

@@ -44,6 +44,7 @@ class ForwardArgs(C.Structure):
         ("packed_geom", _FP), ("packed_colour", _FP), ("packed_cull", _FP),
         ("cur_level", C.c_float),
         ("raw_activations", C.c_int32),
+        ("num_candidates", C.c_int32),
     ]
 
 
@@ -63,6 +64,7 @@ class BackwardArgs(C.Structure):
         ("shs_rest", _FP),
         ("dL_dsh_rest", _FP),
         ("raw_activations", C.c_int32),
+        ("row_sparse", C.c_int32),
     ]
 
 

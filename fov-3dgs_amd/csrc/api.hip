@@ -192,6 +192,7 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 	hipStream_t stream = (hipStream_t)a->stream;
 	a->num_rendered = 0;
 	a->max_tile_instances = 0;
+	a->num_candidates = 0;
 	fr_frame *f = new (std::nothrow) fr_frame;
 	if (!f) { set_error("out of host memory"); return FR_ERR_ALLOC; }
 	struct Guard { fr_frame *f; ~Guard() { delete f; } } guard = { f }; // (released at the end: an early return drops the frame)
@@ -296,11 +297,12 @@ int fr_forward_finish(fr_frame *f)
 	const int64_t early_cap = (same_kind && !a->debug) ? gs.capacity : 0;
 	if (early_cap > 0) early_bin = a->binning_resize(a->resize_user[1], carve_bin(early_cap, nullptr, c.T).bytes);
 
-	uint32_t totals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	uint32_t totals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, candidates = 0;
 	uint32_t *const pinned = f->pin ? f->pin->host : nullptr;
 	if (!pinned)
 	{
 		FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
+		FR_HIP(hipMemcpyAsync(&candidates, c.geom.slab_ctr + 1, sizeof(candidates), hipMemcpyDeviceToHost, stream));
 		FR_HIP(hipStreamSynchronize(stream));
 	}
 	else
@@ -318,7 +320,7 @@ int fr_forward_finish(fr_frame *f)
 				if (__atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != c.totals_seq) { set_error("tile scan did not publish its totals"); return FR_ERR_HIP; }
 			}
 		for (int i = 0; i < 4; i++) totals[i] = v[i];
-		totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7];
+		totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7]; candidates = v[8];
 	}
 	// reference auxiliary.h:156-160: a point behind the near plane although the caller said the cloud was prefiltered
 	// (there: printf + __trap, which kills the context; here an error code)
@@ -327,6 +329,7 @@ int fr_forward_finish(fr_frame *f)
 	if (totals[0] > 0x7fffffffu) { set_error("too many instances (%u)", totals[0]); return FR_ERR_INVALID; }
 	a->num_rendered = (int32_t)totals[0];
 	a->max_tile_instances = (int32_t)totals[1];
+	a->num_candidates = (int32_t)candidates;
 	c.heavy4 = (int)totals[2]; c.heavy2 = (int)totals[3];
 	c.n_items = (int)totals[5]; c.heavy8 = (int)totals[6];
 	// what the next frame of this kind will ask for: a quarter of headroom over the largest frame seen

@@ -260,6 +260,8 @@ struct BwdPreArgs {
 	const uint32_t *vis_list;  // forward's compact list of projected Gaussians
 	const uint32_t *vis_count; // its length (device)
 	int raw;                   // dL_dscale / dL_drot / dL_dopacity w.r.t. the model's raw parameters (fr_backward_args.raw_activations)
+	int row_sparse;            // the outputs are COMPACT: row i belongs to the Gaussian vis_list[i] (fr_backward_args.row_sparse)
+	int M0;                    // coefficients in dL_dsh's rows ([., M0, 3]): M, or 1 with split SH storage
 };
 
 struct V3 { float x, y, z; };
@@ -302,6 +304,7 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 // (xyz | raw scale | rotation | 3D covariance) the forward pass left there: one coalesced row instead of four gathers)
 __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx, const int slot, const float4 *stash)
 {
+	const size_t orow = a.row_sparse ? (size_t)slot : (size_t)idx; // the row of the gradient tensors this Gaussian's gradients go to
 	const float *vm = a.viewmatrix, *pm = a.projmatrix;
 	float4 st0 = make_float4(0, 0, 0, 0), st1 = st0, st2 = st0, st3 = st0;
 	if (stash != nullptr) { st0 = stash[0]; st1 = stash[1]; st2 = stash[2]; st3 = stash[3]; }
@@ -322,12 +325,13 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	const float g_col[3] = { ac0.x, ac0.y, ac0.z };
 	const float g_px = ac0.w, g_py = ac1.x;           // d / d mean2D
 	const float gA = ac1.y, gB = ac1.z, gC = ac1.w;   // d / d conic (gB: half the off-diagonal derivative)
-	a.dL_dmean2D[3 * (size_t)idx] = g_px; a.dL_dmean2D[3 * (size_t)idx + 1] = g_py;
+	a.dL_dmean2D[3 * orow] = g_px; a.dL_dmean2D[3 * orow + 1] = g_py;
+	if (a.row_sparse) a.dL_dmean2D[3 * orow + 2] = 0.0f; // (the dense tensors get their zeros from the fill)
 	// (raw parameters: through the sigmoid, o (1 - o), and below through exp and the normalisation -- what k_activate_bwd does
 	// for all P Gaussians, here only for the rows that are not zero anyway)
-	a.dL_dopacity[idx] = ac2.x;
-	if (a.dL_dcolor != nullptr) { a.dL_dcolor[3 * (size_t)idx] = g_col[0]; a.dL_dcolor[3 * (size_t)idx + 1] = g_col[1]; a.dL_dcolor[3 * (size_t)idx + 2] = g_col[2]; }
-	if (a.dL_dconic != nullptr) { a.dL_dconic[4 * (size_t)idx] = gA; a.dL_dconic[4 * (size_t)idx + 1] = gB; a.dL_dconic[4 * (size_t)idx + 3] = gC; }
+	a.dL_dopacity[orow] = ac2.x;
+	if (a.dL_dcolor != nullptr) { a.dL_dcolor[3 * orow] = g_col[0]; a.dL_dcolor[3 * orow + 1] = g_col[1]; a.dL_dcolor[3 * orow + 2] = g_col[2]; }
+	if (a.dL_dconic != nullptr) { a.dL_dconic[4 * orow] = gA; a.dL_dconic[4 * orow + 1] = gB; a.dL_dconic[4 * orow + 3] = gC; if (a.row_sparse) a.dL_dconic[4 * orow + 2] = 0.0f; }
 
 	// rows of the camera rotation: t = R mean + translation, R[i][r] = vm[4 r + i]
 	const V3 Rx = { vm[0], vm[4], vm[8] }, Ry = { vm[1], vm[5], vm[9] }, Rz = { vm[2], vm[6], vm[10] };
@@ -346,7 +350,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	const float4 rc0 = a.rec[3 * (size_t)slot];
 	const float4 rc1 = a.rec[3 * (size_t)slot + 1]; // (conic c, opacity, ...)
 	const float qa = rc0.z, qb = rc0.w, qc = rc1.x;
-	if (a.raw) a.dL_dopacity[idx] = ac2.x * rc1.y * (1.0f - rc1.y);
+	if (a.raw) a.dL_dopacity[orow] = ac2.x * rc1.y * (1.0f - rc1.y);
 	const float k00 = qa * gA + qb * gB, k01 = qa * gB + qb * gC, k10 = qb * gA + qc * gB, k11 = qb * gB + qc * gC; // Q Ghat
 	const float detq = qa * qc - qb * qb;                     // = 1 / det M
 	const float guard = -1.0f / (1.0f + 0.0000001f * detq * detq); // -(det^2 / (det^2 + 1e-7)), backward.cu:190
@@ -364,7 +368,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	if (a.dL_dcov3D != nullptr)
 	{
 #pragma unroll
-		for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = gSigma[i];
+		for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * orow + i] = gSigma[i];
 	}
 	// dL/dU = 2 Y Sigma (rows w0, w1); dL/dJac[i][k] = dL/dU row i . R row k
 	const V3 w0 = symv(Sigma, y0), w1 = symv(Sigma, y1);
@@ -398,8 +402,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		const bool split = a.shs_rest != nullptr;
 		const int nrest = split ? (a.M - 1) * 3 : a.M * 3 - 3;     // floats available after the DC triple
 		const float *sh_r = split ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 : a.shs + (size_t)idx * a.M * 3 + 3;
-		float *dsh_r = split ? a.dL_dsh_rest + (size_t)idx * (a.M - 1) * 3 : a.dL_dsh + (size_t)idx * a.M * 3 + 3;
-		float *dsh0 = split ? a.dL_dsh + 3 * (size_t)idx : a.dL_dsh + (size_t)idx * a.M * 3;
+		float *dsh_r = split ? a.dL_dsh_rest + orow * (a.M - 1) * 3 : a.dL_dsh + orow * a.M * 3 + 3;
+		float *dsh0 = split ? a.dL_dsh + 3 * orow : a.dL_dsh + orow * a.M * 3;
 		typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 		float coef[48];
 #pragma unroll
@@ -449,15 +453,18 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 			}
 		}
 #undef FR_GSH
+		// (compact rows: the coefficients beyond the active degree get their zeros here -- the dense tensors' come from the fill)
+		if (a.row_sparse)
+			for (int f = nuse; f < nrest; f++) dsh_r[f] = 0.0f;
 		// dir = off / |off|: d dir / d off = (I - dir dir^T) / |off|
 		const float along = dot3(dir, g_dir);
 		g_mean.x += (g_dir.x - along * dir.x) * ilen;
 		g_mean.y += (g_dir.y - along * dir.y) * ilen;
 		g_mean.z += (g_dir.z - along * dir.z) * ilen;
 	}
-	a.dL_dmean3D[3 * (size_t)idx] = g_mean.x;
-	a.dL_dmean3D[3 * (size_t)idx + 1] = g_mean.y;
-	a.dL_dmean3D[3 * (size_t)idx + 2] = g_mean.z;
+	a.dL_dmean3D[3 * orow] = g_mean.x;
+	a.dL_dmean3D[3 * orow + 1] = g_mean.y;
+	a.dL_dmean3D[3 * orow + 2] = g_mean.z;
 	// ---- 3D covariance: Sigma = A^T A, A = diag(s) B(q), B the matrix forward.cu:127-137 builds from the quaternion
 	// (backward.cu:278-341). With Gs the symmetric gradient matrix (off-diagonals halved): dL/dA = 2 A Gs,
 	// dL/ds_i = B_i . (dL/dA)_i, dL/dB_i = s_i (dL/dA)_i (rows), then through the quadratic entries of B.
@@ -501,8 +508,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 			}
 			else gq = make_float4(gq.x * -inv, gq.y * -inv, gq.z * -inv, gq.w * -inv); // clamped denominator: x / 1e-12
 		}
-		a.dL_dscale[3 * (size_t)idx] = gs[0]; a.dL_dscale[3 * (size_t)idx + 1] = gs[1]; a.dL_dscale[3 * (size_t)idx + 2] = gs[2];
-		((float4 *)a.dL_drot)[idx] = gq;
+		a.dL_dscale[3 * orow] = gs[0]; a.dL_dscale[3 * orow + 1] = gs[1]; a.dL_dscale[3 * orow + 2] = gs[2];
+		((float4 *)a.dL_drot)[orow] = gq;
 	}
 }
 
@@ -538,6 +545,18 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 	{
 		const int idx = (int)a.vis_list[i];
 		if (a.radii[idx] > 0) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i);
+		else if (a.row_sparse)
+		{
+			// a candidate that landed in no tile: its compact row is all zeros (every row of the compact tensors is written)
+			const size_t r = (size_t)i;
+			for (int k = 0; k < 3; k++) { a.dL_dmean2D[3 * r + k] = 0.f; a.dL_dmean3D[3 * r + k] = 0.f; if (a.dL_dscale) a.dL_dscale[3 * r + k] = 0.f; if (a.dL_dcolor) a.dL_dcolor[3 * r + k] = 0.f; }
+			a.dL_dopacity[r] = 0.f;
+			if (a.dL_drot) ((float4 *)a.dL_drot)[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (a.dL_dconic) ((float4 *)a.dL_dconic)[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (a.dL_dcov3D) for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * r + k] = 0.f;
+			if (a.dL_dsh) for (int k = 0; k < 3 * a.M0; k++) a.dL_dsh[3 * (size_t)a.M0 * r + k] = 0.f;
+			if (a.dL_dsh_rest) for (int k = 0; k < 3 * (a.M - 1); k++) a.dL_dsh_rest[3 * (size_t)(a.M - 1) * r + k] = 0.f;
+		}
 	}
 }
 
@@ -586,7 +605,7 @@ int launch_backward(const fr_backward_args *a)
 		// 1 TB/s, and outlasted it by 50 us); tensors are 16-byte aligned and their sizes multiples of 4
 		FillArgs fa; fa.n = 0;
 		for (auto &f : fills)
-			if (f.p && f.bytes)
+			if (f.p && f.bytes && !a->row_sparse) // (compact rows: k_preprocess_bwd writes every row it is handed, nothing to clear)
 			{
 				if (((uintptr_t)f.p & 15) != 0 || fa.n == FR_FILL_MAX)
 				{
@@ -636,6 +655,7 @@ int launch_backward(const fr_backward_args *a)
 	p.dL_dmean2D = a->dL_dmean2D; p.dL_dconic = a->dL_dconic; p.dL_dcolor = a->dL_dcolor; p.dL_dopacity = a->dL_dopacity;
 	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dsh_rest = a->dL_dsh_rest; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
 	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1; p.raw = a->raw_activations;
+	p.row_sparse = a->row_sparse; p.M0 = (a->colors_precomp == nullptr && a->shs != nullptr) ? (a->shs_rest ? 1 : a->M) : 0;
 	const int pblocks = (a->P + 255) / 256;
 	hipLaunchKernelGGL(k_preprocess_bwd, dim3(pblocks < 2048 ? pblocks : 2048), dim3(256), 0, stream, p);
 	int rc2 = check_launch("preprocess_bwd", stream, a->debug);

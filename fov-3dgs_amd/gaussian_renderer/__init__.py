@@ -74,6 +74,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     extra = {} if packed is None else {"packed": packed}
     if raw is not None:
         extra["raw_activations"] = True
+    # extension: gradients as row-sparse tensors (rasterizer.py; only meaningful when every rasterizer input is a leaf parameter,
+    # i.e. with the raw parameters and split SH storage)
+    if getattr(pc, "row_sparse_grads", False) and raw is not None and hasattr(pc, "get_features_split") and torch.is_grad_enabled():
+        extra["row_sparse"] = True
     if cuda_type == "pcheck_obb_loss_weighted_max_count":
         out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,
                          scales=scales, rotations=rotations, cov3D_precomp=None, loss_map=loss_map, **extra)

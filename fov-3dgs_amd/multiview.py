@@ -122,6 +122,33 @@ def allreduce_gradients_flat(params, timings=None):
     return dict(mode="flat", bytes=n * flat.element_size())
 
 
+def _allreduce_sparse_rows(params):
+    """Gradients that already ARE row-sparse (the rasterizer's row_sparse extension: torch.sparse_coo with one sparse dimension,
+    the Gaussians this rank's view touched): exchanged as the rows of the union of the ranks' row sets -- no dense [P, ...]
+    tensor is ever made. p.grad becomes the summed sparse tensor over the union's rows (the same rows on every rank)."""
+    grads = [p.grad.coalesce() for p in params]
+    P, dev = grads[0].shape[0], grads[0].device
+    union = torch.zeros(P, dtype=torch.uint8, device=dev)
+    for g in grads:
+        union[g.indices()[0]] = 1
+    dist.all_reduce(union, op=dist.ReduceOp.MAX)
+    idx = torch.nonzero(union, as_tuple=False).squeeze(1)
+    U = int(idx.numel())
+    widths = [g.values()[0].numel() if g.values().shape[0] else int(torch.tensor(g.shape[1:]).prod().item()) for g in grads]
+    rows = torch.zeros((U, sum(widths)), dtype=grads[0].dtype, device=dev)
+    off = 0
+    for g, w in zip(grads, widths):
+        pos = torch.searchsorted(idx, g.indices()[0])
+        rows[pos, off:off + w] = g.values().reshape(-1, w)
+        off += w
+    dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+    off = 0
+    for p_, g, w in zip(params, grads, widths):
+        p_.grad = torch.sparse_coo_tensor(idx.unsqueeze(0), rows[:, off:off + w].reshape((U,) + tuple(g.shape[1:])), g.shape, is_coalesced=True)
+        off += w
+    return dict(mode="sparse_rows", rows=U, of=P, bytes=rows.numel() * rows.element_size() + P)
+
+
 def allreduce_gradients(params, visible=None, sparse_below=0.4, check_rows=False, per_tensor_ms=None):
     """Sum the per-view gradients of the replicated parameters over all ranks. -> dict with what was exchanged.
 
@@ -145,6 +172,8 @@ def allreduce_gradients(params, visible=None, sparse_below=0.4, check_rows=False
     if not grads:
         return dict(mode="none", bytes=0)
     P = grads[0].shape[0]
+    if all(g.is_sparse for g in grads):
+        return _allreduce_sparse_rows([p for p in params if p.grad is not None])
     if visible is not None and all(g.shape[0] == P for g in grads):
         union = visible.to(torch.uint8)
         dist.all_reduce(union, op=dist.ReduceOp.MAX)

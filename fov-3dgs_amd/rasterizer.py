@@ -342,13 +342,18 @@ def _forward_native(*args, **kw):
 
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                      grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None,
-                     want_cov3D_grad=False, want_color_grad=False, raw_activations=False):
+                     want_cov3D_grad=False, want_color_grad=False, raw_activations=False, row_sparse=False, num_candidates=0):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations[, dL_dsh_rest])
     (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3]; dL_dcov3D / dL_dcolors are None unless
-    cov3Ds_precomp / colors_precomp are given or want_cov3D_grad / want_color_grad)"""
+    cov3Ds_precomp / colors_precomp are given or want_cov3D_grad / want_color_grad)
+    row_sparse (extension, fovraster.h): the tensors are COMPACT, [num_candidates, ...], row i = the gradient of the Gaussian
+    vis_list[i] (visible_rows(): the forward call's list of cull survivors, increasing indices); nothing is zero-filled."""
     lib = _native.load()
     dev = means3D.device
     P = means3D.size(0)
+    Pfull = P
+    if row_sparse:
+        P = int(num_candidates)  # rows of the gradient tensors
     H, W = grad_out_color.size(1), grad_out_color.size(2)
     a = _native.BackwardArgs()
     keep = []
@@ -378,9 +383,10 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
         dL_dsh, dL_dscales, dL_drotations = z(P, M0, 3), z(P, 3), z(P, 4)
         dL_dsh_rest = z(P, M - M0, 3) if rest_c is not None else None
         if P != 0:
-            a.variant, a.P, a.D, a.M, a.R = variant, P, int(rs.sh_degree), M, int(num_rendered)
+            a.variant, a.P, a.D, a.M, a.R = variant, Pfull, int(rs.sh_degree), M, int(num_rendered)
             a.W, a.H, a.debug = W, H, int(bool(rs.debug))
             a.raw_activations = int(bool(raw_activations))
+            a.row_sparse = int(bool(row_sparse))
             a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
             a.stream = torch.cuda.current_stream(dev).cuda_stream
             put("background", rs.bg, small=True)
@@ -411,6 +417,13 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
     return out + (dL_dsh_rest,) if dL_dsh_rest is not None else out
 
 
+def visible_rows(variant, P, geomBuffer, num_candidates):
+    """The Gaussian indices (int64 [num_candidates], increasing) of the rows of a row-sparse backward call."""
+    lib = _native.load()
+    off = lib.fr_geometry_vis_list(variant, P, geomBuffer.data_ptr()) - geomBuffer.data_ptr()
+    return geomBuffer[off:off + 4 * int(num_candidates)].view(torch.int32).long()
+
+
 def _mark_visible(positions, rs):
     lib = _native.load()
     _require_gpu(positions)
@@ -434,7 +447,11 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                    raster_settings, loss_map=None, sh_rest=None, packed=None, grad_mode=True, raw_activations=False):
+                    raster_settings, loss_map=None, sh_rest=None, packed=None, grad_mode=True, raw_activations=False,
+                    row_sparse=False):
+            # row_sparse (extension): backward returns the gradients of the [P, ...] inputs as SPARSE tensors (torch.sparse_coo, one
+            # sparse dimension: the Gaussians this view touched) -- for leaf parameters (raw_activations + split SH: every input is
+            # one) optimised by a sparse-aware optimizer or summed with multiview.allreduce_gradients; no 1.5 GB of zero fills
             # raw_activations (extension): opacities / scales / rotations are the model's RAW parameters, the kernels apply
             # sigmoid / exp / normalize themselves and the backward pass returns the gradients w.r.t. the raw parameters
             # sh_rest (extension): the SH coefficients as the two tensors a model stores, sh = features_dc
@@ -452,21 +469,26 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                     raise Exception("loss_map with at least image_height*image_width values is required")
             ctx.split_sh = sh_rest is not None
             ctx.raw_activations = bool(raw_activations)
+            ctx.row_sparse = bool(row_sparse) and has_backward
             # no zero tensors for the gradients of the outputs nobody differentiates (radii, counts, contributions:
             # three [P] fills per step otherwise)
             ctx.set_materialize_grads(False)
+            def run():
+                frame = _forward_begin(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed,
+                                       raw_activations=raw_activations)
+                out = frame.finish()
+                ctx.num_candidates = int(frame.a.num_candidates)
+                return out
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
                 try:
-                    res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed,
-                                          raw_activations=raw_activations)
+                    res = run()
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                res = _forward_native(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed,
-                                          raw_activations=raw_activations)
+                res = run()
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = res[:6]
             if not keep_ws:  # nothing will call backward: do not pin the shared workspaces
                 geomBuffer = binningBuffer = imgBuffer = torch.empty(0, dtype=torch.uint8, device=means3D.device)
@@ -488,35 +510,42 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 # the reference's inference-only extension exports no backward entry point
                 raise RuntimeError("this rasterizer variant is inference-only (no backward in the reference)")
             if grad_out_color is None:  # the image took no part in the loss
-                return (None,) * 14
+                return (None,) * 15
             rs = ctx.raster_settings
             (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
              geomBuffer, binningBuffer, imgBuffer, sh_rest) = ctx.saved_tensors
             args = (variant_id, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                     grad_out_color, sh, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer,
                     sh_rest if ctx.split_sh else None)
+            kw = dict(raw_activations=ctx.raw_activations, row_sparse=ctx.row_sparse, num_candidates=ctx.num_candidates)
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    res = _backward_native(*args, raw_activations=ctx.raw_activations)
+                    res = _backward_native(*args, **kw)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_bw.dump")
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                     raise ex
             else:
-                res = _backward_native(*args, raw_activations=ctx.raw_activations)
+                res = _backward_native(*args, **kw)
+            if ctx.row_sparse:
+                # compact rows -> sparse tensors of the inputs' shapes (indices shared: one [1, C] tensor)
+                P = means3D.size(0)
+                rows = visible_rows(variant_id, P, geomBuffer, ctx.num_candidates).unsqueeze(0)
+                res = tuple(None if g is None else torch.sparse_coo_tensor(rows, g, (P,) + tuple(g.shape[1:]), is_coalesced=True)
+                            for g in res)
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations) = res[:8]
             grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                      grad_rotations, grad_cov3Ds_precomp, None)
-            # loss_map, sh_rest, packed, grad_mode, raw_activations
-            return grads + (None, res[8] if ctx.split_sh else None, None, None, None)
+            # loss_map, sh_rest, packed, grad_mode, raw_activations, row_sparse
+            return grads + (None, res[8] if ctx.split_sh else None, None, None, None, None)
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                            raster_settings, loss_map=None, sh_rest=None, packed=None, raw_activations=False):
+                            raster_settings, loss_map=None, sh_rest=None, packed=None, raw_activations=False, row_sparse=False):
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                          cov3Ds_precomp, raster_settings, loss_map if takes_loss_map else None, sh_rest, packed,
-                                         torch.is_grad_enabled(), raw_activations)
+                                         torch.is_grad_enabled(), raw_activations, row_sparse)
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):
@@ -528,7 +557,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 return _mark_visible(positions, self.raster_settings)
 
         def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                    cov3D_precomp=None, loss_map=None, packed=None, raw_activations=False):
+                    cov3D_precomp=None, loss_map=None, packed=None, raw_activations=False, row_sparse=False):
             raster_settings = self.raster_settings
             if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
                 raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -547,7 +576,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             rotations = empty if rotations is None else rotations
             cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings, loss_map, shs_rest, packed, raw_activations)
+                                       cov3D_precomp, raster_settings, loss_map, shs_rest, packed, raw_activations, row_sparse)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
 

@@ -155,6 +155,8 @@ typedef struct fr_forward_args {
 	 * fr_activate_forward, so the image is bit-identical to activating first. Saves the two streaming passes over all P
 	 * Gaussians around every training step. */
 	int32_t raw_activations;
+	int32_t num_candidates;      /* out: entries of the library's list of the Gaussians that survived its cull pass
+	                              * (fr_geometry_vis_list): the rows of a row-sparse backward call */
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_GEOM = 2, FR_STAGE_COUNT = 3, FR_STAGE_TILE_SCAN = 4, FR_STAGE_EMIT = 5,
@@ -196,6 +198,12 @@ typedef struct fr_backward_args {
 	float *dL_dsh_rest;          /* ... then dL_dsh is [P,1,3] and dL_dsh_rest [P,M-1,3] */
 	int32_t raw_activations;     /* as in the forward call: dL_dscale / dL_drot / dL_dopacity are then gradients w.r.t. the RAW
 	                              * parameters (what fr_activate_backward would make of them) */
+	/* optional (extension; the reference returns dense tensors, rasterize_points.cu:171-179): ROW-SPARSE gradients. The
+	 * gradient tensors are then COMPACT -- [C, .] instead of [P, .], C = fr_forward_args.num_candidates of the forward call --
+	 * and row i belongs to the Gaussian vis_list[i] (fr_geometry_vis_list: increasing indices; every Gaussian the view touches is
+	 * in the list, a candidate that landed in no tile has a zero row). Every row is written, nothing is zero-filled: at 6 M
+	 * Gaussians a training step's backward pass otherwise clears 1.5 GB to write 0.5 GB. */
+	int32_t row_sparse;
 } fr_backward_args;
 
 int fr_abi_version(void);

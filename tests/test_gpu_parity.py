@@ -304,6 +304,55 @@ def test_autograd_module_end_to_end():
     check_grad(cloud._features_rest.grad.cpu().numpy(), og["dL_dsh"][:, 1:], "f_rest")
 
 
+@pytest.mark.parametrize("sh_degree", (3, 1))
+def test_row_sparse_gradients_equal_the_dense_ones(sh_degree):
+    """fr_backward_args.row_sparse (extension; the reference returns dense tensors it zero-fills, rasterize_points.cu:171-179):
+    the backward pass writes compact rows -- one per cull survivor, nothing cleared -- and render() hands autograd sparse tensors.
+    Densified they equal the dense call's gradients (same kernels, same rows; two backward passes differ by the order their float
+    atomics retire in), every Gaussian with a non-zero dense gradient row is among the sparse rows, and rows outside are exact zeros."""
+    _need_gpu()
+    from fov3dgs_amd.gaussian_renderer import render
+    dev = "cuda:0"
+    cam = syn.camera_1k(200, 136).to(dev)
+    bg = torch.tensor([0.1, 0.0, 0.2], device=dev)
+
+    class Pipe:
+        debug = False
+    w = None
+    res = []
+    for sparse in (False, True):
+        cloud = small_cloud(P=4000, seed=29).to(dev).requires_grad_(True)
+        cloud.fuse_activations = True   # raw parameters: every rasterizer input is a leaf
+        cloud.row_sparse_grads = sparse
+        cloud.active_sh_degree = sh_degree
+        out = render(cam, cloud, Pipe(), bg, cuda_type="pcheck_obb_sum")
+        if w is None:
+            w = torch.randn_like(out["render"])
+        (out["render"] * w).sum().backward()
+        grads = dict(xyz=cloud._xyz.grad, scaling=cloud._scaling.grad, rotation=cloud._rotation.grad, opacity=cloud._opacity.grad,
+                     f_dc=cloud._features_dc.grad, f_rest=cloud._features_rest.grad, screen=out["viewspace_points"].grad)
+        assert all(g is not None for g in grads.values())
+        if sparse:
+            assert all(g.is_sparse for g in grads.values())
+            rows = grads["xyz"].coalesce().indices()[0]
+            assert 500 < rows.numel() < 4000 and bool((rows[1:] > rows[:-1]).all())
+            res.append(({k: g.to_dense().cpu().numpy() for k, g in grads.items()}, rows.cpu().numpy(), out["radii"].cpu().numpy()))
+        else:
+            assert not any(g.is_sparse for g in grads.values())
+            res.append(({k: g.cpu().numpy() for k, g in grads.items()}, None, out["radii"].cpu().numpy()))
+    (dense, _, radii), (sp, rows, radii2) = res
+    np.testing.assert_array_equal(radii, radii2)
+    in_rows = np.zeros(4000, bool)
+    in_rows[rows] = True
+    assert in_rows[radii > 0].all()
+    for k in dense:
+        check_grad(sp[k], dense[k], "row-sparse " + k)
+        assert np.abs(dense[k]).max() > 0, k
+        assert not np.abs(dense[k].reshape(4000, -1))[~in_rows].any() and not np.abs(sp[k].reshape(4000, -1))[~in_rows].any()
+        if sh_degree < 3 and k == "f_rest":
+            assert not sp[k][:, (sh_degree + 1) ** 2 - 1:].any()  # coefficients beyond the active degree: zeros, written explicitly
+
+
 @pytest.mark.parametrize("variant", ["original", "pcheck_obb_sum"])
 def test_raw_parameters_in_the_kernels_match_activate_then_render(variant):
     """fr_forward_args.raw_activations: exp / normalize / sigmoid applied inside the kernels give the image of

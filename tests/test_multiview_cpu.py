@@ -47,6 +47,17 @@ def _worker(rank, world, port, q):
     for i, p in enumerate(fl):
         want = torch.arange(p.numel(), dtype=torch.float32).view_as(p) * sum(range(1, world + 1)) + i * world
         assert torch.equal(p.grad, want)
+    # gradients that are row-sparse tensors already (the rasterizer's row_sparse extension): summed over the union of the rows
+    sg = [torch.nn.Parameter(torch.zeros(30, 3)), torch.nn.Parameter(torch.zeros(30, 2, 2))]
+    my_rows = torch.tensor([rank, 7, 20 + rank])
+    for i, p in enumerate(sg):
+        vals = torch.full((3,) + tuple(p.shape[1:]), float((rank + 1) * (i + 1)))
+        p.grad = torch.sparse_coo_tensor(my_rows.unsqueeze(0), vals, p.shape)
+    info_s = multiview.allreduce_gradients(sg)
+    assert info_s["mode"] == "sparse_rows" and info_s["rows"] == 5 and info_s["of"] == 30
+    dense0 = sg[0].grad.to_dense()
+    want_s = torch.zeros(30, 3); want_s[0] = 1.0; want_s[1] = 2.0; want_s[7] = 3.0; want_s[20] = 1.0; want_s[21] = 2.0
+    assert sg[0].grad.is_sparse and torch.equal(dense0, want_s) and torch.equal(sg[1].grad.to_dense()[:, 0, 0], 2 * want_s[:, 0])
     ci = multiview.comm_info()
     assert ci["backend"] == "gloo" and ci["world"] == world
     # row-sparse exchange: rank r's view touches rows {r, 5}; rows outside the union stay exactly zero everywhere
