@@ -324,7 +324,8 @@ __device__ __forceinline__ float view_norm2_bound(const float *vm)
 // 1 % + 2 px, far above the rounding of either formulation; NaN/inf anywhere makes the test pass.
 // rho: upper bound of the spectral norm of the 3D covariance
 template <bool FOV>
-__device__ __forceinline__ bool frame_test_rho(const PreArgs &a, const float *vm, const float *pm, const float p[3], const float rho, float hl, float wn2)
+__device__ __forceinline__ bool frame_test_rho(const PreArgs &a, const float *vm, const float *pm, const float p[3], const float rho, float hl, float wn2,
+	const uint4 *lvb /* the five level boxes, one uint4 apart (k_project keeps them in LDS) */)
 {
 	const float tz = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
 	if (tz <= 0.2f) return false;
@@ -348,7 +349,7 @@ __device__ __forceinline__ bool frame_test_rho(const PreArgs &a, const float *vm
 	if (FOV)
 	{
 		const int k = (int)fminf(fmaxf(ceilf(hl + 1.0f), 0.0f), 4.0f);
-		const uint4 b = *(const uint4 *)(a.lv_bbox + k * FR_LV_BBOX_STRIDE);
+		const uint4 b = lvb[k];
 		x0 = max(x0, a.gx - (int)b.x); y0 = max(y0, a.gy - (int)b.y);
 		x1 = min(x1, (int)b.z); y1 = min(y1, (int)b.w);
 	}
@@ -366,7 +367,7 @@ __device__ __forceinline__ float rho_unit(const float sc[3], const float4 q)
 }
 template <bool FOV>
 __device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, const float *pm, int idx, const float p[3], const float sc[3], float4 q,
-	float hl, float wn2)
+	float hl, float wn2, const uint4 *lvb)
 {
 	const float tz = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
 	if (tz <= 0.2f) return false;
@@ -377,7 +378,7 @@ __device__ __forceinline__ bool frame_test(const PreArgs &a, const float *vm, co
 		rho = fabsf(c[0]) + fabsf(c[3]) + fabsf(c[5]) + 2.0f * (fabsf(c[1]) + fabsf(c[2]) + fabsf(c[4]));
 	}
 	else rho = (a.scale_modifier * a.scale_modifier) * rho_unit(sc, q);
-	return frame_test_rho<FOV>(a, vm, pm, p, rho, hl, wn2);
+	return frame_test_rho<FOV>(a, vm, pm, p, rho, hl, wn2, lvb);
 }
 
 // The reference's per-Gaussian projection (forward.cu:155-262): near plane, 3D covariance, EWA 2D covariance,
@@ -587,6 +588,10 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 	constexpr int DEPTH = PACKED ? FR_PROJ_DEPTH_PACKED : FR_PROJ_DEPTH;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	const int lane = threadIdx.x & 63;
+	// RF: the five level boxes of the frame test, in LDS (one dependent global load per Gaussian otherwise)
+	__shared__ uint4 s_lvb[5];
+	if (FOV && threadIdx.x < 5) s_lvb[threadIdx.x] = *(const uint4 *)(a.lv_bbox + threadIdx.x * FR_LV_BBOX_STRIDE);
+	if (FOV) __syncthreads();
 	// Unpacked model: a survivor's eleven input floats are in this wave's registers right now, and k_bin would have to
 	// fetch them again through four gathers that touch every cache line of means3D / scales / rotations / highest_levels
 	// (a line holds 8-10 Gaussians, one in eight survives: 264 MB of lines per frame for 34 MB of rows). So the survivor
@@ -646,7 +651,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		if (FOV && chunk < c1 && idx < a.P && !(cur.hl == 0.0f || cur.hl == 1.0f || cur.hl == 2.0f || cur.hl == 3.0f)) odd_level = true;
 		if (chunk < c1 && idx < a.P)
 		{
-			if (PACKED) maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * cur.sc[0], cur.hl, wn2);
+			if (PACKED) maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * cur.sc[0], cur.hl, wn2, s_lvb);
 			else if (!FOV && a.raw)
 			{
 				// raw parameters: exp is monotone, so the largest scale is exp(largest raw scale) -- one exp instead of
@@ -654,9 +659,9 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 				// rotations are still fetched: not reading them here takes 20 us off this kernel and puts 45 us on k_bin, which
 				// then finds their lines cold.)
 				const float smax = act_scale(fmaxf(cur.sc[0], fmaxf(cur.sc[1], cur.sc[2])));
-				maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * (smax * smax) * 1.00001f, cur.hl, wn2);
+				maybe = frame_test_rho<FOV>(a, vm, pm, cur.p, (a.scale_modifier * a.scale_modifier) * (smax * smax) * 1.00001f, cur.hl, wn2, s_lvb);
 			}
-			else maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2);
+			else maybe = frame_test<FOV>(a, vm, pm, idx, cur.p, cur.sc, cur.q, cur.hl, wn2, s_lvb);
 			a.radii[idx] = 0; // whole lines (a store with the survivors masked out is a partial-line write); k_bin, which runs
 			                  // after this kernel, writes the radius of every survivor
 			// auxiliary.h:156-160: the reference traps on a near-culled point of a cloud declared prefiltered
