@@ -131,13 +131,13 @@ def algorithmic_bytes(variant, n):
     SURVIVE the filter and per level in their range; R0 / RS / RP (forward.cu:155-262) for every Gaussian inside the frustum:
       project   12 B xyz read + 8 B radii / tiles_touched written per Gaussian; scale 12 + rotation 16 (+ RF highest level 4)
                 read per Gaussian in front of the camera
-      geom + count (the reference's preprocess / filter / compute_fov_colors; this build: k_geom = full projection, k_count = tile
-                counts + colours)
+      bin       (the reference's preprocess / filter / compute_fov_colors; this build: k_bin = full projection of the candidates, tile
+                counts, colours)
                 RF: the candidate's inputs handed on (48 B per candidate) and, per VISIBLE Gaussian, depth 4 + mean2D 8 + conic 12
-                + eigen axes 24 + walk record 64 written [geom]; 180 (rest SH) + 48 (level DCs) + 16 (level opacities) + 4
-                (highest level) read, level range 8 + four level rows 64 written [count]: 48 C + 432 V in all
-                plain: 48 (+ 24 eigen) written per visible Gaussian [geom]; opacity 4 + SH 192 read per Gaussian in front of the
-                camera (B_pre's 224 V_in less the 28 of project) [count]
+                + eigen axes 24 + walk record 64 written; 180 (rest SH) + 48 (level DCs) + 16 (level opacities) + 4 (highest level)
+                read, level range 8 + four level rows 64 written: 48 C + 432 V in all
+                plain: 48 (+ 24 eigen) written per visible Gaussian; opacity 4 + SH 192 read per Gaussian in front of the
+                camera (B_pre's 224 V_in less the 28 of project)
       emit      12 B per instance (key + value) + 44 B read per visible Gaussian;  tile_sort: 12 B per instance (this build moves
                 (depth, item) once per stage instead of a 6-pass radix sort);  tile_scan 16 T;  tile_levels 20 T
       render    RF: 32 D_single + 52 D_blend + 12 Px;  plain: 40 D + 20 Px"""
@@ -145,10 +145,10 @@ def algorithmic_bytes(variant, n):
     b = {"project": 20 * n["P"] + (32 if fov else 28) * n["V_in"],
          "emit": 12 * n["D"] + 44 * n["V"], "tile_sort": 12 * n["D"], "tile_scan": 16 * n["T"], "tile_levels": 20 * n["T"] if fov else 0}
     if fov:
-        b["geom"], b["count"] = 48 * n["C"] + 112 * n["V"], (248 + 72) * n["V"]
+        b["bin"] = 48 * n["C"] + (112 + 248 + 72) * n["V"]
         b["render"] = 32 * n["D_single"] + 52 * n["D_blend"] + 12 * n["Px"]
     else:
-        b["geom"], b["count"] = (48 + 24) * n["V"], 196 * n["V_in"]
+        b["bin"] = (48 + 24) * n["V"] + 196 * n["V_in"]
         b["render"] = 40 * n["D"] + 20 * n["Px"]
     return b
 
@@ -323,7 +323,7 @@ def main():
         for i in range(3):
             frame(GAZES[i % 9], "auto" if args.packed_only else None)
     pre = stage_pass("auto" if args.packed_only else None)
-    dominant = max(("project", "geom", "count", "render", "tile_sort", "emit"), key=lambda k: pre[k])
+    dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: pre[k])
     ev_stages = tuple(dict.fromkeys((dominant, "render")))
     if args.packed_only:
         elapsed_p, spread_p, timed_ms_p = timed_run("auto", ev_stages)
@@ -400,9 +400,9 @@ def main():
         fb = algorithmic_bytes("pcheck_obb_sum", dict(n_tr, C=0, D_single=0, D_blend=0))
         tr_ms = dict(fwd_ms, **bwd_ms)
         kern = {"render": "k_render", "render_bwd": "k_render_bwd", "preprocess_bwd": "k_preprocess_bwd", "fill_zero": "k_fill_zero",
-                "project": "k_project", "geom": "k_geom", "count": "k_count", "emit": "k_emit", "tile_sort": "k_tile_msort*"}
+                "project": "k_project", "bin": "k_bin", "emit": "k_emit", "tile_sort": "k_tile_msort*"}
         rows = {}
-        for k_, byt in list(tb.items()) + [(k2, fb[k2]) for k2 in ("project", "geom", "count", "emit", "tile_sort")]:
+        for k_, byt in list(tb.items()) + [(k2, fb[k2]) for k2 in ("project", "bin", "emit", "tile_sort")]:
             ms_ = tr_ms[k_]
             tr_b, tr_src = prof.traffic_train(kern[k_])
             rows[k_] = dict(kernel=kern[k_], ms=round(ms_, 4), algorithmic_bytes=int(byt), achieved=round(byt / max(ms_, 1e-9) / 1e6, 1),
@@ -470,7 +470,7 @@ def frame_stats(torch, lib, vid, out_state, W, H, T, geom=None, P=0):
 class load_profiles:
     """The committed rocprofv3 summaries (profiles/<tag>_pmc.json, <tag>_render_sq.json). PMC bytes are only quoted when
     the profile was made with this very library build (sha of libfovraster_hip.so recorded by tools/make_profiles.sh)."""
-    STAGE_KERNELS = {"render": ["k_render_fov"], "project": ["k_project"], "geom": ["k_geom"], "count": ["k_count"],
+    STAGE_KERNELS = {"render": ["k_render_fov"], "project": ["k_project"], "bin": ["k_bin"],
                      "tile_sort": ["k_tile_msort", "k_tile_msort_direct", "k_split_long", "k_tile_msort_chunks"], "emit": ["k_emit"],
                      "tile_scan": ["k_tile_scan"], "tile_levels": ["k_tile_levels"]}
 

@@ -14,7 +14,7 @@ ABI_VERSION = 7
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
 VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC, VARIANT_NAIVE_FOV_PCHECK_OBB, VARIANT_MMFR_PCHECK_OBB = 4, 5, 6, 7
-STAGES = ("tile_levels", "project", "geom", "count", "tile_scan", "emit", "tile_sort", "render")
+STAGES = ("tile_levels", "project", "bin", "tile_scan", "emit", "tile_sort", "render")
 NUM_STAGE_EVENTS = len(STAGES) + 1
 VARIANT_IDS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb": 3, "pcheck_obb_max": 4,
                "pcheck_obb_loss_weighted_max_count": 5, "naive_pcheck_obb": 6, "mmfr_pcheck_obb": 7}

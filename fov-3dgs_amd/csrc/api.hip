@@ -247,7 +247,7 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 		fills_done();
 		if (e1 != hipSuccess || e2 != hipSuccess) { set_error("hipMemsetAsync(statistics): %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return FR_ERR_HIP; }
 	}
-	// small clears in front of the first kernel: the per-tile instance counters (k_count's workgroups add their shares to them;
+	// small clears in front of the first kernel: the per-tile instance counters (k_bin's workgroups add their shares to them;
 	// the global-atomics path of huge tile grids counts in them directly) and, next to them, the level boxes (RF:
 	// k_tile_levels raises them with atomicMax; it clears the slab counters itself)
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
@@ -260,10 +260,8 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 	if (is_fov(a->variant)) { rc = launch_tile_levels(c); if (rc) return rc; }
 	mark(FR_STAGE_PROJECT);
 	rc = launch_project(c); if (rc) return rc;
-	mark(FR_STAGE_GEOM);
-	rc = launch_geom(c); if (rc) return rc;
-	mark(FR_STAGE_COUNT);
-	rc = launch_count(c); if (rc) return rc;
+	mark(FR_STAGE_BIN);
+	rc = launch_bin(c); if (rc) return rc;
 	int cur_dev = 0;
 	(void)hipGetDevice(&cur_dev);
 	f->pin = a->debug ? nullptr : take_pinned(cur_dev);

@@ -10,8 +10,8 @@
 #define FR_FOV_LEVELS 4       // RF auxiliary.h:26 fov_num
 #define FR_SORT_LDS_MAX 8192  // longest per-tile list sorted inside LDS (64 KiB of u64 keys)
 #ifndef FR_BIN_THREADS
-#define FR_BIN_THREADS 1024   // workgroup size of k_count (k_emit: FR_EMIT_SHARE times as many): the tile walk is a chain of LDS round
-                              // trips, sixteen waves per CU hide what eight did not (k_count 120 -> ? us)
+#define FR_BIN_THREADS 1024   // workgroup size of k_bin (k_emit: FR_EMIT_SHARE times as many): the tile walk is a chain of LDS round
+                              // trips, sixteen waves per CU hide what eight did not (k_bin 120 -> ? us)
 #endif
 // persistent workgroups of the binning kernels: 2 per CU by LDS (up to 76 KiB each); k_bin's ~145 VGPRs let only one of
 // them run at a time (2 waves/SIMD), the other finds the slab counters empty -- 384-thread workgroups (3 waves/SIMD)
@@ -68,8 +68,8 @@ struct GeomWS {
 	float4 *wrec;       // [4P] walk record of item i at [4i..4i+3], written by k_bin for k_emit:
 	                    //      (cx, cy, e1x, e1y | e2x, e2y, len1, len2 | Gaussian index + flags << 30, depth bits, x0 + y0 << 16, width |
 	                    //      tiles, highest level, -, -); flags: 1 = lands in a tile, 2 = the OBB test applies
-	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity) of item i at [4i..4i+3] (k_count)
-	uint32_t *lrange;   // [P]  per item, written by k_count: 0xffffffff = the item lands in no tile (culled everywhere), else the packed
+	float4 *lvl;        // [4P] RF per-level (r,g,b,opacity) of item i at [4i..4i+3] (k_bin)
+	uint32_t *lrange;   // [P]  per item, written by k_bin: 0xffffffff = the item lands in no tile (culled everywhere), else the packed
 	                    //      level range lo | hi<<8 (RF; 0 for the variants without levels)
 	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {prefiltered violation flag, number of entries in vis_list, workgroups of the cull pass that
 	                    // are done, odd highest level seen}
@@ -418,8 +418,7 @@ int launch_activate_forward(int P, const float *rs, const float *rq, const float
 int launch_activate_backward(int P, const float *rs, const float *rq, const float *ro, const float *gs, const float *gq, const float *go,
 	float *ds, float *dq, float *dop, hipStream_t stream);
 int launch_project(FwdCtx &c); // cull pass + the ordered compaction of its survivors
-int launch_geom(FwdCtx &c);   // full projection of the cull pass's survivors -> walk records, blend records
-int launch_count(FwdCtx &c);  // tile counts from the walk records + the colours of the items that landed somewhere
+int launch_bin(FwdCtx &c);    // projection of the cull pass's survivors, tile counts, colours, item rows
 int launch_tile_scan(FwdCtx &c);
 int launch_emit(FwdCtx &c);
 int launch_tile_sort(FwdCtx &c);

@@ -791,151 +791,97 @@ __device__ __forceinline__ void rows_unpack(float4 (&rows)[N], const float4 (&pi
 	FR_WAVE_LDS_SYNC();
 }
 
-// Stage 2 (reference: the rest of preprocessCUDA, RS forward.cu:155-293 / RF :105-238): the full projection of every survivor
-// of the cull pass -- 3D covariance, EWA 2D covariance, conic, radius, OBB axes, the tile rectangle to walk -- one lane per
-// candidate, no tile walk and no LDS table, so that the per-item math (a ~600-instruction dependent chain per lane) runs at the
-// occupancy its registers allow instead of at the one workgroup per CU of the kernel that owns the tile histogram (round 3's
-// k_bin did both at 1.7 waves per SIMD). A WAVE takes the region of ONE wave of the cull pass: its survivors' inputs (the
-// candidate rows k_project stored, or gathers through vis_seg) are contiguous, and so are its items: wbase[w] .. + count.
-// Writes, per item: the walk record (k_count, k_emit), the blend record with the POSITION in its colour slots (k_colour replaces
-// it by the colour), (training) the backward pass's input row and the cleared gradient row; per Gaussian: the radius; vis_list.
-template <int VARIANT, bool PACKED = false, bool CROW = false>
-__global__ void __launch_bounds__(256) k_geom(const PreArgs a)
+// a candidate's inputs by index: the packed row, or gathers from the model's tensors
+template <bool PACKED, bool FOV>
+__device__ __forceinline__ void load_candidate(const PreArgs &a, const int idx, RawGaussian &g)
 {
-	static_assert(!(PACKED && CROW), "the packed model layout has its own rows");
+	if (PACKED)
+	{
+		// one 64-byte row instead of four or five mostly-unused cache lines
+		const float4 *pg = (const float4 *)a.packed_geom + 4 * (size_t)idx;
+		const float4 g0 = pg[0], g1 = pg[1], g2 = pg[2];
+		g.p[0] = g0.x; g.p[1] = g0.y; g.p[2] = g0.z;
+		g.sc[0] = g0.w; g.sc[1] = g1.x; g.sc[2] = g1.y;
+		g.q = make_float4(g1.z, g1.w, g2.x, g2.y);
+		g.hl = g2.z;
+	}
+	else
+	{
+#pragma unroll
+		for (int i = 0; i < 3; i++) g.p[i] = a.means3D[3 * (size_t)idx + i];
+		if (a.cov3D_precomp == nullptr)
+		{
+#pragma unroll
+			for (int i = 0; i < 3; i++) g.sc[i] = a.scales[3 * (size_t)idx + i];
+			g.q = ((const float4 *)a.rotations)[idx];
+		}
+		if (FOV) g.hl = a.highest_levels[idx];
+	}
+}
+
+// The full projection of ONE candidate (the rest of preprocessCUDA: 3D covariance, EWA 2D covariance, conic, radius, OBB axes, the
+// clipped rectangle to walk) and the rows it leaves: walk record, blend record (position in the colour slots), training: the
+// backward pass's input row (the front end of k_bin).
+struct GeomOut { float4 wrow[4], rrow[3], stash[4]; float inv_qnorm; int radius; bool alive; };
+template <int VARIANT>
+__device__ __forceinline__ void geom_item(const PreArgs &a, const float *cam_vm, const float *cam_pm, const uint4 *lvbox, const bool valid,
+	const int idx, RawGaussian g, const bool raw, GeomOut &o)
+{
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = is_fov(VARIANT);
 	constexpr bool LEVELCOL = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
-	__shared__ float4 s_st[4][4 * 64];
-	// RF: the five level boxes every candidate's walk rectangle is clipped to (walk_rect)
-	__shared__ uint4 s_lvbox[5];
-	if (FOV && threadIdx.x < 5) s_lvbox[threadIdx.x] = *(const uint4 *)(a.lv_bbox + threadIdx.x * FR_LV_BBOX_STRIDE);
-	__syncthreads();
-	const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-	const int w = (int)blockIdx.x * 4 + wv; // the wave of the cull pass whose survivors this wave takes
-	if (w >= a.proj_waves) return;          // (the waves of a workgroup are on their own from here: no workgroup barrier below)
-	const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.geom.proj_counts[w]);
-	if (cnt == 0) return;
-	const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.geom.wbase[w]);
-	const uint32_t row_base = (uint32_t)w * (uint32_t)a.proj_cpw * 64u;
-	float4 *const st = s_st[wv];
-	float cam_vm[16], cam_pm[16];
+	Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0;
+	pr.pix_x = pr.pix_y = pr.depth = pr.conic_a = pr.conic_b = pr.conic_c = 0.f;
 #pragma unroll
-	for (int i = 0; i < 16; i++)
+	for (int i = 0; i < 4; i++) o.stash[i] = make_float4(0, 0, 0, 0);
+	float4 ev = make_float4(0, 0, 0, 0);
+	float2 el = make_float2(0, 0);
+	bool boxtest = false;
+	o.inv_qnorm = 1.0f;
+	if (valid)
 	{
-		cam_vm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.viewmatrix[i])));
-		cam_pm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.projmatrix[i])));
-	}
-	const bool raw = !CROW && !PACKED && !FOV && a.raw && a.cov3D_precomp == nullptr;
-	for (uint32_t c = 0; c < cnt; c += 64)
-	{
-		const int nv = (int)min(64u, cnt - c);
-		const bool valid = lane < nv;
-		const uint32_t item = base + c + (uint32_t)lane;
-		RawGaussian g;
-		g.p[0] = g.p[1] = g.p[2] = 0.f; g.sc[0] = g.sc[1] = g.sc[2] = 0.f; g.q = make_float4(0, 0, 0, 0); g.hl = 0.f;
-		int idx = 0;
-		if (CROW)
+		if (raw)
 		{
-			float4 piece[3], r[3];
-			rows_fetch<3>(piece, a.geom.crow + 3 * (size_t)(row_base + c), nv, lane);
-			rows_unpack<3>(r, piece, st, lane);
-			g.p[0] = r[0].x; g.p[1] = r[0].y; g.p[2] = r[0].z;
-			g.sc[0] = r[0].w; g.sc[1] = r[1].x; g.sc[2] = r[1].y;
-			g.q = make_float4(r[1].z, r[1].w, r[2].x, r[2].y);
-			g.hl = r[2].z;
-			idx = (int)__float_as_uint(r[2].w);
-		}
-		else if (valid)
-		{
-			idx = (int)a.geom.vis_seg[row_base + c + (uint32_t)lane];
-			if (PACKED)
-			{
-				// one 64-byte row instead of four or five mostly-unused cache lines
-				const float4 *pg = (const float4 *)a.packed_geom + 4 * (size_t)idx;
-				const float4 g0 = pg[0], g1 = pg[1], g2 = pg[2];
-				g.p[0] = g0.x; g.p[1] = g0.y; g.p[2] = g0.z;
-				g.sc[0] = g0.w; g.sc[1] = g1.x; g.sc[2] = g1.y;
-				g.q = make_float4(g1.z, g1.w, g2.x, g2.y);
-				g.hl = g2.z;
-			}
-			else
-			{
 #pragma unroll
-				for (int i = 0; i < 3; i++) g.p[i] = a.means3D[3 * (size_t)idx + i];
-				if (a.cov3D_precomp == nullptr)
-				{
-#pragma unroll
-					for (int i = 0; i < 3; i++) g.sc[i] = a.scales[3 * (size_t)idx + i];
-					g.q = ((const float4 *)a.rotations)[idx];
-				}
-				if (FOV) g.hl = a.highest_levels[idx];
-			}
+			for (int i = 0; i < 3; i++) g.sc[i] = act_scale(g.sc[i]);
+			g.q = act_rotation(g.q, &o.inv_qnorm);
 		}
-		Proj pr; pr.alive = false; pr.tnum = 0; pr.x0 = pr.y0 = pr.x1 = pr.y1 = 0; pr.radius = 0;
-		pr.pix_x = pr.pix_y = pr.depth = pr.conic_a = pr.conic_b = pr.conic_c = 0.f;
-		float4 stash_rows[4] = { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) };
-		float4 ev = make_float4(0, 0, 0, 0);
-		float2 el = make_float2(0, 0);
-		bool boxtest = false;
-		float inv_qnorm = 1.0f;
-		if (valid)
+		pr = project_gaussian(a, cam_vm, cam_pm, idx, g.p, g.sc, g.q, o.stash, a.write_cov3D != 0);
+		if (pr.alive)
 		{
-			if (raw)
+			if (CULL && pr.tnum > 1)
 			{
-#pragma unroll
-				for (int i = 0; i < 3; i++) g.sc[i] = act_scale(g.sc[i]);
-				g.q = act_rotation(g.q, &inv_qnorm);
+				// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
+				float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
+				const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
+				e1x *= n1; e1y *= n1;
+				const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
+				e2x *= n2; e2y *= n2;
+				ev = make_float4(e1x, e1y, e2x, e2y);
+				el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
 			}
-			pr = project_gaussian(a, cam_vm, cam_pm, idx, g.p, g.sc, g.q, stash_rows, a.write_cov3D != 0);
-			if (pr.alive)
-			{
-				if (CULL && pr.tnum > 1)
-				{
-					// eigen axes of the 2D covariance: RS forward.cu:244-265 (normalize() restated as 1/sqrt)
-					float e1x = -pr.cov1, e1y = pr.cov0 - pr.lambda1, e2x = -pr.cov1, e2y = pr.cov0 - pr.lambda2;
-					const float n1 = 1.0f / sqrtf(e1x * e1x + e1y * e1y);
-					e1x *= n1; e1y *= n1;
-					const float n2 = 1.0f / sqrtf(e2x * e2x + e2y * e2y);
-					e2x *= n2; e2y *= n2;
-					ev = make_float4(e1x, e1y, e2x, e2y);
-					el = make_float2(3.0f * sqrtf(pr.lambda1), 3.0f * sqrtf(pr.lambda2));
-				}
-				const WalkRect wr = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, g.hl, s_lvbox, 1);
-				pr.x0 = wr.x0; pr.y0 = wr.y0; pr.x1 = wr.x1; pr.y1 = wr.y1; pr.tnum = wr.tnum; boxtest = wr.boxtest;
-				pr.alive = wr.tnum != 0;
-			}
-			// candidates that turn out to reach no tile get radius 0, like every culled Gaussian; k_count clears the radius of
-			// those whose tiles all fail the box / level tests (RS rasterizer_impl.cu:141-145)
-			a.radii[idx] = pr.alive ? pr.radius : 0;
-			a.geom.vis_list[item] = (uint32_t)idx; // the list in index order, for the kernels that go from item to Gaussian
-		}
-		const uint32_t flags = (pr.alive ? 1u : 0u) | (boxtest ? 2u : 0u);
-		const float4 wrow[4] = { make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y), make_float4(ev.z, ev.w, el.x, el.y),
-			make_float4(__uint_as_float((uint32_t)idx | (flags << 30)), pr.depth, __uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)),
-				__uint_as_float((uint32_t)(pr.x1 - pr.x0))),
-			make_float4(__uint_as_float(pr.tnum), g.hl, 0.0f, 0.0f) };
-		rows_store<4>(wrow, st, a.geom.wrec + 4 * (size_t)(base + c), nv, lane);
-		// the blend record; its colour slots carry the position until k_count has evaluated the colour (RF: the colours live in
-		// the level rows, the slots keep the position)
-		const float4 rrow[3] = { make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b),
-			make_float4(pr.conic_c, LEVELCOL ? g.hl : 0.0f, g.p[0], g.p[1]),
-			make_float4(g.p[2], pr.depth, (FOV && !LEVELCOL) ? g.hl : 0.0f, __int_as_float(idx)) };
-		rows_store<3>(rrow, st, a.geom.rec + 3 * (size_t)(base + c), nv, lane);
-		if (a.write_cov3D)
-		{
-			// training variants: the item's inputs and 3D covariance for the backward pass, and its row of gradient sums,
-			// cleared here; the last quarter of that row is not summed into: it carries 1 / |raw quaternion| (raw parameters)
-			rows_store<4>(stash_rows, st, (float4 *)a.geom.cov3D + 4 * (size_t)(base + c), nv, lane);
-			const float4 ac[4] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(inv_qnorm, 0.f, 0.f, 0.f) };
-			rows_store<4>(ac, st, a.geom.acc + 4 * (size_t)(base + c), nv, lane);
+			const WalkRect wr = walk_rect<CULL, FOV>(pr.pix_x, pr.pix_y, pr.radius, a.gx, a.gy, ev, el, g.hl, lvbox, 1);
+			pr.x0 = wr.x0; pr.y0 = wr.y0; pr.x1 = wr.x1; pr.y1 = wr.y1; pr.tnum = wr.tnum; boxtest = wr.boxtest;
+			pr.alive = wr.tnum != 0;
 		}
 	}
+	o.alive = pr.alive; o.radius = pr.radius;
+	const uint32_t flags = (pr.alive ? 1u : 0u) | (boxtest ? 2u : 0u);
+	o.wrow[0] = make_float4(pr.pix_x, pr.pix_y, ev.x, ev.y);
+	o.wrow[1] = make_float4(ev.z, ev.w, el.x, el.y);
+	o.wrow[2] = make_float4(__uint_as_float((uint32_t)idx | (flags << 30)), pr.depth, __uint_as_float((uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16)),
+		__uint_as_float((uint32_t)(pr.x1 - pr.x0)));
+	o.wrow[3] = make_float4(__uint_as_float(pr.tnum), g.hl, 0.0f, 0.0f);
+	// the blend record; its colour slots carry the position until k_bin has evaluated the colour (RF: the colours live in
+	// the level rows, the slots keep the position)
+	o.rrow[0] = make_float4(pr.pix_x, pr.pix_y, pr.conic_a, pr.conic_b);
+	o.rrow[1] = make_float4(pr.conic_c, LEVELCOL ? g.hl : 0.0f, g.p[0], g.p[1]);
+	o.rrow[2] = make_float4(g.p[2], pr.depth, (FOV && !LEVELCOL) ? g.hl : 0.0f, __int_as_float(idx));
 }
 
 // The colour(s) of one item (forward.cu:20-71 computeColorFromSH; RF rasterizer_impl.cu:37-84, 490-530 compute_fov_colors), for
 // the items that landed in a tile only: the SH rows are the largest read of a frame (180-192 bytes per Gaussian, unaligned), and
-// a quarter of the candidates that were projected need none. r: the item's blend record as k_geom left it (position in the
+// a quarter of the candidates that were projected need none. r: the item's blend record as geom_item left it (position in the
 // colour slots); on return the record with opacity / colour / clamp bits (variants with one colour per Gaussian) or, RF, the
 // level rows lv[lo..hi] of the item's level range lr (the others stay zero: nobody reads them).
 template <int VARIANT, bool PACKED>
@@ -1019,32 +965,40 @@ __device__ __forceinline__ void colour_item(const PreArgs &a, const bool rows_ok
 	}
 }
 
-// Stage 3 (RS rasterizer_impl.cu:70-146 OBB_test, RF :264-383 filter; + the colours, forward.cu:20-71 / RF rasterizer_impl.cu:
-// 490-530): count the tiles every item really lands in (OBB / foveal tests) from its walk record alone -- 64 bytes per item,
-// read as contiguous kilobytes -- into a per-workgroup LDS histogram; then, for the items that landed somewhere, the colour(s).
-// One persistent workgroup of FR_BIN_THREADS threads per CU; a wave takes the 64-item slabs wave, wave + waves, ... (STATIC: round
-// 3 handed the slabs out through eight atomic counters -- 15 000 returning atomics on eight addresses were 45 us of the
-// kernel, more than its tile walks; k_emit takes the same slabs, because its bucket offsets are per workgroup).
-// The tile walk is VALU / LDS work that leaves the memory system idle, the colours are the frame's largest scattered read and
-// no arithmetic to speak of: in one kernel, at sixteen waves per CU, one wave's colour round trip runs under the others' walks
-// (as a kernel of its own the colours took 94 us, beside another kernel on a second stream they only took its wave slots).
+// Stage 2 (the rest of preprocessCUDA, RS forward.cu:155-293 / RF :105-238; OBB_test RS rasterizer_impl.cu:70-146, filter RF :264-383;
+// the colours, forward.cu:20-71 / RF rasterizer_impl.cu:490-530): for every survivor of the cull pass
+//   (1) the full projection (geom_item: 3D covariance, EWA 2D covariance, conic, radius, OBB axes, the clipped rectangle to walk)
+//       -- inputs: the candidate row k_project stored (CROW: foveated variants), or the packed row / gathers from the model's tensors;
+//   (2) the tiles it really lands in (OBB / foveal tests, three walks by splat size), counted in a per-workgroup LDS histogram;
+//   (3) for the items that landed somewhere, the colour(s);
+// and its rows out: walk record (k_emit), blend record, RF level rows, training: the backward pass's input row and the cleared
+// gradient row -- all through LDS as contiguous kilobytes.
+// One persistent workgroup of FR_BIN_THREADS threads per CU; a wave takes the 64-item slabs wave, wave + waves, ... (STATIC: rounds
+// 2-3 handed the slabs out through eight atomic counters for balance -- 15 000 returning atomics on eight addresses were 45 us of a
+// 115-us walk kernel, more than its tile walks; k_emit takes the same slabs, because its bucket offsets are per workgroup).
+// The three parts are bound by different things -- gathers and a 600-instruction dependent chain; VALU / LDS work that leaves the
+// memory system idle; the frame's largest scattered read with no arithmetic to speak of -- and at sixteen waves per CU one wave's
+// part runs under the others'. Round 4 took the kernel apart to see: projection alone (k_geom, one wave per cull-pass region, 94
+// registers) 37 us, walks alone 73 us (46 + a 27-us skeleton), colours alone 94 us -- 204 us as three kernels, 182 as two (walks +
+// colours in one), 160 as this one (round 3's form of it, with dynamic slabs at eight waves per CU: 175-178).
 // LDSH: the counters are an LDS-private histogram (T <= 16 Ki tiles) added once per workgroup to the tiles' global counters
 // (the returned values are the workgroup's starts inside the buckets: hist[block][tile]); otherwise (huge tile grids) global
 // atomics on tile_count.
 // LDSH == 2: 16-bit counts, two tiles per word (tile grids of more than 16 Ki tiles: 4K frames); a workgroup then bins fewer
-// than 65 536 items (launch_count admits the mode only when every wave's share of the slabs is below FR_HIST16_MAX_SLABS).
-// Per item it leaves GeomWS::lrange: FR_ITEM_NONE when no tile is left (k_emit skips the item; its radius is cleared), else
-// the level range of RF rasterizer_impl.cu:374-381; and the finished blend record / (RF) level rows.
+// than 65 536 items (launch_bin admits the mode only when every wave's share of the slabs is below FR_HIST16_MAX_SLABS).
+// Per item it also leaves GeomWS::lrange: FR_ITEM_NONE when no tile is left (k_emit skips the item; its radius is cleared), else
+// the level range of RF rasterizer_impl.cu:374-381.
 #define BUMP_TILE(ti) do { if (LDSH == 2) atomicAdd(&lds_hist[(ti) >> 1], 1u << (16 * ((ti) & 1))); \
 	else if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
-template <int VARIANT, int LDSH, bool PACKED = false>
-__global__ void __launch_bounds__(FR_BIN_THREADS) k_count(const PreArgs a)
+template <int VARIANT, int LDSH, bool PACKED = false, bool CROW = false>
+__global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 {
+	static_assert(!(PACKED && CROW), "the packed model layout has its own rows");
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = is_fov(VARIANT);                            // level map + level filter
 	constexpr bool LEVELCOL = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;  // per-level colours / opacities (RF)
 	static_assert(!(PACKED && FOV && !LEVELCOL), "the shared-model foveated variant has no packed layout");
-	extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
+		extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
 	const int lane = threadIdx.x & 63;
 	// RF: every pair step looks its tile's level (and, if kept, its blend flag) up; from global memory those
 	// were two dependent ~1 us round trips in a loop that a near-camera splat runs a hundred times. When they
@@ -1085,6 +1039,8 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_count(const PreArgs a)
 	__shared__ int s_gitem[FR_GIANT_MAX];
 	__shared__ uint32_t s_gcount[FR_GIANT_MAX], s_gmask[FR_GIANT_MAX];
 	__shared__ uint32_t s_ng;
+	__shared__ uint4 s_lvbox[5]; // RF: the five level boxes every candidate's walk rectangle is clipped to (walk_rect)
+	if (FOV && threadIdx.x < 5) s_lvbox[threadIdx.x] = *(const uint4 *)(a.lv_bbox + threadIdx.x * FR_LV_BBOX_STRIDE);
 	if (threadIdx.x < FR_GIANT_MAX) { s_gcount[threadIdx.x] = 0; s_gmask[threadIdx.x] = 0; }
 	if (threadIdx.x == 0) s_ng = 0;
 	__syncthreads();
@@ -1102,6 +1058,28 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_count(const PreArgs a)
 	// lane (see there), and the owner rows of pair_owner_scan)
 	float4 *const s_orec = (float4 *)(lds_hist + ((hist_words + ((FOV && a.lds_tiles) ? tab_words : 0) + 3) & ~3));
 	int *const s_own = (int *)(s_orec + 4 * FR_BIN_THREADS);
+	uint32_t *const s_wbase = (uint32_t *)(s_own + FR_BIN_THREADS); // [proj_waves + 1] first item of every cull-pass region
+	{
+		// (sixteen loads at a time, see the table fill above; visible after the workgroup barrier below)
+		for (int w0 = threadIdx.x; w0 <= a.proj_waves; w0 += 16 * FR_BIN_THREADS)
+		{
+			uint32_t v[16];
+#pragma unroll
+			for (int k = 0; k < 16; k++) v[k] = a.geom.wbase[min(w0 + k * FR_BIN_THREADS, a.proj_waves)];
+#pragma unroll
+			for (int k = 0; k < 16; k++) if (w0 + k * FR_BIN_THREADS <= a.proj_waves) s_wbase[w0 + k * FR_BIN_THREADS] = v[k];
+		}
+		__syncthreads();
+	}
+	float cam_vm[16], cam_pm[16]; // camera matrices in scalar registers
+	{
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+		{
+			cam_vm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.viewmatrix[i])));
+			cam_pm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.projmatrix[i])));
+		}
+	}
 	const int V = (int)a.geom.slab_ctr[1]; // entries of vis_list (the cull pass's last workgroup)
 	const int nslabs = (V + 63) / 64;
 	const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
@@ -1168,11 +1146,61 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_count(const PreArgs a)
 	for (int slab = wave_gid; slab < nslabs; slab += nwaves)
 	{
 	const int nv = min(64, V - slab * 64);
-	float4 cur[4];
-	rows_fetch<4>(cur, a.geom.wrec + 4 * (size_t)slab * 64, nv, lane);
 	const int item = slab * 64 + lane;
 	float4 wr[4];
-	rows_unpack<4>(wr, cur, orec, lane);
+	float3 fpos = make_float3(0.f, 0.f, 0.f), fconic = make_float3(0.f, 0.f, 0.f); // what the blend record needs beside the walk record
+	{
+		// the slab's candidates: item i lives in the region of the cull-pass wave whose running count covers it (uniform binary
+		// search for the slab's first item, the lanes step on from there: a region holds ~300 survivors)
+		RawGaussian g;
+		g.p[0] = g.p[1] = g.p[2] = 0.f; g.sc[0] = g.sc[1] = g.sc[2] = 0.f; g.q = make_float4(0, 0, 0, 0); g.hl = 0.f;
+		int gidx = 0;
+		const bool valid = item < V;
+		if (valid)
+		{
+			int lo = 0, hi = a.proj_waves; // s_wbase[lo] <= first < s_wbase[hi]
+			const uint32_t first = (uint32_t)slab * 64u;
+			while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wbase[mid] <= first) lo = mid; else hi = mid; }
+			int w = lo;
+			while ((uint32_t)item >= s_wbase[w + 1]) w++;
+			const uint32_t slot = (uint32_t)w * (uint32_t)a.proj_cpw * 64u + ((uint32_t)item - s_wbase[w]);
+			if (CROW)
+			{
+				// the row k_project stored beside the index (48 bytes: the lanes' rows lie in one or two contiguous regions)
+				const float4 *cr = a.geom.crow + 3 * (size_t)slot;
+				const float4 r0 = cr[0], r1 = cr[1], r2 = cr[2];
+				g.p[0] = r0.x; g.p[1] = r0.y; g.p[2] = r0.z;
+				g.sc[0] = r0.w; g.sc[1] = r1.x; g.sc[2] = r1.y;
+				g.q = make_float4(r1.z, r1.w, r2.x, r2.y);
+				g.hl = r2.z;
+				gidx = (int)__float_as_uint(r2.w);
+			}
+			else
+			{
+				gidx = (int)a.geom.vis_seg[slot];
+				load_candidate<PACKED, FOV>(a, gidx, g);
+			}
+		}
+		GeomOut go;
+		geom_item<VARIANT>(a, cam_vm, cam_pm, s_lvbox, valid, gidx, g, !PACKED && !FOV && a.raw && a.cov3D_precomp == nullptr, go);
+		if (valid)
+		{
+			a.radii[gidx] = go.alive ? go.radius : 0;
+			a.geom.vis_list[item] = (uint32_t)gidx;
+		}
+		rows_store<4>(go.wrow, orec, a.geom.wrec + 4 * (size_t)slab * 64, nv, lane);
+		rows_store<3>(go.rrow, orec, a.geom.rec + 3 * (size_t)slab * 64, nv, lane);
+		if (a.write_cov3D)
+		{
+			rows_store<4>(go.stash, orec, (float4 *)a.geom.cov3D + 4 * (size_t)slab * 64, nv, lane);
+			const float4 ac[4] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(go.inv_qnorm, 0.f, 0.f, 0.f) };
+			rows_store<4>(ac, orec, a.geom.acc + 4 * (size_t)slab * 64, nv, lane);
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) wr[i] = go.wrow[i];
+		fpos = make_float3(go.rrow[1].z, go.rrow[1].w, go.rrow[2].x);
+		fconic = make_float3(go.rrow[0].z, go.rrow[0].w, go.rrow[1].x);
+	}
 	const uint32_t idf = __float_as_uint(wr[2].x), xy = __float_as_uint(wr[2].z);
 	const int idx = (int)(idf & 0x3fffffffu);
 	const bool alive = item < V && ((idf >> 30) & 1u) != 0, boxtest = ((idf >> 31) & 1u) != 0;
@@ -1319,9 +1347,11 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_count(const PreArgs a)
 	// ---- the colours of the slab's items that landed in a tile; the blend record leaves with them (RF: the level rows) ----
 	if (__any(lr != FR_ITEM_NONE))
 	{
-		float4 piece[3], r[3], lv[FR_FOV_LEVELS];
-		rows_fetch<3>(piece, a.geom.rec + 3 * (size_t)slab * 64, nv, lane);
-		rows_unpack<3>(r, piece, orec, lane);
+		// (the record this wave made above, put together again from what it kept: not read back through the cache)
+		float4 r[3], lv[FR_FOV_LEVELS];
+		r[0] = make_float4(wr[0].x, wr[0].y, fconic.x, fconic.y);
+		r[1] = make_float4(fconic.z, LEVELCOL ? hl : 0.0f, fpos.x, fpos.y);
+		r[2] = make_float4(fpos.z, wr[2].y, (FOV && !LEVELCOL) ? hl : 0.0f, __int_as_float(idx));
 #pragma unroll
 		for (int l = 0; l < FR_FOV_LEVELS; l++) lv[l] = make_float4(0, 0, 0, 0);
 		if (lr != FR_ITEM_NONE) colour_item<VARIANT, PACKED>(a, rows_ok, lr, r, lv);
@@ -1421,7 +1451,7 @@ struct EmitArgs {
 };
 // LDSH: the workgroup's write cursor of every tile lives in LDS, initialised to
 // tile start + (instances of the same tile owned by lower-numbered workgroups).
-#define FR_EMIT_THREADS FR_BIN_THREADS // (the same waves take the same slabs in k_count and k_emit)
+#define FR_EMIT_THREADS FR_BIN_THREADS // (the same waves take the same slabs in k_bin and k_emit)
 // LDSH == 2 (see k_bin): the LDS cursors are 16-bit offsets inside the workgroup's share, two tiles per word; where the share
 // starts comes from global memory with every entry
 #define NEXT_SLOT(ti) (LDSH == 2 ? a.ranges[(ti)].x + pre_row[(ti)] + ((atomicAdd(&lds_cur[(ti) >> 1], 1u << (16 * ((ti) & 1))) >> (16 * ((ti) & 1))) & 0xffffu) \
@@ -1524,7 +1554,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	float2 el = make_float2(0, 0);
 	if (item < V)
 	{
-		// (what k_count found out about the item: one that landed in no tile is not walked again)
+		// (what k_bin found out about the item: one that landed in no tile is not walked again)
 		const uint32_t lr = a.geom.lrange[item];
 		const float4 *wr = a.geom.wrec + 4 * (size_t)item;
 		const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
@@ -1540,7 +1570,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	// the instance's payload is the ITEM (position in vis_list): the per-item records are dense, and items are in index order,
 	// so the per-tile sort by (depth bits, item) gives the reference's stable order
 	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)item;
-	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_count's level test, no box test (single-tile splat)
+	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_bin's level test, no box test (single-tile splat)
 	if (in_place) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
 	{
 		bool deferred = false;
@@ -1599,7 +1629,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	}
 	}; // process(slab)
 	{
-		// the slabs k_count's wave of the same number took (the bucket offsets are per workgroup): wave, wave + waves, ...
+		// the slabs k_bin's wave of the same number took (the bucket offsets are per workgroup): wave, wave + waves, ...
 		const int wave_gid = (int)blockIdx.x * (FR_EMIT_THREADS / 64) + (int)(threadIdx.x >> 6);
 		const int nwaves = (int)gridDim.x * (FR_EMIT_THREADS / 64);
 		for (int slab = wave_gid; slab < nslabs; slab += nwaves) process(slab);
@@ -1771,38 +1801,8 @@ int launch_project(FwdCtx &c)
 	}
 }
 
-// stage "bin", first half: the full projection of the cull pass's survivors (k_geom): one wave per wave of the cull pass
-int launch_geom(FwdCtx &c)
-{
-	const fr_forward_args *a = c.a;
-	PreArgs p = make_pre_args(c);
-	const dim3 grid((c.proj_waves + 3) / 4), block(256);
-	// the packed model layout and the candidate rows are compile-time variants of the kernel (run-time tests on the pointers
-	// cost the ordinary path 5 %): packed needs both packed tensors; the rows exist when k_project stored them (foveated
-	// variants, unpacked cull pass, scales + rotations given)
-	const bool packed = a->packed_geom && a->packed_colour;
-	const bool crow = !packed && is_fov(a->variant) && a->packed_cull == nullptr && a->cov3D_precomp == nullptr;
-#define LAUNCH_GEOM(V) do { if (packed) hipLaunchKernelGGL((k_geom<V, true, false>), grid, block, 0, c.stream, p); \
-	else if (crow) hipLaunchKernelGGL((k_geom<V, false, true>), grid, block, 0, c.stream, p); \
-	else hipLaunchKernelGGL((k_geom<V, false, false>), grid, block, 0, c.stream, p); } while (0)
-	switch (a->variant)
-	{
-	case FR_VARIANT_ORIGINAL: LAUNCH_GEOM(FR_VARIANT_ORIGINAL); break;
-	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_GEOM(FR_VARIANT_FOV_PCHECK_OBB); break;
-	case FR_VARIANT_MMFR_PCHECK_OBB:      // plain colours + the level filter (on the skip key, see k_tile_levels): the same kernels
-	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB:
-		// (no packed instantiation: validate_forward refuses the packed tensors)
-		if (crow) hipLaunchKernelGGL((k_geom<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false, true>), grid, block, 0, c.stream, p);
-		else hipLaunchKernelGGL((k_geom<FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false, false>), grid, block, 0, c.stream, p);
-		break;
-	default: LAUNCH_GEOM(FR_VARIANT_PCHECK_OBB); break; // every other cull variant projects alike
-	}
-#undef LAUNCH_GEOM
-	return check_launch("geom", c.stream, a->debug);
-}
-
-// stage "bin", second half: tile counts (LDS histograms) from the walk records, and the colours (k_count)
-int launch_count(FwdCtx &c)
+// stage "bin": projection of the cull pass's survivors, tile counts (LDS histograms), colours, item rows (k_bin)
+int launch_bin(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	PreArgs p = make_pre_args(c);
@@ -1810,7 +1810,7 @@ int launch_count(FwdCtx &c)
 	const dim3 block(FR_BIN_THREADS);
 	// Where the tiles are counted: an LDS histogram per workgroup of 32-bit counts (grids up to 16 Ki tiles), of 16-bit counts
 	// (up to 34 816 tiles: a workgroup then takes fewer than 65 536 items, so the resident workgroups must cover all
-	// P Gaussians with a margin for waves that finish early), or global counters.
+	// P Gaussians with a margin), or global counters.
 	static thread_local int cus = 0;
 	if (cus == 0)
 	{
@@ -1822,58 +1822,59 @@ int launch_count(FwdCtx &c)
 	c.hist_mode = c.img.hist == nullptr ? 0 : (c.T <= FR_LDS_HIST_MAX_TILES ? 1 :
 		(wgs_lo * (FR_BIN_THREADS / 64) * (int64_t)(FR_HIST16_MAX_SLABS - 1) * 64 >= (int64_t)a->P ? 2 : 0)); // (wave w takes slabs w, w + waves, ...)
 	const bool ldsh = c.hist_mode != 0;
-	// LDS per workgroup: tile histogram (+ RF: the 4-bit tile table)
+	// LDS per workgroup: tile histogram (+ RF: the 4-bit tile table), the waves' staging / owner rows, the cull pass's running counts
 	p.lds_tiles = (is_fov(a->variant) && ldsh) ? 1 : 0;
 	const size_t hist_bytes = c.hist_mode == 2 ? (size_t)((c.T + 1) / 2) * sizeof(uint32_t) : (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0);
 	const size_t lds = ((hist_bytes + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0) + 15) & ~(size_t)15) +
-		(size_t)FR_BIN_THREADS * (4 * sizeof(float4) + sizeof(int)); // + the waves' staging / owner rows
-	// Never more workgroups than the device keeps resident: the slabs are handed out dynamically, so workgroups of a
-	// second round start when the first ones are done, find the counters empty and only cost their LDS set-up, an
-	// all-zero histogram row and the tail of the kernel (measured: 256 of 512 workgroups, 175 -> 211 us).
+		(size_t)FR_BIN_THREADS * (4 * sizeof(float4) + sizeof(int)) + (size_t)(c.proj_waves + 1) * sizeof(uint32_t);
+	// Never more workgroups than the device keeps resident (one per CU: a second one doubles the histogram flushes -- one returning
+	// atomic per workgroup and touched tile -- and the table prologues for slabs that one workgroup's sixteen waves already cover).
 	auto launch = [&](const void *fn, void (*kern)(const PreArgs), size_t dyn) {
-		static thread_local struct { const void *fn; size_t dyn; int wgs; } cache[24];
+		static thread_local struct { const void *fn; size_t dyn; int wgs; } cache[48];
 		static thread_local int ncache = 0;
 		int wgs = 0;
 		for (int i = 0; i < ncache; i++) if (cache[i].fn == fn && cache[i].dyn == dyn) wgs = cache[i].wgs;
 		if (wgs == 0)
 		{
 			if (dyn > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
-			{ set_error("hipFuncSetAttribute(k_count): %s", hipGetErrorString(hipGetLastError())); return FR_ERR_HIP; }
+			{ set_error("hipFuncSetAttribute(k_bin): %s", hipGetErrorString(hipGetLastError())); return FR_ERR_HIP; }
 			int per_cu = 0, dev = 0;
 			hipDeviceProp_t prop;
 			if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
 				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FR_BIN_THREADS, dyn) != hipSuccess || per_cu < 1)
 			{ per_cu = 1; prop.multiProcessorCount = 256; (void)hipGetLastError(); }
 			wgs = per_cu * prop.multiProcessorCount;
-			// one workgroup per CU: a second one on the CU doubles the histogram flushes (one returning atomic per workgroup and
-			// touched tile) and the table prologues for slabs that one workgroup's eight waves already cover
-			if (const char *e = getenv("FR_COUNT_WGS_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) wgs = v * prop.multiProcessorCount; }
-			if (ncache < 24) { cache[ncache].fn = fn; cache[ncache].dyn = dyn; cache[ncache].wgs = wgs; ncache++; }
+			if (ncache < 48) { cache[ncache].fn = fn; cache[ncache].dyn = dyn; cache[ncache].wgs = wgs; ncache++; }
 		}
 		nblk = nblk < wgs ? nblk : wgs;
 		hipLaunchKernelGGL(kern, dim3(nblk), block, dyn, c.stream, p);
 		return FR_OK;
 	};
 	int lrc = FR_OK;
-	// the packed model layout is a compile-time variant of the kernel (run-time tests on the pointers cost the ordinary path 5 %)
+	// the packed model layout and the candidate rows are compile-time variants of the kernel (run-time tests on the pointers cost
+	// the ordinary path 5 %): packed needs both packed tensors; the rows exist when k_project stored them (foveated variants,
+	// unpacked cull pass, scales + rotations given)
 	const bool packed = a->packed_geom && a->packed_colour;
-#define LAUNCH_COUNT_P(V, PK) do { if (c.hist_mode == 2) lrc = launch((const void *)k_count<V, 2, PK>, k_count<V, 2, PK>, lds); \
-	else if (ldsh) lrc = launch((const void *)k_count<V, 1, PK>, k_count<V, 1, PK>, lds); \
-	else lrc = launch((const void *)k_count<V, 0, PK>, k_count<V, 0, PK>, lds); } while (0)
-#define LAUNCH_COUNT(V) do { if (packed) LAUNCH_COUNT_P(V, true); else LAUNCH_COUNT_P(V, false); } while (0)
+	const bool crow = !packed && is_fov(a->variant) && a->packed_cull == nullptr && a->cov3D_precomp == nullptr;
+#define LAUNCH_BIN_PC(V, PK, CR) do { if (c.hist_mode == 2) lrc = launch((const void *)k_bin<V, 2, PK, CR>, k_bin<V, 2, PK, CR>, lds); \
+	else if (ldsh) lrc = launch((const void *)k_bin<V, 1, PK, CR>, k_bin<V, 1, PK, CR>, lds); \
+	else lrc = launch((const void *)k_bin<V, 0, PK, CR>, k_bin<V, 0, PK, CR>, lds); } while (0)
+#define LAUNCH_BIN(V) do { if (packed) LAUNCH_BIN_PC(V, true, false); else if (crow) LAUNCH_BIN_PC(V, false, true); else LAUNCH_BIN_PC(V, false, false); } while (0)
 	switch (a->variant)
 	{
-	case FR_VARIANT_ORIGINAL: LAUNCH_COUNT(FR_VARIANT_ORIGINAL); break;
-	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_COUNT(FR_VARIANT_FOV_PCHECK_OBB); break;
+	case FR_VARIANT_ORIGINAL: LAUNCH_BIN(FR_VARIANT_ORIGINAL); break;
+	case FR_VARIANT_FOV_PCHECK_OBB: LAUNCH_BIN(FR_VARIANT_FOV_PCHECK_OBB); break;
 	case FR_VARIANT_MMFR_PCHECK_OBB:      // plain colours + the level filter (on the skip key, see k_tile_levels): the same kernel
-	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: LAUNCH_COUNT_P(FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false); break; // (no packed layout: validate_forward)
-	default: LAUNCH_COUNT(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: // (no packed instantiation: validate_forward refuses the packed tensors)
+		if (crow) LAUNCH_BIN_PC(FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false, true); else LAUNCH_BIN_PC(FR_VARIANT_NAIVE_FOV_PCHECK_OBB, false, false);
+		break;
+	default: LAUNCH_BIN(FR_VARIANT_PCHECK_OBB); break; // every other cull variant bins alike
 	}
-#undef LAUNCH_COUNT
-#undef LAUNCH_COUNT_P
+#undef LAUNCH_BIN
+#undef LAUNCH_BIN_PC
 	if (lrc) return lrc;
 	c.bin_wgs = nblk;
-	return check_launch("count", c.stream, a->debug);
+	return check_launch("bin", c.stream, a->debug);
 }
 
 int launch_emit(FwdCtx &c)

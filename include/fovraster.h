@@ -159,8 +159,8 @@ typedef struct fr_forward_args {
 	                              * (fr_geometry_vis_list): the rows of a row-sparse backward call */
 } fr_forward_args;
 
-enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_GEOM = 2, FR_STAGE_COUNT = 3, FR_STAGE_TILE_SCAN = 4, FR_STAGE_EMIT = 5,
-	FR_STAGE_TILE_SORT = 6, FR_STAGE_RENDER = 7, FR_NUM_STAGES = 8 };
+enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
+	FR_STAGE_TILE_SORT = 5, FR_STAGE_RENDER = 6, FR_NUM_STAGES = 7 };
 
 typedef struct fr_backward_args {
 	int32_t variant;             /* ORIGINAL, PCHECK_OBB_SUM, PCHECK_OBB_MAX or PCHECK_OBB_LWMC */

@@ -102,7 +102,7 @@ for name, e in train.items():
         e["avg_ns"] = round(ts[name][1])
 kernels = dict(head)
 for name, e in packed.items():
-    if name in ("k_project", "k_geom", "k_count") or name.startswith("k_pack"):
+    if name in ("k_project", "k_bin") or name.startswith("k_pack"):
         kernels[name + ("_packed" if not name.startswith("k_pack") else "")] = e
 # calibration on launches whose byte counts are known (bytes per Gaussian: fovraster.h packed_* rows and their inputs)
 known = {"k_pack_geom": (60, 64), "k_pack_cull": (40, 16), "k_pack_colour": (228, 256)}
@@ -123,7 +123,7 @@ doc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate WRI
        "calibration": calibration, "kernels": kernels, "train": train}
 json.dump(doc, open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "profiles", f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps(calibration)[:400])
-for n in ("k_project", "k_geom", "k_count", "k_emit", "k_render_fov"):
+for n in ("k_project", "k_bin", "k_emit", "k_render_fov"):
     print(n, kernels.get(n))
 PY
 tools/sq_counters.sh $TAG --steps 27 --warmup 9 --no-extra --no-cpu-baseline --headline-only --repeats 1 | tail -3
