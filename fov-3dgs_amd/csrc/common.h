@@ -10,8 +10,8 @@
 #define FR_FOV_LEVELS 4       // RF auxiliary.h:26 fov_num
 #define FR_SORT_LDS_MAX 8192  // longest per-tile list sorted inside LDS (64 KiB of u64 keys)
 #ifndef FR_BIN_THREADS
-#define FR_BIN_THREADS 1024   // workgroup size of k_bin (k_emit: FR_EMIT_SHARE times as many): the tile walk is a chain of LDS round
-                              // trips, sixteen waves per CU hide what eight did not (k_bin 120 -> ? us)
+#define FR_BIN_THREADS 768    // workgroup size of k_bin and k_emit (one persistent workgroup per CU): twelve waves hide each other's round trips
+                              // (eight: foveated bin stage 176 us, twelve: 162, sixteen: 165 -- at sixteen the 128-register cap spills)
 #endif
 // persistent workgroups of the binning kernels: 2 per CU by LDS (up to 76 KiB each); k_bin's ~145 VGPRs let only one of
 // them run at a time (2 waves/SIMD), the other finds the slab counters empty -- 384-thread workgroups (3 waves/SIMD)
