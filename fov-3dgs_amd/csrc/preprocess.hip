@@ -1510,6 +1510,8 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	}
 	__syncthreads();
 	__shared__ int s_own[FR_EMIT_THREADS];
+	// (dynamic LDS behind the cursors and the table, 16-byte aligned: the pair loop's 64-byte owner row per lane, see k_bin)
+	float4 *const s_orec = (float4 *)(lds_cur + ((cur_words + (ldst ? tab_words : 0) + 3) & ~3));
 	__shared__ int s_gidx[FR_GIANT_MAX]; // vis_list positions of the giant splats, walked by the whole workgroup at the end (see k_bin)
 	__shared__ uint32_t s_ng;
 	if (threadIdx.x == 0) s_ng = 0;
@@ -1539,7 +1541,16 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	};
 	const int V = (int)a.geom.slab_ctr[1];
 	const int nslabs = (V + 63) / 64; // wave-sized slabs, as in k_bin
-	auto process = [&](const int slab) __attribute__((always_inline))
+	// a slab's inputs: every lane's walk record and what k_bin found out about the item (fetched one slab ahead, see the loop below)
+	struct SlabIn { float4 w0, w1, w2, w3; uint32_t lr; };
+	auto fetch_slab = [&](const int slab, SlabIn &in) __attribute__((always_inline))
+	{
+		const int item = min(slab * 64 + lane, max(V - 1, 0)); // (clamped, not predicated: the loads go out together)
+		const float4 *wr = a.geom.wrec + 4 * (size_t)item;
+		in.lr = a.geom.lrange[item];
+		in.w0 = wr[0]; in.w1 = wr[1]; in.w2 = wr[2]; in.w3 = wr[3];
+	};
+	auto process = [&](const int slab, const SlabIn &in) __attribute__((always_inline))
 	{
 	const int item = slab * 64 + lane;
 	// everything k_emit needs about the entry sits in its walk record (one coalesced 64-byte read per lane instead of
@@ -1555,9 +1566,8 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	if (item < V)
 	{
 		// (what k_bin found out about the item: one that landed in no tile is not walked again)
-		const uint32_t lr = a.geom.lrange[item];
-		const float4 *wr = a.geom.wrec + 4 * (size_t)item;
-		const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+		const uint32_t lr = in.lr;
+		const float4 w0 = in.w0, w1 = in.w1, w2 = in.w2, w3 = in.w3;
 		const uint32_t idf = __float_as_uint(w2.x), xy = __float_as_uint(w2.z);
 		idx = (int)(idf & 0x3fffffffu);
 		alive = lr != FR_ITEM_NONE && ((idf >> 30) & 1u) != 0; boxtest = (idf >> 31) & 1u;
@@ -1595,6 +1605,21 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		// every lane leaves what a pair of its splat needs in a 64-byte LDS row (k_bin's pair loop: the corner extremes of its box
+		// included -- make_obb once per splat, not once per pair); a pair reads its OWNER's row -- four LDS reads, most of them
+		// broadcasts -- divides by the rectangle's width with a reciprocal and evaluates the box test without branches (this loop
+		// pulled thirteen registers through ds_bpermute, divided twice and rebuilt the box per pair: 60 of the kernel's 104 us)
+		float4 *const orec = s_orec + 4 * (threadIdx.x & ~63);
+		if (total != 0)
+		{
+			const Obb ob = make_obb(cx, cy, ev, el);
+			float4 *mine = orec + 4 * lane;
+			mine[0] = make_float4(cx, cy, ev.x, ev.y);
+			mine[1] = make_float4(ev.z, ev.w, el.x, el.y);
+			mine[2] = make_float4(ob.vxmin, ob.vxmax, ob.vymin, ob.vymax);
+			mine[3] = make_float4(__uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)), __int_as_float(max(x1 - x0, 1)), __uint_as_float(excl), hl + 1);
+			FR_WAVE_LDS_SYNC();
+		}
 		for (uint32_t k = 0; k < total; k += 64)
 		{
 			const uint32_t j = k + lane;
@@ -1602,29 +1627,45 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			const int seg_a = (int)max((long long)excl - (long long)k, 0ll);
 			const int seg_b = (int)min((long long)incl - (long long)k, 64ll);
 			const int owner = max(pair_owner_scan(s_own + (threadIdx.x & ~63), lane, seg_a, seg_b), 0);
-			const uint32_t local = (valid ? j : total - 1) - (uint32_t)__shfl((int)excl, owner);
-			const int ox0 = __shfl(x0, owner), oy0 = __shfl(y0, owner), ow = max(__shfl(x1, owner) - ox0, 1);
-			const int x = ox0 + (int)(local % (uint32_t)ow), y = oy0 + (int)(local / (uint32_t)ow);
+			const float4 *orow = orec + 4 * owner;
+			const float4 o3 = orow[3];
+			const uint32_t oxy = __float_as_uint(o3.x);
+			const int ow = __float_as_int(o3.y);
+			const uint32_t local = (valid ? j : total - 1) - __float_as_uint(o3.z);
+			// local / ow and local % ow for local < 2^23 (a splat of this loop has fewer than 64 tiles)
+			int qy = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)ow));
+			int rx = (int)local - qy * ow;
+			if (rx < 0) { qy--; rx += ow; } else if (rx >= ow) { qy++; rx -= ow; }
+			const int x = (int)(oxy & 0xffffu) + rx, y = (int)(oxy >> 16) + qy;
 			const int ti = y * a.gx + x;
 			const uint64_t opay = ((uint64_t)(uint32_t)__shfl((int)depth_bits, owner) << 32) | (uint32_t)(slab * 64 + owner);
 			bool pass = valid;
 			if (CULL)
 			{
-				const float4 oev = make_float4(__shfl(ev.x, owner), __shfl(ev.y, owner), __shfl(ev.z, owner), __shfl(ev.w, owner));
-				const float2 oel = make_float2(__shfl(el.x, owner), __shfl(el.y, owner));
-				const float ocx = __shfl(cx, owner), ocy = __shfl(cy, owner);
-				if (FOV)
+				const float4 o0 = orow[0], o1 = orow[1], o2 = orow[2];
+				if (FOV) pass = pass && TILE_PASSES(valid ? ti : 0, o3.w);
 				{
-					const float ohl = __shfl(hl, owner);
-					pass = pass && TILE_PASSES(valid ? ti : 0, ohl + 1);
-				}
-				if (pass)
-				{
-					const Obb ob = make_obb(ocx, ocy, oev, oel);
-					pass = obb_hits_tile(ob, x, y);
+					// obb_hits_tile() without its early returns (same expressions, same comparisons: a NaN fails no test)
+					const float tpx = (float)x * (float)FR_TILE + (float)FR_TILE / 2.0f, tpy = (float)y * (float)FR_TILE + (float)FR_TILE / 2.0f;
+					const bool cx_ok = !((o2.y - tpx) < -8.0f || (o2.x - tpx) > 8.0f);
+					const bool cy_ok = !((o2.w - tpy) < -8.0f || (o2.z - tpy) > 8.0f);
+					const float xp = tpx + 8.0f - o0.x, xm = tpx - 8.0f - o0.x, yp = tpy + 8.0f - o0.y, ym = tpy - 8.0f - o0.y;
+					const float a1p = xp * o0.z, a1m = xm * o0.z, b1p = yp * o0.w, b1m = ym * o0.w;
+					const float mn1 = fminf(a1p, a1m) + fminf(b1p, b1m), mx1 = fmaxf(a1p, a1m) + fmaxf(b1p, b1m);
+					const bool e1_ok = !(o1.z < mn1 || -o1.z > mx1);
+					const float a2p = xp * o1.x, a2m = xm * o1.x, b2p = yp * o1.y, b2m = ym * o1.y;
+					const float mn2 = fminf(a2p, a2m) + fminf(b2p, b2m), mx2 = fmaxf(a2p, a2m) + fmaxf(b2p, b2m);
+					const bool e2_ok = !(o1.w < mn2 || -o1.w > mx2);
+					pass = pass && cx_ok && cy_ok && e1_ok && e2_ok;
 				}
 			}
 			if (pass) a.entries[NEXT_SLOT(ti)] = opay;
+		}
+		if (total != 0)
+		{
+			// the rows are rewritten by the next slab: everyone is done reading
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 		}
 	}
 	}; // process(slab)
@@ -1632,7 +1673,18 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		// the slabs k_bin's wave of the same number took (the bucket offsets are per workgroup): wave, wave + waves, ...
 		const int wave_gid = (int)blockIdx.x * (FR_EMIT_THREADS / 64) + (int)(threadIdx.x >> 6);
 		const int nwaves = (int)gridDim.x * (FR_EMIT_THREADS / 64);
-		for (int slab = wave_gid; slab < nslabs; slab += nwaves) process(slab);
+		// one slab AHEAD: the next slab's records are in flight while this one's pairs are walked (the kernel's waves spent 73 %
+		// of their time parked on s_waitcnt: a slab's record loads in front of its walk, its stores behind)
+		SlabIn cur, nxt;
+		int slab = wave_gid;
+		if (slab < nslabs) fetch_slab(slab, cur);
+		for (; slab < nslabs; slab += nwaves)
+		{
+			const bool more = slab + nwaves < nslabs;
+			if (more) fetch_slab(slab + nwaves, nxt);
+			process(slab, cur);
+			if (more) cur = nxt;
+		}
 	}
 	__syncthreads();
 	const int ng = min((int)s_ng, FR_GIANT_MAX);
@@ -1888,21 +1940,26 @@ int launch_emit(FwdCtx &c)
 	const bool ldsh = c.hist_mode != 0; // (as k_bin counted: launch_bin)
 	const dim3 grid(c.bin_wgs), block(FR_EMIT_THREADS);
 	e.lds_tiles = (is_fov(a->variant) && ldsh) ? 1 : 0;
-	const size_t lds = (c.hist_mode == 2 ? (size_t)((c.T + 1) / 2) * sizeof(uint32_t) : (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0)) +
-		(e.lds_tiles ? lds_tile_table_bytes(c.T) : 0);
+	const size_t lds = (((c.hist_mode == 2 ? (size_t)((c.T + 1) / 2) * sizeof(uint32_t) : (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0)) +
+		(e.lds_tiles ? lds_tile_table_bytes(c.T) : 0) + 15) & ~(size_t)15) + (size_t)FR_EMIT_THREADS * 4 * sizeof(float4); // + the pair loop's owner rows
 	if (lds > 64u * 1024u)
 	{
-		static const hipError_t once = [&]() {
-			const hipError_t e1 = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-			const hipError_t e2 = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-			const hipError_t e3 = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_PCHECK_OBB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-			const hipError_t e4 = hipFuncSetAttribute((const void *)k_emit<FR_VARIANT_ORIGINAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-			return e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4)); }();
+		// (cursors + owner rows exceed the default 64 KiB for every tile grid of a 1080p frame: every instantiation gets the raised limit)
+		static const hipError_t once = []() {
+			const void *fns[] = { (const void *)k_emit<FR_VARIANT_ORIGINAL, 0>, (const void *)k_emit<FR_VARIANT_ORIGINAL, 1>, (const void *)k_emit<FR_VARIANT_ORIGINAL, 2>,
+				(const void *)k_emit<FR_VARIANT_PCHECK_OBB, 0>, (const void *)k_emit<FR_VARIANT_PCHECK_OBB, 1>, (const void *)k_emit<FR_VARIANT_PCHECK_OBB, 2>,
+				(const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 0>, (const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 1>, (const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 2> };
+			for (const void *fn : fns)
+			{
+				const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+				if (e1 != hipSuccess) return e1;
+			}
+			return hipSuccess; }();
 		if (once != hipSuccess) { set_error("hipFuncSetAttribute(k_emit): %s", hipGetErrorString(once)); return FR_ERR_HIP; }
 	}
 #define LAUNCH_EMIT(V) do { if (c.hist_mode == 2) hipLaunchKernelGGL((k_emit<V, 2>), grid, block, lds, c.stream, e); \
 	else if (ldsh) hipLaunchKernelGGL((k_emit<V, 1>), grid, block, lds, c.stream, e); \
-	else hipLaunchKernelGGL((k_emit<V, 0>), grid, block, 0, c.stream, e); } while (0)
+	else hipLaunchKernelGGL((k_emit<V, 0>), grid, block, lds, c.stream, e); } while (0)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: LAUNCH_EMIT(FR_VARIANT_ORIGINAL); break;
