@@ -292,6 +292,7 @@ struct PreArgs {
 	int raw;         // scales / rotations / opacities are raw parameters: activate on the fly (fr_forward_args.raw_activations)
 	int prefiltered; // fr_forward_args.prefiltered: a Gaussian behind the near plane is an error (slab_ctr[0] reports it)
 	int proj_waves, proj_cpw; // the cull pass's grid in waves and the chunks each of them took (k_bin finds the regions from them)
+	int wbase_lds;            // k_bin keeps its copy of the cull pass's running counts in LDS (launch_bin: when it fits)
 };
 
 // Projection of one Gaussian: everything up to the tile rectangle.
@@ -1058,8 +1059,12 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// lane (see there), and the owner rows of pair_owner_scan)
 	float4 *const s_orec = (float4 *)(lds_hist + ((hist_words + ((FOV && a.lds_tiles) ? tab_words : 0) + 3) & ~3));
 	int *const s_own = (int *)(s_orec + 4 * FR_BIN_THREADS);
-	uint32_t *const s_wbase = (uint32_t *)(s_own + FR_BIN_THREADS); // [proj_waves + 1] first item of every cull-pass region
+	// [proj_waves + 1] first item of every cull-pass region: a copy in LDS, or -- when the histogram of a 4K tile grid leaves no room
+	// for its 32 KiB -- the table in global memory (the slab's binary search then costs thirteen L2 round trips)
+	const uint32_t *const s_wbase = a.wbase_lds ? (const uint32_t *)(s_own + FR_BIN_THREADS) : a.geom.wbase;
+	if (a.wbase_lds)
 	{
+		uint32_t *const dst = (uint32_t *)(s_own + FR_BIN_THREADS);
 		// (sixteen loads at a time, see the table fill above; visible after the workgroup barrier below)
 		for (int w0 = threadIdx.x; w0 <= a.proj_waves; w0 += 16 * FR_BIN_THREADS)
 		{
@@ -1067,7 +1072,7 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 #pragma unroll
 			for (int k = 0; k < 16; k++) v[k] = a.geom.wbase[min(w0 + k * FR_BIN_THREADS, a.proj_waves)];
 #pragma unroll
-			for (int k = 0; k < 16; k++) if (w0 + k * FR_BIN_THREADS <= a.proj_waves) s_wbase[w0 + k * FR_BIN_THREADS] = v[k];
+			for (int k = 0; k < 16; k++) if (w0 + k * FR_BIN_THREADS <= a.proj_waves) dst[w0 + k * FR_BIN_THREADS] = v[k];
 		}
 		__syncthreads();
 	}
@@ -1790,7 +1795,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
 	PreArgs p;
-	p.lds_tiles = 0;
+	p.lds_tiles = 0; p.wbase_lds = 0;
 	p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H; p.gx = c.gx; p.gy = c.gy;
 	p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.focal_x = c.focal_x; p.focal_y = c.focal_y;
 	p.scale_modifier = a->scale_modifier;
@@ -1877,8 +1882,11 @@ int launch_bin(FwdCtx &c)
 	// LDS per workgroup: tile histogram (+ RF: the 4-bit tile table), the waves' staging / owner rows, the cull pass's running counts
 	p.lds_tiles = (is_fov(a->variant) && ldsh) ? 1 : 0;
 	const size_t hist_bytes = c.hist_mode == 2 ? (size_t)((c.T + 1) / 2) * sizeof(uint32_t) : (ldsh ? (size_t)c.T * sizeof(uint32_t) : 0);
-	const size_t lds = ((hist_bytes + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0) + 15) & ~(size_t)15) +
-		(size_t)FR_BIN_THREADS * (4 * sizeof(float4) + sizeof(int)) + (size_t)(c.proj_waves + 1) * sizeof(uint32_t);
+	const size_t lds_fixed = ((hist_bytes + (p.lds_tiles ? lds_tile_table_bytes(c.T) : 0) + 15) & ~(size_t)15) +
+		(size_t)FR_BIN_THREADS * (4 * sizeof(float4) + sizeof(int));
+	const size_t wbase_bytes = (size_t)(c.proj_waves + 1) * sizeof(uint32_t);
+	p.wbase_lds = lds_fixed + wbase_bytes <= 156u * 1024u ? 1 : 0; // (a 4K grid's 16-bit histogram + a large cloud's 32 KiB of counts do not both fit)
+	const size_t lds = lds_fixed + (p.wbase_lds ? wbase_bytes : 0);
 	// Never more workgroups than the device keeps resident (one per CU: a second one doubles the histogram flushes -- one returning
 	// atomic per workgroup and touched tile -- and the table prologues for slabs that one workgroup's sixteen waves already cover).
 	auto launch = [&](const void *fn, void (*kern)(const PreArgs), size_t dyn) {

@@ -253,6 +253,29 @@ def test_huge_tile_grid_uses_global_counter_path(variant):
         np.testing.assert_array_equal(pk[k], got[k], err_msg="packed " + k)
 
 
+def test_4k_tile_grid_with_a_large_cloud():
+    """4096x2160 (34 560 tiles: 16-bit histograms, two tiles per word) with 600 000 Gaussians: the cull pass then runs its full grid of
+    8192 waves, whose 32 KiB of running counts no longer fit into k_bin's LDS beside the histogram (it reads them from global
+    memory), and every binning wave takes several slabs (static order: wave, wave + waves, ...). Lists and image against the oracle."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    orc.set_threads(os.cpu_count() or 1)
+    cloud = syn.scene_1k(P=600_000, seed=33)
+    cloud._scaling -= 1.2
+    cam = syn.camera_1k(4096, 2160, 70.0)
+    for variant in ("pcheck_obb", "fov_pcheck_obb"):
+        fov = syn.foveation_layers(cloud, seed=34) if variant == "fov_pcheck_obb" else None
+        scene, cd = scene_dict(cloud, variant, fov), cam_dict(cam, gaze=(0.45, 0.5))
+        want = orc.forward(variant, scene, cd)
+        got = hip_forward(variant, scene, cd, debug=False)
+        assert got["num_rendered"] == want["num_rendered"] and want["num_rendered"] > 500_000
+        np.testing.assert_array_equal(got["radii"], want["radii"])
+        np.testing.assert_array_equal(got["ranges"], want["ranges"])
+        np.testing.assert_array_equal(got["point_list"], want["point_list"])
+        check_image(got["color"], want["color"], name=variant + " 4K, 600 k Gaussians")
+    orc.set_threads(1)
+
+
 def test_8k_tile_grid_beyond_the_packed_tile_scan():
     """7680x4320 -> 129 600 tiles: above the 65 535 tiles the tile scan's packed 16-bit positions hold (it takes its
     LDS-atomics form there; tile_scan.h), and above every LDS table of the binning kernels."""
