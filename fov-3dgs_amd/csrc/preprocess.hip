@@ -1467,6 +1467,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
+#ifdef FR_EMIT_TIMERS
+	const uint64_t tm_entry = wall_clock64(); uint64_t tm_pro = 0, tm_loop = 0, tm_walk = 0, tm_big = 0; int tm_slabs = 0, tm_steps = 0;
+#endif
 	// launched before the host knows the frame's instance count (fr_forward): when the binning workspace turns out too
 	// small nothing is emitted, the host replays the stage with a larger one
 	if (a.totals[0] > a.capacity || a.totals[5] > a.items_cap) return;
@@ -1521,6 +1524,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	__shared__ uint32_t s_ng;
 	if (threadIdx.x == 0) s_ng = 0;
 	__syncthreads();
+#ifdef FR_EMIT_TIMERS
+	tm_pro = wall_clock64() - tm_entry;
+#endif
 	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
 	auto walk_uniform = [&](const int ox0, const int oy0, const int ow, const uint32_t on, const Obb &ob, const float olim,
 		const uint64_t opay, const uint32_t k0, const uint32_t kstep) __attribute__((always_inline))
@@ -1615,6 +1621,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		// broadcasts -- divides by the rectangle's width with a reciprocal and evaluates the box test without branches (this loop
 		// pulled thirteen registers through ds_bpermute, divided twice and rebuilt the box per pair: 60 of the kernel's 104 us)
 		float4 *const orec = s_orec + 4 * (threadIdx.x & ~63);
+#ifdef FR_EMIT_TIMERS
+		const uint64_t tw0 = wall_clock64(); tm_steps += (int)((total + 63) / 64);
+#endif
 		if (total != 0)
 		{
 			const Obb ob = make_obb(cx, cy, ev, el);
@@ -1672,6 +1681,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 		}
+#ifdef FR_EMIT_TIMERS
+		tm_walk += wall_clock64() - tw0;
+#endif
 	}
 	}; // process(slab)
 	{
@@ -1683,15 +1695,37 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		SlabIn cur, nxt;
 		int slab = wave_gid;
 		if (slab < nslabs) fetch_slab(slab, cur);
+#ifdef FR_EMIT_TIMERS
+		const uint64_t tl0 = wall_clock64();
+#endif
 		for (; slab < nslabs; slab += nwaves)
 		{
 			const bool more = slab + nwaves < nslabs;
 			if (more) fetch_slab(slab + nwaves, nxt);
 			process(slab, cur);
 			if (more) cur = nxt;
+#ifdef FR_EMIT_TIMERS
+			tm_slabs++;
+#endif
 		}
+#ifdef FR_EMIT_TIMERS
+		tm_loop = wall_clock64() - tl0;
+#endif
 	}
+#ifdef FR_EMIT_TIMERS
+	const uint64_t tb0 = wall_clock64();
+#endif
 	__syncthreads();
+#ifdef FR_EMIT_TIMERS
+	if (lane == 0)
+	{
+		// developer build: per-wave (total so far, prologue, slab loop, wait at the barrier, slabs, pair steps) in 10-ns ticks, in the
+		// covariance rows the inference variants do not use
+		float *d = a.geom.cov3D + (size_t)((int)blockIdx.x * (FR_EMIT_THREADS / 64) + (int)(threadIdx.x >> 6)) * 8;
+		d[0] = (float)(wall_clock64() - tm_entry); d[1] = (float)tm_pro; d[2] = (float)tm_loop; d[3] = (float)(wall_clock64() - tb0);
+		d[4] = (float)tm_slabs; d[5] = (float)tm_steps; d[6] = (float)tm_walk; d[7] = (float)tm_big;
+	}
+#endif
 	const int ng = min((int)s_ng, FR_GIANT_MAX);
 	for (int g = 0; g < ng; g++)
 	{
