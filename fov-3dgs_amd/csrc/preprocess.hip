@@ -1061,7 +1061,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	int *const s_own = (int *)(s_orec + 4 * FR_BIN_THREADS);
 	// [proj_waves + 1] first item of every cull-pass region: a copy in LDS, or -- when the histogram of a 4K tile grid leaves no room
 	// for its 32 KiB -- the table in global memory (the slab's binary search then costs thirteen L2 round trips)
-	const uint32_t *const s_wbase = a.wbase_lds ? (const uint32_t *)(s_own + FR_BIN_THREADS) : a.geom.wbase;
+	// (two typed pointers, never one selected pointer: that one would be a generic address and every probe a flat load)
+	const uint32_t *const s_wbase = (const uint32_t *)(s_own + FR_BIN_THREADS);
+	const uint32_t *const g_wbase = a.geom.wbase;
 	if (a.wbase_lds)
 	{
 		uint32_t *const dst = (uint32_t *)(s_own + FR_BIN_THREADS);
@@ -1163,12 +1165,16 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 		const bool valid = item < V;
 		if (valid)
 		{
-			int lo = 0, hi = a.proj_waves; // s_wbase[lo] <= first < s_wbase[hi]
-			const uint32_t first = (uint32_t)slab * 64u;
-			while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wbase[mid] <= first) lo = mid; else hi = mid; }
-			int w = lo;
-			while ((uint32_t)item >= s_wbase[w + 1]) w++;
-			const uint32_t slot = (uint32_t)w * (uint32_t)a.proj_cpw * 64u + ((uint32_t)item - s_wbase[w]);
+			// region of the item: wb[lo] <= first < wb[hi], then forward over the (rare, short) regions the slab spans
+			auto slot_in = [&](const uint32_t *wb) -> uint32_t {
+				int lo = 0, hi = a.proj_waves;
+				const uint32_t first = (uint32_t)slab * 64u;
+				while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wb[mid] <= first) lo = mid; else hi = mid; }
+				int w = lo;
+				while ((uint32_t)item >= wb[w + 1]) w++;
+				return (uint32_t)w * (uint32_t)a.proj_cpw * 64u + ((uint32_t)item - wb[w]);
+			};
+			const uint32_t slot = a.wbase_lds ? slot_in(s_wbase) : slot_in(g_wbase);
 			if (CROW)
 			{
 				// the row k_project stored beside the index (48 bytes: the lanes' rows lie in one or two contiguous regions)
