@@ -19,31 +19,9 @@
 
 namespace fr {
 
+typedef float bv2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bwd_exp(float p) { return __builtin_amdgcn_exp2f(p * 1.4426950408889634f); }
 
-typedef unsigned int bwd_u2 __attribute__((ext_vector_type(2)));
-typedef float bv2 __attribute__((ext_vector_type(2)));
-// lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l]  (tools/scratch/permlane_test.hip)
-__device__ __forceinline__ float fold32(float a, float b)
-{
-	const bwd_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-	return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// rows of 16 lanes: (a0 + a1, b0 + b1, a2 + a3, b2 + b3)
-__device__ __forceinline__ float fold16(float a, float b)
-{
-	const bwd_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-	return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// sum over each row of 16 lanes, in all its lanes
-__device__ __forceinline__ float row_sum16(float x)
-{
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false)); // row_half_mirror
-	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false)); // row_mirror
-	return x;
-}
 // sum over the wave, valid in lane 63
 __device__ __forceinline__ float wave_sum_b(float x)
 {
@@ -89,12 +67,11 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 	if (n == 0) return;
 	const size_t plane = (size_t)a.W * a.H;
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
-	const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
-	// per pixel (the lane's two pixels as packed pairs, v_pk_* arithmetic): transmittance behind the current entry, the
-	// colour accumulated behind it, the last alpha / colour
+	// per pixel (the lane's two pixels as packed pairs, v_pk_* arithmetic): transmittance behind the current entry and the
+	// colour accumulated behind it, as its product A with dL/dpixel
 	static_assert(PPL == 2, "the lane's pixels are handled as one packed pair");
-	bv2 T, Tfin, pyp, behind0, behind1, behind2, prevA, prev0, prev1, prev2, dp0, dp1, dp2, bgdot;
+	bv2 T, Tfin, pyp, A, dp0, dp1, dp2, bgdot;
 	int lastc[PPL];
 	int wave_last = 0;
 #pragma unroll
@@ -113,7 +90,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 	}
 	T = Tfin;
 	bgdot = bg0 * dp0 + bg1 * dp1 + bg2 * dp2;
-	behind0 = behind1 = behind2 = prevA = prev0 = prev1 = prev2 = (bv2){ 0.f, 0.f };
+	A = (bv2){ 0.f, 0.f };
 	// nothing behind the deepest contributor of this wave's pixels needs to be visited
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
@@ -172,47 +149,40 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 			const bool on_x = pos < lastc[0] && !(power.x > 0.0f) && !(CUTOFF && power.x < -4.5f) && !(alpha.x < 1.0f / 255.0f);
 			const bool on_y = pos < lastc[1] && !(power.y > 0.0f) && !(CUTOFF && power.y < -4.5f) && !(alpha.y < 1.0f / 255.0f);
 			const bool any = on_x || on_y;
-			float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // colour r g b, mean2D x y, conic a b c, opacity
+			float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // colour r g b, mean2D x y (pixels: k_preprocess_bwd scales them), conic a b c (x -2, likewise), opacity
 			if (__any(any))
 			{
+				// A pixel that is not `on` takes part with alpha = 0 and G = 0: 1 / (1 - 0) = 1 leaves its transmittance, 0 c + 1 A its
+				// colour behind, and every sum gets an exact zero (G is cleared, so no infinity of a far-away splat meets a zero factor).
+				const bv2 am = (bv2){ on_x ? alpha.x : 0.0f, on_y ? alpha.y : 0.0f };
 				const bv2 Gm = (bv2){ on_x ? G.x : 0.0f, on_y ? G.y : 0.0f };
-				const bv2 om = 1.0f - alpha;
+				const bv2 om = 1.0f - am;
 				// 1 / (1 - alpha): v_rcp_f32 and one Newton step (the reference divides twice per pixel: ~24 instructions)
 				bv2 r = (bv2){ __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
 				r = r * __builtin_elementwise_fma(-om, r, (bv2){ 2.0f, 2.0f });
 				const bv2 Tn = T * r;
-				T.x = on_x ? Tn.x : T.x; T.y = on_y ? Tn.y : T.y;
-				const bv2 wgt = alpha * Tn;                                    // d channel / d colour
-				const bv2 wm = (bv2){ on_x ? wgt.x : 0.0f, on_y ? wgt.y : 0.0f };
-				const bv2 keep = 1.0f - prevA;
-				const bv2 nb0 = __builtin_elementwise_fma(prevA, prev0, keep * behind0);
-				const bv2 nb1 = __builtin_elementwise_fma(prevA, prev1, keep * behind1);
-				const bv2 nb2 = __builtin_elementwise_fma(prevA, prev2, keep * behind2);
-				behind0.x = on_x ? nb0.x : behind0.x; behind0.y = on_y ? nb0.y : behind0.y;
-				behind1.x = on_x ? nb1.x : behind1.x; behind1.y = on_y ? nb1.y : behind1.y;
-				behind2.x = on_x ? nb2.x : behind2.x; behind2.y = on_y ? nb2.y : behind2.y;
-				prev0.x = on_x ? g1.z : prev0.x; prev0.y = on_y ? g1.z : prev0.y;
-				prev1.x = on_x ? g1.w : prev1.x; prev1.y = on_y ? g1.w : prev1.y;
-				prev2.x = on_x ? g2.x : prev2.x; prev2.y = on_y ? g2.x : prev2.y;
-				bv2 dL_dalpha = (g1.z - nb0) * dp0;
-				dL_dalpha = __builtin_elementwise_fma(g1.w - nb1, dp1, dL_dalpha);
-				dL_dalpha = __builtin_elementwise_fma(g2.x - nb2, dp2, dL_dalpha);
-				const bv2 c0 = wm * dp0, c1 = wm * dp1, c2 = wm * dp2;
+				T = Tn;
+				const bv2 wgt = am * Tn;                                       // d channel / d colour
+				const bv2 c0 = wgt * dp0, c1 = wgt * dp1, c2 = wgt * dp2;
 				v[0] = c0.x + c0.y; v[1] = c1.x + c1.y; v[2] = c2.x + c2.y;
-				dL_dalpha = dL_dalpha * Tn;
-				prevA.x = on_x ? alpha.x : prevA.x; prevA.y = on_y ? alpha.y : prevA.y;
-				dL_dalpha = __builtin_elementwise_fma(-(Tfin * r), bgdot, dL_dalpha); // the background's share
-				const bv2 dA = (bv2){ on_x ? dL_dalpha.x : 0.0f, on_y ? dL_dalpha.y : 0.0f };
+				// backward.cu:507-514 keeps the colour accumulated behind the entry per channel and forms sum_ch (c_ch - behind_ch) dpix_ch;
+				// here the products with dpix are taken first: cdot = c . dpix of this entry, A = behind . dpix -- one state per pixel
+				// instead of three, updated with the entry itself once its gradient has been taken (the reference's last_alpha /
+				// last_color are the same update, applied one entry later)
+				const bv2 cdot = __builtin_elementwise_fma((bv2){ g2.x, g2.x }, dp2, __builtin_elementwise_fma((bv2){ g1.w, g1.w }, dp1, g1.z * dp0));
+				bv2 dA = (cdot - A) * Tn;
+				dA = __builtin_elementwise_fma(-(Tfin * r), bgdot, dA);         // the background's share
+				A = __builtin_elementwise_fma(am, cdot, om * A);
 				const bv2 dL_dG = g1.y * dA;
 				const bv2 gdx = Gm * dx, gdy = Gm * dy;
 				const bv2 mx = dL_dG * (-(gdx * g0.z) - gdy * g0.w);
 				const bv2 my = dL_dG * (-(gdy * g1.x) - gdx * g0.w);
 				const bv2 ka = (gdx * dx) * dL_dG, kb = (gdx * dy) * dL_dG, kc = (gdy * dy) * dL_dG, ko = Gm * dA;
-				v[3] = (mx.x + mx.y) * ddelx_dx;
-				v[4] = (my.x + my.y) * ddely_dy;
-				v[5] = -0.5f * (ka.x + ka.y);
-				v[6] = -0.5f * (kb.x + kb.y);
-				v[7] = -0.5f * (kc.x + kc.y);
+				v[3] = mx.x + mx.y;
+				v[4] = my.x + my.y;
+				v[5] = ka.x + ka.y;
+				v[6] = kb.x + kb.y;
+				v[7] = kc.x + kc.y;
 				v[8] = ko.x + ko.y;
 			}
 			if (__any(any))
@@ -323,8 +293,10 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	// (retain_graph, torch.autograd.grad twice). The last quarter (1 / |raw quaternion|) belongs to the forward pass and stays.
 	a.acc[4 * (size_t)slot] = a.acc[4 * (size_t)slot + 1] = a.acc[4 * (size_t)slot + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
 	const float g_col[3] = { ac0.x, ac0.y, ac0.z };
-	const float g_px = ac0.w, g_py = ac1.x;           // d / d mean2D
-	const float gA = ac1.y, gB = ac1.z, gC = ac1.w;   // d / d conic (gB: half the off-diagonal derivative)
+	// (k_render_bwd leaves the pixel-space sums unscaled: d pixel / d ndc = W / 2, H / 2 (backward.cu:430-431), and the -1/2 of the
+	// exponent's quadratic form (backward.cu:536-538))
+	const float g_px = ac0.w * (0.5f * a.W), g_py = ac1.x * (0.5f * a.H);         // d / d mean2D
+	const float gA = -0.5f * ac1.y, gB = -0.5f * ac1.z, gC = -0.5f * ac1.w;        // d / d conic (gB: half the off-diagonal derivative)
 	a.dL_dmean2D[3 * orow] = g_px; a.dL_dmean2D[3 * orow + 1] = g_py;
 	if (a.row_sparse) a.dL_dmean2D[3 * orow + 2] = 0.0f; // (the dense tensors get their zeros from the fill)
 	// (raw parameters: through the sigmoid, o (1 - o), and below through exp and the normalisation -- what k_activate_bwd does

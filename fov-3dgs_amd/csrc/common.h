@@ -369,6 +369,30 @@ __device__ __forceinline__ bool band_reaches(int w, int tx, int ty, float gx, fl
 void set_error(const char *fmt, ...);
 int check_launch(const char *what, hipStream_t stream, bool debug);
 
+// ---- cross-row folds of gfx950 (k_render_bwd's nine gradient sums, k_render's contribution sums)
+typedef unsigned int bwd_u2 __attribute__((ext_vector_type(2)));
+// lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l]  (tools/scratch/permlane_test.hip)
+__device__ __forceinline__ float fold32(float a, float b)
+{
+	const bwd_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+	return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// rows of 16 lanes: (a0 + a1, b0 + b1, a2 + a3, b2 + b3)
+__device__ __forceinline__ float fold16(float a, float b)
+{
+	const bwd_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+	return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// sum over each row of 16 lanes, in all its lanes
+__device__ __forceinline__ float row_sum16(float x)
+{
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false)); // row_half_mirror
+	x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false)); // row_mirror
+	return x;
+}
+
 // GaussianModel's activations (scene/gaussian_model.py:200-240) as the kernels apply them: k_activate_fwd as a pass of its
 // own, k_project / k_bin on the fly when the caller hands over raw parameters (fr_forward_args.raw_activations).
 __device__ __forceinline__ float act_scale(float raw) { return expf(raw); }

@@ -296,11 +296,11 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			t.col = make_float4(g1.z, g1.w, s2[j], g1.y); // r, g, b, opacity
 			return t;
 		};
-		auto blend = [&](const Ent &t)
+		auto blend = [&](const Ent &t, float &contrib_sum, bool &any_contrib)
 		{
 			const int j = t.j;
-			float contrib_sum = 0.0f, contrib_max = 0.0f;
-			bool any_contrib = false;
+			float contrib_max = 0.0f;
+			contrib_sum = 0.0f; any_contrib = false;
 			if (PMAX)
 			{
 				// ..._max forward.cu:381: +1 for every live pixel inside the splat's support (before the alpha test)
@@ -327,14 +327,6 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 					const bool bx = ax && (w.x > best_w[2 * h]), by = ay && (w.y > best_w[2 * h + 1]);
 					best_w[2 * h] = bx ? w.x : best_w[2 * h]; best_id[2 * h] = bx ? sid[j] : best_id[2 * h];
 					best_w[2 * h + 1] = by ? w.y : best_w[2 * h + 1]; best_id[2 * h + 1] = by ? sid[j] : best_id[2 * h + 1];
-				}
-			}
-			if (SUM)
-			{
-				if (__any(any_contrib))
-				{
-					const float tot = wave_sum(contrib_sum);
-					if (st == 0) atomicAdd(&a.contributions[sid[j]], tot);
 				}
 			}
 			if (PMAX)
@@ -374,8 +366,43 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 				for (int h = 0; h < HP; h++) anyhit = anyhit || (t[g].inx[h] && S[h].T.x > 0.0f) || (t[g].iny[h] && S[h].T.y > 0.0f);
 			}
 			if (!__any(anyhit)) continue; // the splats miss every live pixel of this wave's rows
+			float csum[FR_RENDER_GROUP_PLAIN];
+			bool cany[FR_RENDER_GROUP_PLAIN];
 #pragma unroll
-			for (int g = 0; g < FR_RENDER_GROUP_PLAIN; g++) blend(t[g]);
+			for (int g = 0; g < FR_RENDER_GROUP_PLAIN; g++) blend(t[g], csum[g], cany[g]);
+			if (SUM)
+			{
+				// RS forward.cu:400: contributions[id] += alpha T per pixel. The group's sums are reduced TOGETHER (cross-row folds, as in
+				// k_render_bwd): a wave-wide sum per entry was a dependent chain of seven instructions and a one-lane atomic each;
+				// here the totals end up in different lanes, which add them with one atomic instruction (377 -> 358 us).
+				static_assert(FR_RENDER_GROUP_PLAIN == 2 || FR_RENDER_GROUP_PLAIN == 4, "contribution fold: two or four entries per group");
+				bool anyg = false;
+#pragma unroll
+				for (int g = 0; g < FR_RENDER_GROUP_PLAIN; g++) anyg = anyg || cany[g];
+				if (__any(anyg))
+				{
+					if (FR_RENDER_GROUP_PLAIN == 2)
+					{
+						// lanes 0-31: entry 0, lanes 32-63: entry 1; row sums, then rows 1 / 3 add their lower neighbours
+						float f = row_sum16(fold32(csum[0], csum[1]));
+						f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x142, 0xA, 0xF, false)); // row_bcast15
+						const bool has0 = __any(cany[0]), has1 = __any(cany[1]);
+						if ((st == 31 && has0) || (st == 63 && has1)) atomicAdd(&a.contributions[sid[st == 31 ? jj[0] : jj[1]]], f);
+					}
+					else
+					{
+						// row r of 16 lanes: entry (r & 1) * 2 + (r >> 1) ... fold32 pairs (0,1) and (2,3), fold16 interleaves them
+						const int gi = FR_RENDER_GROUP_PLAIN - 1; // (indices kept in range for the two-entry build)
+						const float f01 = fold32(csum[0], csum[1 & gi]), f23 = fold32(csum[2 & gi], csum[3 & gi]);
+						const float f = row_sum16(fold16(f01, f23)); // rows: entry 0, entry 2, entry 1, entry 3
+						const int row = st >> 4;
+						const int g = ((row & 1) << 1) | (row >> 1);
+						const unsigned has = (__any(cany[0]) ? 1u : 0u) | (__any(cany[1 & gi]) ? 2u : 0u) | (__any(cany[2 & gi]) ? 4u : 0u) | (__any(cany[3 & gi]) ? 8u : 0u);
+						const int jg = g == 0 ? jj[0] : (g == 1 ? jj[1 & gi] : (g == 2 ? jj[2 & gi] : jj[3 & gi]));
+						if ((st & 15) == 15 && ((has >> g) & 1u)) atomicAdd(&a.contributions[sid[jg]], f);
+					}
+				}
+			}
 		}
 	}
 
