@@ -20,6 +20,13 @@
 namespace fr {
 
 typedef float bv2 __attribute__((ext_vector_type(2)));
+// x + y of a packed pair as ONE v_add_f32 (left to itself the compiler pairs such sums up: three moves and a packed add for two)
+__device__ __forceinline__ float hsum(bv2 a)
+{
+	float r;
+	asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a.x), "v"(a.y));
+	return r;
+}
 __device__ __forceinline__ float bwd_exp(float p) { return __builtin_amdgcn_exp2f(p * 1.4426950408889634f); }
 
 // sum over the wave, valid in lane 63
@@ -149,7 +156,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 			const bool on_x = pos < lastc[0] && !(power.x > 0.0f) && !(CUTOFF && power.x < -4.5f) && !(alpha.x < 1.0f / 255.0f);
 			const bool on_y = pos < lastc[1] && !(power.y > 0.0f) && !(CUTOFF && power.y < -4.5f) && !(alpha.y < 1.0f / 255.0f);
 			const bool any = on_x || on_y;
-			float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // colour r g b, mean2D x y (pixels: k_preprocess_bwd scales them), conic a b c (x -2, likewise), opacity
+			float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // colour r g b, moments M10 M01 M20 M11 M02 M00 of G dL/dalpha
 			if (__any(any))
 			{
 				// A pixel that is not `on` takes part with alpha = 0 and G = 0: 1 / (1 - 0) = 1 leaves its transmittance, 0 c + 1 A its
@@ -164,7 +171,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 				T = Tn;
 				const bv2 wgt = am * Tn;                                       // d channel / d colour
 				const bv2 c0 = wgt * dp0, c1 = wgt * dp1, c2 = wgt * dp2;
-				v[0] = c0.x + c0.y; v[1] = c1.x + c1.y; v[2] = c2.x + c2.y;
+				v[0] = hsum(c0); v[1] = hsum(c1); v[2] = hsum(c2);
 				// backward.cu:507-514 keeps the colour accumulated behind the entry per channel and forms sum_ch (c_ch - behind_ch) dpix_ch;
 				// here the products with dpix are taken first: cdot = c . dpix of this entry, A = behind . dpix -- one state per pixel
 				// instead of three, updated with the entry itself once its gradient has been taken (the reference's last_alpha /
@@ -173,17 +180,12 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 				bv2 dA = (cdot - A) * Tn;
 				dA = __builtin_elementwise_fma(-(Tfin * r), bgdot, dA);         // the background's share
 				A = __builtin_elementwise_fma(am, cdot, om * A);
-				const bv2 dL_dG = g1.y * dA;
-				const bv2 gdx = Gm * dx, gdy = Gm * dy;
-				const bv2 mx = dL_dG * (-(gdx * g0.z) - gdy * g0.w);
-				const bv2 my = dL_dG * (-(gdy * g1.x) - gdx * g0.w);
-				const bv2 ka = (gdx * dx) * dL_dG, kb = (gdx * dy) * dL_dG, kc = (gdy * dy) * dL_dG, ko = Gm * dA;
-				v[3] = mx.x + mx.y;
-				v[4] = my.x + my.y;
-				v[5] = ka.x + ka.y;
-				v[6] = kb.x + kb.y;
-				v[7] = kc.x + kc.y;
-				v[8] = ko.x + ko.y;
+				// the six moments of G dL/dalpha about the splat's centre: what the gradients of the mean, the conic and the opacity are
+				// linear in (backward.cu:524-541 forms the products per pixel; k_preprocess_bwd forms them once per Gaussian)
+				const bv2 w = Gm * dA;
+				const bv2 wx = w * dx, wy = w * dy;
+				const bv2 m20 = wx * dx, m11 = wx * dy, m02 = wy * dy;
+				v[3] = hsum(wx); v[4] = hsum(wy); v[5] = hsum(m20); v[6] = hsum(m11); v[7] = hsum(m02); v[8] = hsum(w);
 			}
 			if (__any(any))
 			{
@@ -293,10 +295,13 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	// (retain_graph, torch.autograd.grad twice). The last quarter (1 / |raw quaternion|) belongs to the forward pass and stays.
 	a.acc[4 * (size_t)slot] = a.acc[4 * (size_t)slot + 1] = a.acc[4 * (size_t)slot + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
 	const float g_col[3] = { ac0.x, ac0.y, ac0.z };
-	// (k_render_bwd leaves the pixel-space sums unscaled: d pixel / d ndc = W / 2, H / 2 (backward.cu:430-431), and the -1/2 of the
-	// exponent's quadratic form (backward.cu:536-538))
-	const float g_px = ac0.w * (0.5f * a.W), g_py = ac1.x * (0.5f * a.H);         // d / d mean2D
-	const float gA = -0.5f * ac1.y, gB = -0.5f * ac1.z, gC = -0.5f * ac1.w;        // d / d conic (gB: half the off-diagonal derivative)
+	// k_render_bwd sums the moments M_ij = sum over pixels of G dL/dalpha dx^i dy^j (dx, dy: centre - pixel); with the conic Q and the
+	// opacity o of the forward pass (backward.cu:524-541): dL/dmean2D = -o Q (M10, M01) * (W / 2, H / 2), dL/dconic = -o/2 (M20, M11, M02)
+	// (the off-diagonal one counted once), dL/dopacity = M00
+	const float4 rq0 = a.rec[3 * (size_t)slot], rq1 = a.rec[3 * (size_t)slot + 1];
+	const float m10 = ac0.w, m01 = ac1.x, opac = rq1.y;
+	const float g_px = -opac * (rq0.z * m10 + rq0.w * m01) * (0.5f * a.W), g_py = -opac * (rq1.x * m01 + rq0.w * m10) * (0.5f * a.H);
+	const float gA = -0.5f * opac * ac1.y, gB = -0.5f * opac * ac1.z, gC = -0.5f * opac * ac1.w;
 	a.dL_dmean2D[3 * orow] = g_px; a.dL_dmean2D[3 * orow + 1] = g_py;
 	if (a.row_sparse) a.dL_dmean2D[3 * orow + 2] = 0.0f; // (the dense tensors get their zeros from the fill)
 	// (raw parameters: through the sigmoid, o (1 - o), and below through exp and the normalisation -- what k_activate_bwd does
@@ -319,8 +324,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	const V3 u0 = axpy3(j00, Rx, { j02 * Rz.x, j02 * Rz.y, j02 * Rz.z });
 	const V3 u1 = axpy3(j11, Ry, { j12 * Rz.x, j12 * Rz.y, j12 * Rz.z });
 	// H = -Q Ghat Q with the conic Q the forward pass stored
-	const float4 rc0 = a.rec[3 * (size_t)slot];
-	const float4 rc1 = a.rec[3 * (size_t)slot + 1]; // (conic c, opacity, ...)
+	const float4 rc0 = rq0, rc1 = rq1; // (..., conic a, conic b), (conic c, opacity, ...)
 	const float qa = rc0.z, qb = rc0.w, qc = rc1.x;
 	if (a.raw) a.dL_dopacity[orow] = ac2.x * rc1.y * (1.0f - rc1.y);
 	const float k00 = qa * gA + qb * gB, k01 = qa * gB + qb * gC, k10 = qb * gA + qc * gB, k11 = qb * gB + qc * gC; // Q Ghat
