@@ -231,6 +231,7 @@ struct BwdPreArgs {
 	float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscale, *dL_drot;
 	const uint32_t *vis_list;  // forward's compact list of projected Gaussians
 	const uint32_t *vis_count; // its length (device)
+	const uint32_t *lrange;    // per item: FR_ITEM_NONE when it landed in no tile (k_bin)
 	int raw;                   // dL_dscale / dL_drot / dL_dopacity w.r.t. the model's raw parameters (fr_backward_args.raw_activations)
 	int row_sparse;            // the outputs are COMPACT: row i belongs to the Gaussian vis_list[i] (fr_backward_args.row_sparse)
 	int M0;                    // coefficients in dL_dsh's rows ([., M0, 3]): M, or 1 with split SH storage
@@ -514,13 +515,18 @@ __global__ void __launch_bounds__(256) k_fill_zero(const FillArgs a)
 // kernel that walks all Gaussians in index order, clears every chunk's rows with coalesced stores and works the
 // chunk's visible ones off from an LDS list -- every row written once, no fill at all: 722 us against 539 + fill; at
 // 158 registers the kernel does not have the occupancy to stream 1.5 GB of zeros.)
-__global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
+#ifndef FR_PBWD_WAVES
+#define FR_PBWD_WAVES 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FR_PBWD_WAVES, FR_PBWD_WAVES))) k_preprocess_bwd(const BwdPreArgs a)
 {
 	const int V = (int)*a.vis_count;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x)
 	{
 		const int idx = (int)a.vis_list[i];
-		if (a.radii[idx] > 0) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i);
+		// (radii[idx] > 0, read from the item's dense word instead of a 64-byte line per Gaussian: k_bin clears the radius of exactly
+		// the items it marks FR_ITEM_NONE)
+		if (a.lrange[i] != FR_ITEM_NONE) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i);
 		else if (a.row_sparse)
 		{
 			// a candidate that landed in no tile: its compact row is all zeros (every row of the compact tensors is written)
@@ -630,7 +636,7 @@ int launch_backward(const fr_backward_args *a)
 	p.radii = a->radii; p.rec = geom.rec; p.cov3D_ws = geom.cov3D; p.acc = geom.acc;
 	p.dL_dmean2D = a->dL_dmean2D; p.dL_dconic = a->dL_dconic; p.dL_dcolor = a->dL_dcolor; p.dL_dopacity = a->dL_dopacity;
 	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dsh_rest = a->dL_dsh_rest; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
-	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1; p.raw = a->raw_activations;
+	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1; p.lrange = geom.lrange; p.raw = a->raw_activations;
 	p.row_sparse = a->row_sparse; p.M0 = (a->colors_precomp == nullptr && a->shs != nullptr) ? (a->shs_rest ? 1 : a->M) : 0;
 	const int pblocks = (a->P + 255) / 256;
 	hipLaunchKernelGGL(k_preprocess_bwd, dim3(pblocks < 2048 ? pblocks : 2048), dim3(256), 0, stream, p);
