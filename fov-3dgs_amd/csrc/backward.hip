@@ -275,7 +275,9 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 
 // slot: the Gaussian's position in the visible list (its row of gradient sums; with `stash` != null also its 64-byte row
 // (xyz | raw scale | rotation | 3D covariance) the forward pass left there: one coalesced row instead of four gathers)
-__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx, const int slot, const float4 *stash)
+// sh_row: the Gaussian's 45 rest coefficients in LDS (k_preprocess_bwd fetched the wave's rows together), replaced in place by
+// their gradients (stored together as well); null: read / written here, per lane
+__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx, const int slot, const float4 *stash, float *sh_row)
 {
 	const size_t orow = a.row_sparse ? (size_t)slot : (size_t)idx; // the row of the gradient tensors this Gaussian's gradients go to
 	const float *vm = a.viewmatrix, *pm = a.projmatrix;
@@ -381,22 +383,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		const float *sh_r = split ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 : a.shs + (size_t)idx * a.M * 3 + 3;
 		float *dsh_r = split ? a.dL_dsh_rest + orow * (a.M - 1) * 3 : a.dL_dsh + orow * a.M * 3 + 3;
 		float *dsh0 = split ? a.dL_dsh + 3 * orow : a.dL_dsh + orow * a.M * 3;
-		typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-		float coef[48];
-#pragma unroll
-		for (int i = 0; i < 48; i++) coef[i] = 0.0f;
 		const int nuse = 3 * ((a.D + 1) * (a.D + 1)) - 3; // rest floats the active degree reads / writes
-		if (nrest >= 45)
-		{
-#pragma unroll
-			for (int q = 0; q < 11; q++) { const f4u t = *(const f4u *)(sh_r + 4 * q); coef[3 + 4 * q] = t.x; coef[4 + 4 * q] = t.y; coef[5 + 4 * q] = t.z; coef[6 + 4 * q] = t.w; }
-			coef[47] = sh_r[44];
-		}
-		else
-		{
-#pragma unroll
-			for (int i = 0; i < 45; i++) if (i < nuse) coef[3 + i] = sh_r[i];
-		}
 		// a channel clamped at zero in the forward pass passes no gradient (forward.cu:63-70)
 		const uint32_t clamp_bits = __float_as_uint(a.rec[3 * (size_t)slot + 2].z);
 		const float g[3] = { (clamp_bits & 1u) ? 0.f : g_col[0], (clamp_bits & 2u) ? 0.f : g_col[1], (clamp_bits & 4u) ? 0.f : g_col[2] };
@@ -410,6 +397,39 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		sh_basis_grad(a.D, dir.x, dir.y, dir.z, bas, grd);
 		dsh0[0] = bas[0] * g[0]; dsh0[1] = bas[0] * g[1]; dsh0[2] = bas[0] * g[2];
 		V3 g_dir = { 0, 0, 0 };
+		if (sh_row != nullptr)
+		{
+			// coefficient k's triple out of the LDS row, its gradient triple bas_k g back into the same three words (basis functions
+			// beyond the active degree are zero: so are their gradients)
+#pragma unroll
+			for (int k = 1; k < 16; k++)
+			{
+				float *c = sh_row + 3 * (k - 1);
+				if (3 * k <= nuse) // (a coefficient of the active degree: the others were not fetched)
+				{
+					const float wk = c[0] * g[0] + c[1] * g[1] + c[2] * g[2];
+					g_dir = axpy3(wk, grd[k], g_dir);
+				}
+				c[0] = bas[k] * g[0]; c[1] = bas[k] * g[1]; c[2] = bas[k] * g[2];
+			}
+		}
+		else
+		{
+		typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+		float coef[48];
+#pragma unroll
+		for (int i = 0; i < 48; i++) coef[i] = 0.0f;
+		if (nrest >= 45)
+		{
+#pragma unroll
+			for (int q = 0; q < 11; q++) { const f4u t = *(const f4u *)(sh_r + 4 * q); coef[3 + 4 * q] = t.x; coef[4 + 4 * q] = t.y; coef[5 + 4 * q] = t.z; coef[6 + 4 * q] = t.w; }
+			coef[47] = sh_r[44];
+		}
+		else
+		{
+#pragma unroll
+			for (int i = 0; i < 45; i++) if (i < nuse) coef[3 + i] = sh_r[i];
+		}
 #pragma unroll
 		for (int k = 1; k < 16; k++)
 		{
@@ -433,6 +453,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		// (compact rows: the coefficients beyond the active degree get their zeros here -- the dense tensors' come from the fill)
 		if (a.row_sparse)
 			for (int f = nuse; f < nrest; f++) dsh_r[f] = 0.0f;
+		}
 		// dir = off / |off|: d dir / d off = (I - dir dir^T) / |off|
 		const float along = dot3(dir, g_dir);
 		g_mean.x += (g_dir.x - along * dir.x) * ilen;
@@ -515,19 +536,63 @@ __global__ void __launch_bounds__(256) k_fill_zero(const FillArgs a)
 // kernel that walks all Gaussians in index order, clears every chunk's rows with coalesced stores and works the
 // chunk's visible ones off from an LDS list -- every row written once, no fill at all: 722 us against 539 + fill; at
 // 158 registers the kernel does not have the occupancy to stream 1.5 GB of zeros.)
-#ifndef FR_PBWD_WAVES
-#define FR_PBWD_WAVES 2
-#endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FR_PBWD_WAVES, FR_PBWD_WAVES))) k_preprocess_bwd(const BwdPreArgs a)
+__global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 {
+	// The SH rows of a wave's 64 Gaussians move TOGETHER: fifteen lanes read / write one row's 180 bytes of rest coefficients as
+	// 12-byte pieces (four rows per instruction) and the rows wait in LDS, where every lane works on its own. One lane per row
+	// with 16-byte accesses -- 64 different rows per instruction -- spent 100 us on these reads and 175 us on the writes of a
+	// 0.5 ms kernel (both measured by leaving them out).
+	constexpr int ROWF = 45;              // rest floats of a degree-3 row
+	__shared__ float s_rows[4][64 * ROWF];
+	__shared__ int s_idx[4][64];          // per lane of the wave: its Gaussian, or -1
+	__shared__ long long s_orow[4][64];   // ... and the row of the gradient tensors it writes, or -1
 	const int V = (int)*a.vis_count;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x)
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const bool have_sh = a.colors_precomp == nullptr && a.shs != nullptr;
+	const bool split = a.shs_rest != nullptr;
+	const int nrest = split ? (a.M - 1) * 3 : a.M * 3 - 3;
+	const bool coop = have_sh && nrest >= ROWF;   // (fewer coefficients per row: the per-lane path of preprocess_bwd_one)
+	const int nuse = 3 * ((a.D + 1) * (a.D + 1)) - 3;
+	const size_t src_stride = split ? (size_t)(a.M - 1) * 3 : (size_t)a.M * 3, src_off = split ? 0 : 3;
+	const float *src = split ? a.shs_rest : a.shs;
+	float *dst = split ? a.dL_dsh_rest : a.dL_dsh;
+	const int r_in = lane / 15, part = lane - 15 * r_in; // this lane's row of a group of four and its piece of that row
+	for (int base = (blockIdx.x * blockDim.x + wv * 64); base < V; base += gridDim.x * blockDim.x)
 	{
-		const int idx = (int)a.vis_list[i];
+		const int i = base + lane;
+		const int idx = i < V ? (int)a.vis_list[i] : 0;
 		// (radii[idx] > 0, read from the item's dense word instead of a 64-byte line per Gaussian: k_bin clears the radius of exactly
 		// the items it marks FR_ITEM_NONE)
-		if (a.lrange[i] != FR_ITEM_NONE) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i);
-		else if (a.row_sparse)
+		const bool alive = i < V && a.lrange[i] != FR_ITEM_NONE;
+		if (coop)
+		{
+			s_idx[wv][lane] = alive ? idx : -1;
+			s_orow[wv][lane] = alive ? (a.row_sparse ? (long long)i : (long long)idx) : -1;
+			FR_WAVE_LDS_SYNC();
+			float t[16][3];
+#pragma unroll
+			for (int it = 0; it < 16; it++)
+			{
+				const int r = 4 * it + r_in;
+				const int g = lane < 60 ? s_idx[wv][r] : -1;
+				t[it][0] = t[it][1] = t[it][2] = 0.0f;
+				if (g >= 0 && 3 * part < nuse)
+				{
+					const float *q = src + (size_t)g * src_stride + src_off + 3 * part;
+					t[it][0] = q[0]; t[it][1] = q[1]; t[it][2] = q[2];
+				}
+			}
+#pragma unroll
+			for (int it = 0; it < 16; it++)
+				if (lane < 60)
+				{
+					float *w = &s_rows[wv][(4 * it + r_in) * ROWF + 3 * part];
+					w[0] = t[it][0]; w[1] = t[it][1]; w[2] = t[it][2];
+				}
+			FR_WAVE_LDS_SYNC();
+		}
+		if (alive) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i, coop ? &s_rows[wv][lane * ROWF] : nullptr);
+		else if (a.row_sparse && i < V)
 		{
 			// a candidate that landed in no tile: its compact row is all zeros (every row of the compact tensors is written)
 			const size_t r = (size_t)i;
@@ -538,6 +603,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FR_PBW
 			if (a.dL_dcov3D) for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * r + k] = 0.f;
 			if (a.dL_dsh) for (int k = 0; k < 3 * a.M0; k++) a.dL_dsh[3 * (size_t)a.M0 * r + k] = 0.f;
 			if (a.dL_dsh_rest) for (int k = 0; k < 3 * (a.M - 1); k++) a.dL_dsh_rest[3 * (size_t)(a.M - 1) * r + k] = 0.f;
+		}
+		if (coop)
+		{
+			FR_WAVE_LDS_SYNC();
+			// the gradient rows leave the way the coefficients came (dense tensors: the active degree's part, the rest is the fill's;
+			// compact rows: all of it)
+			const int nstore = a.row_sparse ? ROWF : nuse;
+#pragma unroll
+			for (int it = 0; it < 16; it++)
+			{
+				const int r = 4 * it + r_in;
+				const long long o = lane < 60 ? s_orow[wv][r] : -1;
+				if (o >= 0 && 3 * part < nstore)
+				{
+					const float *w = &s_rows[wv][r * ROWF + 3 * part];
+					float *q = dst + (size_t)o * src_stride + src_off + 3 * part;
+					q[0] = w[0]; q[1] = w[1]; q[2] = w[2];
+				}
+			}
+			FR_WAVE_LDS_SYNC(); // the rows and tables are rewritten by the next round
 		}
 	}
 }

@@ -369,6 +369,10 @@ __device__ __forceinline__ bool band_reaches(int w, int tx, int ty, float gx, fl
 void set_error(const char *fmt, ...);
 int check_launch(const char *what, hipStream_t stream, bool debug);
 
+// the lanes of ONE wave exchange data through LDS: writes before, reads after
+#define FR_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 // ---- cross-row folds of gfx950 (k_render_bwd's nine gradient sums, k_render's contribution sums)
 typedef unsigned int bwd_u2 __attribute__((ext_vector_type(2)));
 // lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l]  (tools/scratch/permlane_test.hip)

@@ -762,8 +762,6 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 // instruction of the lanes' own rows touches 24-32 cache lines (~3 cycles per lane of the CU's one address unit: eleven such
 // stores per slab were a quarter of round 2's binning kernel). Transposed through the wave's LDS rows an instruction moves one
 // contiguous kilobyte. st: the wave's staging area of >= 64 N float4; nitems: valid items of the wave (0..64).
-#define FR_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <int N>
 __device__ __forceinline__ void rows_store(const float4 (&rows)[N], float4 *st, float4 *dst, const int nitems, const int lane)
 {
