@@ -74,6 +74,8 @@ def parse_args(argv=None):
                          "frame). Off by default: the views are independent and the path has no exchange step.")
     ap.add_argument("--activation-pass", action="store_true",
                     help="--mode train: activate the model's parameters with the fused pass instead of inside the rasterizer's kernels")
+    ap.add_argument("--row-sparse", action="store_true",
+                    help="--mode train: row-sparse gradients (an extension; the reference's contract, and the default, is dense)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch / rendezvous only (gloo without a GPU): rank 0 prints a line with n_gpus and exits")
     ap.add_argument("--master-port", type=int, default=0)
@@ -795,6 +797,7 @@ def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, 
     H, W = args.height, args.width
     tr = cloud.requires_grad_(True)
     tr.fuse_activations = not args.activation_pass
+    tr.row_sparse_grads = bool(args.row_sparse)
     target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))
     params = list(tr.parameters())
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
@@ -838,7 +841,7 @@ def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, 
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "S-6M cloud, pcheck_obb_sum forward + fused 0.8 L1 + 0.2 (1 - SSIM) + backward per rank (model "
                                    "activations " + ("inside the rasterizer's kernels" if tr.fuse_activations else "as one fused pass each way")
-                                   + "), gradient sum over ranks (multiview.allreduce_gradients)", "gaussians": args.points, "width": W, "height": H,
+                                   + (", row-sparse gradients" if args.row_sparse else "") + "), gradient sum over ranks (multiview.allreduce_gradients)", "gaussians": args.points, "width": W, "height": H,
                        "parallelism": f"views{world}"},
             "fwd_bwd_ms": round(fbm, 4), "collective_ms": round(com, 4), "views_per_s": round(world * K / elapsed, 3),
             "collective": dict(info or {}, algbw_GBs=None if algbw is None else round(algbw, 2),

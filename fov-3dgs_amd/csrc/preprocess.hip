@@ -1460,7 +1460,9 @@ struct EmitArgs {
 };
 // LDSH: the workgroup's write cursor of every tile lives in LDS, initialised to
 // tile start + (instances of the same tile owned by lower-numbered workgroups).
-#define FR_EMIT_THREADS FR_BIN_THREADS // (the same waves take the same slabs in k_bin and k_emit)
+#ifndef FR_EMIT_THREADS
+#define FR_EMIT_THREADS FR_BIN_THREADS // (a workgroup takes the slabs k_bin's workgroup of the same number took; its waves share them out)
+#endif
 // LDSH == 2 (see k_bin): the LDS cursors are 16-bit offsets inside the workgroup's share, two tiles per word; where the share
 // starts comes from global memory with every entry
 #define NEXT_SLOT(ti) (LDSH == 2 ? a.ranges[(ti)].x + pre_row[(ti)] + ((atomicAdd(&lds_cur[(ti) >> 1], 1u << (16 * ((ti) & 1))) >> (16 * ((ti) & 1))) & 0xffffu) \
@@ -1692,22 +1694,27 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	}; // process(slab)
 	{
 		// the slabs k_bin's wave of the same number took (the bucket offsets are per workgroup): wave, wave + waves, ...
-		const int wave_gid = (int)blockIdx.x * (FR_EMIT_THREADS / 64) + (int)(threadIdx.x >> 6);
-		const int nwaves = (int)gridDim.x * (FR_EMIT_THREADS / 64);
+		constexpr int BW = FR_BIN_THREADS / 64, EW = FR_EMIT_THREADS / 64;
+		const int bin_waves = (int)gridDim.x * BW;
+		// the workgroup's s-th slab: k_bin's wave (s mod BW) of this workgroup took it in its round s / BW
+		auto slab_of = [&](const int s) { return (int)blockIdx.x * BW + s % BW + (s / BW) * bin_waves; };
 		// one slab AHEAD: the next slab's records are in flight while this one's pairs are walked (the kernel's waves spent 73 %
 		// of their time parked on s_waitcnt: a slab's record loads in front of its walk, its stores behind)
 		SlabIn cur, nxt;
-		int slab = wave_gid;
+		int sq = (int)(threadIdx.x >> 6);
+		int slab = slab_of(sq);
 		if (slab < nslabs) fetch_slab(slab, cur);
 #ifdef FR_EMIT_TIMERS
 		const uint64_t tl0 = wall_clock64();
 #endif
-		for (; slab < nslabs; slab += nwaves)
+		for (; slab < nslabs; )
 		{
-			const bool more = slab + nwaves < nslabs;
-			if (more) fetch_slab(slab + nwaves, nxt);
+			const int next = slab_of(sq + EW); // (grows with s along a wave's sequence: EW >= BW)
+			const bool more = next < nslabs;
+			if (more) fetch_slab(next, nxt);
 			process(slab, cur);
 			if (more) cur = nxt;
+			sq += EW; slab = next;
 #ifdef FR_EMIT_TIMERS
 			tm_slabs++;
 #endif
@@ -1997,7 +2004,7 @@ int launch_emit(FwdCtx &c)
 				(const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 0>, (const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 1>, (const void *)k_emit<FR_VARIANT_FOV_PCHECK_OBB, 2> };
 			for (const void *fn : fns)
 			{
-				const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+				const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (FR_EMIT_THREADS > 768 ? 154 : 156) * 1024);
 				if (e1 != hipSuccess) return e1;
 			}
 			return hipSuccess; }();
