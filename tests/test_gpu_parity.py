@@ -135,6 +135,27 @@ def test_backward_matches_oracle(variant):
         check_grad(got[k].reshape(want[k].shape), want[k], k)
 
 
+@pytest.mark.parametrize("sh_degree", (0, 1, 2))
+def test_backward_at_lower_sh_degrees(sh_degree):
+    """Active SH degree below the allocated one (early training, scene/gaussian_model.py oneupSHdegree): only the coefficients of
+    the active degree are read and get a gradient (backward.cu:20-139), the rest of the [P,16,3] row stays zero -- the path of
+    k_preprocess_bwd that moves a wave's SH rows together handles rows that are only partly used."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_backward, hip_forward
+    scene, cam = small_case("pcheck_obb_sum")
+    cam = dict(cam, sh_degree=sh_degree)
+    want_f = orc.forward("pcheck_obb_sum", scene, cam)
+    dpix = np.random.default_rng(17 + sh_degree).normal(size=want_f["color"].shape).astype(np.float32)
+    want = orc.backward("pcheck_obb_sum", scene, cam, want_f, dpix)
+    got_f = hip_forward("pcheck_obb_sum", scene, cam)
+    check_image(got_f["color"], want_f["color"])
+    got = hip_backward("pcheck_obb_sum", got_f, dpix)
+    for k in ("dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot"):
+        check_grad(got[k].reshape(want[k].shape), want[k], f"{k} (degree {sh_degree})")
+    used = (sh_degree + 1) ** 2
+    assert np.all(got["dL_dsh"].reshape(-1, 16, 3)[:, used:] == 0.0)
+
+
 @pytest.mark.parametrize("variant", ("original", "fov_pcheck_obb"))
 def test_1k_scene_256(variant):
     """BASELINE config 1 (S-1k, 256x256) on the GPU path."""
