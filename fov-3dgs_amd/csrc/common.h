@@ -22,7 +22,8 @@
 #define FR_LDS_HIST_MAX_TILES 16384 // per-workgroup LDS tile histogram of 32-bit counts up to 64 KiB
 #define FR_ITEM_NONE 0xffffffffu    // GeomWS::lrange of an item that lands in no tile
 #define FR_LDS_HIST16_MAX_TILES 34816 // ... of 16-bit counts (two tiles per word) beyond that: a 4K frame has 32 400 tiles
-#define FR_HIST16_MAX_SLABS 127       // slabs a wave of k_bin takes at most then: 8 waves x 127 x 64 items < 65 536 per workgroup
+#define FR_HIST16_MAX_SLABS (65535 / FR_BIN_THREADS) // slabs a wave of k_bin takes at most then (85 of 64 items for twelve waves): a
+                                     // workgroup's waves x slabs x 64 items stay below 65 536, so no tile's 16-bit count can wrap
 #define FR_BIG_TNUM 64        // splats with at least this many tiles are binned by a whole wave at a time
 #define FR_GIANT_TNUM 1024     // ... and splats with this many by the whole workgroup, after its slab loop
 #define FR_GIANT_MAX 64         // giant splats a workgroup can set aside (more: handled like big ones)
