@@ -8,13 +8,14 @@
 //
 // MI355X design. The reference issues 9 float atomics per contributing (pixel, Gaussian) pair into four [P, .] arrays.
 // Here (k_render_bwd) a work item is one band of a tile (one wave, two pixels per lane, as in the forward blend); for
-// every list entry that reaches the band the 64 lanes' nine partial sums are reduced with gfx950's cross-row swaps
+// every list entry that reaches the band the 64 lanes' nine partial sums (three colour sums and the six moments of
+// G dL/dalpha about the splat centre: what backward.cu:524-541's five gradients are linear in) are reduced with gfx950's cross-row swaps
 // (v_permlane32_swap / v_permlane16_swap fold eight values into two registers in 12 instructions, four DPP steps finish
 // each row; 26 instructions instead of 54 for nine separate butterflies) so that the totals end up in nine DIFFERENT
 // lanes, which add them with ONE atomic instruction into ONE 64-byte row per Gaussian (`acc`, indexed by the
 // Gaussian's position in the forward pass's visible list: dense, zeroed by the forward pass, read back coalesced).
-// k_preprocess_bwd then walks all Gaussians in index order and writes every gradient row once: zeros or the fused
-// cov2D / projection / SH / cov3D chain rule (see there).
+// k_preprocess_bwd then walks the visible list and writes every visible Gaussian's gradient rows: the mean2D / conic / opacity
+// gradients from the moments, then the fused cov2D / projection / SH / cov3D chain rule (see there).
 #include "common.h"
 
 namespace fr {

@@ -63,9 +63,10 @@ struct GeomWS {
 	float4 *rec;        // [3P]
 	float *cov3D;       // training variants: [16P] one 64-byte row per item, written by k_bin for the
 	                    // backward pass: (xyz | raw scale | rotation | 3D covariance) -- one coalesced row instead of four gathers
-	float4 *acc;        // training variants: [4P] one 64-byte row of gradient sums per item, zeroed by k_bin,
+	float4 *acc;        // training variants: [4P] one 64-byte row of sums per item, zeroed by k_bin,
 	                    //      accumulated by k_render_bwd (one atomic instruction per list entry and wave), read by k_preprocess_bwd:
-	                    //      (dL/d colour r, g, b, dL/d mean2D x | y, dL/d conic a, b, c | dL/d opacity, -, -, - | -)
+	                    //      (dL/d colour r, g, b, M10 | M01, M20, M11, M02 | M00, -, -, - | 1 / |raw quaternion|, -, -, -) with M_ij the
+	                    //      moments of G dL/dalpha about the splat centre (the mean2D / conic / opacity gradients are linear in them)
 	float4 *wrec;       // [4P] walk record of item i at [4i..4i+3], written by k_bin for k_emit:
 	                    //      (cx, cy, e1x, e1y | e2x, e2y, len1, len2 | Gaussian index + flags << 30, depth bits, x0 + y0 << 16, width |
 	                    //      tiles, highest level, -, -); flags: 1 = lands in a tile, 2 = the OBB test applies
