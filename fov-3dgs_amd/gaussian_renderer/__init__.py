@@ -9,7 +9,7 @@ import math
 import torch
 
 from ..gaussian_wrapper import get_gs_rasterizer
-from ..rasterizer import GaussianRasterizationSettings, zero_points_like
+from ..rasterizer import GaussianRasterizationSettings, zero_points_leaf, zero_points_like
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, masking=False,
@@ -19,7 +19,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     xyz = pc.get_xyz
     # zero tensor that makes autograd return the gradient of the 2D (screen-space) means
     if torch.is_grad_enabled():
-        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+        screenspace_points = zero_points_leaf(xyz)
         try:
             screenspace_points.retain_grad()
         except Exception:

@@ -168,6 +168,23 @@ def zero_points_like(xyz):
     return row.expand(xyz.shape)
 
 
+_zero_leaves = {}
+
+
+def zero_points_leaf(xyz):
+    """render()'s `viewspace_points` of a training step: a NEW leaf tensor (requires_grad, its own .grad) of zeros shaped like xyz
+    -- the reference's torch.zeros_like(xyz, requires_grad=True) -- over ONE cached zero buffer per (device, dtype, shape): the
+    tensor only carries the gradient of the 2D means, its values are never read or written, and filling 72 MB per step at 6 M
+    Gaussians is 16 us at the head of every forward pass. Read-only by convention."""
+    key = (xyz.device, xyz.dtype, tuple(xyz.shape))
+    buf = _zero_leaves.get(key)
+    if buf is None:
+        if len(_zero_leaves) >= 4:
+            _zero_leaves.clear()  # (a model that changes size every few steps: densification)
+        buf = _zero_leaves[key] = torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device)
+    return buf.detach().requires_grad_(True)
+
+
 class PackedModel:
     """Packed copies of a STATIC model's rasterizer inputs (include/fovraster.h: packed_geom [P,16] /
     packed_colour [P,64] / packed_cull [P,4]): made once per model with pack_model(), passed to GaussianRasterizer(..., packed=...) next
