@@ -989,6 +989,7 @@ __device__ __forceinline__ void colour_item(const PreArgs &a, const bool rows_ok
 // the level range of RF rasterizer_impl.cu:374-381.
 #define BUMP_TILE(ti) do { if (LDSH == 2) atomicAdd(&lds_hist[(ti) >> 1], 1u << (16 * ((ti) & 1))); \
 	else if (LDSH) atomicAdd(&lds_hist[(ti)], 1u); else atomicAdd(&a.tile_count[(ti)], 1u); } while (0)
+static_assert((FR_BIN_THREADS / 64) * FR_HIST16_MAX_SLABS * 64 <= 65535, "a workgroup's items must fit a 16-bit tile count (LDSH == 2)");
 template <int VARIANT, int LDSH, bool PACKED = false, bool CROW = false>
 __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 {
