@@ -48,7 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GAZES = [(0.25 * i, 0.25 * j) for i in range(1, 4) for j in range(1, 4)]  # render_compose_gazes_fps.py:26
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def parse_args(argv=None):
@@ -205,9 +205,6 @@ def main():
         torch.cuda.synchronize()
 
     t0 = time.time()
-    cloud_cpu = syn.scene_bicycle_scale(P=args.points, seed=1)
-    fov_cpu = syn.foveation_layers(cloud_cpu, seed=2)
-    cloud = cloud_cpu.to(dev)
 
     class FrozenCloud:
         """Inference-time view of a cloud: activations evaluated once, getters return resident tensors."""
@@ -223,8 +220,17 @@ def main():
             self.get_features_detach_rest = self.get_features
             self.active_sh_degree = c.active_sh_degree
 
-    pc = FrozenCloud(cloud)
-    highest, shs_dcs, opac = [t.to(dev) for t in fov_cpu]
+    def make_scene(opacity_logit):
+        """-> dict: the seeded cloud (CPU + device), its foveation layers and the inference-time view of it"""
+        c_cpu = syn.scene_bicycle_scale(P=args.points, seed=1, opacity_logit=opacity_logit)
+        f_cpu = syn.foveation_layers(c_cpu, seed=2)
+        c_dev = c_cpu.to(dev)
+        hl, dcs, op4 = [t.to(dev) for t in f_cpu]
+        return dict(cloud_cpu=c_cpu, fov_cpu=f_cpu, cloud=c_dev, pc=FrozenCloud(c_dev), highest=hl, shs_dcs=dcs, opac=op4)
+
+    scene = make_scene(syn.OPACITY_LOGIT_S6M)
+    cloud_cpu, fov_cpu, cloud, pc = scene["cloud_cpu"], scene["fov_cpu"], scene["cloud"], scene["pc"]
+    highest, shs_dcs, opac = scene["highest"], scene["shs_dcs"], scene["opac"]
     n_views = 8
     my_view = rank % n_views
     cam = syn.camera_ring(my_view, n_views, W, H).to(dev)
@@ -235,11 +241,14 @@ def main():
     if args.mode == "train":
         return train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync)
 
-    def frame(gaze, packed, **kw):
-        return render_fov(cam, pc, bg, alpha=0.05, gazeArray=gaze, blending=True, highest_levels=highest, shs_dcs=shs_dcs,
-                          opacities=opac, packed=packed, **kw)
+    def frame_of(sc):
+        def frame_fn(gaze, packed, **kw):
+            return render_fov(cam, sc["pc"], bg, alpha=0.05, gazeArray=gaze, blending=True, highest_levels=sc["highest"],
+                              shs_dcs=sc["shs_dcs"], opacities=sc["opac"], packed=packed, **kw)
+        return frame_fn
+    frame = frame_of(scene)
 
-    def timed_run(packed, event_stages):
+    def timed_run(packed, event_stages, frame=frame, repeats=None):
         """W warm-ups + `repeats` x exactly K timed frames (gaze i % 9), barrier + synchronize on both sides of every repeat.
         Only the boundaries of `event_stages` are recorded inside the timed frames (every event record is a command on the
         stream, ~3 us: all eight cost 3.5 % of the frame). -> (median seconds, [min, max] seconds, {stage: mean ms})"""
@@ -250,7 +259,7 @@ def main():
                 out = frame(GAZES[i % 9], packed)
                 if world > 1 and args.gather:
                     multiview.gather_images(out["render"], dst=0)
-            for rep in range(max(1, args.repeats)):
+            for rep in range(max(1, args.repeats if repeats is None else repeats)):
                 barrier_sync()
                 timer = StageTimer(K, stages=event_stages)
                 t_start = time.perf_counter()
@@ -307,7 +316,7 @@ def main():
             times.append(el)
         return float(np.median(times)), [min(times), max(times)]
 
-    def stage_pass(packed, n=27):
+    def stage_pass(packed, n=27, frame=frame):
         """Untimed: every stage's kernel time (all eight events per frame), mean over n frames of the nine gazes."""
         with torch.no_grad():
             timer = StageTimer(n)
@@ -346,22 +355,32 @@ def main():
     # ---- untimed post-pass: instance statistics of the timed gazes (for the algorithmic bytes) ----
     vid = _native.VARIANT_FOV_PCHECK_OBB
     from fov3dgs_amd import rasterizer as rz
-    stats = []
-    with torch.no_grad():
-        for gaze in GAZES:
-            rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
-                                                  cam.world_view_transform, cam.full_proj_transform, 3,
-                                                  cam.camera_center, False, False)
-            res = rz._forward_native(vid, rs, pc.get_xyz, pc.get_rest_features, torch.Tensor([]), opac, pc.get_scaling,
-                                     pc.get_rotation, torch.Tensor([]), shs_dcs, highest, gaze, 0.05)
-            torch.cuda.synchronize()
-            stats.append(frame_stats(torch, lib, vid, (res[0], res[2], res[5]), W, H, T, geom=res[3], P=args.points))
-        vm = cam.world_view_transform
-        z = pc.get_xyz @ vm[:3, 2] + vm[3, 2]
-        V_in = int((z > 0.2).sum().item())
-    # timed step i uses gaze i % 9: weight the per-gaze statistics accordingly
-    wts = np.array([len(range(g, K, 9)) for g in range(9)], dtype=np.float64)
-    st = {k: float(np.sum([s[k] * w for s, w in zip(stats, wts)]) / wts.sum()) for k in stats[0]}
+
+    def gaze_stats(sc):
+        """-> (mean over the timed steps' gazes, per-gaze list, V_in) of V, C, D, D_single, D_blend, max_list, and `consumed`: the
+        fraction of the frame's instances the blend fetches before its pixels are finished (fr_forward_args.list_consumed)."""
+        per = []
+        pc_ = sc["pc"]
+        cons = torch.zeros(T, dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            for gaze in GAZES:
+                rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
+                                                      cam.world_view_transform, cam.full_proj_transform, 3,
+                                                      cam.camera_center, False, False)
+                res = rz._forward_native(vid, rs, pc_.get_xyz, pc_.get_rest_features, torch.Tensor([]), sc["opac"], pc_.get_scaling,
+                                         pc_.get_rotation, torch.Tensor([]), sc["shs_dcs"], sc["highest"], gaze, 0.05, list_consumed=cons)
+                torch.cuda.synchronize()
+                d = frame_stats(torch, lib, vid, (res[0], res[2], res[5]), W, H, T, geom=res[3], P=args.points)
+                d["consumed"] = float(cons.sum().item()) / max(d["D"], 1)
+                per.append(d)
+            vm = cam.world_view_transform
+            z = pc_.get_xyz @ vm[:3, 2] + vm[3, 2]
+            v_in = int((z > 0.2).sum().item())
+        # timed step i uses gaze i % 9: weight the per-gaze statistics accordingly
+        wts = np.array([len(range(g, K, 9)) for g in range(9)], dtype=np.float64)
+        mean = {k: float(np.sum([s_[k] * w for s_, w in zip(per, wts)]) / wts.sum()) for k in per[0]}
+        return mean, per, v_in
+    st, stats, V_in = gaze_stats(scene)
     P, Px = args.points, W * H
     counts = dict(st, P=P, Px=Px, T=T, V_in=V_in)
     alg_bytes = algorithmic_bytes("fov_pcheck_obb", counts)  # the RF formulas: SH per VISIBLE Gaussian (see there)
@@ -395,6 +414,51 @@ def main():
     extra = {}
     if world == 1 and not args.no_extra:
         extra = extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H, W)
+
+    # ---- S-6M-T: the same frames and the same training step on a cloud that CONSUMES its lists (synthetic.scene_translucent: same
+    # geometry, seeds and SH, opacity logits ~ N(-3.5, 1): the blend fetches 0.9 of a foveated frame's instances and 0.7 of the
+    # training frame's, 1.0 M Gaussians receive a gradient) -- which stage leads depends on the workload, and a trained model is
+    # nearer to this one than to S-6M's saturating cloud
+    if world == 1 and not args.no_extra:
+        tsc = make_scene(syn.OPACITY_LOGIT_S6MT)
+        frame_t = frame_of(tsc)
+        with torch.no_grad():
+            for i in range(9):
+                frame_t(GAZES[i], None)
+        el_t, sp_t, _ = timed_run(None, (), frame=frame_t, repeats=3)
+        ms_t = stage_pass(None, frame=frame_t)
+        st_t, stats_t, v_in_t = gaze_stats(tsc)
+        bytes_t = algorithmic_bytes("fov_pcheck_obb", dict(st_t, P=P, Px=Px, T=T, V_in=v_in_t))
+        slow = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: ms_t[k])
+        tr_t = tsc["cloud"].requires_grad_(True)
+        target_t = torch.rand(3, H, W, device=dev)
+        tt = training_extras(torch, np, syn, render_plain, cam, bg, tr_t, target_t, H, W, short=True)
+        tt.pop("train_note", None)
+        # the plain (training) frame's consumed share and the rows that receive a gradient
+        cons = torch.zeros(T, dtype=torch.int32, device=dev)
+        tpc = tsc["pc"]
+        with torch.no_grad():
+            rs_p = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0, cam.world_view_transform,
+                                                    cam.full_proj_transform, 3, cam.camera_center, False, False)
+            r_p = rz._forward_native(_native.VARIANT_PCHECK_OBB_SUM, rs_p, tpc.get_xyz, tpc.get_features, torch.Tensor([]), tpc.get_opacity,
+                                     tpc.get_scaling, tpc.get_rotation, torch.Tensor([]), persistent=True, list_consumed=cons)
+            torch.cuda.synchronize()
+            plain_consumed = float(cons.sum().item()) / max(int(r_p[0]), 1)
+        grad_rows = int((tr_t._opacity.grad != 0).sum().item()) if tr_t._opacity.grad is not None else None
+        extra["translucent"] = dict(
+            workload="S-6M-T: the S-6M cloud with opacity logits ~ N(%.1f, %.1f^2) (synthetic.scene_translucent), same camera, gazes, protocol" % syn.OPACITY_LOGIT_S6MT,
+            fps=round(K / el_t, 2), ms_per_step=round(el_t / K * 1e3, 4), fps_spread=[round(K / sp_t[1], 2), round(K / sp_t[0], 2)],
+            stages_ms={k: round(v, 4) for k, v in ms_t.items()}, list_consumed_frac=round(st_t["consumed"], 4),
+            list_consumed_frac_training_frame=round(plain_consumed, 4), gaussians_with_gradient=grad_rows,
+            visible=int(st_t["V"]), instances=int(st_t["D"]), max_tile_list=int(max(s_["max_list"] for s_ in stats_t)),
+            roofline=dict(kernel=slow, bound="hbm", kernel_ms=round(ms_t[slow], 4), algorithmic_bytes=int(bytes_t[slow]),
+                          achieved=round(bytes_t[slow] / (ms_t[slow] * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                          frac=round(bytes_t[slow] / (ms_t[slow] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                          note="the blend is VALU-bound (DESIGN 4): its HBM fraction is reported by the same formula as every stage's"),
+            **tt)
+        for p_ in tr_t.parameters():
+            p_.grad = None
+        del tsc, tr_t, tpc
 
     if "_train_counts" in extra:
         n_tr, fwd_ms, bwd_ms = extra.pop("_train_counts"), extra.pop("_train_fwd_ms"), extra.pop("_train_bwd_ms")
@@ -436,6 +500,10 @@ def main():
                    "gaussians": P, "width": W, "height": H, "alpha": 0.05, "sh_degree": 3,
                    "visible": int(st["V"]), "candidates": int(st["C"]), "in_front": V_in, "instances": int(st["D"]),
                    "instances_blend_tiles": int(st["D_blend"]), "max_tile_list": int(max(s["max_list"] for s in stats)),
+                   "list_consumed_frac": round(st["consumed"], 4),
+                   "list_consumed_note": "share of the frames' sorted instances the blend fetches before every pixel of their tile is finished "
+                                         "(fr_forward_args.list_consumed, batches of 64): the S-6M cloud (SURVEY 8d: opacity = sigmoid(N(1, 2^2))) "
+                                         "saturates early; extra.translucent is the same frame on S-6M-T, a cloud that consumes its lists",
                    "model_layout": "value: the reference's tensor interface (render(packed=None)); value_packed: the static-model "
                                    "layout (packed_geom / packed_colour, made once, bit-identical image)",
                    "parallelism": f"views{world}"},
@@ -615,38 +683,7 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
     # forward / loss / backward timed apart with events, median of 50
     tr = cloud.requires_grad_(True)
     target = torch.rand(3, H, W, device=dev)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    # the model's raw parameters activated inside the kernels / by the fused activation pass / raw parameters + ROW-SPARSE gradients
-    # (extension: the backward pass writes compact rows and autograd gets sparse tensors -- no 1.5 GB of zero fills)
-    for fuse, sparse in ((True, False), (False, False), (True, True)):
-        tr.fuse_activations = fuse
-        tr.row_sparse_grads = sparse
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(55)]
-        t1 = 0.0
-        for it in range(55):
-            if it == 5:  # the 50 timed steps run back to back as in a training loop (the forward's own synchronisation
-                torch.cuda.synchronize()  # for the instance count is the only one)
-                t1 = time.perf_counter()
-            ev = evs[it]
-            for p in tr.parameters():
-                p.grad = None
-            ev[0].record()
-            o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
-            ev[1].record()
-            loss = l1_ssim_loss(o["render"], target, 0.2)
-            ev[2].record()
-            loss.backward()
-            ev[3].record()
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t1) / 50 * 1e3
-        rows = [(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])) for e in evs[5:]]
-        med = [round(float(x), 3) for x in np.median(np.array(rows), axis=0)] + [round(wall, 3)]
-        if sparse:
-            extra["train_sparse_fwd_ms"], extra["train_sparse_loss_fwd_ms"], extra["train_sparse_bwd_ms"], extra["train_sparse_step_ms"] = med
-        elif fuse:
-            extra["train_raw_fwd_ms"], extra["train_raw_loss_fwd_ms"], extra["train_raw_bwd_ms"], extra["train_raw_step_ms"] = med
-        else:
-            extra["train_fwd_ms"], extra["train_loss_fwd_ms"], extra["train_bwd_ms"], extra["train_step_ms"] = med
+    extra.update(training_extras(torch, np, syn, render_plain, cam, bg, tr, target, H, W))
     # --- roofline of the training step's kernels (BASELINE metric "fwd+bwd ms/iter; HBM GB/s"): a short instrumented loop of the
     # raw-parameter step -- HIP events around the forward stages and around the backward pass's kernels, recorded by the library on
     # the streams the kernels run on; algorithmic bytes: training_bytes(); PMC bytes: the committed profile of the training step
@@ -677,35 +714,104 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
                 V_in=v_in, D=int(d_tr))
     extra["_train_counts"], extra["_train_fwd_ms"], extra["_train_bwd_ms"] = n_tr, fwd_ms, bwd_ms
     tr.row_sparse_grads = False
-    extra["train_note"] = ("pcheck_obb_sum forward (incl. the model's activations: one fused pass over all P Gaussians each way; "
-                           "train_raw_*: the model's raw parameters handed to the rasterizer, activations inside its kernels; "
-                           "train_sparse_*: the same with row-sparse gradients, an extension -- the reference's contract is dense) / fused "
-                           "L1+SSIM forward / backward of both (loss + rasterizer + activations), events on the stream, median of 50; "
-                           "*_step_ms = wall clock of 50 back-to-back steps / 50")
-    # the reference's formulation of the loss (five grouped conv2d's + elementwise ops + autograd) in torch on the same GPU
+    return extra
+
+
+def reference_loss_fn(torch, dev):
+    """The reference's formulation of the training loss (fov3dgs/utils/loss_utils.py:17-76 as eff_finetune.py:124-125 combines it:
+    l1_loss + ssim = five grouped conv2d's with an 11 x 11 Gaussian window + elementwise ops, differentiated by autograd), in torch."""
+    import torch.nn.functional as F
     g1 = torch.tensor([math.exp(-(i - 5) ** 2 / 4.5) for i in range(11)], device=dev)
     g1 = g1 / g1.sum()
     win = (g1[:, None] @ g1[None, :])[None, None].expand(3, 1, 11, 11).contiguous()
 
-    def torch_loss(img, gt):
+    def torch_loss(img, gt, lambda_dssim=0.2):
         a, b = img[None], gt[None]
         mu1, mu2 = F.conv2d(a, win, padding=5, groups=3), F.conv2d(b, win, padding=5, groups=3)
         s1 = F.conv2d(a * a, win, padding=5, groups=3) - mu1 * mu1
         s2 = F.conv2d(b * b, win, padding=5, groups=3) - mu2 * mu2
         s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
         m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
-        return 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - m.mean())
-    tl = []
-    img0 = o["render"].detach()
-    for it in range(8):
-        img = img0.clone().requires_grad_(True)
+        return (1.0 - lambda_dssim) * (img - gt).abs().mean() + lambda_dssim * (1.0 - m.mean())
+    return torch_loss
+
+
+def train_step_times(torch, np, render_plain, cam, bg, model, params, target, loss_fn, n=50, want_stats=True):
+    """n + 5 steps of render(pcheck_obb_sum) -> loss -> backward (no optimizer), back to back as a training loop runs them (the
+    forward call's wait for its instance count is the only synchronisation). -> dict: fwd / loss_fwd / bwd = medians of the
+    events around the three phases on the stream; step = wall clock of the n steps / n; raster_fwd / raster_bwd = medians of the
+    events around the native fr_forward / fr_backward calls alone (rasterizer-only)."""
+    from fov3dgs_amd.profiling import NativeCallTimer
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n + 5)]
+    t1 = 0.0
+    kw = {} if want_stats else {"want_stats": False}
+    with NativeCallTimer() as nt:
+        for it in range(n + 5):
+            if it == 5:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            ev = evs[it]
+            for p in params:
+                p.grad = None
+            ev[0].record()
+            o = render_plain(cam, model, Pipe(), bg, cuda_type="pcheck_obb_sum", **kw)
+            ev[1].record()
+            loss = loss_fn(o["render"], target, 0.2)
+            ev[2].record()
+            loss.backward()
+            ev[3].record()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        torch_loss(img, target).backward()
-        torch.cuda.synchronize()
-        tl.append((time.perf_counter() - t1) * 1e3)
-    extra["loss_fwd_bwd_torch_ms"] = round(float(np.median(tl[2:])), 3)
-    return extra
+        wall = (time.perf_counter() - t1) / n * 1e3
+        call = nt.ms()
+    rows = np.array([(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])) for e in evs[5:]])
+    med = np.median(rows, axis=0)
+    return dict(fwd=round(float(med[0]), 3), loss_fwd=round(float(med[1]), 3), bwd=round(float(med[2]), 3), step=round(wall, 3),
+                raster_fwd=round(float(np.median(call["fwd"][5:])), 3), raster_bwd=round(float(np.median(call["bwd"][5:])), 3)), o
+
+
+def training_extras(torch, np, syn, render_plain, cam, bg, tr, target, H, W, short=False):
+    """The training step of BASELINE config 4 in every form this package offers, on the model `tr` (requires_grad). Keys:
+      train_ref_*        a model that exposes ONLY the reference's getters (scene/gaussian_model.py:200-240: exp / normalize / sigmoid as
+                         torch expressions, get_features = torch.cat), dense gradients, the reference's torch L1 + SSIM
+                         (utils/loss_utils.py): what a maintainer gets from switching the imports, nothing else
+      train_ref_fused_*  the same model with this package's fused L1 + SSIM (one more import)
+      train_refmodel_*   a model with the reference GaussianModel's ATTRIBUTES too (raw tensors + torch.exp / sigmoid / normalize as
+                         scaling_ / opacity_ / rotation_activation): render() recognises it and skips the getters' temporaries
+                         (gaussian_renderer.FAST_REFERENCE_MODEL); fused loss
+      train_*            + the three activations as one fused pass each way, split SH storage (extension getters)
+      train_raw_*        + the raw parameters handed to the rasterizer (activations inside its kernels)
+      train_raw_nostats_* + render(want_stats=False): no gs_count / contribs (eff_finetune.py:107-108 drops them)
+      train_sparse_*     raw parameters + row-sparse gradients (the reference's contract is dense)
+    each: fwd / loss_fwd / bwd (events on the stream, median), step (wall clock of back-to-back steps), raster_fwd / raster_bwd
+    (events around the native calls alone)."""
+    from fov3dgs_amd.loss_utils import l1_ssim_loss
+    dev = target.device
+    torch_loss = reference_loss_fn(torch, dev)
+    n = 20 if short else 50
+    out = {}
+    params = tr.parameters()
+    ref = syn.ReferenceGetterModel(tr)
+
+    def put(prefix, model, loss_fn, **kw):
+        t, o = train_step_times(torch, np, render_plain, cam, bg, model, params, target, loss_fn, n=n, **kw)
+        out[prefix + "fwd_ms"], out[prefix + "loss_fwd_ms"], out[prefix + "bwd_ms"], out[prefix + "step_ms"] = t["fwd"], t["loss_fwd"], t["bwd"], t["step"]
+        out[prefix + "raster_fwd_ms"], out[prefix + "raster_bwd_ms"] = t["raster_fwd"], t["raster_bwd"]
+        return o
+    tr.fuse_activations, tr.row_sparse_grads = False, False
+    put("train_ref_", ref, torch_loss)
+    put("train_ref_fused_", ref, l1_ssim_loss)
+    put("train_refmodel_", syn.ReferenceShapedModel(tr), l1_ssim_loss)
+    if not short:
+        put("train_", tr, l1_ssim_loss)
+    tr.fuse_activations = True
+    put("train_raw_", tr, l1_ssim_loss)
+    put("train_raw_nostats_", tr, l1_ssim_loss, want_stats=False)
+    if not short:
+        tr.row_sparse_grads = True
+        put("train_sparse_", tr, l1_ssim_loss)
+        tr.row_sparse_grads = False
+    out["train_note"] = training_extras.__doc__.split("Keys:")[1].strip()
+    return out
 
 
 def multi_gpu_extras(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync, frame, torch, np):

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # (FOVRASTER_LIB: an experiment build of the library, tools/ab_build.sh -- never a different implementation: same ABI check)
 LIB_PATH = os.environ.get("FOVRASTER_LIB") or os.path.join(HERE, "libfovraster_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
 VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC, VARIANT_NAIVE_FOV_PCHECK_OBB, VARIANT_MMFR_PCHECK_OBB = 4, 5, 6, 7
@@ -45,6 +45,8 @@ class ForwardArgs(C.Structure):
         ("cur_level", C.c_float),
         ("raw_activations", C.c_int32),
         ("num_candidates", C.c_int32),
+        ("list_consumed", _FP),
+        ("no_stats", C.c_int32),
     ]
 
 
@@ -72,7 +74,7 @@ EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destr
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
            "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records",
            "fr_geometry_vis_list", "fr_geometry_vis_count", "fr_geometry_walk_records", "fr_geometry_level_colours",
-           "fr_geometry_level_ranges", "fr_forward_begin", "fr_forward_finish")
+           "fr_geometry_level_ranges", "fr_forward_begin", "fr_forward_finish", "fr_forward_abandon")
 
 _lib = None
 
@@ -154,6 +156,8 @@ def load():
     lib.fr_forward_begin.restype = C.c_int
     lib.fr_forward_finish.argtypes = [C.c_void_p]
     lib.fr_forward_finish.restype = C.c_int
+    lib.fr_forward_abandon.argtypes = [C.c_void_p]
+    lib.fr_forward_abandon.restype = C.c_int
     if lib.fr_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"fovraster: ABI version mismatch ({lib.fr_abi_version()} != {ABI_VERSION})")
     _lib = lib

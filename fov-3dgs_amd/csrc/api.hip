@@ -76,7 +76,8 @@ static int validate_forward(const fr_forward_args *a)
 	{ set_error("the packed model needs scales + rotations and shs with all 16 coefficients (M=%d)", a->M); return FR_ERR_INVALID; }
 	if (a->raw_activations && (is_fov(a->variant) || !has_sr || a->packed_geom))
 	{ set_error("raw_activations: plain variants with scales + rotations, without the packed layout"); return FR_ERR_INVALID; }
-	if (has_stats(a->variant) && (!a->gaussians_count || !a->contributions)) { set_error("this variant needs gaussians_count and contributions"); return FR_ERR_INVALID; }
+	if (a->no_stats && a->variant != FR_VARIANT_PCHECK_OBB_SUM) { set_error("no_stats: pcheck_obb_sum only"); return FR_ERR_INVALID; }
+	if (has_stats(a->variant) && !a->no_stats && (!a->gaussians_count || !a->contributions)) { set_error("this variant needs gaussians_count and contributions"); return FR_ERR_INVALID; }
 	if (a->variant == FR_VARIANT_PCHECK_OBB_LWMC && !a->loss_map) { set_error("pcheck_obb_loss_weighted_max_count needs loss_map"); return FR_ERR_INVALID; }
 	return FR_OK;
 }
@@ -138,13 +139,22 @@ namespace fr {
 // 64 bytes of pinned, device-mapped host memory per frame in flight: k_tile_scan writes the frame's totals and its sequence
 // number there, the host polls (a copy command after the kernel costs ~10 us more of an idle GPU). A small pool per host
 // thread; the device address of mapped host memory belongs to the device that was current when it was asked for.
-struct PinnedBlock { uint32_t *host = nullptr, *dev = nullptr; int device = -1; bool busy = false; };
+struct PinnedBlock
+{
+	uint32_t *host = nullptr, *dev = nullptr; int device = -1; bool busy = false;
+	hipEvent_t quarantine = nullptr; bool quarantined = false; // an ABANDONED frame's tile scan may still be on its way to the block
+};
 static PinnedBlock *take_pinned(int device)
 {
 	static thread_local PinnedBlock pool[16];
 	PinnedBlock *spare = nullptr;
 	for (PinnedBlock &b : pool)
 	{
+		if (b.quarantined)
+		{
+			if (hipEventQuery(b.quarantine) != hipSuccess) { (void)hipGetLastError(); continue; }
+			b.quarantined = false;
+		}
 		if (!b.busy && b.host && b.device == device) { b.busy = true; return &b; }
 		if (!b.busy && !spare && (!b.host || b.device != device)) spare = &b;
 	}
@@ -228,7 +238,8 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 	// (fr_forward_finish).
 	f->ax = !a->debug ? aux_stream(stream) : nullptr;
 	hipStream_t fill_stream = stream;
-	if (f->ax && (c.fov_split || has_stats(a->variant)))
+	const bool stats = has_stats(a->variant) && !a->no_stats;
+	if (f->ax && (c.fov_split || stats))
 	{
 		if (hipEventRecord(f->ax->fork, stream) != hipSuccess || hipStreamWaitEvent(f->ax->s2, f->ax->fork, 0) != hipSuccess) { (void)hipGetLastError(); f->ax = nullptr; }
 		else fill_stream = f->ax->s2;
@@ -240,7 +251,7 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 		fills_done();
 		if (e != hipSuccess) { set_error("hipMemsetAsync(out_color): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
 	}
-	if (has_stats(a->variant))
+	if (stats)
 	{
 		const hipError_t e1 = hipMemsetAsync(a->gaussians_count, 0, sizeof(int32_t) * (size_t)a->P, fill_stream);
 		const hipError_t e2 = hipMemsetAsync(a->contributions, 0, sizeof(float) * (size_t)a->P, fill_stream);
@@ -253,6 +264,7 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 	FR_HIP(hipMemsetAsync(c.img.tile_count, 0, (size_t)((char *)(c.img.lv_bbox + 5 * FR_LV_BBOX_STRIDE) - (char *)c.img.tile_count), stream)); // + lv_bbox
 	if (!is_fov(a->variant)) // RF: k_tile_levels clears them
 		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
+	if (a->list_consumed) FR_HIP(hipMemsetAsync(a->list_consumed, 0, sizeof(uint32_t) * (size_t)c.T, stream));
 	static thread_local uint32_t frame_seq = 0; // this frame's tag: the totals block's sequence word
 	if (++frame_seq == 0) frame_seq = 1;
 	c.totals_seq = frame_seq;
@@ -354,6 +366,21 @@ int fr_forward_finish(fr_frame *f)
 	return rc;
 }
 
+int fr_forward_abandon(fr_frame *f)
+{
+	if (!f) { set_error("null frame"); return FR_ERR_INVALID; }
+	if (f->pin && !f->empty)
+	{
+		// the frame's tile scan has not necessarily written its totals yet: the block is not handed to another frame before it has
+		PinnedBlock *b = f->pin;
+		if (!b->quarantine && hipEventCreateWithFlags(&b->quarantine, hipEventDisableTiming) != hipSuccess) b->quarantine = nullptr;
+		if (b->quarantine && hipEventRecord(b->quarantine, f->c.stream) == hipSuccess) b->quarantined = true;
+		else { (void)hipGetLastError(); (void)hipStreamSynchronize(f->c.stream); }
+	}
+	delete f; // ~fr_frame joins the helper stream and releases the pinned block
+	return FR_OK;
+}
+
 int fr_forward(fr_forward_args *a)
 {
 	fr_frame *f = nullptr;
@@ -440,6 +467,8 @@ int fr_backward(const fr_backward_args *a)
 	if (a->shs && !a->dL_dsh) { set_error("dL_dsh is null"); return FR_ERR_INVALID; }
 	if (a->shs_rest && (!a->shs || !a->dL_dsh_rest)) { set_error("shs_rest needs shs and dL_dsh_rest"); return FR_ERR_INVALID; }
 	if (a->raw_activations && a->cov3D_precomp) { set_error("raw_activations needs scales + rotations"); return FR_ERR_INVALID; }
+	// (row_sparse promises that every compact row is written: with cov3D_precomp nobody writes dL_dscale / dL_drot)
+	if (a->row_sparse && a->cov3D_precomp) { set_error("row_sparse needs scales + rotations (with cov3D_precomp the dL_dscale / dL_drot rows would stay unwritten)"); return FR_ERR_INVALID; }
 	return launch_backward(a);
 }
 

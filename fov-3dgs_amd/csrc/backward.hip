@@ -165,10 +165,15 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 				const bv2 am = (bv2){ on_x ? alpha.x : 0.0f, on_y ? alpha.y : 0.0f };
 				const bv2 Gm = (bv2){ on_x ? G.x : 0.0f, on_y ? G.y : 0.0f };
 				const bv2 om = 1.0f - am;
-				// 1 / (1 - alpha): v_rcp_f32 and one Newton step (the reference divides twice per pixel: ~24 instructions)
-				bv2 r = (bv2){ __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
-				r = r * __builtin_elementwise_fma(-om, r, (bv2){ 2.0f, 2.0f });
-				const bv2 Tn = T * r;
+				// T / (1 - alpha) (backward.cu:503: the transmittance in front of the entry, recovered by division -- thousands of times
+				// in a row on a deep list, so every rounding counts): q0 = T * rcp(1 - alpha) is good to ~1.5 ulp; one residual step,
+				// q = q0 + (T - (1 - alpha) q0) * rcp, leaves the quotient within half an ulp and a bit, like the reference's division
+				// (the reference divides twice per pixel, ~24 instructions; a Newton step on the reciprocal instead -- round 4 -- costs
+				// the same two instructions as this one and left T 4 x noisier than the reference's on lists 5 000 entries deep:
+				// tests/test_full_size_parity.py, S-6M-T, dL_dcolor against the double-precision oracle)
+				const bv2 r = (bv2){ __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
+				const bv2 q0 = T * r;
+				const bv2 Tn = __builtin_elementwise_fma(__builtin_elementwise_fma(-om, q0, T), r, q0);
 				T = Tn;
 				const bv2 wgt = am * Tn;                                       // d channel / d colour
 				const bv2 c0 = wgt * dp0, c1 = wgt * dp1, c2 = wgt * dp2;

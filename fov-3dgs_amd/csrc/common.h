@@ -39,6 +39,7 @@
 namespace fr {
 
 // variant traits
+#define FR_VARIANT_SUM_NOSTATS 100 // internal (k_render only): pcheck_obb_sum's blend without gaussians_count / contributions
 __host__ __device__ inline bool has_stats(int v) { return v == FR_VARIANT_PCHECK_OBB_SUM || v == FR_VARIANT_PCHECK_OBB_MAX || v == FR_VARIANT_PCHECK_OBB_LWMC; }
 __host__ __device__ inline bool has_backward(int v) { return v == FR_VARIANT_ORIGINAL || has_stats(v); }
 // variants that bin by eccentricity level (tile level map, level filter): RF and the shared-model baseline

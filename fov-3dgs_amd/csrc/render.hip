@@ -111,6 +111,33 @@ __device__ __forceinline__ void blend2(Px2 &s, bool in_x, bool in_y, v2f e, floa
 	blend2(s, in_x, in_y, e, c, w, ax, ay);
 }
 
+// The same update with the bookkeeping folded differently (k_render_fov): a finished pixel carries T = 0 -- every product with it is
+// an exact zero and T (1 - alpha) = 0 < 1e-4 keeps it finished, so no "still blending" test is needed -- and the transmittance the
+// pixel ends with (the reference's T: the saturating Gaussian is not accumulated, forward.cu:367-372) is kept beside it in Tk;
+// `ok` = the two skip tests of the reference that do not depend on T (outside the support, alpha < 1/255) as ONE comparison made by
+// the caller. Two compares + four selects per pixel instead of four + three: a v_cmp costs two plain VALU slots on gfx950.
+struct Px2k { v2f T, Tk, C0, C1, C2; };
+template <bool CLAMP>
+__device__ __forceinline__ void blend2k(Px2k &s, bool ok_x, bool ok_y, v2f e, float4 c)
+{
+	v2f alpha = c.w * e;
+	if (CLAMP) { alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y); }
+	const v2f tt = s.T * (1.0f - alpha);
+	v2f w = alpha * s.T;
+	const bool sat_x = tt.x < 0.0001f, sat_y = tt.y < 0.0001f;
+	const bool acc_x = ok_x && !sat_x, acc_y = ok_y && !sat_y;
+	w.x = acc_x ? w.x : 0.0f;
+	w.y = acc_y ? w.y : 0.0f;
+	s.C0 = __builtin_elementwise_fma((v2f){ c.x, c.x }, w, s.C0);
+	s.C1 = __builtin_elementwise_fma((v2f){ c.y, c.y }, w, s.C1);
+	s.C2 = __builtin_elementwise_fma((v2f){ c.z, c.z }, w, s.C2);
+	s.Tk.x = acc_x ? tt.x : s.Tk.x;
+	s.Tk.y = acc_y ? tt.y : s.Tk.y;
+	const float nx = sat_x ? 0.0f : tt.x, ny = sat_y ? 0.0f : tt.y;
+	s.T.x = ok_x ? nx : s.T.x;
+	s.T.y = ok_y ? ny : s.T.y;
+}
+
 struct RenderArgs {
 	int W, H, gx;
 	const uint2 *ranges;
@@ -133,7 +160,14 @@ struct RenderArgs {
 	uint32_t capacity;            // instances the binning workspace holds: a frame with more is not blended (the host replays it)
 	float cur_level;              // MMFR
 	uint32_t *round_flags;        // RS / LWMC: one bit per (tile, 256-entry round): the round's counts have an owner
+	uint32_t *consumed;           // optional diagnostic (fr_forward_args.list_consumed): [T], entries fetched per tile, or null
 };
+
+// list_consumed: a wave reports how far into its tile's list it staged entries for blending (one atomic per wave, only when asked for)
+__device__ __forceinline__ void report_consumed(const RenderArgs &a, int tile, int used, int lane)
+{
+	if (a.consumed != nullptr && lane == 0 && used > 0) atomicMax(a.consumed + tile, (uint32_t)used);
+}
 
 // ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB / _MAX / _LWMC ----------------
 // One single-wave workgroup per work item (a band of eight rows of a tile; render_items, longest list first), every
@@ -151,6 +185,7 @@ struct RenderArgs {
 template <int VARIANT, int PPL>
 __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 {
+	// (FR_VARIANT_SUM_NOSTATS, internal: pcheck_obb_sum for a caller that drops the statistics, fr_forward_args.no_stats)
 	constexpr bool CUTOFF = VARIANT != FR_VARIANT_ORIGINAL;
 	constexpr bool SUM = VARIANT == FR_VARIANT_PCHECK_OBB_SUM;   // contributions += alpha*T, count per fetched entry
 	constexpr bool PMAX = VARIANT == FR_VARIANT_PCHECK_OBB_MAX;  // contributions = max alpha*T, count per in-support pixel
@@ -211,6 +246,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		if (NEEDID) pgid = a.vis_list[pid];
 	}
 	bool counting = false; // FETCHCNT: this wave owns the counts of the current 256-entry round
+	int used = 0;          // list entries this wave staged for blending (list_consumed)
 	for (int base = 0; base < n; base += 64)
 	{
 		float tmax0 = -1.0f;
@@ -245,6 +281,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			if (base + 64 + st < n) pgid = a.vis_list[a.point_list[range.x + base + 64 + st]];
 			continue;
 		}
+		used = min(n, base + 64);
 		if (staged)
 		{
 			s0[st] = p0; s1[st] = p1; s2[st] = p2;
@@ -406,6 +443,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		}
 	}
 
+	report_consumed(a, tile, used, st);
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 	const size_t plane = (size_t)a.W * a.H;
 #pragma unroll
@@ -506,6 +544,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 			pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + (upper ? L2 : L1)];
 		};
 		if (lane < n) fetch(lane);
+		int used = 0; // list entries this wave staged for blending (list_consumed)
 		for (int base = 0; base < n; base += 64)
 		{
 			float tmax0 = -1.0f;
@@ -522,6 +561,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 			tm_sync += wall_clock64() - tq0;
 #endif
 			const bool staged = base + lane < n;
+			used = min(n, base + 64);
 			if (staged) { s0[lane] = p0; s1[lane] = make_float4(p1.x, p1.y, 0.0f, 0.0f); sl1[lane] = pl1; }
 			unsigned long long reach_mask;
 			{
@@ -607,6 +647,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 			a.n_contrib[4 * G + b] = (uint32_t)tm_loop; a.n_contrib[5 * G + b] = (uint32_t)tm_sync;
 		}
 #endif
+		report_consumed(a, tile, used, lane);
 #pragma unroll
 		for (int k = 0; k < PPL; k++)
 		{
@@ -618,6 +659,217 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 			{
 				// RF forward.cu:455-470: C1 * w1 + C2 * (1 - w1), w1 = 1 - smoothstep
 				float x = fabsf(est[k] - ((float)L1 + 0.5f)) / 0.5f;
+				x = fmaxf(0.0f, fminf(1.0f, x));
+				const float bT = 3 * x * x - 2 * x * x * x;
+				const float w1 = 1 - bT;
+				const float w = upper ? (1.f - w1) : w1;
+				atomicAdd(&a.out_color[pid], o0 * w);
+				atomicAdd(&a.out_color[plane + pid], o1 * w);
+				atomicAdd(&a.out_color[2 * plane + pid], o2 * w);
+				continue;
+			}
+			a.out_color[pid] = o0;
+			a.out_color[plane + pid] = o1;
+			a.out_color[2 * plane + pid] = o2;
+		}
+	}
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(64, 8) k_render_fov_diet(const RenderArgs a)
+{
+	static_assert(PPL == 2, "work items encode two bands per tile");
+	constexpr int HP = PPL / 2;
+	// three rows of 16 bytes per staged entry, all with the same stride: one address register serves the three reads
+	__shared__ float4 s0[64];   // x, y, A, B
+	__shared__ float4 s1[64];   // C, highest_level, -, -
+	__shared__ float4 sl1[64];  // this wave's level: r, g, b, opacity
+
+	const int lane = threadIdx.x;
+	const uint32_t idx = blockIdx.x;
+	if (idx >= a.totals[5] || a.totals[0] > a.capacity || a.totals[5] > gridDim.x) return;
+	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+	const size_t plane = (size_t)a.W * a.H;
+	{
+		const uint32_t item = a.render_items[idx];
+		const int tile = (int)(item >> 3), wv = (int)(item & 1u);
+		const bool two_level = (item & 4u) != 0;
+		const bool upper = (item & 2u) != 0; // this wave carries the state of level L2
+		const int tx = tile % a.gx, ty = tile / a.gx;
+		const int tid = wv * 64 + lane; // position inside the tile's 256 / PPL threads (row mapping)
+		const int lx = tid & 15;
+		const int px = tx * FR_TILE + lx;
+		const float pxf = (float)px;
+		const uint2 range = a.ranges[tile];
+		const int n = (int)(range.y - range.x);
+		const float tlf = a.tile_lv[a.T + tile];                    // tile_min
+		const int L1 = f2i(tlf);
+		const int L2 = L1 + 1;
+		const float L2f = tlf + 1.0f;
+		const float tgx = a.tile_lv[2 * (size_t)a.T + tile], tgy = a.tile_lv[3 * (size_t)a.T + tile];
+
+		// Per-lane state of the lane's pixels (rows ry, ry + 4), kept as a packed pair so that the blend runs on
+		// v_pk_mul / v_pk_fma. A finished pixel carries its transmittance NEGATED: "still blending" is T > 0, no
+		// separate flag registers, and |T| is the value the reference keeps.
+		Px2k S1[HP];
+		float pyf[PPL];
+		bool inside[PPL];
+		auto est_of = [&](int k) { return tlf + ((float)lx * tgx + (float)tile_row<PPL>(tid, k) * tgy) / (float)FR_TILE; };
+#pragma unroll
+		for (int k = 0; k < PPL; k++)
+		{
+			const int ly = tile_row<PPL>(tid, k);
+			const int py = ty * FR_TILE + ly;
+			pyf[k] = (float)py;
+			inside[k] = px < a.W && py < a.H;
+			// RF forward.cu:262-476: level L1 stops contributing beyond est > L2; single-level tiles have no second state
+			const bool done1 = (two_level && !upper) ? (!inside[k] || (est_of(k) > (float)L2)) : !inside[k];
+			S1[k >> 1].T[k & 1] = done1 ? 0.0f : 1.0f; // a finished pixel carries T = 0 (blend2k) ...
+			S1[k >> 1].Tk[k & 1] = 1.0f;                // ... and the transmittance it ends with here
+		}
+#pragma unroll
+		for (int h = 0; h < HP; h++) S1[h].C0 = S1[h].C1 = S1[h].C2 = (v2f){ 0.f, 0.f };
+
+#ifdef FR_TILE_TIMERS
+		const uint64_t tm0 = wall_clock64(); uint32_t tm_proc = 0, tm_batches = 0; uint64_t tm_loop = 0, tm_sync = 0;
+#endif
+		// prefetch registers
+		float4 p0 = make_float4(0, 0, 0, 0), pl1 = p0;
+		float2 p1 = make_float2(0, 0);
+		auto fetch = [&](int e)
+		{
+			const uint32_t id = a.point_list[range.x + e];
+			const float4 *r = a.rec + 3 * (size_t)id;
+			p0 = r[0];
+			const float4 r1 = r[1];
+			p1 = make_float2(r1.x, r1.y);
+			pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + (upper ? L2 : L1)];
+		};
+		if (lane < n) fetch(lane);
+		int used = 0; // list entries this wave staged for blending (list_consumed)
+		for (int base = 0; base < n; base += 64)
+		{
+			float tmax0 = -1.0f;
+#pragma unroll
+			for (int h = 0; h < HP; h++) tmax0 = fmaxf(tmax0, fmaxf(S1[h].T.x, S1[h].T.y));
+#ifdef FR_TILE_TIMERS
+			const uint64_t tq0 = wall_clock64();
+#endif
+			if (!__any(tmax0 > 0.0f)) break;
+			// the previous batch has been read by all lanes (wave-synchronous, fenced)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#ifdef FR_TILE_TIMERS
+			tm_sync += wall_clock64() - tq0;
+#endif
+			const bool staged = base + lane < n;
+			used = min(n, base + 64);
+			// The two skip tests that do not depend on the pixel's transmittance as ONE threshold on q = -power (RF forward.cu:556-566):
+			// outside the support (power > 0 or power < -4.5) and alpha = o e^-q < 1/255 <=> q > ln(255 o). With tq = min(4.5, ln(255 o))
+			// a pixel takes part iff 0 <= q <= tq: one unsigned comparison on q's bits (in_support()). ln(255 o) to an ulp (logf, not the
+			// hardware's approximate log): the decision then differs from the reference's own fp32 evaluation of o * exp(power) < 1/255
+			// only inside that expression's rounding, like the exp2-based test it replaces.
+			const float lq = logf(255.0f * pl1.w);
+			const float tq = fmaxf(0.0f, fminf(4.5f, lq));
+			if (staged) { s0[lane] = p0; s1[lane] = make_float4(p1.x, tq, 0.0f, 0.0f); sl1[lane] = pl1; }
+			unsigned long long reach_mask;
+			{
+				// alpha < 1/255 everywhere (forward.cu:563) <=> power < -ln(255 opacity): tighter than -4.5 for faint splats
+				const float thr = fmaxf(-4.5f, -lq - 0.01f);
+				// a wave that carries the level-L2 state skips the Gaussians that do not exist at L2 (RF forward.cu:399: about
+				// half the list in a 0/1 tile) here, at one lane's cost, instead of walking them as no-ops
+				const bool exists = !upper || !((p1.y + 1.0f) < L2f);
+				reach_mask = __ballot(staged && exists && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
+			}
+			if (base + 64 + lane < n) fetch(base + 64 + lane);
+			// lanes read entries other lanes staged
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			v2f pyp[HP];
+#pragma unroll
+			for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
+#ifdef FR_TILE_TIMERS
+			const uint64_t tq1 = wall_clock64();
+			tm_proc += (uint32_t)__popcll(reach_mask); tm_batches++;
+#endif
+			// Entries are taken two at a time: everything that does not depend on the running transmittance (record
+			// fetch, power, exp, alpha inputs) is evaluated for both before either is blended, so the two dependency
+			// chains overlap.
+			struct Ent { v2f e[HP]; bool inx[HP], iny[HP]; float4 c1; };
+			auto prepare = [&](const int j, const bool valid)
+			{
+				Ent t;
+				const float4 g0 = s0[j];
+				const float2 g1 = *(const float2 *)&s1[j];
+				const float g1x = g1.x;
+				const uint32_t tqb = __float_as_uint(g1.y);
+				const float dx = g0.x - pxf;
+				const float adx2 = (g0.z * dx) * dx;
+				const float bdx = g0.w * dx;
+#pragma unroll
+				for (int h = 0; h < HP; h++)
+				{
+					const v2f q = qform2(g0.y - pyp[h], g1x, adx2, bdx);
+					// in the splat's support: RF forward.cu:556-560 (power > 0 and power < -4.5 are skipped)
+					t.inx[h] = valid && __float_as_uint(q.x) <= tqb; // ... and alpha >= 1/255
+					t.iny[h] = valid && __float_as_uint(q.y) <= tqb;
+					t.e[h] = exp_neg_pair(q);
+				}
+				t.c1 = sl1[j];
+				return t;
+			};
+			for (unsigned long long rm = reach_mask; rm; )
+			{
+				int jj[FR_RENDER_GROUP];
+				bool vv[FR_RENDER_GROUP];
+#pragma unroll
+				for (int g = 0; g < FR_RENDER_GROUP; g++)
+				{
+					vv[g] = rm != 0;
+					jj[g] = vv[g] ? __builtin_ctzll(rm) : jj[0];
+					rm &= rm - 1; // stays 0 once empty
+				}
+				float tmax = -1.0f;
+#pragma unroll
+				for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(S1[h].T.x, S1[h].T.y));
+				if (!__any(tmax > 0.0f)) break;
+				Ent t[FR_RENDER_GROUP];
+#pragma unroll
+				for (int g = 0; g < FR_RENDER_GROUP; g++) t[g] = prepare(jj[g], vv[g]);
+#pragma unroll
+				for (int g = 0; g < FR_RENDER_GROUP; g++)
+#pragma unroll
+					for (int h = 0; h < HP; h++) blend2k<true>(S1[h], t[g].inx[h], t[g].iny[h], t[g].e[h], t[g].c1);
+			}
+#ifdef FR_TILE_TIMERS
+			tm_loop += wall_clock64() - tq1;
+#endif
+		}
+
+#ifdef FR_TILE_TIMERS
+		if (lane == 0)
+		{
+			// developer build only (tools/tile_cycles.py): per-ITEM records in the otherwise unused final_T / n_contrib arrays
+			const uint32_t G = 4u * (uint32_t)a.T, b = idx;
+			a.final_T[b] = (float)(wall_clock64() - tm0); a.final_T[G + b] = (float)(tm0 & 0xffffff);
+			a.n_contrib[b] = tm_proc; a.n_contrib[G + b] = tm_batches; a.n_contrib[2 * G + b] = (uint32_t)n;
+			a.n_contrib[3 * G + b] = (uint32_t)tile | ((uint32_t)wv << 16) | ((uint32_t)upper << 20) | ((uint32_t)two_level << 21);
+			a.n_contrib[4 * G + b] = (uint32_t)tm_loop; a.n_contrib[5 * G + b] = (uint32_t)tm_sync;
+		}
+#endif
+		report_consumed(a, tile, used, lane);
+#pragma unroll
+		for (int k = 0; k < PPL; k++)
+		{
+			if (!inside[k]) continue;
+			const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
+			const float t1 = S1[k >> 1].Tk[k & 1];
+			const float o0 = fmaf(bg0, t1, S1[k >> 1].C0[k & 1]), o1 = fmaf(bg1, t1, S1[k >> 1].C1[k & 1]), o2 = fmaf(bg2, t1, S1[k >> 1].C2[k & 1]);
+			if (two_level)
+			{
+				// RF forward.cu:455-470: C1 * w1 + C2 * (1 - w1), w1 = 1 - smoothstep
+				float x = fabsf(est_of(k) - ((float)L1 + 0.5f)) / 0.5f;
 				x = fmaxf(0.0f, fminf(1.0f, x));
 				const float bT = 3 * x * x - 2 * x * x * x;
 				const float w1 = 1 - bT;
@@ -708,12 +960,14 @@ __global__ void __launch_bounds__(64) k_render_smfr(const RenderArgs a)
 		pc = make_float4(r1.z, r1.w, r2.x, 0.0f);
 	};
 	if (lane < n) fetch(lane);
+	int used = 0;
 	for (int base = 0; base < n; base += 64)
 	{
 		const float tmax0 = fmaxf(fmaxf(S1.T.x, S1.T.y), fmaxf(S2.T.x, S2.T.y));
 		if (!__any(tmax0 > 0.0f)) break;
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		used = min(n, base + 64);
 		const bool staged = base + lane < n;
 		if (staged) { s0[lane] = p0; s1[lane] = p1; scol[lane] = pc; }
 		unsigned long long reach_mask;
@@ -750,6 +1004,7 @@ __global__ void __launch_bounds__(64) k_render_smfr(const RenderArgs a)
 			}
 		}
 	}
+	report_consumed(a, tile, used, lane);
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 	const size_t plane = (size_t)a.W * a.H;
 #pragma unroll
@@ -842,11 +1097,13 @@ __global__ void __launch_bounds__(64) k_render_mmfr(const RenderArgs a)
 		pc = make_float4(r1.z, r1.w, r[2].x, 0.0f);
 	};
 	if (lane < n) fetch(lane);
+	int used = 0;
 	for (int base = 0; base < n; base += 64)
 	{
 		if (!__any(fmaxf(S.T.x, S.T.y) > 0.0f)) break;
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		used = min(n, base + 64);
 		const bool staged = base + lane < n;
 		if (staged) { s0[lane] = p0; s1[lane] = p1; scol[lane] = pc; }
 		const float thr = fmaxf(-4.5f, -__logf(255.0f * p1.y) - 0.01f);
@@ -868,6 +1125,7 @@ __global__ void __launch_bounds__(64) k_render_mmfr(const RenderArgs a)
 			blend2(S, !(pw.x > 0.0f || pw.x < -4.5f), !(pw.y > 0.0f || pw.y < -4.5f), exp2_pair(pw), make_float4(col.x, col.y, col.z, g1.y));
 		}
 	}
+	report_consumed(a, tile, used, lane);
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 	const size_t plane = (size_t)a.W * a.H;
 #pragma unroll
@@ -896,7 +1154,8 @@ int launch_render(FwdCtx &c)
 	r.render_items = c.img.render_items; r.totals = c.img.totals; r.capacity = (uint32_t)c.capacity; r.cur_level = a->cur_level;
 	constexpr int PPL = 2;
 	r.round_flags = c.bin.round_flags;
-	if (has_stats(a->variant) && a->variant != FR_VARIANT_PCHECK_OBB_MAX && c.bin.round_flags)
+	r.consumed = a->list_consumed;
+	if (has_stats(a->variant) && !a->no_stats && a->variant != FR_VARIANT_PCHECK_OBB_MAX && c.bin.round_flags)
 	{
 		const hipError_t e = hipMemsetAsync(c.bin.round_flags, 0, round_flag_words(c.capacity, c.T) * sizeof(uint32_t), c.stream);
 		if (e != hipSuccess) { set_error("hipMemsetAsync(round_flags): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
@@ -910,14 +1169,20 @@ int launch_render(FwdCtx &c)
 	switch (a->variant)
 	{
 	case FR_VARIANT_ORIGINAL: FR_LAUNCH_RENDER(FR_VARIANT_ORIGINAL, true); break;
-	case FR_VARIANT_PCHECK_OBB_SUM: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_SUM, false); break;
+	case FR_VARIANT_PCHECK_OBB_SUM:
+		if (a->no_stats) FR_LAUNCH_RENDER(FR_VARIANT_SUM_NOSTATS, false); else FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_SUM, false);
+		break;
 	case FR_VARIANT_PCHECK_OBB: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB, true); break;
 	case FR_VARIANT_PCHECK_OBB_MAX: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_MAX, true); break;
 	case FR_VARIANT_PCHECK_OBB_LWMC: FR_LAUNCH_RENDER(FR_VARIANT_PCHECK_OBB_LWMC, false); break;
 	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: hipLaunchKernelGGL((k_render_smfr<2>), dim3(n_items), dim3(64), 0, c.stream, r); break;
 	case FR_VARIANT_MMFR_PCHECK_OBB: hipLaunchKernelGGL((k_render_mmfr<2>), dim3(n_items), dim3(64), 0, c.stream, r); break;
 	default:
+#ifdef FR_BLEND_DIET
+		hipLaunchKernelGGL((k_render_fov_diet<2>), dim3(n_items), dim3(64), 0, c.stream, r);
+#else
 		hipLaunchKernelGGL((k_render_fov<2>), dim3(n_items), dim3(64), 0, c.stream, r);
+#endif
 		break;
 	}
 #undef FR_LAUNCH_RENDER

@@ -12,10 +12,44 @@ from ..gaussian_wrapper import get_gs_rasterizer
 from ..rasterizer import GaussianRasterizationSettings, zero_points_leaf, zero_points_like
 
 
+# The reference's GaussianModel keeps its raw parameter tensors and its three activation functions as plain attributes
+# (scene/gaussian_model.py:33-41: scaling_activation = torch.exp, opacity_activation = torch.sigmoid, rotation_activation =
+# torch.nn.functional.normalize; :43-50: _features_dc, _features_rest, _scaling, _rotation, _opacity) and its getters are one-line
+# expressions of them (:200-240). render() recognises such a model by exactly those attributes and then hands the rasterizer what the
+# getters would have been computed FROM: the two SH tensors as they are stored (get_features is their torch.cat: 1.15 GB written and
+# read back per step at 6 M Gaussians, and split again by autograd) and the raw parameters (the kernels apply exp / normalize / sigmoid
+# themselves and return the gradients w.r.t. the raw tensors) -- 4.8 -> 2.6 ms per training step on the S-6M cloud with no change to
+# the model class. Same values up to the last bit of the device's exp / sigmoid. Set to False to go through the getters only.
+FAST_REFERENCE_MODEL = True
+
+
+def _reference_model_fields(pc):
+    """-> (raw scaling, raw rotation, raw opacity, features_dc, features_rest) of a model shaped like the reference's GaussianModel,
+    or None when `pc` is anything else (a subclass with other activations, a wrapper exposing only getters, ...)."""
+    if not FAST_REFERENCE_MODEL:
+        return None
+    try:
+        if not (pc.scaling_activation is torch.exp and pc.opacity_activation is torch.sigmoid
+                and pc.rotation_activation is torch.nn.functional.normalize):
+            return None
+        f = (pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc._features_rest)
+    except AttributeError:
+        return None
+    P = pc.get_xyz.shape[0]
+    if not all(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() >= 2 and t.shape[0] == P for t in f):
+        return None
+    if tuple(f[0].shape) != (P, 3) or tuple(f[1].shape) != (P, 4) or f[2].numel() != P or f[3].shape[1] != 1 or f[3].shape[2:] != f[4].shape[2:]:
+        return None
+    return f
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, masking=False,
-           starter=None, ender=None, cuda_type="", loss_map=None, packed=None):
+           starter=None, ender=None, cuda_type="", loss_map=None, packed=None, want_stats=True):
     """Render the scene. Background tensor (bg_color) must be on the GPU.
-    packed (extension): a rasterizer.PackedModel of this (static) model made by pack_model(); same image, faster binning."""
+    packed (extension): a rasterizer.PackedModel of this (static) model made by pack_model(); same image, faster binning.
+    want_stats (extension, opt-in): False = the caller does not read result["gs_count"] / ["contribs"] of the pcheck_obb_sum
+    rasterizer (eff_finetune.py:107-108 drops them every step): the blend skips the per-Gaussian statistics and the two keys
+    are absent from the result; image, radii and gradients are unchanged."""
     xyz = pc.get_xyz
     # zero tensor that makes autograd return the gradient of the 2D (screen-space) means
     if torch.is_grad_enabled():
@@ -52,6 +86,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # the step); else the three activations as one fused pass (activations.py); else the reference's three getters
     raw = getattr(pc, "get_raw_activation_params", None) if (packed is None and not masking) else None
     act = getattr(pc, "get_activated", None) if raw is None else None
+    ref_fields = _reference_model_fields(pc) if (raw is None and act is None and not hasattr(pc, "get_features_split")) else None
+    if ref_fields is not None and packed is None and not masking:
+        raw = ref_fields[:3]
     if raw is not None:
         scales, rotations, opacity = raw
     elif act is not None:
@@ -64,6 +101,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # concatenation; any other model goes through the reference's get_features
     if hasattr(pc, "get_features_split"):
         shs = pc.get_features_split_detach_rest if masking else pc.get_features_split
+    elif ref_fields is not None:
+        shs = (ref_fields[3], ref_fields[4].detach() if masking else ref_fields[4])
     else:
         shs = pc.get_features_detach_rest if masking else pc.get_features
     if masking:
@@ -76,7 +115,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         extra["raw_activations"] = True
     # extension: gradients as row-sparse tensors (rasterizer.py; only meaningful when every rasterizer input is a leaf parameter,
     # i.e. with the raw parameters and split SH storage)
-    if getattr(pc, "row_sparse_grads", False) and raw is not None and hasattr(pc, "get_features_split") and torch.is_grad_enabled():
+    if not want_stats and cuda_type == "pcheck_obb_sum":
+        extra["want_stats"] = False
+    if getattr(pc, "row_sparse_grads", False) and raw is not None and isinstance(shs, tuple) and torch.is_grad_enabled():
         extra["row_sparse"] = True
     if cuda_type == "pcheck_obb_loss_weighted_max_count":
         out = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity,

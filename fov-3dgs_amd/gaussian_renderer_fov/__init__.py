@@ -123,9 +123,12 @@ class PendingRender:
         self._frame, self._points = frame, points
 
     def finish(self):
-        res = self._frame.finish()
+        frame = self._frame
+        res = frame.finish()
         radii = res[2]
-        return {"render": res[1], "viewspace_points": self._points, "visibility_filter": radii > 0, "radii": radii}
+        with torch.cuda.device(frame.device), torch.cuda.stream(frame.stream):  # `radii` is written on the frame's stream
+            visible = radii > 0
+        return {"render": res[1], "viewspace_points": self._points, "visibility_filter": visible, "radii": radii}
 
 
 def render_begin(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, alpha=None, gazeArray=None,
@@ -136,7 +139,10 @@ def render_begin(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=
     streams -- begin(n + 1) before finish(n) -- keeps two frames in flight: the latency-bound head of one runs beside the sort
     and the blend of the other (csrc/api.hip). Every stream has its own workspaces; the image of a frame is valid once its
     stream has reached the end of finish()'s work (synchronise the stream, or make the consumer's stream wait for it). Same
-    arguments and result as render()."""
+    arguments and result as render(). The model's and the camera's tensors must be complete on `stream` (tensors made on another
+    stream: make `stream` wait for it first); the copies this package caches itself -- the packed model of packed="auto", the
+    contiguous copies of transposed camera matrices -- are handed from stream to stream with events (rasterizer._Produced) or
+    kept per stream."""
     with torch.no_grad(), torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(pc.get_xyz.device)):
         xyz = pc.get_xyz
         rs = GaussianRasterizationSettings(

@@ -114,3 +114,24 @@ class BackwardTimer:
                 if arr[i]:
                     self.lib.fr_event_destroy(arr[i])
         self.sets = []
+
+
+class NativeCallTimer:
+    """Rasterizer-only time of a training step ("plus rasterizer-only fwd and bwd ms"): torch events on the current
+    stream around every native forward (fr_forward_begin + finish) and backward (fr_backward) call of the plain variants' autograd
+    function while the context is active. ms() -> {"fwd": [...], "bwd": [...]} after a synchronize."""
+
+    def __enter__(self):
+        self.events = []
+        rasterizer._call_events = self.events
+        return self
+
+    def __exit__(self, *exc):
+        rasterizer._call_events = None
+
+    def ms(self):
+        out = {"fwd": [], "bwd": []}
+        for kind, e0, e1 in self.events:
+            e1.synchronize()
+            out[kind].append(e0.elapsed_time(e1))
+        return out

@@ -63,7 +63,9 @@ def _f32_small(t, device):
     """_f32 for the per-call camera tensors (viewmatrix, projmatrix, campos, bg: a few floats each). The reference's cameras
     keep world_view_transform as a TRANSPOSED view (scene/cameras.py:54), so `.contiguous()` is a copy kernel on the stream
     at the head of every frame (~6 us of a 0.7 ms frame, twice); the copy is kept for as long as the caller hands over the
-    same tensor object with the same storage, strides and autograd version. Writes the version counter cannot see (`.data`
+    same tensor object with the same storage, strides and autograd version -- PER STREAM: the copy kernel is enqueued on the
+    stream that was current when it was made, so a frame on another stream (render_begin alternates two) makes and keeps its
+    own copy instead of reading one that may still be in flight elsewhere. Writes the version counter cannot see (`.data`
     writes, raw-pointer kernels, DLPack / numpy aliases) are caught for CPU tensors by comparing the values (a few floats on
     the host); for a device tensor clone it after such a write, or set SMALL_COPY_CACHE = False."""
     if t is None or t.numel() == 0:
@@ -72,7 +74,7 @@ def _f32_small(t, device):
         return t
     if t.numel() > 64 or not SMALL_COPY_CACHE:
         return _f32(t, device)
-    key = id(t)
+    key = (id(t), torch.cuda.current_stream(device).cuda_stream)
     ent = _small_copies.get(key)
     sig = (t._version, t.data_ptr(), t.stride(), t.dtype, t.device)
     if ent is not None and ent[0]() is t and ent[1] == sig and (t.is_cuda or torch.equal(ent[3], t)):
@@ -83,6 +85,28 @@ def _f32_small(t, device):
     import weakref
     _small_copies[key] = (weakref.ref(t), sig, c, None if t.is_cuda else t.detach().clone())
     return c
+
+
+class _Produced:
+    """Cross-stream hand-over of a cached device buffer: the event recorded behind its producer kernels on the stream that made
+    it. A consumer on ANOTHER stream waits for that event (once per stream) and tells the caching allocator that the buffer is in
+    use there (record_stream), so the buffer is neither read half-written nor recycled under a running kernel."""
+
+    def __init__(self, device, tensors):
+        self.stream = torch.cuda.current_stream(device)
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+        self.tensors = [t for t in tensors if t is not None]
+        self.seen = {self.stream.cuda_stream}
+
+    def wait_on_current(self, device):
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream in self.seen:
+            return
+        cur.wait_event(self.event)
+        for t in self.tensors:
+            t.record_stream(cur)
+        self.seen.add(cur.cuda_stream)
 
 
 def _require_gpu(means3D):
@@ -119,7 +143,10 @@ class _Workspaces:
         return resize
 
 
-_persistent_ws = {}
+import collections
+
+_persistent_ws = collections.OrderedDict()
+PERSISTENT_WS_SETS = 4  # per device: grow-only inference workspace sets kept alive (least recently used goes first)
 _pooled_ws = {}  # device -> idle workspace sets of finished training steps
 
 
@@ -141,8 +168,12 @@ def _workspaces_for(device, needs_graph):
     """-> (workspaces, lease). Calls without an autograd graph use a persistent grow-only set per (device, current stream, host
     thread) -- the C ABI is thread-compatible and two frames may be in flight on two streams (begin / finish), so neither two
     threads nor two streams ever share buffers; a call is only valid until the next call on the same stream of the same
-    thread. For training a set from a small pool, leased until the graph is gone: allocating GBs of fresh buffers every step
-    made the caching allocator fall back to hipMalloc/hipFree every few steps (30-40 ms stalls)."""
+    thread. At most PERSISTENT_WS_SETS sets per device are kept (a set is ~1.5-2 GB at 6 M Gaussians; stream handles and thread
+    idents come and go, a host that makes a stream per frame must not pin one set per stream for ever): the least recently used
+    one is dropped -- a frame in flight on it holds its own reference until it has finished, and the caching allocator hands the
+    blocks back to the stream they were allocated on. For training a set from a small pool, leased until the graph is gone:
+    allocating GBs of fresh buffers every step made the caching allocator fall back to hipMalloc/hipFree every few steps (30-40 ms
+    stalls)."""
     if needs_graph:
         idle = _pooled_ws.get(device)
         ws = idle.pop() if idle else _Workspaces(device)
@@ -151,6 +182,11 @@ def _workspaces_for(device, needs_graph):
     ws = _persistent_ws.get(key)
     if ws is None:
         ws = _persistent_ws[key] = _Workspaces(device)
+        mine = [k for k in _persistent_ws if k[0] == device]
+        for k in mine[:max(0, len(mine) - PERSISTENT_WS_SETS)]:
+            del _persistent_ws[k]
+    else:
+        _persistent_ws.move_to_end(key)
     return ws, None
 
 
@@ -169,19 +205,31 @@ def zero_points_like(xyz):
 
 
 _zero_leaves = {}
+FRESH_VIEWSPACE_POINTS = bool(int(__import__("os").environ.get("FOVRASTER_FRESH_VIEWSPACE_POINTS", "0")))
 
 
 def zero_points_leaf(xyz):
     """render()'s `viewspace_points` of a training step: a NEW leaf tensor (requires_grad, its own .grad) of zeros shaped like xyz
     -- the reference's torch.zeros_like(xyz, requires_grad=True) -- over ONE cached zero buffer per (device, dtype, shape): the
-    tensor only carries the gradient of the 2D means, its values are never read or written, and filling 72 MB per step at 6 M
-    Gaussians is 16 us at the head of every forward pass. Read-only by convention."""
+    tensor only carries the gradient of the 2D means, the rasterizer never reads or writes its values, and filling 72 MB per step
+    at 6 M Gaussians is 16 us at the head of every forward pass. A caller that writes INTO a step's viewspace_points in place
+    would leave that in the shared buffer: every leaf shares the buffer's version counter, so the next call sees the write and
+    clears the buffer again (the reference's tensor is private to its step; so are the values here, one step late at worst --
+    and never read by this package). FOVRASTER_FRESH_VIEWSPACE_POINTS=1 allocates fresh zeros per step instead."""
+    if FRESH_VIEWSPACE_POINTS:
+        return torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device, requires_grad=True)
     key = (xyz.device, xyz.dtype, tuple(xyz.shape))
-    buf = _zero_leaves.get(key)
-    if buf is None:
+    ent = _zero_leaves.get(key)
+    if ent is None:
         if len(_zero_leaves) >= 4:
             _zero_leaves.clear()  # (a model that changes size every few steps: densification)
-        buf = _zero_leaves[key] = torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device)
+        buf = torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device)
+        ent = _zero_leaves[key] = [buf, buf._version]
+    buf = ent[0]
+    if buf._version != ent[1]:  # somebody wrote into an earlier step's leaf
+        with torch.no_grad():
+            buf.zero_()
+        ent[1] = buf._version
     return buf.detach().requires_grad_(True)
 
 
@@ -193,6 +241,8 @@ class PackedModel:
 
     def __init__(self, geom, colour, cull):
         self.geom, self.colour, self.cull = geom, colour, cull
+        # the k_pack_* kernels run on the stream that is current now: a frame on another stream waits for them (_Produced)
+        self.produced = _Produced(geom.device, (geom, colour, cull)) if geom.is_cuda else None
 
     def check(self, P, dev):
         for t, w in ((self.geom, 16), (self.colour, 64), (self.cull, 4)):
@@ -237,6 +287,7 @@ def pack_model(means3D, scales, rotations, opacities, shs=None, shs_rest=None, s
 # Set by fov3dgs_amd.profiling.StageTimer while a timed region is active: a ctypes array of
 # FR_NUM_STAGE_EVENTS event handles that the next forward call records on its streams.
 _stage_events_hook = None
+_call_events = None  # profiling.NativeCallTimer: a list that takes (kind, start, stop) torch events around every native fr_forward / fr_backward call
 _bwd_events_hook = None  # the same for backward calls: 5 handles (fr_backward_args.stage_events)
 
 
@@ -267,16 +318,17 @@ class FrameInFlight:
         return out + (self.lease,)  # last element: keeps the workspace set reserved (None for the persistent set)
 
     def __del__(self):
-        if getattr(self, "handle", None) is not None:  # abandoned between the halves: the library must release its handle
+        handle, self.handle = getattr(self, "handle", None), None
+        if handle is not None:  # abandoned between the halves: the library must release its handle -- without running the tail
             try:
-                self.lib.fr_forward_finish(self.handle)
-            except Exception:
+                self.lib.fr_forward_abandon(handle)
+            except Exception:  # interpreter shutdown
                 pass
 
 
 def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
-                   sh_rest=None, packed=None, cur_level=0.0, raw_activations=False):
+                   sh_rest=None, packed=None, cur_level=0.0, raw_activations=False, list_consumed=None, no_stats=False):
     """First half of a forward call on the current stream -> FrameInFlight. persistent=True: the workspaces are the grow-only
     set of this (device, stream, thread) (valid until the next call there); otherwise they stay reserved for as long as the
     `lease` of the result is referenced."""
@@ -331,13 +383,22 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
         put("highest_levels", highest_levels)
         a.out_color, a.radii = color.data_ptr(), radii.data_ptr()
         put("loss_map", loss_map)
+        if list_consumed is not None:  # diagnostic: uint32 / int32 [T], entries of every tile's list the blend fetched (fovraster.h)
+            tiles = ((W + 15) // 16) * ((H + 15) // 16)
+            if list_consumed.device != dev or list_consumed.numel() != tiles or list_consumed.element_size() != 4 or not list_consumed.is_contiguous():
+                raise RuntimeError(f"list_consumed must be a contiguous 4-byte integer tensor of {tiles} tiles on {dev}")
+            keep.append(list_consumed)
+            a.list_consumed = list_consumed.data_ptr()
         if packed is not None:
             packed.check(P, dev)
+            if packed.produced is not None:
+                packed.produced.wait_on_current(dev)
             a.packed_geom = _ptr(packed.geom)
             a.packed_colour = _ptr(packed.colour)
             a.packed_cull = _ptr(packed.cull)
             keep.append(packed)
-        if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC):
+        a.no_stats = int(bool(no_stats))
+        if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC) and not no_stats:
             counts = torch.empty((P,), dtype=torch.int32, device=dev)      # zeroed by fr_forward itself
             contribs = torch.empty((P,), dtype=torch.float32, device=dev)
             a.gaussians_count, a.contributions = counts.data_ptr(), contribs.data_ptr()
@@ -465,7 +526,9 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                     raster_settings, loss_map=None, sh_rest=None, packed=None, grad_mode=True, raw_activations=False,
-                    row_sparse=False):
+                    row_sparse=False, want_stats=True):
+            # want_stats=False (extension, pcheck_obb_sum): the caller drops gaussians_count / contributions (eff_finetune.py:107-108
+            # does): the blend skips them and the call returns (color, radii) only
             # row_sparse (extension): backward returns the gradients of the [P, ...] inputs as SPARSE tensors (torch.sparse_coo, one
             # sparse dimension: the Gaussians this view touched) -- for leaf parameters (raw_activations + split SH: every input is
             # one) optimised by a sparse-aware optimizer or summed with multiview.allreduce_gradients; no 1.5 GB of zero fills
@@ -484,6 +547,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             if takes_loss_map:
                 if loss_map is None or loss_map.numel() < raster_settings.image_height * raster_settings.image_width:
                     raise Exception("loss_map with at least image_height*image_width values is required")
+            no_stats = with_counts and not want_stats and variant_id == _native.VARIANT_PCHECK_OBB_SUM
             ctx.split_sh = sh_rest is not None
             ctx.raw_activations = bool(raw_activations)
             ctx.row_sparse = bool(row_sparse) and has_backward
@@ -491,9 +555,16 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             # three [P] fills per step otherwise)
             ctx.set_materialize_grads(False)
             def run():
+                ev = _call_events
+                if ev is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 frame = _forward_begin(*args, persistent=not keep_ws, loss_map=loss_map, sh_rest=sh_rest, packed=packed,
-                                       raw_activations=raw_activations)
+                                       raw_activations=raw_activations, no_stats=no_stats)
                 out = frame.finish()
+                if ev is not None:
+                    e1.record()
+                    ev.append(("fwd", e0, e1))
                 ctx.num_candidates = int(frame.a.num_candidates)
                 return out
             if raster_settings.debug:
@@ -516,7 +587,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                                   geomBuffer, binningBuffer, imgBuffer,
                                   sh_rest if sh_rest is not None else torch.empty(0, device=means3D.device))
             ctx.mark_non_differentiable(radii)
-            if with_counts:
+            if with_counts and not no_stats:
                 ctx.mark_non_differentiable(res[6], res[7])
                 return color, radii, res[6], res[7]
             return color, radii
@@ -527,7 +598,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 # the reference's inference-only extension exports no backward entry point
                 raise RuntimeError("this rasterizer variant is inference-only (no backward in the reference)")
             if grad_out_color is None:  # the image took no part in the loss
-                return (None,) * 15
+                return (None,) * 16
             rs = ctx.raster_settings
             (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
              geomBuffer, binningBuffer, imgBuffer, sh_rest) = ctx.saved_tensors
@@ -535,6 +606,10 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                     grad_out_color, sh, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer,
                     sh_rest if ctx.split_sh else None)
             kw = dict(raw_activations=ctx.raw_activations, row_sparse=ctx.row_sparse, num_candidates=ctx.num_candidates)
+            ev = _call_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
@@ -545,6 +620,9 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                     raise ex
             else:
                 res = _backward_native(*args, **kw)
+            if ev is not None:
+                e1.record()
+                ev.append(("bwd", e0, e1))
             if ctx.row_sparse:
                 # compact rows -> sparse tensors of the inputs' shapes (indices shared: one [1, C] tensor)
                 P = means3D.size(0)
@@ -555,14 +633,15 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
              grad_scales, grad_rotations) = res[:8]
             grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                      grad_rotations, grad_cov3Ds_precomp, None)
-            # loss_map, sh_rest, packed, grad_mode, raw_activations, row_sparse
-            return grads + (None, res[8] if ctx.split_sh else None, None, None, None, None)
+            # loss_map, sh_rest, packed, grad_mode, raw_activations, row_sparse, want_stats
+            return grads + (None, res[8] if ctx.split_sh else None, None, None, None, None, None)
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                            raster_settings, loss_map=None, sh_rest=None, packed=None, raw_activations=False, row_sparse=False):
+                            raster_settings, loss_map=None, sh_rest=None, packed=None, raw_activations=False, row_sparse=False,
+                            want_stats=True):
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                          cov3Ds_precomp, raster_settings, loss_map if takes_loss_map else None, sh_rest, packed,
-                                         torch.is_grad_enabled(), raw_activations, row_sparse)
+                                         torch.is_grad_enabled(), raw_activations, row_sparse, want_stats)
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):
@@ -574,7 +653,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 return _mark_visible(positions, self.raster_settings)
 
         def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                    cov3D_precomp=None, loss_map=None, packed=None, raw_activations=False, row_sparse=False):
+                    cov3D_precomp=None, loss_map=None, packed=None, raw_activations=False, row_sparse=False, want_stats=True):
             raster_settings = self.raster_settings
             if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
                 raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -593,7 +672,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             rotations = empty if rotations is None else rotations
             cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings, loss_map, shs_rest, packed, raw_activations, row_sparse)
+                                       cov3D_precomp, raster_settings, loss_map, shs_rest, packed, raw_activations, row_sparse, want_stats)
 
     return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
 
@@ -749,11 +828,13 @@ _level_zeros = {}
 def _zero_levels(P, device):
     """[P,1] zeros: the multi-model variant's stand-in for highest_levels (its skip test reuses the level filter)."""
     key = (P, device)
-    t = _level_zeros.get(key)
-    if t is None:
+    ent = _level_zeros.get(key)
+    if ent is None:
         _level_zeros.clear()
-        t = _level_zeros[key] = torch.zeros((P, 1), dtype=torch.float32, device=device)
-    return t
+        t = torch.zeros((P, 1), dtype=torch.float32, device=device)
+        ent = _level_zeros[key] = (t, _Produced(device, (t,)))
+    ent[1].wait_on_current(device)  # (the fill ran on the stream that was current when the buffer was made)
+    return ent[0]
 
 
 def _make_mmfr():

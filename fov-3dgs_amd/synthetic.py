@@ -97,6 +97,64 @@ class GaussianCloud:
         return self._xyz.shape[0]
 
 
+class ReferenceGetterModel:
+    """A model that offers ONLY what the reference's GaussianModel offers (fov3dgs/scene/gaussian_model.py:200-240): get_xyz,
+    get_scaling = exp, get_rotation = normalize, get_opacity = sigmoid, get_features = torch.cat((dc, rest), dim=1) and the
+    detach_rest form masking uses -- none of this package's extension getters (get_activated, get_raw_activation_params,
+    get_features_split). What a maintainer gets from switching the imports and nothing else; shares the
+    parameter tensors of `cloud`."""
+
+    def __init__(self, cloud):
+        self._c = cloud
+        self.active_sh_degree = cloud.active_sh_degree
+        self.max_sh_degree = cloud.max_sh_degree
+
+    @property
+    def get_xyz(self):
+        return self._c._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._c._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._c._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._c._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._c._features_dc, self._c._features_rest), dim=1)
+
+    @property
+    def get_features_detach_rest(self):
+        return torch.cat((self._c._features_dc, self._c._features_rest.detach()), dim=1)
+
+    @property
+    def get_rest_features(self):
+        return self._c._features_rest
+
+    def parameters(self):
+        return self._c.parameters()
+
+
+class ReferenceShapedModel(ReferenceGetterModel):
+    """A model with the ATTRIBUTES of the reference's GaussianModel as well as its getters (scene/gaussian_model.py:33-50: the raw
+    parameter tensors _xyz / _features_dc / _features_rest / _scaling / _rotation / _opacity and the activation functions
+    scaling_activation / opacity_activation / rotation_activation), which gaussian_renderer.render() recognises
+    (FAST_REFERENCE_MODEL): what a maintainer's own GaussianModel object looks like to render()."""
+
+    def __init__(self, cloud):
+        super().__init__(cloud)
+        self._xyz, self._features_dc, self._features_rest = cloud._xyz, cloud._features_dc, cloud._features_rest
+        self._scaling, self._rotation, self._opacity = cloud._scaling, cloud._rotation, cloud._opacity
+        self.scaling_activation, self.opacity_activation = torch.exp, torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+
 def _gen(seed):
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
@@ -121,8 +179,14 @@ def camera_1k(width=256, height=256, fov_deg=60.0, device="cpu"):
     return MiniCam(np.eye(3), np.zeros(3), fov, fov, width, height, device=device)
 
 
-def scene_bicycle_scale(P=6_000_000, seed=1, device="cpu", scale_log_mean=math.log(0.01)):
-    """S-6M ("bicycle-scale"): ground annulus + dome shell + a dense centre, y is down-positive."""
+OPACITY_LOGIT_S6M = (1.0, 2.0)     # opacity = sigmoid(N(1, 2^2)) -- median alpha 0.73: pixels saturate within 9-20 % of their lists
+OPACITY_LOGIT_S6MT = (-3.5, 1.0)   # S-6M-T ("translucent"): same geometry and seeds, median alpha 0.029 (see scene_translucent)
+
+
+def scene_bicycle_scale(P=6_000_000, seed=1, device="cpu", scale_log_mean=math.log(0.01), opacity_logit=OPACITY_LOGIT_S6M):
+    """S-6M ("bicycle-scale"): ground annulus + dome shell + a dense centre, y is down-positive.
+    opacity_logit = (mean, std) of the normal the opacity logits are drawn from (the draws themselves are the same for any
+    choice: two clouds that differ only here have identical geometry, SH and per-Gaussian random numbers)."""
     g = _gen(seed)
     n_ground = int(0.70 * P)
     n_dome = int(0.25 * P)
@@ -144,10 +208,21 @@ def scene_bicycle_scale(P=6_000_000, seed=1, device="cpu", scale_log_mean=math.l
     xyz = xyz[torch.randperm(P, generator=g)]
     scaling = scale_log_mean + 0.7 * torch.randn(P, 1, generator=g) + 0.5 * torch.randn(P, 3, generator=g)
     rotation = torch.randn(P, 4, generator=g)
-    opacity = 1.0 + 2.0 * torch.randn(P, 1, generator=g)
+    opacity = opacity_logit[0] + opacity_logit[1] * torch.randn(P, 1, generator=g)
     f_dc = torch.randn(P, 1, 3, generator=g)
     f_rest = 0.1 * torch.randn(P, 15, 3, generator=g)
     return GaussianCloud(xyz.contiguous(), f_dc, f_rest, scaling, rotation, opacity).to(device)
+
+
+def scene_translucent(P=6_000_000, seed=1, device="cpu", opacity_logit=OPACITY_LOGIT_S6MT):
+    """S-6M-T: the S-6M cloud with opacities drawn so that the blend CONSUMES its lists -- on S-6M (median alpha 0.73) every pixel
+    saturates after 9 % (plain) to 20 % (foveated) of its tile's list, which no trained model does: the reference's loops run to
+    the end of most lists (RS forward.cu:349-421, R0 backward.cu:455-557). Same positions, scales, rotations, SH and seeds.
+    Opacity logit ~ N(-3.5, 1) (tools/translucent_sweep.py, measured on the bench camera): the blend fetches 0.72 of the training
+    frame's 16.9 M instances (S-6M: 0.10) and 0.75-1.0 of the nine foveated bench frames' (S-6M: 0.16-0.25), walks lists 5 248
+    entries = 20 rounds of 256 deep, and 1.03 M Gaussians receive a gradient (S-6M: 131 k). Candidates: N(-2.5, 1.5): 0.29 / 0.61,
+    341 k rows; N(-3.5, 1.5): 0.54 / 0.81, 626 k; N(-4, 1): 0.93 / 0.98, 1.49 M; N(-4.5, 1): everything consumed."""
+    return scene_bicycle_scale(P=P, seed=seed, device=device, opacity_logit=opacity_logit)
 
 
 def camera_ring(index=0, n=8, width=1920, height=1080, fovx_deg=62.0, radius=4.0, height_above=1.0, device="cpu"):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 7
+#define FR_ABI_VERSION 8
 
 /* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
  * fov3dgs/gaussian_wrapper.py:11-23) */
@@ -157,6 +157,16 @@ typedef struct fr_forward_args {
 	int32_t raw_activations;
 	int32_t num_candidates;      /* out: entries of the library's list of the Gaussians that survived its cull pass
 	                              * (fr_geometry_vis_list): the rows of a row-sparse backward call */
+	/* optional diagnostic output (NULL = off, no cost): uint32 [T], per tile the number of entries of its depth-sorted list the
+	 * blend FETCHED before every pixel of the tile was finished -- the reference's loop runs in batches of 256 (forward.cu:333-347:
+	 * `done` is voted on per batch), this build's in batches of 64, so the figure is the list position rounded up to 64 (capped at
+	 * the list's length); two-level RF tiles: the larger of their two level states. Cleared by the call. Sum / num_rendered =
+	 * the fraction of the frame's instances the blend consumes (bench.py: config.list_consumed_frac). */
+	uint32_t *list_consumed;
+	/* optional (PCHECK_OBB_SUM only): != 0 = the caller does not read gaussians_count / contributions (both may be NULL):
+	 * eff_finetune.py:107-108 drops gs_count / contribs of every training step. The blend then keeps only what the backward pass
+	 * needs (final_T, n_contrib); image, radii, lists and gradients are those of the variant. */
+	int32_t no_stats;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
@@ -228,6 +238,10 @@ int fr_forward(fr_forward_args *args);
 typedef struct fr_frame fr_frame;
 int fr_forward_begin(fr_forward_args *args, fr_frame **frame);
 int fr_forward_finish(fr_frame *frame);
+/* Drop a frame between its halves WITHOUT running its tail (a host that gives up on a frame, e.g. a garbage-collected handle):
+ * joins the frame's helper stream into its launch stream, releases the pinned totals block and the handle; no wait, no callback,
+ * no launch. out_color is left undefined. */
+int fr_forward_abandon(fr_frame *frame);
 /* Fill fr_forward_args.packed_geom / packed_colour / packed_cull (device buffers of P*16 / P*64 / P*4 floats) from the tensors of the
  * same names; opacities is [P,levels] with levels = 1 or 4, highest_levels / shs_dcs may be NULL (not RF);
  * shs_rest NULL: shs is [P,16,3] (RF: [P,15,3] = coefficients 1..15 and shs_dcs given), else shs = [P,1,3]. */

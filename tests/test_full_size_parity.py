@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.checks import check_grad, check_image
+from tests.checks import FULL_FRAME_GRAD_BUDGETS, FULL_FRAME_GRAD_GROSS, FULL_FRAME_GRAD_REL_L2, check_against_noise, check_grad, check_image
 from tests.helpers import cam_dict, scene_dict, syn
 from tests import parity_report
 from oracle import oracle as orc
@@ -48,15 +48,19 @@ def gaussian_lists(lib, vid, P, D, geom, binb):
 
 
 class S6M:
-    """The bench scene, built once per session: CPU cloud (oracle inputs) + device tensors (rasterizer inputs)."""
+    """The bench scene, built once per session: CPU cloud (oracle inputs) + device tensors (rasterizer inputs).
+    opacity_logit: synthetic.OPACITY_LOGIT_S6M (the headline cloud) or OPACITY_LOGIT_S6MT (S-6M-T: same geometry and
+    seeds, opacities drawn so that the blend consumes its lists -- 0.9 of a foveated frame's instances, 0.7 of the training
+    frame's, lists walked 20 rounds deep, > 1 M Gaussians with a gradient; bench.py extra.translucent)."""
 
-    def __init__(self):
+    def __init__(self, opacity_logit=syn.OPACITY_LOGIT_S6M, name="S-6M"):
         assert torch.cuda.is_available(), "no GPU visible: -m gpu tests must run on the MI355X box"
         from fov3dgs_amd import _native, rasterizer as rz
         self.rz, self.native, self.lib = rz, _native, _native.load()
         self.dev = torch.device("cuda", 0)
+        self.name = name
         orc.set_threads(os.cpu_count() or 1)
-        self.cloud = syn.scene_bicycle_scale(P=6_000_000, seed=1)
+        self.cloud = syn.scene_bicycle_scale(P=6_000_000, seed=1, opacity_logit=opacity_logit)
         self.fov = syn.foveation_layers(self.cloud, seed=2)
         self.cam = syn.camera_ring(0, 8, W, H)  # the bench's camera at N = 1
         self.scene_plain = scene_dict(self.cloud, "pcheck_obb")
@@ -87,6 +91,7 @@ class S6M:
         """-> dict of numpy / tensors from one native forward call of `variant` on the resident scene."""
         rz, vid, E = self.rz, self.native.VARIANT_IDS[variant], torch.Tensor([])
         pk = None
+        cons = torch.zeros(T, dtype=torch.int32, device=self.dev)
         with torch.no_grad():
             if variant == "fov_pcheck_obb":
                 if packed:
@@ -95,20 +100,20 @@ class S6M:
                                                         highest_levels=self.highest)
                     pk = self.packed_fov
                 res = rz._forward_native(vid, self.rs, self.xyz, self.rest, E, self.opac4, self.sc, self.rot, E, self.shs_dcs,
-                                         self.highest, gaze, 0.05, packed=pk)
+                                         self.highest, gaze, 0.05, packed=pk, list_consumed=cons)
             else:
                 if packed:
                     if self.packed_plain is None:
                         self.packed_plain = rz.pack_model(self.xyz, self.sc, self.rot, self.opac, shs=self.sh)
                     pk = self.packed_plain
-                res = rz._forward_native(vid, self.rs, self.xyz, self.sh, E, self.opac, self.sc, self.rot, E, packed=pk)
+                res = rz._forward_native(vid, self.rs, self.xyz, self.sh, E, self.opac, self.sc, self.rot, E, packed=pk, list_consumed=cons)
             torch.cuda.synchronize()
         D, color, radii, geom, binb, img = res[:6]
 
         def view(buf, ptr, count, dtype):
             off = ptr - buf.data_ptr()
             return buf[off:off + 4 * count].view(dtype)
-        out = dict(num_rendered=D, color=color, radii=radii, buffers=(geom, binb, img), lease=res[-1], res=res)
+        out = dict(num_rendered=D, color=color, radii=radii, buffers=(geom, binb, img), lease=res[-1], res=res, consumed=cons)
         out["ranges"] = view(img, self.lib.fr_image_ranges(vid, W, H, img.data_ptr()), 2 * T, torch.int32).view(T, 2).long()
         out["point_list"] = gaussian_lists(self.lib, vid, self.xyz.shape[0], D, geom, binb)
         if variant == "pcheck_obb_sum":
@@ -121,6 +126,20 @@ class S6M:
 @pytest.fixture(scope="module")
 def s6m():
     return S6M()
+
+
+@pytest.fixture(scope="module")
+def s6mt():
+    return S6M(syn.OPACITY_LOGIT_S6MT, "S-6M-T")
+
+
+def consumed_stats(got):
+    """What the blend consumed of the frame's lists (fr_forward_args.list_consumed: per tile, entries fetched, in batches of 64)."""
+    cons = got["consumed"].cpu().numpy().astype(np.int64)
+    lens = (got["ranges"][:, 1] - got["ranges"][:, 0]).cpu().numpy()
+    assert (cons <= lens).all() and ((cons % 64 == 0) | (cons == lens)).all()
+    return dict(list_consumed_frac=float(cons.sum() / max(lens.sum(), 1)), deepest_list_position=int(cons.max()),
+                rounds_of_256_deepest=int((cons.max() + 255) // 256))
 
 
 def window_tiles(win):
@@ -175,24 +194,39 @@ def scope(win):
 
 def test_plain_forward_full_size(s6m):
     """Config 2: pcheck_obb over the whole S-6M cloud -- radii of all 6 M Gaussians, lists + pixels of every tile."""
+    _plain_forward(s6m)
+
+
+def test_plain_forward_full_size_translucent(s6mt):
+    """Config 2 on S-6M-T: the same lists (the opacities do not enter the binning), blended 0.7 of the way down instead of 0.1."""
+    _plain_forward(s6mt)
+
+
+def _plain_forward(s6m):
     win, owin = pick(CENTRE_WIN)
     want = orc.forward("pcheck_obb", s6m.scene_plain, s6m.cam_dict(window=owin))
     for packed in (False, True):
         got = s6m.hip("pcheck_obb", packed=packed)
-        tag = f"pcheck_obb S-6M {scope(win)} packed={packed}"
+        tag = f"pcheck_obb {s6m.name} {scope(win)} packed={packed}"
         np.testing.assert_array_equal(got["radii"].cpu().numpy(), want["radii"], err_msg=tag + ": radii over all Gaussians")
         if WHOLE:
             assert got["num_rendered"] == want["num_rendered"], tag
         n, longest = compare_lists(got, want, win, tag)
-        check_image(crop(got["color"], win).cpu().numpy(), crop(want["color"], win), name=tag, count=FRAME_COUNT_BUDGET if WHOLE else None)
+        check_image(crop(got["color"], win).cpu().numpy(), crop(want["color"], win), name=tag, count=FRAME_COUNT_BUDGETS[s6m.name] if WHOLE else None)
         parity_report.record("lists", tag, gaussians=int(s6m.xyz.shape[0]), visible=int((want["radii"] > 0).sum()),
                              compared_instances=n, longest_compared_list=longest, frame_instances=int(got["num_rendered"]),
-                             tiles_compared=int(len(window_tiles(win))))
+                             tiles_compared=int(len(window_tiles(win))), **consumed_stats(got))
     s6m.plain_radii = want["radii"]
 
 
 BENCH_GAZES = [(0.25 * i, 0.25 * j) for i in range(1, 4) for j in range(1, 4)]  # bench.py GAZES (render_compose_gazes_fps.py:26)
-FRAME_COUNT_BUDGET = 24  # values of a 1080p frame allowed beyond 1e-4: 8 flipped pixels x 3 channels (measured: <= 9 over the twelve gazes)
+# values of a whole 1080p frame (6.2 M) allowed beyond 1e-4 -- flipped (pixel, Gaussian) pairs at a blend threshold, three channels each:
+# S-6M: measured <= 9 over the twelve gazes; S-6M-T blends five to seven times as many pairs per frame, most of them faint (median
+# alpha 0.03: far more pairs sit near alpha = 1/255), measured <= 28 (largest 2.1e-3). Budgets = measured worst x 1.25.
+FRAME_COUNT_BUDGETS = {"S-6M": 12, "S-6M-T": 36}
+# training frame: share of the pixels whose final_T lies outside 1e-4 relative although n_contrib agrees (a flipped pair in the middle
+# of a list moves T by its alpha >= 1/255 without moving n_contrib): measured 1.4e-6 (S-6M, 3 pixels) / 1.06e-5 (S-6M-T, 22 pixels)
+FINAL_T_OUTLIERS = {"S-6M": 1e-5, "S-6M-T": 2e-5}
 
 
 @pytest.mark.parametrize("gaze_id", ("centre", "lissajous10", "lissajous47") + tuple(f"bench{i}" for i in range(9) if i != 4))
@@ -200,6 +234,18 @@ def test_foveated_forward_full_size(s6m, gaze_id):
     """Config 3: fov_pcheck_obb, centred gaze and two gazes of the bench's Lissajous path, ordinary and packed model; and the
     other eight of the bench's nine fixed gazes (bench4 is the centre), ordinary model -- every frame the headline times is
     compared whole (on a host with the cores for it)."""
+    _foveated_forward(s6m, gaze_id)
+
+
+@pytest.mark.parametrize("gaze_id", ("centre", "bench2", "lissajous47"))
+def test_foveated_forward_full_size_translucent(s6mt, gaze_id):
+    """Config 3 on S-6M-T (RF forward.cu:322-475 run to the end of most lists: two-level tiles whose upper state runs long, single-
+    level tiles thousands of entries deep): whole frames at the centre, one off-centre bench gaze and one gaze of the moving path."""
+    _foveated_forward(s6mt, gaze_id)
+    assert s6mt.last_consumed["list_consumed_frac"] >= 0.5, s6mt.last_consumed
+
+
+def _foveated_forward(s6m, gaze_id):
     if gaze_id.startswith("bench"):
         if not WHOLE:
             pytest.skip("the eight off-centre bench gazes are whole-frame comparisons (host with >= 64 cores)")
@@ -213,15 +259,16 @@ def test_foveated_forward_full_size(s6m, gaze_id):
         "the window should cross all four levels and hold two-level tiles"
     for packed in ((False,) if gaze_id.startswith("bench") else (False, True)):
         got = s6m.hip("fov_pcheck_obb", gaze=gaze, packed=packed)
-        tag = f"fov_pcheck_obb S-6M {scope(win)} gaze={gaze_id} packed={packed}"
+        tag = f"fov_pcheck_obb {s6m.name} {scope(win)} gaze={gaze_id} packed={packed}"
         np.testing.assert_array_equal(got["radii"].cpu().numpy(), want["radii"], err_msg=tag + ": radii over all Gaussians")
         if WHOLE:
             assert got["num_rendered"] == want["num_rendered"], tag
         n, longest = compare_lists(got, want, win, tag)
-        check_image(crop(got["color"], win).cpu().numpy(), crop(want["color"], win), name=tag, count=FRAME_COUNT_BUDGET if WHOLE else None)
+        check_image(crop(got["color"], win).cpu().numpy(), crop(want["color"], win), name=tag, count=FRAME_COUNT_BUDGETS[s6m.name] if WHOLE else None)
         parity_report.record("lists", tag, visible=int((want["radii"] > 0).sum()), compared_instances=n, longest_compared_list=longest,
                              frame_instances=int(got["num_rendered"]), two_level_tiles_compared=int(want["tile_blend"][tiles].sum()),
-                             tiles_compared=int(len(tiles)))
+                             tiles_compared=int(len(tiles)), **consumed_stats(got))
+        s6m.last_consumed = consumed_stats(got)
 
 
 def _native_lists(s6m, vid, res):
@@ -291,14 +338,36 @@ def test_training_step_full_size(s6m):
     the whole-frame oracle: lists / pixels / final_T / n_contrib of all 8160 tiles, gaussians_count and contributions
     of all 6 M Gaussians (the round-claiming scheme of k_render on 40-round lists, RS forward.cu:349-361,400), and the
     backward pass with dL_dpix non-zero everywhere (all 1.9 M visible Gaussians)."""
+    _training_step(s6m, min_rows=100_000)
+
+
+def test_training_step_full_size_translucent(s6mt):
+    """Config 4 on S-6M-T: the blend walks 0.7 of the frame's 16.9 M instances (lists consumed 20 rounds of 256 deep: the
+    round-claiming counts of RS forward.cu:349-361 far beyond the first rounds), the backward pass recovers T by division down
+    thousands of entries (R0 backward.cu:503-507) and > 1 M Gaussians receive a gradient (S-6M: 131 k)."""
+    _training_step(s6mt, min_rows=1_000_000)
+    if WHOLE:
+        assert s6mt.last_consumed["list_consumed_frac"] >= 0.5 and s6mt.last_consumed["rounds_of_256_deepest"] >= 20, s6mt.last_consumed
+
+
+def budget_kw(s6m, tensor):
+    """check_grad's outlier budget of a whole-frame tensor (tests/checks.py FULL_FRAME_GRAD_BUDGETS); the default budget on a window."""
+    b = FULL_FRAME_GRAD_BUDGETS.get(s6m.name, {}).get(tensor) if WHOLE else None
+    if os.environ.get("FOVRASTER_MEASURE_BUDGETS") == "1":
+        return dict(outlier_frac=1.0, gross_frac=1.0, rel_l2=1.0, cosine=1.0)  # calibration run: record, do not judge
+    return {} if b is None else dict(outlier_frac=b, rel_l2=FULL_FRAME_GRAD_REL_L2, gross_frac=FULL_FRAME_GRAD_GROSS)
+
+
+def _training_step(s6m, min_rows):
     from fov3dgs_amd.rasterizer import _backward_native
     win, owin = pick(BWD_WIN)
     want = orc.forward("pcheck_obb_sum", s6m.scene_plain, s6m.cam_dict(window=owin))
     got = s6m.hip("pcheck_obb_sum")
-    tag = f"pcheck_obb_sum S-6M {scope(win)}"
+    tag = f"pcheck_obb_sum {s6m.name} {scope(win)}"
+    s6m.last_consumed = consumed_stats(got)
     np.testing.assert_array_equal(got["radii"].cpu().numpy(), want["radii"], err_msg=tag + ": radii")
     n, longest = compare_lists(got, want, win, tag)
-    check_image(crop(got["color"], win).cpu().numpy(), crop(want["color"], win), name=tag)
+    check_image(crop(got["color"], win).cpu().numpy(), crop(want["color"], win), name=tag, count=FRAME_COUNT_BUDGETS[s6m.name] if WHOLE else None)
     g_nc, w_nc = crop(got["n_contrib"], win).cpu().numpy().astype(np.uint32), crop(want["n_contrib"], win)
     same = g_nc == w_nc
     parity_report.record("count", tag + " n_contrib", frac_differ=float(np.mean(~same)), n=int(same.size))
@@ -306,21 +375,41 @@ def test_training_step_full_size(s6m):
     gT, wT = crop(got["final_T"], win).cpu().numpy()[same], crop(want["final_T"], win)[same]
     offT = np.abs(gT - wT) > 1e-4 * np.abs(wT) + 1e-7  # a flipped pair in the middle of a list moves T by <= alpha without moving n_contrib
     parity_report.record("count", tag + " final_T outside 1e-4 relative", frac=float(offT.mean()), max_rel=float((np.abs(gT - wT) / np.maximum(np.abs(wT), 1e-12)).max()))
-    assert offT.mean() <= 1e-5 and np.abs(gT - wT).max() <= 1.5e-2
+    assert offT.mean() <= FINAL_T_OUTLIERS[s6m.name] and np.abs(gT - wT).max() <= 1.5e-2
     if WHOLE:
         # RS statistics: +1 per entry of every 256-entry round a tile starts -- integer, expected bit-exact; a tile whose
         # last live pixel saturates within an ulp of T = 1e-4 at a round boundary may start one round more or less
         differ = compare_statistics(got, want, tag)
         assert differ <= 1e-5, f"gaussians_count differs on {differ:.2e} of the Gaussians"
-        check_grad(got["contributions"].cpu().numpy(), want["contributions"], tag + " contributions")
+        check_grad(got["contributions"].cpu().numpy(), want["contributions"], tag + " contributions",
+                   **budget_kw(s6m, "contributions"))
         parity_report.record("lists", tag, compared_instances=n, longest_compared_list=longest, rounds_of_longest_list=int((longest + 255) // 256),
-                             tiles_compared=int(len(window_tiles(win))))
+                             tiles_compared=int(len(window_tiles(win))), **s6m.last_consumed)
     # backward: random dL_dpix (inside the window only when the oracle only has the window's lists)
     x0, y0, x1, y1 = win
     dpix = np.zeros((3, H, W), np.float32)
     ys, xs = slice(y0 * 16, min(y1 * 16, H)), slice(x0 * 16, min(x1 * 16, W))
     dpix[:, ys, xs] = np.random.default_rng(3).normal(size=dpix[:, ys, xs].shape)
+    # The gradients are compared where the two FORWARD passes agree. A (pixel, Gaussian) pair that flips at a blend threshold
+    # (v_exp_f32 against expf, a few pixels per frame: the image / final_T checks above count them) changes that pixel's
+    # transmittance by >= 1/255 for EVERY entry behind it -- hundreds to thousands of Gaussians, each of which then differs by 0.4 %
+    # of that pixel's share of its gradient. On S-6M-T's deep lists the two dozen flipped pixels put 1.4e-3 of the 1 M rows outside
+    # 1e-4 relative, three times what the arithmetic itself does: a property of the forward pass, already measured there. So the
+    # loss gradient is zero on the pixels whose n_contrib or final_T differ (both sides get the same dL_dpix).
+    fT_g, fT_w = crop(got["final_T"], win).cpu().numpy(), crop(want["final_T"], win)
+    agree = same & ~(np.abs(fT_g - fT_w) > 1e-5 * np.abs(fT_w) + 1e-9)
+    parity_report.record("count", tag + " pixels left out of the backward comparison (forward state differs)", n=int((~agree).sum()), frac=float((~agree).mean()))
+    assert (~agree).mean() <= 2.0 * FINAL_T_OUTLIERS[s6m.name]
+    dpix[:, ys, xs] *= agree[None].astype(np.float32)
     wg = orc.backward("pcheck_obb_sum", s6m.scene_plain, s6m.cam_dict(window=owin), want, dpix)
+    wg64 = None
+    if WHOLE:
+        # the same arithmetic in DOUBLE on the fp32 forward's state (lists, n_contrib, final_T: no discrete decision differs): what the
+        # reference's own fp32 arithmetic loses on this frame -- the yardstick for the rows outside 1e-4 (check_against_noise)
+        want64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in want.items()}
+        wg64 = orc.backward("pcheck_obb_sum", {k: v.astype(np.float64) for k, v in s6m.scene_plain.items()}, s6m.cam_dict(window=owin), want64,
+                            dpix.astype(np.float64), dtype=np.float64)
+        del want64
     geom, binb, img = got["buffers"]
     E = torch.Tensor([])
 
@@ -340,8 +429,10 @@ def test_training_step_full_size(s6m):
         if k == "dL_dopacity":
             touched = rows
         assert not (grows & ~rows).any() or np.abs(g[grows & ~rows]).max() < 1e-6, k + ": gradient on a Gaussian the window cannot reach"
-        check_grad(g[rows], wg[k][rows], f"{tag} {k}")
-    assert touched.sum() > (100_000 if WHOLE else 10_000)  # (the cloud is dense: of 1.9 M visible Gaussians 131 k reach a pixel before it saturates)
+        check_grad(g[rows], wg[k][rows], f"{tag} {k}", **budget_kw(s6m, k))
+        if wg64 is not None:
+            check_against_noise(g[rows], wg[k][rows], wg64[k][rows], f"{tag} {k}")
+    assert touched.sum() > (min_rows if WHOLE else min_rows // 10)  # (S-6M is dense: of 1.9 M visible Gaussians 131 k reach a pixel before it saturates)
     parity_report.record("count", tag + " Gaussians with a gradient", n=int(touched.sum()))
     # the check is sensitive where round 2's was not: a 1 % error in the degree-3 SH gradients (coefficients 9..15) fails it
     sh_g = res[5].cpu().numpy().reshape(wg["dL_dsh"].shape)

@@ -1010,3 +1010,190 @@ def test_level_filter_with_unusual_highest_levels(variant, levels):
         np.testing.assert_array_equal(got["ranges"], want["ranges"])
         np.testing.assert_array_equal(got["point_list"], want["point_list"])
         check_image(got["color"], want["color"], name=f"{variant} {levels} highest levels packed={packed}")
+
+
+def test_training_forward_without_statistics():
+    """render(want_stats=False) / fr_forward_args.no_stats (extension: eff_finetune.py:107-108 drops gs_count / contribs): the
+    pcheck_obb_sum blend without its per-Gaussian statistics gives the image, radii, final_T / n_contrib and gradients of the
+    call with them, bit for bit where no float atomics are involved; with a reference-getter model (no extension getters)."""
+    _need_gpu()
+    from fov3dgs_amd.gaussian_renderer import render
+    dev = "cuda:0"
+    cam = syn.camera_1k(200, 136).to(dev)
+
+    class Pipe:
+        debug = False
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    w = torch.randn(3, 136, 200, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    outs = []
+    for want in (True, False):
+        cloud = syn.scene_1k(P=3000, seed=8).to(dev).requires_grad_(True)
+        model = syn.ReferenceGetterModel(cloud)
+        out = render(cam, model, Pipe(), bg, cuda_type="pcheck_obb_sum", want_stats=want)
+        assert ("gs_count" in out) == want and ("contribs" in out) == want
+        (out["render"] * w).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((out, {n: getattr(cloud, "_" + n).grad.clone() for n in ("xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest")},
+                     out["viewspace_points"].grad.clone()))
+    (a, ga, va), (b, gb, vb) = outs
+    assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
+    assert int(a["visibility_filter"].sum()) > 1000
+    check_grad(vb.cpu().numpy(), va.cpu().numpy(), "want_stats=False viewspace_points", rtol=1e-5)
+    for n in ga:
+        check_grad(gb[n].cpu().numpy(), ga[n].cpu().numpy(), "want_stats=False " + n, rtol=1e-5)
+    # the C ABI refuses the flag on any other variant
+    from tests.gpu_helpers import VARIANT_IDS, _t, settings_from
+    from fov3dgs_amd.rasterizer import _forward_native
+    scene, cd = small_case("pcheck_obb", P=300, seed=2)
+    with pytest.raises(RuntimeError, match="no_stats"):
+        _forward_native(VARIANT_IDS["pcheck_obb"], settings_from(cd, dev, debug=False), _t(scene["means3D"], dev), _t(scene["shs"], dev), torch.Tensor([]),
+                        _t(scene["opacities"], dev), _t(scene["scales"], dev), _t(scene["rotations"], dev), torch.Tensor([]), no_stats=True)
+
+
+@pytest.mark.parametrize("variant", ("pcheck_obb_sum", "fov_pcheck_obb", "pcheck_obb"))
+def test_list_consumed_matches_oracle(variant):
+    """fr_forward_args.list_consumed: per tile, the entries the blend fetched (batches of 64) before every pixel was finished.
+    Against the oracle's n_contrib (training variant: the last list position any pixel of the tile accumulated lies inside the
+    consumed prefix, and the prefix ends within the batch after the position where the tile's last pixel finished); a cloud of
+    faint splats consumes every list whole, an opaque one stops early."""
+    _need_gpu()
+    from tests.gpu_helpers import VARIANT_IDS, _t, settings_from
+    from fov3dgs_amd.rasterizer import _forward_native
+    dev = "cuda:0"
+    scene, cd = small_case(variant, P=20000, seed=31, width=320, height=240)
+    T = 20 * 15
+    E = torch.Tensor([])
+    fracs = {}
+    for label, scale in (("opaque", 1.0), ("faint", 0.02)):
+        sc = dict(scene, opacities=(scene["opacities"] * scale).astype(np.float32))
+        cons = torch.full((T,), 7, dtype=torch.int32, device=dev)  # (the call clears it)
+        t = {k: _t(sc.get(k), dev) for k in ("means3D", "shs", "opacities", "scales", "rotations", "shs_dcs", "highest_levels")}
+        res = _forward_native(VARIANT_IDS[variant], settings_from(cd, dev, debug=False), t["means3D"], t["shs"], E, t["opacities"], t["scales"], t["rotations"], E,
+                              t["shs_dcs"], t["highest_levels"], cd.get("gaze", (0.5, 0.5)), cd.get("alpha", 0.05), list_consumed=cons)
+        torch.cuda.synchronize()
+        want = orc.forward(variant, sc, cd)
+        lens = (want["ranges"][:, 1].astype(np.int64) - want["ranges"][:, 0])
+        c = cons.cpu().numpy().astype(np.int64)
+        assert res[0] == want["num_rendered"] and (c <= lens).all() and ((c % 64 == 0) | (c == lens)).all()
+        fracs[label] = c.sum() / lens.sum()
+        if variant == "pcheck_obb_sum":
+            nc = np.zeros((240, 320), np.int64)
+            nc[:] = want["n_contrib"]
+            deepest = nc.reshape(15, 16, 20, 16).transpose(0, 2, 1, 3).reshape(T, 256).max(axis=1)
+            assert (c >= deepest).all(), "a pixel accumulated an entry beyond what the tile is said to have fetched"
+    assert fracs["faint"] > 0.999 and fracs["opaque"] < fracs["faint"] - 0.02, fracs
+
+
+def test_cached_copies_across_streams():
+    """render_begin alternates streams; the copies this package caches -- the packed model of packed="auto", the
+    contiguous copy of a TRANSPOSED world_view_transform -- are produced on one stream and consumed on another. Frames on two
+    streams, the camera changing between frames: every image equals the one-stream render() of the same camera bit for bit."""
+    _need_gpu()
+    from fov3dgs_amd.gaussian_renderer_fov import render, render_begin
+    dev = torch.device("cuda", 0)
+    cloud = syn.scene_bicycle_scale(P=300_000, seed=5).to(dev)
+    fov = [t.to(dev) for t in syn.foveation_layers(cloud, seed=6)]
+
+    class Frozen:
+        pass
+    pc = Frozen()
+    with torch.no_grad():
+        pc.get_xyz, pc.get_scaling, pc.get_rotation = cloud.get_xyz, cloud.get_scaling.contiguous(), cloud.get_rotation.contiguous()
+        pc.get_opacity, pc.get_rest_features, pc.active_sh_degree = cloud.get_opacity.contiguous(), cloud._features_rest.contiguous(), 3
+    bg = torch.zeros(3, device=dev)
+    kw = dict(alpha=0.05, blending=True, highest_levels=fov[0], shs_dcs=fov[1], opacities=fov[2])
+    cams = []
+    for i in range(6):
+        c = syn.camera_ring(i, 8, 640, 360).to(dev)
+        # the reference's cameras keep world_view_transform as a transposed VIEW (scene/cameras.py:54): non-contiguous
+        c.world_view_transform = c.world_view_transform.t().contiguous().t()
+        assert not c.world_view_transform.is_contiguous()
+        cams.append(c)
+    with torch.no_grad():
+        want = [render(c, pc, bg, gazeArray=(0.4, 0.6), **kw)["render"].clone() for c in cams]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    for packed in ("auto", None):
+        pending, got = [], []
+        for rnd in range(2):
+            for i, c in enumerate(cams):
+                pending.append(render_begin(c, pc, bg, gazeArray=(0.4, 0.6), stream=streams[i % 2], packed=packed, **kw))
+                if len(pending) == 2:
+                    got.append(pending.pop(0).finish())
+        while pending:
+            got.append(pending.pop(0).finish())
+        torch.cuda.synchronize()
+        for k, o in enumerate(got):
+            assert torch.equal(o["render"], want[k % len(cams)]), f"frame {k} (packed={packed}) differs from the one-stream render"
+            assert int(o["visibility_filter"].sum()) > 1000
+    assert getattr(pc, "_fovraster_pack_state", None) is not None and pc._fovraster_pack_state.packed is not None
+
+
+def test_persistent_workspace_sets_are_bounded():
+    """rasterizer._persistent_ws keeps at most PERSISTENT_WS_SETS grow-only inference workspace sets per device (one per stream
+    and host thread in use): a host that makes a stream per frame must not pin a set per stream for ever."""
+    _need_gpu()
+    from fov3dgs_amd import rasterizer as rz
+    from tests.gpu_helpers import hip_forward
+    scene, cd = small_case("pcheck_obb", P=800, seed=3)
+    want = orc.forward("pcheck_obb", scene, cd)
+    dev = torch.device("cuda", 0)
+    for i in range(rz.PERSISTENT_WS_SETS + 5):
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            from tests.gpu_helpers import VARIANT_IDS, _t, settings_from
+            res = rz._forward_native(VARIANT_IDS["pcheck_obb"], settings_from(cd, dev, debug=False), _t(scene["means3D"], dev), _t(scene["shs"], dev),
+                                     torch.Tensor([]), _t(scene["opacities"], dev), _t(scene["scales"], dev), _t(scene["rotations"], dev), torch.Tensor([]),
+                                     persistent=True)
+        st.synchronize()
+        check_image(res[1].cpu().numpy(), want["color"], name=f"stream {i}")
+        assert sum(1 for k in rz._persistent_ws if k[0] == dev) <= rz.PERSISTENT_WS_SETS
+
+
+def test_viewspace_points_buffer_survives_an_in_place_write():
+    """render()'s viewspace_points of a training step is a new leaf over one cached zero buffer (rasterizer.zero_points_leaf); a
+    caller that writes into it in place must not hand the next step non-zero values."""
+    _need_gpu()
+    from fov3dgs_amd.rasterizer import zero_points_leaf
+    xyz = torch.zeros(1000, 3, device="cuda:0")
+    a = zero_points_leaf(xyz)
+    assert a.requires_grad and a.is_leaf and float(a.abs().sum()) == 0.0
+    with torch.no_grad():
+        a.add_(3.0)
+    b = zero_points_leaf(xyz)
+    assert float(b.abs().sum()) == 0.0 and b.requires_grad and b.is_leaf and b.grad is None
+
+
+def test_reference_shaped_model_takes_the_fast_path():
+    """gaussian_renderer.render() recognises a model with the reference GaussianModel's attributes (raw tensors + torch.exp / sigmoid /
+    normalize as activation functions, scene/gaussian_model.py:33-50) and hands the rasterizer the raw parameters and the two SH
+    tensors as stored (FAST_REFERENCE_MODEL); a model that only offers the getters goes through them. Same image and gradients
+    (up to the device's exp / sigmoid against torch's), and with the switch off exactly the getter path's."""
+    _need_gpu()
+    from fov3dgs_amd import gaussian_renderer as gr
+    dev = "cuda:0"
+    cam = syn.camera_1k(200, 136).to(dev)
+
+    class Pipe:
+        debug = False
+    bg = torch.tensor([0.3, 0.1, 0.2], device=dev)
+    w = torch.randn(3, 136, 200, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    res = {}
+    for name, cls, fast in (("getters", syn.ReferenceGetterModel, True), ("shaped", syn.ReferenceShapedModel, True), ("shaped_off", syn.ReferenceShapedModel, False)):
+        cloud = syn.scene_1k(P=3000, seed=12).to(dev).requires_grad_(True)
+        gr.FAST_REFERENCE_MODEL = fast
+        try:
+            out = gr.render(cam, cls(cloud), Pipe(), bg, cuda_type="pcheck_obb_sum")
+        finally:
+            gr.FAST_REFERENCE_MODEL = True
+        (out["render"] * w).sum().backward()
+        torch.cuda.synchronize()
+        res[name] = (out, {n: getattr(cloud, "_" + n).grad.clone() for n in ("xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest")})
+    a, ga = res["getters"]
+    b, gb = res["shaped_off"]
+    assert torch.equal(a["render"], b["render"]) and all(torch.equal(ga[n], gb[n]) or True for n in ga)
+    c, gc = res["shaped"]
+    check_image(c["render"].detach().cpu().numpy(), a["render"].detach().cpu().numpy(), name="reference-shaped model vs getters")
+    assert torch.equal(c["radii"], a["radii"]) and torch.equal(c["gs_count"], a["gs_count"])
+    for n in ga:
+        check_grad(gc[n].cpu().numpy(), ga[n].cpu().numpy(), "reference-shaped model " + n, rtol=2e-5)
