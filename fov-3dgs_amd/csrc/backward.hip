@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 	constexpr int PPL = 2;
 	__shared__ float4 s0[64];  // x, y, conic a, conic b
 	__shared__ float4 s1[64];  // conic c, opacity, r, g
-	__shared__ float2 s2[64];  // b, row of the gradient sums (int bits)
+	__shared__ float4 s2[64];  // b, row of the gradient sums (int bits), tq (the forward blend's threshold on q = -power), -
 
 	if (blockIdx.x >= a.n_items) return;
 	const uint32_t item = a.render_items[blockIdx.x]; // longest lists first
@@ -115,18 +115,23 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 		p0 = r[0]; p1 = r[1];
 		p2 = make_float2(r[2].x, __uint_as_float(id));
 	};
+	// the forward blend's skip tests (k_render: outside the support, alpha < 1/255) as its ONE threshold on q = -power: the very same
+	// expression, so that the backward pass takes the gradient of exactly the pairs the forward pass blended
+	auto q_threshold = [&](float opacity, float &lq) { lq = logf(255.0f * opacity); return fmaxf(0.0f, CUTOFF ? fminf(4.5f, lq) : lq); };
 	if (lane < wave_last) fetch(wave_last - 1 - lane);
 	for (int top = wave_last; top > 0; top -= 64)
 	{
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous batch has been read by all lanes
 		__builtin_amdgcn_wave_barrier();
 		const bool staged = lane < min(64, top);
-		if (staged) { s0[lane] = p0; s1[lane] = p1; s2[lane] = p2; }
+		float lq;
+		const float tq = q_threshold(p1.y, lq);
+		if (staged) { s0[lane] = p0; s1[lane] = p1; s2[lane] = make_float4(p2.x, p2.y, tq, 0.0f); }
 		unsigned long long reach;
 		{
 			// entries that cannot touch this wave's rows are skipped: same thresholds as the per-pixel tests below
 			// (power < -4.5, alpha < 1/255 <=> power < -ln(255 opacity)), see splat_reaches()
-			const float thr_a = -__logf(255.0f * p1.y) - 0.01f;
+			const float thr_a = -lq - 0.01f;
 			const float thr = CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a;
 			reach = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
 		}
@@ -140,22 +145,23 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 			const int pos = top - 1 - j; // 0-based position in the tile list
 			const float4 g0 = s0[j];
 			const float4 g1 = s1[j];
-			const float2 g2 = s2[j];
+			const float4 g2 = s2[j];
+			const uint32_t tqb = __float_as_uint(g2.z);
 			const float dx = g0.x - pxf;
 			const float adx2 = (g0.z * dx) * dx;
 			const float bdx = g0.w * dx;
 			const bv2 dy = g0.y - pyp;
 			const bv2 s = __builtin_elementwise_fma(g1.x * dy, dy, (bv2){ adx2, adx2 });
-			const bv2 power = __builtin_elementwise_fma((bv2){ -0.5f, -0.5f }, s, -(bdx * dy));
-			const bv2 pe = power * 1.4426950408889634f;
+			const bv2 q = __builtin_elementwise_fma((bv2){ 0.5f, 0.5f }, s, bdx * dy); // -power, bit for bit (render.hip qform2)
+			const bv2 pe = q * -1.4426950408889634f;
 			const bv2 G = (bv2){ __builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y) };
 			bv2 alpha = g1.y * G;
 			alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y);
 			// backward.cu:468-497: behind the pixel's last contributor / outside the support / negligible. Everything
 			// below is predicated: a pixel that is not `on` keeps its state and adds exact zeros (its G is cleared first,
 			// so no infinity of a far-away splat can meet a zero factor).
-			const bool on_x = pos < lastc[0] && !(power.x > 0.0f) && !(CUTOFF && power.x < -4.5f) && !(alpha.x < 1.0f / 255.0f);
-			const bool on_y = pos < lastc[1] && !(power.y > 0.0f) && !(CUTOFF && power.y < -4.5f) && !(alpha.y < 1.0f / 255.0f);
+			const bool on_x = pos < lastc[0] && __float_as_uint(q.x) <= tqb; // 0 <= q <= tq: in the support and alpha >= 1/255
+			const bool on_y = pos < lastc[1] && __float_as_uint(q.y) <= tqb;
 			const bool any = on_x || on_y;
 			float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // colour r g b, moments M10 M01 M20 M11 M02 M00 of G dL/dalpha
 			if (__any(any))

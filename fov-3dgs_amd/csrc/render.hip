@@ -117,11 +117,13 @@ __device__ __forceinline__ void blend2(Px2 &s, bool in_x, bool in_y, v2f e, floa
 // `ok` = the two skip tests of the reference that do not depend on T (outside the support, alpha < 1/255) as ONE comparison made by
 // the caller. Two compares + four selects per pixel instead of four + three: a v_cmp costs two plain VALU slots on gfx950.
 struct Px2k { v2f T, Tk, C0, C1, C2; };
-template <bool CLAMP>
-__device__ __forceinline__ void blend2k(Px2k &s, bool ok_x, bool ok_y, v2f e, float4 c)
+// ALPHATEST: `ok` only holds the support test, the alpha < 1/255 skip is made here (the _max flavour counts pixels between the two)
+template <bool CLAMP, bool ALPHATEST = false>
+__device__ __forceinline__ void blend2k(Px2k &s, bool ok_x, bool ok_y, v2f e, float4 c, v2f &w_out, bool &acc_xo, bool &acc_yo)
 {
 	v2f alpha = c.w * e;
 	if (CLAMP) { alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y); }
+	if (ALPHATEST) { ok_x = ok_x && !(alpha.x < 1.0f / 255.0f); ok_y = ok_y && !(alpha.y < 1.0f / 255.0f); }
 	const v2f tt = s.T * (1.0f - alpha);
 	v2f w = alpha * s.T;
 	const bool sat_x = tt.x < 0.0001f, sat_y = tt.y < 0.0001f;
@@ -136,6 +138,13 @@ __device__ __forceinline__ void blend2k(Px2k &s, bool ok_x, bool ok_y, v2f e, fl
 	const float nx = sat_x ? 0.0f : tt.x, ny = sat_y ? 0.0f : tt.y;
 	s.T.x = ok_x ? nx : s.T.x;
 	s.T.y = ok_y ? ny : s.T.y;
+	w_out = w; acc_xo = acc_x; acc_yo = acc_y;
+}
+template <bool CLAMP>
+__device__ __forceinline__ void blend2k(Px2k &s, bool ok_x, bool ok_y, v2f e, float4 c)
+{
+	v2f w; bool ax, ay;
+	blend2k<CLAMP>(s, ok_x, ok_y, e, c, w, ax, ay);
 }
 
 struct RenderArgs {
@@ -198,7 +207,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 
 	__shared__ float4 s0[64];
 	__shared__ float4 s1[64];
-	__shared__ float s2[64];
+	__shared__ float2 s2[64];   // b, tq: the threshold on q = -power below which a pixel takes part (see the staging)
 	__shared__ int sid[NEEDID ? 64 : 1];
 
 	const int st = threadIdx.x; // lane = staging slot
@@ -213,8 +222,8 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 	const uint2 range = a.ranges[tile];
 	const int n = (int)(range.y - range.x);
 
-	// pixel state as packed row pairs, finished pixels carry -T (see Px2)
-	Px2 S[HP];
+	// pixel state as packed row pairs; a finished pixel carries T = 0 and the transmittance it ended with in Tk (see Px2k)
+	Px2k S[HP];
 	float pyf[PPL];
 	uint32_t last[PPL];
 	bool inside[PPL];
@@ -224,7 +233,8 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		const int py = ty * FR_TILE + tile_row<PPL>(tid, k);
 		pyf[k] = (float)py;
 		inside[k] = px < a.W && py < a.H;
-		S[k >> 1].T[k & 1] = inside[k] ? 1.0f : -1.0f;
+		S[k >> 1].T[k & 1] = inside[k] ? 1.0f : 0.0f;
+		S[k >> 1].Tk[k & 1] = 1.0f;
 		last[k] = 0;
 	}
 #pragma unroll
@@ -282,16 +292,23 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			continue;
 		}
 		used = min(n, base + 64);
+		// The skip tests that do not depend on the pixel's transmittance as ONE threshold on q = -power (forward.cu:349-365, RS :376-380):
+		// power > 0, (CUTOFF) power < -4.5, and alpha = o e^-q < 1/255 <=> q > ln(255 o): a pixel takes part iff 0 <= q <= tq with
+		// tq = min(4.5, ln(255 o)), one unsigned comparison on q's bits. ln(255 o) to an ulp (logf): the decision then differs from the
+		// reference's own fp32 evaluation of o * exp(power) < 1/255 only inside that expression's rounding, like the exp2-based test it
+		// replaces. The _max flavour counts pixels between the support test and the alpha test: its threshold is the support's alone.
+		const float lq = logf(255.0f * p1.y);
+		const float tq = PMAX ? 4.5f : fmaxf(0.0f, CUTOFF ? fminf(4.5f, lq) : lq);
 		if (staged)
 		{
-			s0[st] = p0; s1[st] = p1; s2[st] = p2;
+			s0[st] = p0; s1[st] = p1; s2[st] = make_float2(p2, tq);
 			if (NEEDID) sid[st] = (int)pgid;
 		}
 		unsigned long long reach_own;
 		{
 			// which entries can touch this band at all (see splat_reaches)? alpha < 1/255 (forward.cu:336) <=> power <
 			// -ln(255 opacity); the _max flavour counts pixels BEFORE the alpha test, so only the support cutoff applies
-			const float thr_a = -__logf(255.0f * p1.y) - 0.01f;
+			const float thr_a = -lq - 0.01f;
 			const float thr = PMAX ? -4.5f : (CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a);
 			reach_own = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
 		}
@@ -318,6 +335,8 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			t.j = j;
 			const float4 g0 = s0[j];
 			const float4 g1 = s1[j];
+			const float2 g2 = s2[j];
+			const uint32_t tqb = __float_as_uint(g2.y);
 			const float dx = g0.x - pxf;
 			const float adx2 = (g0.z * dx) * dx;     // A*dx*dx
 			const float bdx = g0.w * dx;             // B*dx
@@ -326,11 +345,11 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			{
 				// (forward.cu:349-351: power > 0 is skipped; RS :376-380 also power < -4.5 -- one comparison on q's bits, see qform2)
 				const v2f q = qform2(g0.y - pyp[h], g1.x, adx2, bdx);
-				t.inx[h] = valid && (CUTOFF ? in_support(q.x) : __float_as_int(q.x) >= 0);
-				t.iny[h] = valid && (CUTOFF ? in_support(q.y) : __float_as_int(q.y) >= 0);
+				t.inx[h] = valid && __float_as_uint(q.x) <= tqb; // 0 <= q <= tq
+				t.iny[h] = valid && __float_as_uint(q.y) <= tqb;
 				t.e[h] = exp_neg_pair(q);
 			}
-			t.col = make_float4(g1.z, g1.w, s2[j], g1.y); // r, g, b, opacity
+			t.col = make_float4(g1.z, g1.w, g2.x, g1.y); // r, g, b, opacity
 			return t;
 		};
 		auto blend = [&](const Ent &t, float &contrib_sum, bool &any_contrib)
@@ -351,7 +370,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			for (int h = 0; h < HP; h++)
 			{
 				v2f w; bool ax, ay;
-				blend2(S[h], t.inx[h], t.iny[h], t.e[h], t.col, w, ax, ay);
+				blend2k<true, PMAX>(S[h], t.inx[h], t.iny[h], t.e[h], t.col, w, ax, ay);
 				if (AUX)
 				{
 					last[2 * h] = ax ? (uint32_t)(base + j + 1) : last[2 * h];
@@ -451,7 +470,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 	{
 		if (!inside[k]) continue;
 		const size_t pid2 = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
-		const float Tk = fabsf(S[k >> 1].T[k & 1]);
+		const float Tk = S[k >> 1].Tk[k & 1];
 		if (AUX) { a.final_T[pid2] = Tk; a.n_contrib[pid2] = last[k]; }
 		if (LWMC) atomicAdd(&a.contributions[best_id[k]], a.loss_map[pid2]); // …_count forward.cu:435
 		a.out_color[pid2] = fmaf(Tk, bg0, S[k >> 1].C0[k & 1]);
@@ -476,207 +495,6 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 // workgroups IS the load balancer); s_setprio by round or by remaining list length: nothing.
 template <int PPL>
 __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
-{
-	static_assert(PPL == 2, "work items encode two bands per tile");
-	constexpr int HP = PPL / 2;
-	// three rows of 16 bytes per staged entry, all with the same stride: one address register serves the three reads
-	__shared__ float4 s0[64];   // x, y, A, B
-	__shared__ float4 s1[64];   // C, highest_level, -, -
-	__shared__ float4 sl1[64];  // this wave's level: r, g, b, opacity
-
-	const int lane = threadIdx.x;
-	const uint32_t idx = blockIdx.x;
-	if (idx >= a.totals[5] || a.totals[0] > a.capacity || a.totals[5] > gridDim.x) return;
-	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
-	const size_t plane = (size_t)a.W * a.H;
-	{
-		const uint32_t item = a.render_items[idx];
-		const int tile = (int)(item >> 3), wv = (int)(item & 1u);
-		const bool two_level = (item & 4u) != 0;
-		const bool upper = (item & 2u) != 0; // this wave carries the state of level L2
-		const int tx = tile % a.gx, ty = tile / a.gx;
-		const int tid = wv * 64 + lane; // position inside the tile's 256 / PPL threads (row mapping)
-		const int lx = tid & 15;
-		const int px = tx * FR_TILE + lx;
-		const float pxf = (float)px;
-		const uint2 range = a.ranges[tile];
-		const int n = (int)(range.y - range.x);
-		const float tlf = a.tile_lv[a.T + tile];                    // tile_min
-		const int L1 = f2i(tlf);
-		const int L2 = L1 + 1;
-		const float L2f = tlf + 1.0f;
-		const float tgx = a.tile_lv[2 * (size_t)a.T + tile], tgy = a.tile_lv[3 * (size_t)a.T + tile];
-
-		// Per-lane state of the lane's pixels (rows ry, ry + 4), kept as a packed pair so that the blend runs on
-		// v_pk_mul / v_pk_fma. A finished pixel carries its transmittance NEGATED: "still blending" is T > 0, no
-		// separate flag registers, and |T| is the value the reference keeps.
-		Px2 S1[HP];
-		float pyf[PPL], est[PPL];
-		bool inside[PPL];
-#pragma unroll
-		for (int k = 0; k < PPL; k++)
-		{
-			const int ly = tile_row<PPL>(tid, k);
-			const int py = ty * FR_TILE + ly;
-			pyf[k] = (float)py;
-			inside[k] = px < a.W && py < a.H;
-			est[k] = tlf + ((float)lx * tgx + (float)ly * tgy) / (float)FR_TILE;
-			// RF forward.cu:262-476: level L1 stops contributing beyond est > L2; single-level tiles have no second state
-			const bool done1 = (two_level && !upper) ? (!inside[k] || (est[k] > (float)L2)) : !inside[k];
-			S1[k >> 1].T[k & 1] = done1 ? -1.0f : 1.0f;
-		}
-#pragma unroll
-		for (int h = 0; h < HP; h++) S1[h].C0 = S1[h].C1 = S1[h].C2 = (v2f){ 0.f, 0.f };
-
-#ifdef FR_TILE_TIMERS
-		const uint64_t tm0 = wall_clock64(); uint32_t tm_proc = 0, tm_batches = 0; uint64_t tm_loop = 0, tm_sync = 0;
-#endif
-		// prefetch registers
-		float4 p0 = make_float4(0, 0, 0, 0), pl1 = p0;
-		float2 p1 = make_float2(0, 0);
-		auto fetch = [&](int e)
-		{
-			const uint32_t id = a.point_list[range.x + e];
-			const float4 *r = a.rec + 3 * (size_t)id;
-			p0 = r[0];
-			const float4 r1 = r[1];
-			p1 = make_float2(r1.x, r1.y);
-			pl1 = a.lvl[(size_t)id * FR_FOV_LEVELS + (upper ? L2 : L1)];
-		};
-		if (lane < n) fetch(lane);
-		int used = 0; // list entries this wave staged for blending (list_consumed)
-		for (int base = 0; base < n; base += 64)
-		{
-			float tmax0 = -1.0f;
-#pragma unroll
-			for (int h = 0; h < HP; h++) tmax0 = fmaxf(tmax0, fmaxf(S1[h].T.x, S1[h].T.y));
-#ifdef FR_TILE_TIMERS
-			const uint64_t tq0 = wall_clock64();
-#endif
-			if (!__any(tmax0 > 0.0f)) break;
-			// the previous batch has been read by all lanes (wave-synchronous, fenced)
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-#ifdef FR_TILE_TIMERS
-			tm_sync += wall_clock64() - tq0;
-#endif
-			const bool staged = base + lane < n;
-			used = min(n, base + 64);
-			if (staged) { s0[lane] = p0; s1[lane] = make_float4(p1.x, p1.y, 0.0f, 0.0f); sl1[lane] = pl1; }
-			unsigned long long reach_mask;
-			{
-				// alpha < 1/255 everywhere (forward.cu:563) <=> power < -ln(255 opacity): tighter than -4.5 for faint splats
-				const float thr = fmaxf(-4.5f, -__logf(255.0f * pl1.w) - 0.01f);
-				// a wave that carries the level-L2 state skips the Gaussians that do not exist at L2 (RF forward.cu:399: about
-				// half the list in a 0/1 tile) here, at one lane's cost, instead of walking them as no-ops
-				const bool exists = !upper || !((p1.y + 1.0f) < L2f);
-				reach_mask = __ballot(staged && exists && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
-			}
-			if (base + 64 + lane < n) fetch(base + 64 + lane);
-			// lanes read entries other lanes staged
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			v2f pyp[HP];
-#pragma unroll
-			for (int h = 0; h < HP; h++) pyp[h] = (v2f){ pyf[2 * h], pyf[2 * h + 1] };
-#ifdef FR_TILE_TIMERS
-			const uint64_t tq1 = wall_clock64();
-			tm_proc += (uint32_t)__popcll(reach_mask); tm_batches++;
-#endif
-			// Entries are taken two at a time: everything that does not depend on the running transmittance (record
-			// fetch, power, exp, alpha inputs) is evaluated for both before either is blended, so the two dependency
-			// chains overlap.
-			struct Ent { v2f e[HP]; bool inx[HP], iny[HP]; float4 c1; };
-			auto prepare = [&](const int j, const bool valid)
-			{
-				Ent t;
-				const float4 g0 = s0[j];
-				const float g1x = s1[j].x;
-				const float dx = g0.x - pxf;
-				const float adx2 = (g0.z * dx) * dx;
-				const float bdx = g0.w * dx;
-#pragma unroll
-				for (int h = 0; h < HP; h++)
-				{
-					const v2f q = qform2(g0.y - pyp[h], g1x, adx2, bdx);
-					// in the splat's support: RF forward.cu:556-560 (power > 0 and power < -4.5 are skipped)
-					t.inx[h] = valid && in_support(q.x);
-					t.iny[h] = valid && in_support(q.y);
-					t.e[h] = exp_neg_pair(q);
-				}
-				t.c1 = sl1[j];
-				return t;
-			};
-			for (unsigned long long rm = reach_mask; rm; )
-			{
-				int jj[FR_RENDER_GROUP];
-				bool vv[FR_RENDER_GROUP];
-#pragma unroll
-				for (int g = 0; g < FR_RENDER_GROUP; g++)
-				{
-					vv[g] = rm != 0;
-					jj[g] = vv[g] ? __builtin_ctzll(rm) : jj[0];
-					rm &= rm - 1; // stays 0 once empty
-				}
-				float tmax = -1.0f;
-#pragma unroll
-				for (int h = 0; h < HP; h++) tmax = fmaxf(tmax, fmaxf(S1[h].T.x, S1[h].T.y));
-				if (!__any(tmax > 0.0f)) break;
-				Ent t[FR_RENDER_GROUP];
-#pragma unroll
-				for (int g = 0; g < FR_RENDER_GROUP; g++) t[g] = prepare(jj[g], vv[g]);
-#pragma unroll
-				for (int g = 0; g < FR_RENDER_GROUP; g++)
-#pragma unroll
-					for (int h = 0; h < HP; h++) blend2(S1[h], t[g].inx[h], t[g].iny[h], t[g].e[h], t[g].c1);
-			}
-#ifdef FR_TILE_TIMERS
-			tm_loop += wall_clock64() - tq1;
-#endif
-		}
-
-#ifdef FR_TILE_TIMERS
-		if (lane == 0)
-		{
-			// developer build only (tools/tile_cycles.py): per-ITEM records in the otherwise unused final_T / n_contrib arrays
-			const uint32_t G = 4u * (uint32_t)a.T, b = idx;
-			a.final_T[b] = (float)(wall_clock64() - tm0); a.final_T[G + b] = (float)(tm0 & 0xffffff);
-			a.n_contrib[b] = tm_proc; a.n_contrib[G + b] = tm_batches; a.n_contrib[2 * G + b] = (uint32_t)n;
-			a.n_contrib[3 * G + b] = (uint32_t)tile | ((uint32_t)wv << 16) | ((uint32_t)upper << 20) | ((uint32_t)two_level << 21);
-			a.n_contrib[4 * G + b] = (uint32_t)tm_loop; a.n_contrib[5 * G + b] = (uint32_t)tm_sync;
-		}
-#endif
-		report_consumed(a, tile, used, lane);
-#pragma unroll
-		for (int k = 0; k < PPL; k++)
-		{
-			if (!inside[k]) continue;
-			const size_t pid = (size_t)a.W * (size_t)(ty * FR_TILE + tile_row<PPL>(tid, k)) + px;
-			const float t1 = fabsf(S1[k >> 1].T[k & 1]);
-			const float o0 = fmaf(bg0, t1, S1[k >> 1].C0[k & 1]), o1 = fmaf(bg1, t1, S1[k >> 1].C1[k & 1]), o2 = fmaf(bg2, t1, S1[k >> 1].C2[k & 1]);
-			if (two_level)
-			{
-				// RF forward.cu:455-470: C1 * w1 + C2 * (1 - w1), w1 = 1 - smoothstep
-				float x = fabsf(est[k] - ((float)L1 + 0.5f)) / 0.5f;
-				x = fmaxf(0.0f, fminf(1.0f, x));
-				const float bT = 3 * x * x - 2 * x * x * x;
-				const float w1 = 1 - bT;
-				const float w = upper ? (1.f - w1) : w1;
-				atomicAdd(&a.out_color[pid], o0 * w);
-				atomicAdd(&a.out_color[plane + pid], o1 * w);
-				atomicAdd(&a.out_color[2 * plane + pid], o2 * w);
-				continue;
-			}
-			a.out_color[pid] = o0;
-			a.out_color[plane + pid] = o1;
-			a.out_color[2 * plane + pid] = o2;
-		}
-	}
-}
-
-template <int PPL>
-__global__ void __launch_bounds__(64, 8) k_render_fov_diet(const RenderArgs a)
 {
 	static_assert(PPL == 2, "work items encode two bands per tile");
 	constexpr int HP = PPL / 2;
@@ -1178,11 +996,7 @@ int launch_render(FwdCtx &c)
 	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: hipLaunchKernelGGL((k_render_smfr<2>), dim3(n_items), dim3(64), 0, c.stream, r); break;
 	case FR_VARIANT_MMFR_PCHECK_OBB: hipLaunchKernelGGL((k_render_mmfr<2>), dim3(n_items), dim3(64), 0, c.stream, r); break;
 	default:
-#ifdef FR_BLEND_DIET
-		hipLaunchKernelGGL((k_render_fov_diet<2>), dim3(n_items), dim3(64), 0, c.stream, r);
-#else
 		hipLaunchKernelGGL((k_render_fov<2>), dim3(n_items), dim3(64), 0, c.stream, r);
-#endif
 		break;
 	}
 #undef FR_LAUNCH_RENDER
