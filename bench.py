@@ -58,6 +58,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=9)
     ap.add_argument("--mode", choices=("render", "train"), default="render")
     ap.add_argument("--points", type=int, default=6_000_000)
+    ap.add_argument("--cloud", choices=("S-6M", "S-6M-T"), default="S-6M",
+                    help="S-6M: the headline cloud (SURVEY 8d). S-6M-T: the same cloud with opacities that make the blend consume its lists "
+                         "(synthetic.scene_translucent) as the main workload -- profiling passes (tools/make_profiles.sh); the default run "
+                         "reports S-6M-T under extra.translucent")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--repeats", type=int, default=5,
@@ -228,7 +232,7 @@ def main():
         hl, dcs, op4 = [t.to(dev) for t in f_cpu]
         return dict(cloud_cpu=c_cpu, fov_cpu=f_cpu, cloud=c_dev, pc=FrozenCloud(c_dev), highest=hl, shs_dcs=dcs, opac=op4)
 
-    scene = make_scene(syn.OPACITY_LOGIT_S6M)
+    scene = make_scene(syn.OPACITY_LOGIT_S6MT if args.cloud == "S-6M-T" else syn.OPACITY_LOGIT_S6M)
     cloud_cpu, fov_cpu, cloud, pc = scene["cloud_cpu"], scene["fov_cpu"], scene["cloud"], scene["pc"]
     highest, shs_dcs, opac = scene["highest"], scene["shs_dcs"], scene["opac"]
     n_views = 8
@@ -240,6 +244,7 @@ def main():
 
     if args.mode == "train":
         return train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync)
+    cloud_name = args.cloud
 
     def frame_of(sc):
         def frame_fn(gaze, packed, **kw):
@@ -362,16 +367,18 @@ def main():
         per = []
         pc_ = sc["pc"]
         cons = torch.zeros(T, dtype=torch.int32, device=dev)
+        pairs = torch.zeros(T, dtype=torch.int32, device=dev)
         with torch.no_grad():
             for gaze in GAZES:
                 rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
                                                       cam.world_view_transform, cam.full_proj_transform, 3,
                                                       cam.camera_center, False, False)
                 res = rz._forward_native(vid, rs, pc_.get_xyz, pc_.get_rest_features, torch.Tensor([]), sc["opac"], pc_.get_scaling,
-                                         pc_.get_rotation, torch.Tensor([]), sc["shs_dcs"], sc["highest"], gaze, 0.05, list_consumed=cons)
+                                         pc_.get_rotation, torch.Tensor([]), sc["shs_dcs"], sc["highest"], gaze, 0.05, list_consumed=cons, blend_pairs=pairs)
                 torch.cuda.synchronize()
                 d = frame_stats(torch, lib, vid, (res[0], res[2], res[5]), W, H, T, geom=res[3], P=args.points)
                 d["consumed"] = float(cons.sum().item()) / max(d["D"], 1)
+                d["pairs"] = int(pairs.long().sum().item())  # (band of eight rows, list entry) pairs the blend evaluated
                 per.append(d)
             vm = cam.world_view_transform
             z = pc_.get_xyz @ vm[:3, 2] + vm[3, 2]
@@ -404,6 +411,8 @@ def main():
     roofline = dict(bound="hbm", **roof(dominant))
     roofline["blend"] = roof("render")
     roofline["blend"].update(prof.blend_sq())
+    if roofline["blend"].get("valu_insts"):
+        roofline["blend"]["valu_insts_per_blend_pair"] = round(roofline["blend"]["valu_insts"] / max(st["pairs"], 1), 1)
     frame_bytes = sum(alg_bytes.values())
     ms_step = elapsed / K * 1e3
     roofline["frame"] = dict(algorithmic_bytes=int(frame_bytes), ms=round(ms_step, 4),
@@ -419,7 +428,7 @@ def main():
     # geometry, seeds and SH, opacity logits ~ N(-3.5, 1): the blend fetches 0.9 of a foveated frame's instances and 0.7 of the
     # training frame's, 1.0 M Gaussians receive a gradient) -- which stage leads depends on the workload, and a trained model is
     # nearer to this one than to S-6M's saturating cloud
-    if world == 1 and not args.no_extra:
+    if world == 1 and not args.no_extra and args.cloud == "S-6M":
         tsc = make_scene(syn.OPACITY_LOGIT_S6MT)
         frame_t = frame_of(tsc)
         with torch.no_grad():
@@ -448,7 +457,7 @@ def main():
         extra["translucent"] = dict(
             workload="S-6M-T: the S-6M cloud with opacity logits ~ N(%.1f, %.1f^2) (synthetic.scene_translucent), same camera, gazes, protocol" % syn.OPACITY_LOGIT_S6MT,
             fps=round(K / el_t, 2), ms_per_step=round(el_t / K * 1e3, 4), fps_spread=[round(K / sp_t[1], 2), round(K / sp_t[0], 2)],
-            stages_ms={k: round(v, 4) for k, v in ms_t.items()}, list_consumed_frac=round(st_t["consumed"], 4),
+            stages_ms={k: round(v, 4) for k, v in ms_t.items()}, list_consumed_frac=round(st_t["consumed"], 4), blend_pairs=int(st_t["pairs"]),
             list_consumed_frac_training_frame=round(plain_consumed, 4), gaussians_with_gradient=grad_rows,
             visible=int(st_t["V"]), instances=int(st_t["D"]), max_tile_list=int(max(s_["max_list"] for s_ in stats_t)),
             roofline=dict(kernel=slow, bound="hbm", kernel_ms=round(ms_t[slow], 4), algorithmic_bytes=int(bytes_t[slow]),
@@ -495,12 +504,12 @@ def main():
         "value_pipelined": round(world * K / elapsed_pl, 3), "ms_per_step_pipelined": round(elapsed_pl / K * 1e3, 4),
         "value_pipelined_spread": [round(world * K / spread_pl[1], 3), round(world * K / spread_pl[0], 3)],
         "pipeline_depth": 2,
-        "config": {"workload": "S-6M bicycle-scale cloud, 4-layer foveated render (fov_pcheck_obb), the reference's 9 fixed gazes "
+        "config": {"workload": cloud_name + " bicycle-scale cloud, 4-layer foveated render (fov_pcheck_obb), the reference's 9 fixed gazes "
                                "(0.25 i, 0.25 j) in turn, one camera per GPU" + (", frames gathered on rank 0" if (world > 1 and args.gather) else ""),
                    "gaussians": P, "width": W, "height": H, "alpha": 0.05, "sh_degree": 3,
                    "visible": int(st["V"]), "candidates": int(st["C"]), "in_front": V_in, "instances": int(st["D"]),
                    "instances_blend_tiles": int(st["D_blend"]), "max_tile_list": int(max(s["max_list"] for s in stats)),
-                   "list_consumed_frac": round(st["consumed"], 4),
+                   "list_consumed_frac": round(st["consumed"], 4), "blend_pairs": int(st["pairs"]),
                    "list_consumed_note": "share of the frames' sorted instances the blend fetches before every pixel of their tile is finished "
                                          "(fr_forward_args.list_consumed, batches of 64): the S-6M cloud (SURVEY 8d: opacity = sigmoid(N(1, 2^2))) "
                                          "saturates early; extra.translucent is the same frame on S-6M-T, a cloud that consumes its lists",
@@ -708,10 +717,17 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
         from fov3dgs_amd import rasterizer as rz_
         rs_ = rz_.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0, cam.world_view_transform,
                                                 cam.full_proj_transform, 3, cam.camera_center, False, False)
-        d_tr = rz_._forward_native(_nat.VARIANT_PCHECK_OBB_SUM, rs_, pc.get_xyz, pc.get_features, torch.Tensor([]), pc.get_opacity,
-                                   pc.get_scaling, pc.get_rotation, torch.Tensor([]), persistent=True)[0]  # the frame's instances
+        T_ = ((W + 15) // 16) * ((H + 15) // 16)
+        pf, pb = torch.zeros(T_, dtype=torch.int32, device=dev), torch.zeros(T_, dtype=torch.int32, device=dev)
+        r_tr = rz_._forward_native(_nat.VARIANT_PCHECK_OBB_SUM, rs_, pc.get_xyz, pc.get_features, torch.Tensor([]), pc.get_opacity,
+                                   pc.get_scaling, pc.get_rotation, torch.Tensor([]), blend_pairs=pf)
+        d_tr = r_tr[0]  # the frame's instances
+        E_ = torch.Tensor([])
+        rz_._backward_native(_nat.VARIANT_PCHECK_OBB_SUM, rs_, pc.get_xyz, r_tr[2], E_, pc.get_opacity, pc.get_scaling, pc.get_rotation, E_,
+                             torch.rand(3, H, W, device=dev), pc.get_features, r_tr[3], d_tr, r_tr[4], r_tr[5], blend_pairs=pb)
+        torch.cuda.synchronize()
     n_tr = dict(P=int(tr.get_xyz.shape[0]), Px=H * W, T=((W + 15) // 16) * ((H + 15) // 16), V=int(o["visibility_filter"].sum().item()),
-                V_in=v_in, D=int(d_tr))
+                V_in=v_in, D=int(d_tr), blend_pairs_fwd=int(pf.long().sum().item()), blend_pairs_bwd=int(pb.long().sum().item()))
     extra["_train_counts"], extra["_train_fwd_ms"], extra["_train_bwd_ms"] = n_tr, fwd_ms, bwd_ms
     tr.row_sparse_grads = False
     return extra

@@ -47,6 +47,7 @@ class ForwardArgs(C.Structure):
         ("num_candidates", C.c_int32),
         ("list_consumed", _FP),
         ("no_stats", C.c_int32),
+        ("blend_pairs", _FP),
     ]
 
 
@@ -67,6 +68,7 @@ class BackwardArgs(C.Structure):
         ("dL_dsh_rest", _FP),
         ("raw_activations", C.c_int32),
         ("row_sparse", C.c_int32),
+        ("blend_pairs", _FP),
     ]
 
 

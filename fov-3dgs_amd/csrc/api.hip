@@ -265,6 +265,7 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 	if (!is_fov(a->variant)) // RF: k_tile_levels clears them
 		FR_HIP(hipMemsetAsync(c.geom.slab_ctr, 0, FR_SLAB_CTR_WORDS * sizeof(uint32_t), stream));
 	if (a->list_consumed) FR_HIP(hipMemsetAsync(a->list_consumed, 0, sizeof(uint32_t) * (size_t)c.T, stream));
+	if (a->blend_pairs) FR_HIP(hipMemsetAsync(a->blend_pairs, 0, sizeof(uint32_t) * (size_t)c.T, stream));
 	static thread_local uint32_t frame_seq = 0; // this frame's tag: the totals block's sequence word
 	if (++frame_seq == 0) frame_seq = 1;
 	c.totals_seq = frame_seq;

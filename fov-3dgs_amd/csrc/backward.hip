@@ -51,6 +51,7 @@ struct BwdRenderArgs {
 	const uint32_t *n_contrib;
 	const float *dL_dpix;
 	float *acc; // [V][16] gradient sums per visible-list entry, see GeomWS::acc
+	uint32_t *pairs; // optional diagnostic (fr_backward_args.blend_pairs): [T], (band, entry) pairs evaluated, or null
 };
 
 template <bool CUTOFF>
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 	// expression, so that the backward pass takes the gradient of exactly the pairs the forward pass blended
 	auto q_threshold = [&](float opacity, float &lq) { lq = logf(255.0f * opacity); return fmaxf(0.0f, CUTOFF ? fminf(4.5f, lq) : lq); };
 	if (lane < wave_last) fetch(wave_last - 1 - lane);
+	uint32_t npairs = 0;
 	for (int top = wave_last; top > 0; top -= 64)
 	{
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous batch has been read by all lanes
@@ -134,7 +136,8 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 			const float thr_a = -lq - 0.01f;
 			const float thr = CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a;
 			reach = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
-		}
+			npairs += (uint32_t)__popcll(reach);
+			}
 		if (top - 64 - lane > 0) fetch(top - 64 - 1 - lane);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // lanes read entries other lanes staged
 		__builtin_amdgcn_wave_barrier();
@@ -182,8 +185,9 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 				const bv2 Tn = __builtin_elementwise_fma(__builtin_elementwise_fma(-om, q0, T), r, q0);
 				T = Tn;
 				const bv2 wgt = am * Tn;                                       // d channel / d colour
-				const bv2 c0 = wgt * dp0, c1 = wgt * dp1, c2 = wgt * dp2;
-				v[0] = hsum(c0); v[1] = hsum(c1); v[2] = hsum(c2);
+				// (the lane's two pixels' terms as a product and a fused multiply-add: two plain instructions where a packed product and
+				// the sum of its halves are three instruction slots)
+				v[0] = fmaf(wgt.y, dp0.y, wgt.x * dp0.x); v[1] = fmaf(wgt.y, dp1.y, wgt.x * dp1.x); v[2] = fmaf(wgt.y, dp2.y, wgt.x * dp2.x);
 				// backward.cu:507-514 keeps the colour accumulated behind the entry per channel and forms sum_ch (c_ch - behind_ch) dpix_ch;
 				// here the products with dpix are taken first: cdot = c . dpix of this entry, A = behind . dpix -- one state per pixel
 				// instead of three, updated with the entry itself once its gradient has been taken (the reference's last_alpha /
@@ -194,10 +198,16 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 				A = __builtin_elementwise_fma(am, cdot, om * A);
 				// the six moments of G dL/dalpha about the splat's centre: what the gradients of the mean, the conic and the opacity are
 				// linear in (backward.cu:524-541 forms the products per pixel; k_preprocess_bwd forms them once per Gaussian)
+				// A lane's two pixels share their column, i.e. dx: the x factors are taken out of the lane's sums (M10 = dx (w0 + w1),
+				// M20 = dx M10, M11 = dx M01): three packed products and three plain ones where six packed products were
 				const bv2 w = Gm * dA;
-				const bv2 wx = w * dx, wy = w * dy;
-				const bv2 m20 = wx * dx, m11 = wx * dy, m02 = wy * dy;
-				v[3] = hsum(wx); v[4] = hsum(wy); v[5] = hsum(m20); v[6] = hsum(m11); v[7] = hsum(m02); v[8] = hsum(w);
+				const float m00 = hsum(w);
+				const float m10 = m00 * dx, m20 = m10 * dx;
+				const bv2 wy = w * dy;
+				const float m01 = hsum(wy);
+				const float m11 = m01 * dx;
+				const float m02 = fmaf(wy.y, dy.y, wy.x * dy.x);
+				v[3] = m10; v[4] = m01; v[5] = m20; v[6] = m11; v[7] = m02; v[8] = m00;
 			}
 			if (__any(any))
 			{
@@ -216,6 +226,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 			}
 		}
 	}
+	if (a.pairs != nullptr && lane == 0 && npairs != 0) atomicAdd(a.pairs + tile, npairs);
 }
 
 // ---- per-Gaussian chain rule ------------------------------------------------------------------
@@ -646,6 +657,12 @@ static int launch_render_bwd(const fr_backward_args *a, const GeomWS &geom, cons
 	r.point_list = bin.point_list; r.rec = geom.rec;
 	r.bg = a->background; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.dL_dpix = a->dL_dpix;
 	r.acc = (float *)geom.acc;
+	r.pairs = a->blend_pairs;
+	if (r.pairs != nullptr)
+	{
+		const hipError_t e = hipMemsetAsync(r.pairs, 0, sizeof(uint32_t) * (size_t)T, stream);
+		if (e != hipSuccess) { set_error("hipMemsetAsync(blend_pairs): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
+	}
 	if (a->variant == FR_VARIANT_ORIGINAL)
 		hipLaunchKernelGGL((k_render_bwd<false>), dim3(r.n_items), dim3(64), 0, stream, r);
 	else

@@ -170,12 +170,14 @@ struct RenderArgs {
 	float cur_level;              // MMFR
 	uint32_t *round_flags;        // RS / LWMC: one bit per (tile, 256-entry round): the round's counts have an owner
 	uint32_t *consumed;           // optional diagnostic (fr_forward_args.list_consumed): [T], entries fetched per tile, or null
+	uint32_t *pairs;              // optional diagnostic (fr_forward_args.blend_pairs): [T], (band, entry) pairs evaluated, or null
 };
 
 // list_consumed: a wave reports how far into its tile's list it staged entries for blending (one atomic per wave, only when asked for)
-__device__ __forceinline__ void report_consumed(const RenderArgs &a, int tile, int used, int lane)
+__device__ __forceinline__ void report_consumed(const RenderArgs &a, int tile, int used, int lane, uint32_t npairs = 0)
 {
 	if (a.consumed != nullptr && lane == 0 && used > 0) atomicMax(a.consumed + tile, (uint32_t)used);
+	if (a.pairs != nullptr && lane == 0 && npairs > 0) atomicAdd(a.pairs + tile, npairs);
 }
 
 // ---------------- ORIGINAL / PCHECK_OBB_SUM / PCHECK_OBB / _MAX / _LWMC ----------------
@@ -257,6 +259,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 	}
 	bool counting = false; // FETCHCNT: this wave owns the counts of the current 256-entry round
 	int used = 0;          // list entries this wave staged for blending (list_consumed)
+	uint32_t npairs = 0;   // ... and how many of them can reach its band (blend_pairs)
 	for (int base = 0; base < n; base += 64)
 	{
 		float tmax0 = -1.0f;
@@ -311,7 +314,8 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			const float thr_a = -lq - 0.01f;
 			const float thr = PMAX ? -4.5f : (CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a);
 			reach_own = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
-		}
+			npairs += (uint32_t)__popcll(reach_own);
+			}
 		if (base + 64 + st < n)
 		{
 			pid = a.point_list[range.x + base + 64 + st];
@@ -462,7 +466,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		}
 	}
 
-	report_consumed(a, tile, used, st);
+	report_consumed(a, tile, used, st, npairs);
 	const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 	const size_t plane = (size_t)a.W * a.H;
 #pragma unroll
@@ -565,6 +569,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 		};
 		if (lane < n) fetch(lane);
 		int used = 0; // list entries this wave staged for blending (list_consumed)
+		uint32_t npairs = 0;
 		for (int base = 0; base < n; base += 64)
 		{
 			float tmax0 = -1.0f;
@@ -598,7 +603,8 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 				// half the list in a 0/1 tile) here, at one lane's cost, instead of walking them as no-ops
 				const bool exists = !upper || !((p1.y + 1.0f) < L2f);
 				reach_mask = __ballot(staged && exists && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
-			}
+				npairs += (uint32_t)__popcll(reach_mask);
+				}
 			if (base + 64 + lane < n) fetch(base + 64 + lane);
 			// lanes read entries other lanes staged
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -676,7 +682,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 			a.n_contrib[4 * G + b] = (uint32_t)tm_loop; a.n_contrib[5 * G + b] = (uint32_t)tm_sync;
 		}
 #endif
-		report_consumed(a, tile, used, lane);
+		report_consumed(a, tile, used, lane, npairs);
 #pragma unroll
 		for (int k = 0; k < PPL; k++)
 		{
@@ -972,7 +978,7 @@ int launch_render(FwdCtx &c)
 	r.render_items = c.img.render_items; r.totals = c.img.totals; r.capacity = (uint32_t)c.capacity; r.cur_level = a->cur_level;
 	constexpr int PPL = 2;
 	r.round_flags = c.bin.round_flags;
-	r.consumed = a->list_consumed;
+	r.consumed = a->list_consumed; r.pairs = a->blend_pairs;
 	if (has_stats(a->variant) && !a->no_stats && a->variant != FR_VARIANT_PCHECK_OBB_MAX && c.bin.round_flags)
 	{
 		const hipError_t e = hipMemsetAsync(c.bin.round_flags, 0, round_flag_words(c.capacity, c.T) * sizeof(uint32_t), c.stream);

@@ -328,7 +328,7 @@ class FrameInFlight:
 
 def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
-                   sh_rest=None, packed=None, cur_level=0.0, raw_activations=False, list_consumed=None, no_stats=False):
+                   sh_rest=None, packed=None, cur_level=0.0, raw_activations=False, list_consumed=None, no_stats=False, blend_pairs=None):
     """First half of a forward call on the current stream -> FrameInFlight. persistent=True: the workspaces are the grow-only
     set of this (device, stream, thread) (valid until the next call there); otherwise they stay reserved for as long as the
     `lease` of the result is referenced."""
@@ -389,6 +389,12 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
                 raise RuntimeError(f"list_consumed must be a contiguous 4-byte integer tensor of {tiles} tiles on {dev}")
             keep.append(list_consumed)
             a.list_consumed = list_consumed.data_ptr()
+        if blend_pairs is not None:  # diagnostic: [T], (band, entry) pairs the blend evaluated (fovraster.h)
+            tiles = ((W + 15) // 16) * ((H + 15) // 16)
+            if blend_pairs.device != dev or blend_pairs.numel() != tiles or blend_pairs.element_size() != 4 or not blend_pairs.is_contiguous():
+                raise RuntimeError(f"blend_pairs must be a contiguous 4-byte integer tensor of {tiles} tiles on {dev}")
+            keep.append(blend_pairs)
+            a.blend_pairs = blend_pairs.data_ptr()
         if packed is not None:
             packed.check(P, dev)
             if packed.produced is not None:
@@ -420,7 +426,7 @@ def _forward_native(*args, **kw):
 
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                      grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None,
-                     want_cov3D_grad=False, want_color_grad=False, raw_activations=False, row_sparse=False, num_candidates=0):
+                     want_cov3D_grad=False, want_color_grad=False, raw_activations=False, row_sparse=False, num_candidates=0, blend_pairs=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations[, dL_dsh_rest])
     (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3]; dL_dcov3D / dL_dcolors are None unless
     cov3Ds_precomp / colors_precomp are given or want_cov3D_grad / want_color_grad)
@@ -488,6 +494,9 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
             a.dL_dscale, a.dL_drot = dL_dscales.data_ptr(), dL_drotations.data_ptr()
             if _bwd_events_hook is not None:
                 a.stage_events = _bwd_events_hook()
+            if blend_pairs is not None:
+                keep.append(blend_pairs)
+                a.blend_pairs = blend_pairs.data_ptr()
             rc = lib.fr_backward(C.byref(a))
             if rc != 0:
                 raise RuntimeError(f"fovraster backward failed ({rc}): {_native.last_error()}")

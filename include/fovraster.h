@@ -167,6 +167,11 @@ typedef struct fr_forward_args {
 	 * eff_finetune.py:107-108 drops gs_count / contribs of every training step. The blend then keeps only what the backward pass
 	 * needs (final_T, n_contrib); image, radii, lists and gradients are those of the variant. */
 	int32_t no_stats;
+	/* optional diagnostic output (NULL = off): uint32 [T], per tile the number of (band of eight rows, list entry) pairs the blend
+	 * evaluated -- the entries of the fetched batches that can reach the band at all (the kernels' reach mask), two-level RF tiles
+	 * counted per level state. Cleared by the call. The unit the blend kernels' VALU time is proportional to (bench.py /
+	 * profiles: vector instructions per blended pair). */
+	uint32_t *blend_pairs;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
@@ -214,6 +219,7 @@ typedef struct fr_backward_args {
 	 * in the list, a candidate that landed in no tile has a zero row). Every row is written, nothing is zero-filled: at 6 M
 	 * Gaussians a training step's backward pass otherwise clears 1.5 GB to write 0.5 GB. */
 	int32_t row_sparse;
+	uint32_t *blend_pairs;       /* optional diagnostic, as fr_forward_args.blend_pairs: [T], pairs k_render_bwd evaluated; cleared by the call */
 } fr_backward_args;
 
 int fr_abi_version(void);

@@ -222,7 +222,7 @@ def _plain_forward(s6m):
 BENCH_GAZES = [(0.25 * i, 0.25 * j) for i in range(1, 4) for j in range(1, 4)]  # bench.py GAZES (render_compose_gazes_fps.py:26)
 # values of a whole 1080p frame (6.2 M) allowed beyond 1e-4 -- flipped (pixel, Gaussian) pairs at a blend threshold, three channels each:
 # S-6M: measured <= 9 over the twelve gazes; S-6M-T blends five to seven times as many pairs per frame, most of them faint (median
-# alpha 0.03: far more pairs sit near alpha = 1/255), measured <= 28 (largest 2.1e-3). Budgets = measured worst x 1.25.
+# alpha 0.03: far more pairs sit near alpha = 1/255), measured <= 29 (largest 2.2e-3). Budgets = measured worst x 1.25.
 FRAME_COUNT_BUDGETS = {"S-6M": 12, "S-6M-T": 36}
 # training frame: share of the pixels whose final_T lies outside 1e-4 relative although n_contrib agrees (a flipped pair in the middle
 # of a list moves T by its alpha >= 1/255 without moving n_contrib): measured 1.4e-6 (S-6M, 3 pixels) / 1.06e-5 (S-6M-T, 22 pixels)

@@ -10,5 +10,5 @@ if [ "$1" != "--" ]; then echo "$0: missing -- before the command" >&2; exit 2; 
 shift
 for r in $(seq $R); do for n in "${names[@]}"; do
 	L=$PWD/fov-3dgs_amd/ab/$n.so; [ "$n" == "base" ] && L=$PWD/fov-3dgs_amd/libfovraster_hip.so
-	echo "== $n: $(FOVRASTER_LIB=$L "$@" 2>/dev/null | tail -1 | cut -c1-400)"
+	echo "== $n: $(FOVRASTER_LIB=$L "$@" 2>/dev/null | tail -1 | cut -c1-1200)"
 done; done

@@ -43,6 +43,27 @@ KERNELC(k_salu, float, "v", "s_add_u32 s20, s20, 1\ns_add_u32 s21, s21, 1\ns_add
 KERNELC(k_mix_valu_salu, float, "v", "v_fma_f32 %0, %4, %5, %0\ns_add_u32 s20, s20, 1\nv_fma_f32 %1, %4, %5, %1\ns_add_u32 s21, s21, 1", "s20","s21","scc")
 KERNELC(k_dsread, float, "v", "ds_read_b128 v[40:43], %0\nds_read_b128 v[44:47], %0\nds_read_b128 v[48:51], %0\nds_read_b128 v[52:55], %0\ns_waitcnt lgkmcnt(0)", "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55")
 
+// does a wave64 VALU instruction with one 32-lane half of EXEC empty take one pass instead of two?
+#define KERNEL_HALF(name, BODY, EXECSET)                                                          \
+__global__ void __launch_bounds__(256) name(int iters, float *sink)                              \
+{                                                                                                 \
+	float a0 = (float)threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, x = a0 * 0.5f, y = a0 * 0.25f; \
+	asm volatile(EXECSET ::: "exec");                                                             \
+	for (int i = 0; i < iters; i++)                                                               \
+	{                                                                                             \
+		_Pragma("unroll") for (int r = 0; r < REP / 4; r++)                                       \
+			asm volatile(BODY : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(y));          \
+	}                                                                                             \
+	asm volatile("s_mov_b64 exec, -1" ::: "exec");                                                \
+	float s = a0 + a1 + a2 + a3;                                                                  \
+	if (s == 1.2345f) *sink = s;                                                                  \
+}
+KERNEL_HALF(k_fma_lo32, "v_fma_f32 %0, %4, %5, %0\nv_fma_f32 %1, %4, %5, %1\nv_fma_f32 %2, %4, %5, %2\nv_fma_f32 %3, %4, %5, %3", "s_mov_b32 exec_hi, 0")
+KERNEL_HALF(k_fma_hi32, "v_fma_f32 %0, %4, %5, %0\nv_fma_f32 %1, %4, %5, %1\nv_fma_f32 %2, %4, %5, %2\nv_fma_f32 %3, %4, %5, %3", "s_mov_b32 exec_lo, 0")
+KERNEL_HALF(k_fma_even16, "v_fma_f32 %0, %4, %5, %0\nv_fma_f32 %1, %4, %5, %1\nv_fma_f32 %2, %4, %5, %2\nv_fma_f32 %3, %4, %5, %3", "s_mov_b32 exec_lo, 0xffff\ns_mov_b32 exec_hi, 0xffff")
+KERNEL_HALF(k_exp_lo32, "v_exp_f32 %0, %0\nv_exp_f32 %1, %1\nv_exp_f32 %2, %2\nv_exp_f32 %3, %3", "s_mov_b32 exec_hi, 0")
+KERNEL_HALF(k_cmp_lo32, "v_cmp_lt_f32 vcc, %4, %0\nv_cmp_lt_f32 vcc, %4, %1\nv_cmp_lt_f32 vcc, %4, %2\nv_cmp_lt_f32 vcc, %4, %3", "s_mov_b32 exec_hi, 0")
+
 template <typename K> static void run(const char *name, K k, int waves_per_simd, int iters, float *sink, double ghz)
 {
 	const int blocks = 256 * waves_per_simd; // 256-thread workgroups = 4 waves = one per SIMD
@@ -68,6 +89,7 @@ int main()
 	const int it = 20000;
 #define R(k) run(#k, k, 8, it, sink, ghz); run(#k, k, 1, it * 4, sink, ghz);
 	R(k_fma) R(k_mul) R(k_fmac) R(k_sub) R(k_min) R(k_mov) R(k_and) R(k_pkfma) R(k_pkmul) R(k_pkadd) R(k_exp) R(k_cndmask) R(k_cmp) R(k_cmp_s)
+	R(k_fma_lo32) R(k_fma_hi32) R(k_fma_even16) R(k_exp_lo32) R(k_cmp_lo32)
 	R(k_dep_fma) R(k_dep_pkfma) R(k_dep_exp) R(k_salu) R(k_mix_valu_salu) R(k_dsread)
 	return 0;
 }
