@@ -39,6 +39,42 @@ __device__ __forceinline__ float wave_sum_b(float x)
 	return x;
 }
 
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ float dpp_add(float x)
+{
+	return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, false));
+}
+// The nine per-lane partial sums of TWO list entries folded together (tools/scratch/fold18_test.hip): 18 totals end up in 18 different
+// lanes. a / b: the first / second entry's sums (colour r g b, M10 M01 M20 M11 M02, M00). Every step halves the lanes a value is
+// spread over while another value moves into the freed half: cross-half swaps (v_permlane32_swap: lanes 0-31 a's, 32-63 b's), cross-row
+// swaps (v_permlane16_swap: rows of 16 lanes hold (a, 2k) (a, 2k+1) (b, 2k) (b, 2k+1)), then within the rows DPP adds with a select
+// between two registers each (half-rows of 8: k = 0 | 1 and 2 | 3; quads: which register), two quad steps; the two M00 ride a fold of
+// their own. 47 instructions for 18 totals where the one-entry fold takes 38 for 9.
+// -> the lane's total (valid where `writer`), whose it is (entry 0 / 1) and which component (0..8) of the gradient-sum row
+__device__ __forceinline__ float fold18(const float (&a)[9], const float (&b)[9], const int lane, int &entry, int &comp, bool &writer)
+{
+	float f[9];
+#pragma unroll
+	for (int i = 0; i < 9; i++) f[i] = fold32(a[i], b[i]);
+	float g[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) g[k] = fold16(f[2 * k], f[2 * k + 1]);
+	const float s0 = dpp_add<0x128>(g[0]), s1 = dpp_add<0x128>(g[1]), s2 = dpp_add<0x128>(g[2]), s3 = dpp_add<0x128>(g[3]); // row_ror:8
+	const bool hi8 = (lane & 8) != 0;
+	const float h0 = hi8 ? s1 : s0, h1 = hi8 ? s3 : s2;
+	const float u0 = dpp_add<0x141>(h0), u1 = dpp_add<0x141>(h1);    // row_half_mirror: lane l + lane 7 - l of its group of eight
+	float m = (lane & 4) ? u1 : u0;
+	m = dpp_add<0xB1>(m); m = dpp_add<0x4E>(m);                       // the quad's total in all its lanes
+	float z = row_sum16(f[8]);
+	z = dpp_add<0x142, 0xA>(z);                                       // rows 1, 3 += lane 15 of rows 0, 2: lane 31 a's M00, lane 63 b's
+	const int r = lane >> 4, p = (lane >> 3) & 1, which = (lane >> 2) & 1;
+	const bool last = (lane & 31) == 31;
+	entry = r >> 1;
+	comp = last ? 8 : 2 * (which * 2 + p) + (r & 1);
+	writer = last || (lane & 3) == 0;
+	return last ? z : m;
+}
+
 struct BwdRenderArgs {
 	int W, H, gx;
 	const uint2 *ranges;
@@ -55,7 +91,7 @@ struct BwdRenderArgs {
 };
 
 template <bool CUTOFF>
-__global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
+__global__ void __launch_bounds__(64, 6) k_render_bwd(const BwdRenderArgs a)
 {
 	constexpr int PPL = 2;
 	__shared__ float4 s0[64];  // x, y, conic a, conic b
@@ -121,6 +157,25 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 	auto q_threshold = [&](float opacity, float &lq) { lq = logf(255.0f * opacity); return fmaxf(0.0f, CUTOFF ? fminf(4.5f, lq) : lq); };
 	if (lane < wave_last) fetch(wave_last - 1 - lane);
 	uint32_t npairs = 0;
+	// an entry's nine sums wait for the next entry's: two entries are folded together (fold18)
+	float pend[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	int pend_row = 0;
+	bool have_pend = false;
+	auto fold_one = [&](const float (&v)[9], const int row) __attribute__((always_inline))
+	{
+		// eight sums folded into two registers: afterwards row r of 16 lanes holds value 2 r in t0 and 2 r + 1 in t1
+		const float f0 = fold32(v[0], v[4]), f1 = fold32(v[1], v[5]), f2 = fold32(v[2], v[6]), f3 = fold32(v[3], v[7]);
+		const float t0 = row_sum16(fold16(f0, f2)), t1 = row_sum16(fold16(f1, f3));
+		const float t8 = wave_sum_b(v[8]); // lane 63
+		const int sel = lane & 15;
+		const bool writer = sel < 2 || lane == 63;
+		if (writer)
+		{
+			const int comp = lane == 63 ? 8 : 2 * (lane >> 4) + sel;
+			const float val = lane == 63 ? t8 : (sel ? t1 : t0);
+			atomicAdd(a.acc + 16 * (size_t)row + comp, val); // nine lanes, one cache line
+		}
+	};
 	for (int top = wave_last; top > 0; top -= 64)
 	{
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous batch has been read by all lanes
@@ -211,21 +266,24 @@ __global__ void __launch_bounds__(64) k_render_bwd(const BwdRenderArgs a)
 			}
 			if (__any(any))
 			{
-				// eight sums folded into two registers: afterwards row r of 16 lanes holds value 2 r in t0 and 2 r + 1 in t1
-				const float f0 = fold32(v[0], v[4]), f1 = fold32(v[1], v[5]), f2 = fold32(v[2], v[6]), f3 = fold32(v[3], v[7]);
-				const float t0 = row_sum16(fold16(f0, f2)), t1 = row_sum16(fold16(f1, f3));
-				const float t8 = wave_sum_b(v[8]); // lane 63
-				const int sel = lane & 15;
-				const bool writer = sel < 2 || lane == 63;
-				if (writer)
+				const int row = __float_as_int(g2.y); // the entry's row of gradient sums (wave-uniform)
+				if (!have_pend)
 				{
-					const int comp = lane == 63 ? 8 : 2 * (lane >> 4) + sel;
-					const float val = lane == 63 ? t8 : (sel ? t1 : t0);
-					atomicAdd(a.acc + 16 * (size_t)__float_as_int(g2.y) + comp, val); // nine lanes, one cache line
+			#pragma unroll
+					for (int i = 0; i < 9; i++) pend[i] = v[i];
+					pend_row = row; have_pend = true;
+				}
+				else
+				{
+					int e, comp; bool writer;
+					const float val = fold18(pend, v, lane, e, comp, writer);
+					if (writer) atomicAdd(a.acc + 16 * (size_t)(e ? row : pend_row) + comp, val); // eighteen lanes, two cache lines
+					have_pend = false;
 				}
 			}
 		}
 	}
+	if (have_pend) fold_one(pend, pend_row); // an odd entry is left
 	if (a.pairs != nullptr && lane == 0 && npairs != 0) atomicAdd(a.pairs + tile, npairs);
 }
 
