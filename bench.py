@@ -485,8 +485,9 @@ def main():
                             frac_traffic=None if not tr_b else round(tr_b / max(ms_, 1e-9) / 1e6 / HBM_PEAK_GBS, 5))
         roofline["train"] = dict(unit="GB/s", peak=HBM_PEAK_GBS, counts=n_tr, kernels=rows,
                                  note="training step (pcheck_obb_sum, raw parameters, fused L1 + SSIM): median of 10 instrumented steps, HIP events "
-                                      "recorded by the library on the streams the kernels run on (fill_zero runs on the helper stream beside "
-                                      "render_bwd); bytes: training_bytes() / algorithmic_bytes() of the plain frame; traffic: " + str(prof.train_source()))
+                                      "recorded by the library on the streams the kernels run on (fill_zero: the gradient tensors' zero fill, enqueued at the "
+                                      "end of the forward call on a side stream -- it runs beside the loss kernels and the head of render_bwd); bytes: "
+                                      "training_bytes() / algorithmic_bytes() of the plain frame; traffic: " + str(prof.train_source()))
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         try:
@@ -700,8 +701,9 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
     from fov3dgs_amd import _native as _nat
     tr.fuse_activations, tr.row_sparse_grads = True, False
     n_inst = 12
-    ft, bt = StageTimer(n_inst), BackwardTimer(n_inst)
-    with ft, bt:
+    from fov3dgs_amd.profiling import NativeCallTimer
+    ft, bt, nt = StageTimer(n_inst), BackwardTimer(n_inst), NativeCallTimer()
+    with ft, bt, nt:
         for it in range(n_inst):
             for p in tr.parameters():
                 p.grad = None
@@ -709,7 +711,11 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
             l1_ssim_loss(o["render"], target, 0.2).backward()
     torch.cuda.synchronize()
     fwd_ms = {k: float(np.median([r_[k] for r_ in ft.stage_ms()[2:]])) for k in _nat.STAGES}
-    bwd_ms = {k: float(np.median([r_[k] for r_ in bt.stage_ms()[2:]])) for k in ("render_bwd", "preprocess_bwd", "fill_zero")}
+    bwd_ms = {k: float(np.median([r_[k] for r_ in bt.stage_ms()[2:]])) for k in ("render_bwd", "preprocess_bwd")}
+    # the gradient tensors' zero fill: enqueued at the end of the forward call on a side stream (rasterizer.prefill_gradients), it runs
+    # beside the loss kernels and the head of k_render_bwd; its own duration from events on that stream
+    fills = nt.ms()["fill"]
+    bwd_ms["fill_zero"] = float(np.median(fills[2:])) if len(fills) > 2 else float("nan")
     ft.close(); bt.close()
     with torch.no_grad():
         vmat = cam.world_view_transform

@@ -69,6 +69,7 @@ class BackwardArgs(C.Structure):
         ("raw_activations", C.c_int32),
         ("row_sparse", C.c_int32),
         ("blend_pairs", _FP),
+        ("outputs_zeroed", C.c_int32),
     ]
 
 
@@ -76,7 +77,7 @@ EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destr
            "fr_geometry_bytes", "fr_image_bytes", "fr_binning_bytes", "fr_image_ranges",
            "fr_binning_point_list", "fr_image_final_T", "fr_image_n_contrib", "fr_image_tile_levels", "fr_geometry_records",
            "fr_geometry_vis_list", "fr_geometry_vis_count", "fr_geometry_walk_records", "fr_geometry_level_colours",
-           "fr_geometry_level_ranges", "fr_forward_begin", "fr_forward_finish", "fr_forward_abandon")
+           "fr_geometry_level_ranges", "fr_forward_begin", "fr_forward_finish", "fr_forward_abandon", "fr_backward_prefill")
 
 _lib = None
 
@@ -158,6 +159,8 @@ def load():
     lib.fr_forward_begin.restype = C.c_int
     lib.fr_forward_finish.argtypes = [C.c_void_p]
     lib.fr_forward_finish.restype = C.c_int
+    lib.fr_backward_prefill.argtypes = [C.POINTER(BackwardArgs), C.c_void_p]
+    lib.fr_backward_prefill.restype = C.c_int
     lib.fr_forward_abandon.argtypes = [C.c_void_p]
     lib.fr_forward_abandon.restype = C.c_int
     if lib.fr_abi_version() != ABI_VERSION:

@@ -728,6 +728,42 @@ static int launch_render_bwd(const fr_backward_args *a, const GeomWS &geom, cons
 	return check_launch("render_bwd", stream, a->debug);
 }
 
+// the dense gradient tensors of a backward call cleared by ONE kernel on stream `fs` (seven fill commands in a row ran at 2.7 TB/s
+// beside k_render_bwd, the small ones at 1 TB/s, and outlasted it by 50 us); tensors are 16-byte aligned and their sizes multiples of 4
+int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events)
+{
+	if (a->row_sparse) return FR_OK; // (compact rows: k_preprocess_bwd writes every row it is handed, nothing to clear)
+	const bool have_sh = a->colors_precomp == nullptr && a->shs != nullptr;
+	const size_t P = (size_t)a->P;
+	const size_t m0 = have_sh ? (a->shs_rest ? 1 : (size_t)a->M) : 0;
+	struct { void *p; size_t bytes; } fills[] = {
+		{ a->dL_dmean3D, 12 * P }, { a->dL_dmean2D, 12 * P }, { a->dL_dopacity, 4 * P }, { a->dL_dscale, 12 * P }, { a->dL_drot, 16 * P },
+		{ a->dL_dsh, 12 * m0 * P }, { a->dL_dsh_rest, have_sh && a->shs_rest ? 12 * ((size_t)a->M - 1) * P : 0 },
+		{ a->dL_dcolor, 12 * P }, { a->dL_dconic, 16 * P }, { a->dL_dcov3D, 24 * P } };
+	FillArgs fa; fa.n = 0;
+	for (auto &f : fills)
+		if (f.p && f.bytes)
+		{
+			if (((uintptr_t)f.p & 15) != 0 || fa.n == FR_FILL_MAX)
+			{
+				const hipError_t e = hipMemsetAsync(f.p, 0, f.bytes, fs);
+				if (e != hipSuccess) { set_error("hipMemsetAsync(gradient): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
+				continue;
+			}
+			fa.p[fa.n] = (float *)f.p; fa.words[fa.n] = f.bytes / 4; fa.n++;
+		}
+	if (fa.n)
+	{
+		// (optional events 3 / 4: around the fill kernel, on the stream it runs on)
+		if (events && a->stage_events && a->stage_events[3]) (void)hipEventRecord((hipEvent_t)a->stage_events[3], fs);
+		hipLaunchKernelGGL(k_fill_zero, dim3(FR_FILL_BLOCKS), dim3(256), 0, fs, fa);
+		const int rcf = check_launch("fill_zero", fs, a->debug);
+		if (events && a->stage_events && a->stage_events[4]) (void)hipEventRecord((hipEvent_t)a->stage_events[4], fs);
+		if (rcf) return rcf;
+	}
+	return FR_OK;
+}
+
 int launch_backward(const fr_backward_args *a)
 {
 	hipStream_t stream = (hipStream_t)a->stream;
@@ -741,41 +777,16 @@ int launch_backward(const fr_backward_args *a)
 	// k_render_bwd runs on the caller's (1.5 GB of fills at 6 M Gaussians, ~0.3 ms that the reference -- and round 1 --
 	// spend before the backward pass starts).
 	{
-		const bool have_sh = a->colors_precomp == nullptr && a->shs != nullptr;
-		const size_t P = (size_t)a->P;
-		const size_t m0 = have_sh ? (a->shs_rest ? 1 : (size_t)a->M) : 0;
-		struct { void *p; size_t bytes; } fills[] = {
-			{ a->dL_dmean3D, 12 * P }, { a->dL_dmean2D, 12 * P }, { a->dL_dopacity, 4 * P }, { a->dL_dscale, 12 * P }, { a->dL_drot, 16 * P },
-			{ a->dL_dsh, 12 * m0 * P }, { a->dL_dsh_rest, have_sh && a->shs_rest ? 12 * ((size_t)a->M - 1) * P : 0 },
-			{ a->dL_dcolor, 12 * P }, { a->dL_dconic, 16 * P }, { a->dL_dcov3D, 24 * P } };
-		AuxStream *ax = (a->R > 0 && !a->debug) ? aux_stream(stream) : nullptr;
+		AuxStream *ax = (a->R > 0 && !a->debug && !a->outputs_zeroed && !a->row_sparse) ? aux_stream(stream) : nullptr;
 		hipStream_t fs = stream;
 		if (ax)
 		{
 			if (hipEventRecord(ax->fork, stream) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess) { (void)hipGetLastError(); ax = nullptr; }
 			else fs = ax->s;
 		}
-		// one kernel for all of them (seven fill commands in a row ran at 2.7 TB/s beside k_render_bwd, the small ones at
-		// 1 TB/s, and outlasted it by 50 us); tensors are 16-byte aligned and their sizes multiples of 4
-		FillArgs fa; fa.n = 0;
-		for (auto &f : fills)
-			if (f.p && f.bytes && !a->row_sparse) // (compact rows: k_preprocess_bwd writes every row it is handed, nothing to clear)
-			{
-				if (((uintptr_t)f.p & 15) != 0 || fa.n == FR_FILL_MAX)
-				{
-					const hipError_t e = hipMemsetAsync(f.p, 0, f.bytes, fs);
-					if (e != hipSuccess) { set_error("hipMemsetAsync(gradient): %s", hipGetErrorString(e)); return FR_ERR_HIP; }
-					continue;
-				}
-				fa.p[fa.n] = (float *)f.p; fa.words[fa.n] = f.bytes / 4; fa.n++;
-			}
-		if (fa.n)
+		if (!a->outputs_zeroed)
 		{
-			// (optional events 3 / 4: around the fill kernel, on the stream it runs on)
-			if (a->stage_events && a->stage_events[3]) (void)hipEventRecord((hipEvent_t)a->stage_events[3], fs);
-			hipLaunchKernelGGL(k_fill_zero, dim3(FR_FILL_BLOCKS), dim3(256), 0, fs, fa);
-			const int rcf = check_launch("fill_zero", fs, a->debug);
-			if (a->stage_events && a->stage_events[4]) (void)hipEventRecord((hipEvent_t)a->stage_events[4], fs);
+			const int rcf = launch_gradient_fill(a, fs, true);
 			if (rcf)
 			{
 				// (whatever was enqueued on the helper stream is joined before the caller gets its tensors back)

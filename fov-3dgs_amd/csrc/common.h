@@ -455,6 +455,7 @@ int launch_emit(FwdCtx &c);
 int launch_tile_sort(FwdCtx &c);
 int launch_render(FwdCtx &c);
 int launch_backward(const fr_backward_args *a);
+int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events);
 int launch_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present, hipStream_t s);
 
 } // namespace fr

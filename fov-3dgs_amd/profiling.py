@@ -130,7 +130,7 @@ class NativeCallTimer:
         rasterizer._call_events = None
 
     def ms(self):
-        out = {"fwd": [], "bwd": []}
+        out = {"fwd": [], "bwd": [], "fill": []}  # fill: the gradient tensors' zero fill on its side stream (rasterizer.prefill_gradients)
         for kind, e0, e1 in self.events:
             e1.synchronize()
             out[kind].append(e0.elapsed_time(e1))

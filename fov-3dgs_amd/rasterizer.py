@@ -424,9 +424,73 @@ def _forward_native(*args, **kw):
     return _forward_begin(*args, **kw).finish()
 
 
+def _alloc_gradients(z, P, M0, Mrest, has_cov, has_col):
+    """The dense gradient tensors of one backward call, in _backward_native's order; z(*shape) allocates."""
+    return (z(P, 3), z(P, 3), z(P, 1), z(P, 6) if has_cov else None, z(P, 3) if has_col else None, z(P, M0, 3), z(P, 3), z(P, 4),
+            z(P, Mrest, 3) if Mrest is not None else None)
+
+
+# Opt-in: the gradient tensors of a training step allocated and CLEARED at the end of the forward call, on a side stream that waits for
+# the forward's kernels (fr_backward_prefill, fr_backward_args.outputs_zeroed), so that the 1.5 GB of fills of a 6 M-Gaussian model do
+# not run beside k_render_bwd (which pays 0.11 ms for the company). Measured (tools/train_ab.py, S-6M / S-6M-T): the backward pass gets
+# 0.21 / 0.06 ms shorter, the image loss between the two calls 0.27 ms LONGER (its kernels read two images; a 1.5 GB stream of writes
+# raises the latency of every read on the chip): 2.43 -> 2.50 / 4.37 -> 4.58 ms per step. k_render_bwd -- arithmetic -- stays the one
+# kernel of the step a fill hides behind; the switch is for hosts with something arithmetic-bound between their two calls.
+PREZERO_GRADIENTS = False
+_side_streams = {}
+
+
+def _side_stream(dev):
+    st = _side_streams.get(dev)
+    if st is None:
+        st = _side_streams[dev] = torch.cuda.Stream(dev)
+    return st
+
+
+def prefill_gradients(dev, P, M0, Mrest, has_cov, has_col, has_sh):
+    """-> (tensors in _alloc_gradients' order, event): allocated on the current stream, zero-filled by ONE kernel on the side stream
+    behind everything the current stream holds now; the event marks the end of the fill."""
+    lib = _native.load()
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g = _alloc_gradients(z, P, M0, Mrest, has_cov, has_col)
+        a = _native.BackwardArgs()
+        a.P, a.M = P, M0 + (Mrest or 0)
+        # (fr_backward_prefill only looks at which of shs / shs_rest / colors_precomp are given, not at what they hold)
+        a.shs = g[5].data_ptr() if has_sh else None
+        a.shs_rest = g[8].data_ptr() if Mrest is not None else None
+        a.colors_precomp = None
+        a.dL_dmean3D, a.dL_dmean2D, a.dL_dopacity = g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr()
+        a.dL_dcov3D = g[3].data_ptr() if g[3] is not None else None
+        a.dL_dcolor = g[4].data_ptr() if g[4] is not None else None
+        a.dL_dsh = g[5].data_ptr() if (has_sh and M0) else None
+        a.dL_dscale, a.dL_drot = g[6].data_ptr(), g[7].data_ptr()
+        a.dL_dsh_rest = g[8].data_ptr() if g[8] is not None else None
+        side.wait_stream(main)
+        evs = _call_events
+        if evs is not None:  # profiling.NativeCallTimer: the fill's own duration, on the stream it runs on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+        rc = lib.fr_backward_prefill(C.byref(a), side.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"fovraster backward_prefill failed ({rc}): {_native.last_error()}")
+        if evs is not None:
+            e1.record(side)
+            evs.append(("fill", e0, e1))
+        for t in g:
+            if t is not None:
+                t.record_stream(side)  # (freed before the fill has run -- a graph dropped without backward --: not reused under it)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    return g, ev
+
+
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                      grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None,
-                     want_cov3D_grad=False, want_color_grad=False, raw_activations=False, row_sparse=False, num_candidates=0, blend_pairs=None):
+                     want_cov3D_grad=False, want_color_grad=False, raw_activations=False, row_sparse=False, num_candidates=0, blend_pairs=None,
+                     prezeroed=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations[, dL_dsh_rest])
     (dL_dsh_rest only with split SH storage: then dL_dsh is the DC part [P,1,3]; dL_dcov3D / dL_dcolors are None unless
     cov3Ds_precomp / colors_precomp are given or want_cov3D_grad / want_color_grad)
@@ -457,20 +521,22 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
         # zero-fills 1.8 GB per step at 6 M Gaussians); P == 0 never reaches the library, hence zeros for that case
         z = (lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)) if P != 0 else \
             (lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev))
-        dL_dmeans3D, dL_dmeans2D, dL_dopacity = z(P, 3), z(P, 3), z(P, 1)
         # outputs only when the 3D covariances / colours are inputs; otherwise intermediates the library keeps per
         # visible Gaussian in its geometry workspace
         has_cov = want_cov3D_grad or (cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0)
         has_col = want_color_grad or (colors_precomp is not None and colors_precomp.numel() != 0)
-        dL_dcov3D = z(P, 6) if has_cov else None
-        dL_dcolors = z(P, 3) if has_col else None
-        dL_dsh, dL_dscales, dL_drotations = z(P, M0, 3), z(P, 3), z(P, 4)
-        dL_dsh_rest = z(P, M - M0, 3) if rest_c is not None else None
+        if prezeroed is not None:
+            # allocated and zero-filled at the end of the forward call (prefill_gradients), beside the work between the two calls
+            (dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcov3D, dL_dcolors, dL_dsh, dL_dscales, dL_drotations, dL_dsh_rest) = prezeroed
+        else:
+            (dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcov3D, dL_dcolors, dL_dsh, dL_dscales, dL_drotations, dL_dsh_rest) = \
+                _alloc_gradients(z, P, M0, M - M0 if rest_c is not None else None, has_cov, has_col)
         if P != 0:
             a.variant, a.P, a.D, a.M, a.R = variant, Pfull, int(rs.sh_degree), M, int(num_rendered)
             a.W, a.H, a.debug = W, H, int(bool(rs.debug))
             a.raw_activations = int(bool(raw_activations))
             a.row_sparse = int(bool(row_sparse))
+            a.outputs_zeroed = int(prezeroed is not None)
             a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
             a.stream = torch.cuda.current_stream(dev).cuda_stream
             put("background", rs.bg, small=True)
@@ -592,6 +658,12 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
             ctx.raster_settings = raster_settings
             ctx.num_rendered = num_rendered
             ctx.ws_lease = res[-1] if keep_ws else None
+            ctx.prezero = None
+            if keep_ws and PREZERO_GRADIENTS and not ctx.row_sparse and means3D.size(0) > 0:
+                has_sh = sh.numel() != 0
+                M0 = sh.size(1) if has_sh else 0
+                ctx.prezero = prefill_gradients(means3D.device, means3D.size(0), M0, sh_rest.size(1) if sh_rest is not None else None,
+                                                cov3Ds_precomp.numel() != 0, colors_precomp.numel() != 0, has_sh)
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                                   geomBuffer, binningBuffer, imgBuffer,
                                   sh_rest if sh_rest is not None else torch.empty(0, device=means3D.device))
@@ -615,6 +687,10 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                     grad_out_color, sh, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer,
                     sh_rest if ctx.split_sh else None)
             kw = dict(raw_activations=ctx.raw_activations, row_sparse=ctx.row_sparse, num_candidates=ctx.num_candidates)
+            pre, ctx.prezero = ctx.prezero, None  # (a second backward over the same graph allocates its own tensors)
+            if pre is not None:
+                torch.cuda.current_stream(means3D.device).wait_event(pre[1])
+                kw["prezeroed"] = pre[0]
             ev = _call_events
             if ev is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

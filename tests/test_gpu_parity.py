@@ -1197,3 +1197,48 @@ def test_reference_shaped_model_takes_the_fast_path():
     assert torch.equal(c["radii"], a["radii"]) and torch.equal(c["gs_count"], a["gs_count"])
     for n in ga:
         check_grad(gc[n].cpu().numpy(), ga[n].cpu().numpy(), "reference-shaped model " + n)
+
+
+def test_gradient_tensors_cleared_at_the_end_of_the_forward_call():
+    """rasterizer.PREZERO_GRADIENTS (opt-in; fr_backward_prefill + fr_backward_args.outputs_zeroed): the dense gradient tensors are
+    allocated and zero-filled on a side stream at the end of the forward call instead of beside k_render_bwd. Same gradients as with the fill
+    inside fr_backward; a second backward over the same graph (retain_graph) allocates its own tensors and gives them again; a graph
+    that is dropped without a backward pass leaves nothing behind."""
+    _need_gpu()
+    from fov3dgs_amd import rasterizer as rz
+    from fov3dgs_amd.gaussian_renderer import render
+    dev = "cuda:0"
+    cam = syn.camera_1k(232, 152).to(dev)
+
+    class Pipe:
+        debug = False
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    w = torch.randn(3, 152, 232, device=dev, generator=torch.Generator(device=dev).manual_seed(21))
+    names = ("xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest")
+    res = {}
+    for pre in (False, True):
+        rz.PREZERO_GRADIENTS = pre
+        try:
+            cloud = syn.scene_1k(P=4000, seed=15).to(dev).requires_grad_(True)
+            out = render(cam, syn.ReferenceShapedModel(cloud), Pipe(), bg, cuda_type="pcheck_obb_sum")
+            loss = (out["render"] * w).sum()
+            loss.backward(retain_graph=True)
+            first = {n: getattr(cloud, "_" + n).grad.clone() for n in names}
+            vs = out["viewspace_points"].grad.clone()
+            for n in names:
+                getattr(cloud, "_" + n).grad = None
+            loss.backward()
+            second = {n: getattr(cloud, "_" + n).grad.clone() for n in names}
+            # a graph nobody differentiates
+            dropped = render(cam, syn.ReferenceShapedModel(cloud), Pipe(), bg, cuda_type="pcheck_obb_sum")
+            del dropped
+            torch.cuda.synchronize()
+        finally:
+            rz.PREZERO_GRADIENTS = False
+        res[pre] = (first, second, vs)
+    for n in names:
+        check_grad(res[True][0][n].cpu().numpy(), res[False][0][n].cpu().numpy(), "gradients cleared at forward time: " + n, rtol=1e-5)
+        check_grad(res[True][1][n].cpu().numpy(), res[True][0][n].cpu().numpy(), "second backward over a pre-cleared graph: " + n, rtol=1e-5)
+        # rows of Gaussians the view does not touch are exact zeros either way
+        assert torch.equal(res[True][0][n] == 0, res[False][0][n] == 0), n
+    check_grad(res[True][2].cpu().numpy(), res[False][2].cpu().numpy(), "gradients cleared at forward time: viewspace_points", rtol=1e-5)
