@@ -47,7 +47,7 @@ def run(tag, perm):
                 r = f(GAZES[i % 9])
         torch.cuda.synchronize()
         st = timer.stage_ms(); timer.close()
-    print(f"{tag}: {np.median(walls):.4f} ms D={r[0]} [" + " ".join(f"{k[:5]}={np.mean([s[k] for s in st]):.3f}" for k in _native.STAGES) + "]", flush=True)
+    print(f"{tag}: {np.median(walls):.4f} ms D={r[0]} image sum {float(r[1].double().sum()):.6f} [" + " ".join(f"{k[:5]}={np.mean([s[k] for s in st]):.3f}" for k in _native.STAGES) + "]", flush=True)
 
 
 run("model as it is", None)
@@ -60,7 +60,7 @@ with torch.no_grad():
     py = ((hom[:, 1] * w + 1) * H - 1) * 0.5
     vm = cam.world_view_transform
     z = x @ vm[:3, 2] + vm[3, 2]
-    for R in (16, 8, 4, 2):
+    for R in (8, 4, 2, 1):
         gx, gy = (W + 16 * R - 1) // (16 * R), (H + 16 * R - 1) // (16 * R)
         rx = torch.clamp((px / (16 * R)).floor().long(), 0, gx - 1)
         ry = torch.clamp((py / (16 * R)).floor().long(), 0, gy - 1)
