@@ -1631,52 +1631,6 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 #ifdef FR_EMIT_TIMERS
 		const uint64_t tw0 = wall_clock64(); tm_steps += (int)((total + 63) / 64);
 #endif
-#ifdef FR_EMIT_BALLOT
-		// EXPERIMENT (tile-major walk): the wave steps through the tiles of the UNION of its items' rectangles; at every tile each lane
-		// tests its own item (inside its rectangle, level filter, box test) and the lanes that pass take CONSECUTIVE slots of the tile's
-		// bucket -- one LDS atomic per (wave, tile) and one contiguous run per store instruction, where the pair walk issues one atomic
-		// and one scattered 8-byte store per entry. Only pays when a wave's items are spatially coherent (region-ordered items).
-		if (total != 0 && LDSH == 1)
-		{
-			const bool part = my_n != 0;
-			const int w = max(x1 - x0, 1), h = part ? (int)tnum / w : 0;
-			const int y1 = y0 + h;
-			int ux0 = part ? x0 : 0x7fffffff, uy0 = part ? y0 : 0x7fffffff, ux1 = part ? x1 : 0, uy1 = part ? y1 : 0;
-#pragma unroll
-			for (int off = 32; off > 0; off >>= 1)
-			{
-				ux0 = min(ux0, __shfl_xor(ux0, off)); uy0 = min(uy0, __shfl_xor(uy0, off));
-				ux1 = max(ux1, __shfl_xor(ux1, off)); uy1 = max(uy1, __shfl_xor(uy1, off));
-			}
-			ux0 = __builtin_amdgcn_readfirstlane(ux0); uy0 = __builtin_amdgcn_readfirstlane(uy0);
-			ux1 = __builtin_amdgcn_readfirstlane(ux1); uy1 = __builtin_amdgcn_readfirstlane(uy1);
-			const Obb ob = make_obb(cx, cy, ev, el);
-			const float olim = hl + 1;
-			const unsigned long long lt = (1ull << lane) - 1ull;
-			for (int y = uy0; y < uy1; y++)
-			{
-				const bool rowin = part && y >= y0 && y < y1;
-				if (!__any(rowin)) continue;
-				for (int x = ux0; x < ux1; x++)
-				{
-					const int ti = y * a.gx + x;
-					bool pass = rowin && x >= x0 && x < x1;
-					if (CULL)
-					{
-						if (FOV) pass = pass && TILE_PASSES(ti, olim);
-						pass = pass && obb_hits_tile(ob, x, y);
-					}
-					const unsigned long long m = __ballot(pass);
-					if (m == 0) continue;
-					uint32_t base = 0;
-					if (lane == 0) base = atomicAdd(&lds_cur[ti], (uint32_t)__popcll(m));
-					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-					if (pass) a.entries[base + (uint32_t)__popcll(m & lt)] = payload;
-				}
-			}
-		}
-		else
-#endif
 		if (total != 0)
 		{
 			const Obb ob = make_obb(cx, cy, ev, el);
@@ -1687,12 +1641,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			mine[3] = make_float4(__uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)), __int_as_float(max(x1 - x0, 1)), __uint_as_float(excl), hl + 1);
 			FR_WAVE_LDS_SYNC();
 		}
-#ifdef FR_EMIT_BALLOT
-		const uint32_t total_pairs = LDSH == 1 ? 0u : total;
-#else
-		const uint32_t total_pairs = total;
-#endif
-		for (uint32_t k = 0; k < total_pairs; k += 64)
+		for (uint32_t k = 0; k < total; k += 64)
 		{
 			const uint32_t j = k + lane;
 			const bool valid = j < total;
