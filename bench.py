@@ -479,6 +479,8 @@ def main():
         rows = {}
         for k_, byt in list(tb.items()) + [(k2, fb[k2]) for k2 in ("project", "bin", "emit", "tile_sort")]:
             ms_ = tr_ms[k_]
+            if not (isinstance(ms_, float) and math.isfinite(ms_) and ms_ > 0):
+                continue
             tr_b, tr_src = prof.traffic_train(kern[k_])
             rows[k_] = dict(kernel=kern[k_], ms=round(ms_, 4), algorithmic_bytes=int(byt), achieved=round(byt / max(ms_, 1e-9) / 1e6, 1),
                             frac=round(byt / max(ms_, 1e-9) / 1e6 / HBM_PEAK_GBS, 5), traffic=tr_b,
@@ -523,7 +525,18 @@ def main():
         "stages_ms_packed": {k: round(v, 4) for k, v in mean_ms_p.items()},
         "extra": dict(extra, **multi),
     }
-    print(json.dumps(line), flush=True)
+    print(json.dumps(_finite(line)), flush=True)
+
+
+def _finite(x):
+    """NaN / inf (a stage event that was never recorded) -> None: the line must be strict JSON"""
+    if isinstance(x, float):
+        return x if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
 
 
 def frame_stats(torch, lib, vid, out_state, W, H, T, geom=None, P=0):
@@ -711,11 +724,13 @@ def extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H
             l1_ssim_loss(o["render"], target, 0.2).backward()
     torch.cuda.synchronize()
     fwd_ms = {k: float(np.median([r_[k] for r_ in ft.stage_ms()[2:]])) for k in _nat.STAGES}
-    bwd_ms = {k: float(np.median([r_[k] for r_ in bt.stage_ms()[2:]])) for k in ("render_bwd", "preprocess_bwd")}
-    # the gradient tensors' zero fill: enqueued at the end of the forward call on a side stream (rasterizer.prefill_gradients), it runs
-    # beside the loss kernels and the head of k_render_bwd; its own duration from events on that stream
+    bwd_rows = bt.stage_ms()[2:]
+    bwd_ms = {k: float(np.median([r_[k] for r_ in bwd_rows])) for k in ("render_bwd", "preprocess_bwd", "fill_zero")}
+    # the gradient tensors' zero fill: by default inside fr_backward, on the helper stream beside k_render_bwd (events 3 / 4 of the call);
+    # with rasterizer.PREZERO_GRADIENTS at the end of the forward call on a side stream (its own duration from events on that stream)
     fills = nt.ms()["fill"]
-    bwd_ms["fill_zero"] = float(np.median(fills[2:])) if len(fills) > 2 else float("nan")
+    if len(fills) > 2:
+        bwd_ms["fill_zero"] = float(np.median(fills[2:]))
     ft.close(); bt.close()
     with torch.no_grad():
         vmat = cam.world_view_transform
@@ -974,7 +989,7 @@ def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, 
             "fwd_bwd_ms": round(fbm, 4), "collective_ms": round(com, 4), "views_per_s": round(world * K / elapsed, 3),
             "collective": dict(info or {}, algbw_GBs=None if algbw is None else round(algbw, 2),
                                busbw_GBs=None if algbw is None else round(algbw * 2 * (world - 1) / world, 2))}
-    print(json.dumps(line), flush=True)
+    print(json.dumps(_finite(line)), flush=True)
 
 
 def cpu_baseline(cloud_cpu, fov_cpu, cam, gaze, T_tiles, gx, gy):
