@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64, 6) k_render_bwd(const BwdRenderArgs a)
 	};
 	// the forward blend's skip tests (k_render: outside the support, alpha < 1/255) as its ONE threshold on q = -power: the very same
 	// expression, so that the backward pass takes the gradient of exactly the pairs the forward pass blended
-	auto q_threshold = [&](float opacity, float &lq) { lq = logf(255.0f * opacity); return fmaxf(0.0f, CUTOFF ? fminf(4.5f, lq) : lq); };
+	auto q_threshold = [&](float opacity, float &lq) { lq = logf(255.0f * opacity); return lq >= 0.0f ? (CUTOFF ? fminf(4.5f, lq) : lq) : 0.0f; };
 	if (lane < wave_last) fetch(wave_last - 1 - lane);
 	uint32_t npairs = 0;
 	// an entry's nine sums wait for the next entry's: two entries are folded together (fold18)
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64, 6) k_render_bwd(const BwdRenderArgs a)
 			// (power < -4.5, alpha < 1/255 <=> power < -ln(255 opacity)), see splat_reaches()
 			const float thr_a = -lq - 0.01f;
 			const float thr = CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a;
-			reach = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
+			reach = __ballot(staged && lq >= 0.0f && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
 			npairs += (uint32_t)__popcll(reach);
 			}
 		if (top - 64 - lane > 0) fetch(top - 64 - 1 - lane);

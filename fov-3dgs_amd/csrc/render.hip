@@ -301,7 +301,8 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		// reference's own fp32 evaluation of o * exp(power) < 1/255 only inside that expression's rounding, like the exp2-based test it
 		// replaces. The _max flavour counts pixels between the support test and the alpha test: its threshold is the support's alone.
 		const float lq = logf(255.0f * p1.y);
-		const float tq = PMAX ? 4.5f : fmaxf(0.0f, CUTOFF ? fminf(4.5f, lq) : lq);
+		// (lq >= 0 is false for the NaN of a negative opacity: such an entry takes part nowhere, as alpha < 1/255 says in the reference)
+		const float tq = PMAX ? 4.5f : (lq >= 0.0f ? (CUTOFF ? fminf(4.5f, lq) : lq) : 0.0f);
 		if (staged)
 		{
 			s0[st] = p0; s1[st] = p1; s2[st] = make_float2(p2, tq);
@@ -313,7 +314,8 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			// -ln(255 opacity); the _max flavour counts pixels BEFORE the alpha test, so only the support cutoff applies
 			const float thr_a = -lq - 0.01f;
 			const float thr = PMAX ? -4.5f : (CUTOFF ? fmaxf(-4.5f, thr_a) : thr_a);
-			reach_own = __ballot(staged && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
+			// (an opacity below 1/255 -- or a NaN -- passes the alpha test nowhere: forward.cu:363)
+			reach_own = __ballot(staged && (PMAX || lq >= 0.0f) && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
 			npairs += (uint32_t)__popcll(reach_own);
 			}
 		if (base + 64 + st < n)
@@ -593,7 +595,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 			// hardware's approximate log): the decision then differs from the reference's own fp32 evaluation of o * exp(power) < 1/255
 			// only inside that expression's rounding, like the exp2-based test it replaces.
 			const float lq = logf(255.0f * pl1.w);
-			const float tq = fmaxf(0.0f, fminf(4.5f, lq));
+			const float tq = lq >= 0.0f ? fminf(4.5f, lq) : 0.0f; // (false for the NaN of a negative opacity: takes part nowhere)
 			if (staged) { s0[lane] = p0; s1[lane] = make_float4(p1.x, tq, 0.0f, 0.0f); sl1[lane] = pl1; }
 			unsigned long long reach_mask;
 			{
@@ -602,7 +604,7 @@ __global__ void __launch_bounds__(64, 8) k_render_fov(const RenderArgs a)
 				// a wave that carries the level-L2 state skips the Gaussians that do not exist at L2 (RF forward.cu:399: about
 				// half the list in a 0/1 tile) here, at one lane's cost, instead of walking them as no-ops
 				const bool exists = !upper || !((p1.y + 1.0f) < L2f);
-				reach_mask = __ballot(staged && exists && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
+				reach_mask = __ballot(staged && exists && lq >= 0.0f && band_reaches<PPL>(wv, tx, ty, p0.x, p0.y, p0.z, p0.w, p1.x, thr));
 				npairs += (uint32_t)__popcll(reach_mask);
 				}
 			if (base + 64 + lane < n) fetch(base + 64 + lane);

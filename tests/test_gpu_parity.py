@@ -1242,3 +1242,37 @@ def test_gradient_tensors_cleared_at_the_end_of_the_forward_call():
         # rows of Gaussians the view does not touch are exact zeros either way
         assert torch.equal(res[True][0][n] == 0, res[False][0][n] == 0), n
     check_grad(res[True][2].cpu().numpy(), res[False][2].cpu().numpy(), "gradients cleared at forward time: viewspace_points", rtol=1e-5)
+
+
+@pytest.mark.parametrize("variant", ("pcheck_obb", "pcheck_obb_sum", "fov_pcheck_obb", "original"))
+def test_opacities_that_never_pass_the_alpha_test(variant):
+    """Opacities of 0, just below 1/255 and (garbage in) negative: alpha = o exp(power) < 1/255 skips them everywhere in the reference
+    (forward.cu:363, backward.cu:487); the blend kernels' threshold on q = -power (tq = min(4.5, ln(255 o)), NaN for o < 0) must too --
+    image, statistics and gradients are the oracle's."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward, hip_backward
+    scene, cd = small_case(variant, P=2500, seed=41, width=232, height=152)
+    op = scene["opacities"].copy()
+    n = len(op)
+    op[0:n:7] = 0.0
+    op[1:n:7] = 0.0039  # < 1/255 = 0.003922
+    op[2:n:7] = -0.2
+    op[3:n:7] = 1.0     # and the clamp at 0.99
+    scene["opacities"] = op
+    want = orc.forward(variant, scene, cd)
+    got = hip_forward(variant, scene, cd)
+    assert got["num_rendered"] == want["num_rendered"]
+    np.testing.assert_array_equal(got["point_list"], want["point_list"])
+    check_image(got["color"], want["color"], name=f"{variant}: opacities 0 / 0.0039 / -0.2 / 1")
+    if variant == "pcheck_obb_sum":
+        np.testing.assert_array_equal(got["gaussians_count"], want["gaussians_count"])
+        np.testing.assert_array_equal(got["n_contrib"], want["n_contrib"])
+    if variant in ("original", "pcheck_obb_sum"):
+        dpix = np.random.default_rng(2).normal(size=(3, 152, 232)).astype(np.float32)
+        gg, wg = hip_backward(variant, got, dpix), orc.backward(variant, scene, cd, want, dpix)
+        for k in ("dL_dopacity", "dL_dmean2D", "dL_dsh"):
+            # (519 rows with a gradient: four cancelling dL_dopacity rows of 1e-6 .. 1e-8 sit at 2e-4 .. 2e-3 of the double-precision
+            # value on BOTH sides -- tools/scratch/dbg_op.py)
+            check_grad(gg[k].reshape(wg[k].shape), wg[k], f"{variant} odd opacities {k}", **({"outlier_frac": 2e-2} if k == "dL_dopacity" else {}))
+        dead = (op[:, 0] <= 0.0039) if op.ndim == 2 else (op <= 0.0039)
+        assert np.abs(gg["dL_dsh"].reshape(n, -1)[dead]).max() == 0.0, "a Gaussian that is never blended has no colour gradient"
