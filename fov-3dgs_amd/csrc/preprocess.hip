@@ -1024,7 +1024,9 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			for (int k = 0; k < 16; k++)
 			{
 				const int t = t0 + k * FR_BIN_THREADS;
-				uint32_t nib = t < a.T ? ((uint32_t)min(max(f2i(v[k]), 0), 7) | (f[k] != 0.0f ? 8u : 0u)) : 0u;
+				// (a NaN level -- a gaze far outside the frame with a steep alpha -- fails `tile_min < highest level + 1` for every Gaussian in the
+				// reference, RF rasterizer_impl.cu:802: coded as 7, which fails it for the highest levels 0..3 the table serves)
+				uint32_t nib = t < a.T ? ((v[k] == v[k] ? (uint32_t)min(max(f2i(v[k]), 0), 7) : 7u) | (f[k] != 0.0f ? 8u : 0u)) : 0u;
 				nib <<= 4 * (lane & 7);
 				nib |= (uint32_t)__shfl_xor((int)nib, 1); nib |= (uint32_t)__shfl_xor((int)nib, 2); nib |= (uint32_t)__shfl_xor((int)nib, 4);
 				if ((lane & 7) == 0 && (t >> 3) < tab_words) lds_tab[t >> 3] = nib;
@@ -1500,7 +1502,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			for (int k = 0; k < 16; k++)
 			{
 				const int t = t0 + k * FR_EMIT_THREADS;
-				uint32_t nib = t < a.T ? (uint32_t)min(max(f2i(v[k]), 0), 7) : 0u;
+				uint32_t nib = t < a.T ? (v[k] == v[k] ? (uint32_t)min(max(f2i(v[k]), 0), 7) : 7u) : 0u; // (NaN level: no Gaussian passes, see k_bin)
 				nib <<= 4 * (lane & 7);
 				nib |= (uint32_t)__shfl_xor((int)nib, 1); nib |= (uint32_t)__shfl_xor((int)nib, 2); nib |= (uint32_t)__shfl_xor((int)nib, 4);
 				if ((lane & 7) == 0 && (t >> 3) < tab_words) lds_tab[t >> 3] = nib;

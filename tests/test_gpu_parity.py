@@ -1276,3 +1276,27 @@ def test_opacities_that_never_pass_the_alpha_test(variant):
             check_grad(gg[k].reshape(wg[k].shape), wg[k], f"{variant} odd opacities {k}", **({"outlier_frac": 2e-2} if k == "dL_dopacity" else {}))
         dead = (op[:, 0] <= 0.0039) if op.ndim == 2 else (op <= 0.0039)
         assert np.abs(gg["dL_dsh"].reshape(n, -1)[dead]).max() == 0.0, "a Gaussian that is never blended has no colour gradient"
+
+
+@pytest.mark.parametrize("variant", ("fov_pcheck_obb", "naive_pcheck_obb"))
+def test_tiles_whose_level_is_nan(variant):
+    """A gaze outside the frame with a steep alpha makes the level formula (RF rasterizer_impl.cu:120-177: acosf / tanf of angles past
+    their domains) return NaN for some tiles. In the reference every comparison with that level is false: `tile_min < highest level + 1`
+    (:802) keeps no Gaussian in such a tile and its pixels stay background. Found by tests/stress_parity.py (round 5): the 4-bit tile
+    table of k_bin / k_emit coded a NaN level as 0 and binned the tile like a level-0 one."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_forward
+    for (P, W, H, gaze, alpha, seed) in ((500, 291, 521, (0.8587010485146724, -0.1137553160911004), 0.2, 5), (6000, 165, 488, (1.25, -0.2), 0.2, 9)):
+        scene, cd = small_case("fov_pcheck_obb", P=P, seed=seed, width=W, height=H, gaze=gaze, alpha=alpha)
+        if variant == "naive_pcheck_obb":  # the shared-model baseline: the plain model + the foveated model's highest levels
+            plain, _ = small_case("pcheck_obb", P=P, seed=seed, width=W, height=H)
+            scene = dict(plain, highest_levels=scene["highest_levels"])
+        want = orc.forward(variant, scene, cd)
+        nan_tiles = int(np.isnan(want["tile_min"]).sum())
+        assert nan_tiles > 0, "the case should hold tiles with a NaN level"
+        got = hip_forward(variant, scene, cd, debug=False)
+        assert got["num_rendered"] == want["num_rendered"]
+        np.testing.assert_array_equal(got["radii"], want["radii"])
+        np.testing.assert_array_equal(got["ranges"], want["ranges"])
+        np.testing.assert_array_equal(got["point_list"], want["point_list"])
+        check_image(got["color"], want["color"], name=f"{variant}: {nan_tiles} tiles with a NaN level")
