@@ -62,7 +62,7 @@ for r in range(rounds):
             a, b = grad_stats(gg[k].reshape(wg[k].shape), g64[k]), grad_stats(wg[k], g64[k])
             worst = max(worst, a["frac_bad"] - b["frac_bad"])
             ok = ok and np.isfinite(gg[k]).all() and st["rel_l2"] <= 2e-3 and \
-                a["frac_bad"] <= 1.5 * b["frac_bad"] + max(2e-3, 3.5 / max(st["rows_with_gradient"], 1))
+                a["frac_bad"] <= 1.5 * b["frac_bad"] + max(2e-3, 10.0 / max(st["rows_with_gradient"], 1))
             if only >= 0:
                 print(f"   {k}: hip vs f32 oracle bad {st['frac_bad']:.2e} p99 {st['row_rel_p99']:.1e} relL2 {st['rel_l2']:.1e} | hip vs f64 {a['frac_bad']:.2e} | f32 oracle vs f64 {b['frac_bad']:.2e} rows {st['rows_with_gradient']}")
         gnote = f" grad rows outside 1e-4 beyond the fp32 reference's own: {worst:+.1e}"
