@@ -12,6 +12,9 @@ only = int(os.environ.get("STRESS_ONLY", "-1"))  # replay the sweep's random num
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 variants = ("original", "pcheck_obb_sum", "pcheck_obb", "fov_pcheck_obb", "pcheck_obb_max")
+WIDE = os.environ.get("STRESS_WIDE", "0") == "1"  # also: random camera, scale modifier, SH degree, background, the shared-model variant
+if WIDE:
+    variants = variants + ("naive_pcheck_obb", "fov_pcheck_obb")
 bad = 0
 for r in range(rounds):
     variant = variants[r % len(variants)]
@@ -22,12 +25,24 @@ for r in range(rounds):
     if rng.random() < 0.3 and P >= 8:
         cloud._scaling[: max(1, P // 50)] += 3.0  # a few frame-filling splats
     cam = small_camera(W, H)
-    fov = syn.foveation_layers(cloud, seed=r) if variant == "fov_pcheck_obb" else None
-    scene = scene_dict(cloud, variant, fov)
+    extra_cd = {}
+    if WIDE:
+        import math
+        eye = (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-2.0, 3.0)))
+        Rm, tv = syn.look_at(eye, (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), 4.0))
+        fovx = math.radians(float(rng.uniform(35.0, 110.0)))
+        cam = syn.MiniCam(Rm, tv, fovx, 2 * math.atan(H / (2 * (W / (2 * math.tan(fovx / 2))))), W, H)
+        extra_cd = dict(scale_modifier=float(rng.choice([1.0, 0.4, 2.5])), sh_degree=int(rng.integers(0, 4)),
+                        bg=tuple(float(x) for x in rng.uniform(0, 1, 3)))
+    fov = syn.foveation_layers(cloud, seed=r) if variant in ("fov_pcheck_obb", "naive_pcheck_obb") else None
+    if variant == "naive_pcheck_obb":
+        scene = dict(scene_dict(cloud, "pcheck_obb"), highest_levels=fov[0].numpy())
+    else:
+        scene = scene_dict(cloud, variant, fov)
     # opacities scaled down in a third of the rounds each by 10 / 50: translucent clouds whose lists are consumed to the end
     osc = float(rng.choice([1.0, 0.1, 0.02]))
     scene["opacities"] = (scene["opacities"] * osc).astype(np.float32)
-    cd = cam_dict(cam, gaze=(float(rng.uniform(-0.3, 1.3)), float(rng.uniform(-0.3, 1.3))), alpha=float(rng.choice([0.05, 0.02, 0.2])))
+    cd = cam_dict(cam, gaze=(float(rng.uniform(-0.3, 1.3)), float(rng.uniform(-0.3, 1.3))), alpha=float(rng.choice([0.05, 0.02, 0.2])), **extra_cd)
     if only >= 0 and r != only:
         if variant in ("original", "pcheck_obb_sum"):
             rng.normal(size=(3, H, W))
@@ -38,7 +53,7 @@ for r in range(rounds):
         np.array_equal(got["ranges"], want["ranges"]) and np.array_equal(got["point_list"], want["point_list"])
     d = np.abs(got["color"] - want["color"])
     ok = ok and np.isfinite(got["color"]).all() and d.max() <= 2e-2 and np.mean(d > 1e-4) <= 2e-3
-    if ok and scene.get("scales") is not None and scene.get("shs") is not None:  # packed layout: bit-identical
+    if ok and scene.get("scales") is not None and scene.get("shs") is not None and variant != "naive_pcheck_obb":  # packed layout: bit-identical
         pk = hip_forward(variant, scene, cd, packed=True)
         ok = pk["num_rendered"] == got["num_rendered"] and all(np.array_equal(pk[k], got[k]) for k in ("radii", "ranges", "point_list", "color"))
     gnote = ""
