@@ -254,8 +254,10 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 	{
 		pid = a.point_list[range.x + st];
 		const float4 *r = a.rec + 3 * (size_t)pid;
-		p0 = r[0]; p1 = r[1]; p2 = r[2].x;
-		if (NEEDID) pgid = a.vis_list[pid];
+		p0 = r[0]; p1 = r[1];
+		// (statistics: the Gaussian's index is the last word of the item's own record -- the same cache line as the colour's third
+		// channel -- where round 4 gathered it from vis_list, a line of its own per entry)
+		if (NEEDID) { const float4 r2 = r[2]; p2 = r2.x; pgid = __float_as_uint(r2.w); } else p2 = r[2].x;
 	}
 	bool counting = false; // FETCHCNT: this wave owns the counts of the current 256-entry round
 	int used = 0;          // list entries this wave staged for blending (list_consumed)
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		if (FETCHCNT && wave_done)
 		{
 			// this band is finished but owns the round: only its remaining counts are due
-			if (base + 64 + st < n) pgid = a.vis_list[a.point_list[range.x + base + 64 + st]];
+			if (base + 64 + st < n) pgid = __float_as_uint(a.rec[3 * (size_t)a.point_list[range.x + base + 64 + st] + 2].w);
 			continue;
 		}
 		used = min(n, base + 64);
@@ -322,8 +324,8 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		{
 			pid = a.point_list[range.x + base + 64 + st];
 			const float4 *r = a.rec + 3 * (size_t)pid;
-			p0 = r[0]; p1 = r[1]; p2 = r[2].x;
-			if (NEEDID) pgid = a.vis_list[pid];
+			p0 = r[0]; p1 = r[1];
+			if (NEEDID) { const float4 r2 = r[2]; p2 = r2.x; pgid = __float_as_uint(r2.w); } else p2 = r[2].x;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // lanes read entries other lanes staged
 		__builtin_amdgcn_wave_barrier();
