@@ -115,10 +115,14 @@ for r in range(rounds):
             st = grad_stats(gg[k].reshape(wg[k].shape), wg[k])
             a, b = grad_stats(gg[k].reshape(wg[k].shape), g64[k]), grad_stats(wg[k], g64[k])
             worst = max(worst, a["frac_bad"] - b["frac_bad"])
-            ok = ok and np.isfinite(gg[k]).all() and st["rel_l2"] <= 2e-3 and \
+            # (the whole-tensor norm is carried by a few near-camera rows of huge, cancelling gradients: judged against the double-precision
+            # result like the rows, where it exceeds 1e-4 at all. Seed 61 round 71 with STRESS_WIDE: dL_dmean3D / dL_drot / dL_dscale 5.6e-5 / 4.7e-5 /
+            # 1.7e-4 from the double result here against the reference arithmetic's 1.8e-3 / 1.5e-3 / 4.7e-4, dL_dcov3D 2.9e-4 against 6.2e-5:
+            # the matrix form of the chain rule is the better conditioned one for the parameters, the worse one for the intermediate)
+            ok = ok and np.isfinite(gg[k]).all() and (st["rel_l2"] <= 1e-4 or a["rel_l2"] <= 6.0 * b["rel_l2"] + 1e-5) and \
                 a["frac_bad"] <= 2.0 * b["frac_bad"] + max(2e-3, 10.0 / max(st["rows_with_gradient"], 1))
             if only >= 0:
-                print(f"   {k}: hip vs f32 oracle bad {st['frac_bad']:.2e} p99 {st['row_rel_p99']:.1e} relL2 {st['rel_l2']:.1e} | hip vs f64 {a['frac_bad']:.2e} | f32 oracle vs f64 {b['frac_bad']:.2e} rows {st['rows_with_gradient']}")
+                print(f"   {k}: hip vs f32 oracle bad {st['frac_bad']:.2e} p99 {st['row_rel_p99']:.1e} relL2 {st['rel_l2']:.1e} | hip vs f64 {a['frac_bad']:.2e} (relL2 {a['rel_l2']:.1e}) | f32 oracle vs f64 {b['frac_bad']:.2e} (relL2 {b['rel_l2']:.1e}) rows {st['rows_with_gradient']}")
         gnote = f" grad rows outside 1e-4 beyond the fp32 reference's own: {worst:+.1e}"
     print(f"{r:3d} {variant:16s} P={P:6d} {W}x{H} big={big} opac x{osc} D={want['num_rendered']:8d}" + gnote + f" max list {int((want['ranges'][:,1]-want['ranges'][:,0]).max()):6d} "
           f"img max diff {d.max():.2e} -> {'ok' if ok else 'MISMATCH'}", flush=True)
