@@ -318,6 +318,14 @@ struct BwdPreArgs {
 	int M0;                    // coefficients in dL_dsh's rows ([., M0, 3]): M, or 1 with split SH storage
 };
 
+// The gradient rows are written once and read by nobody in this library, and so are the zeros of k_fill_zero: both leave with
+// NON-TEMPORAL stores (`global_store ... nt`: the lines are first to go from L2). Plain stores left 1.5 GB of dirty zero lines and
+// 0.5 GB of rows pushing k_render_bwd's records and this kernel's own reads out of the cache: k_render_bwd beside the fill 0.48 -> 0.43
+// ms, k_preprocess_bwd 0.51 -> 0.41, the fill itself 0.365 -> 0.30 (S-6M, A / B on one box). Non-temporal LOADS of the rows this
+// kernel reads once (stash, sums, records, coefficients) cost 30 us instead: left as they are.
+typedef float nt_f4v __attribute__((ext_vector_type(4)));
+#define FR_ST(p, v) __builtin_nontemporal_store((v), (p))
+__device__ __forceinline__ void st_f4(float4 *p, const float4 v) { __builtin_nontemporal_store((nt_f4v){ v.x, v.y, v.z, v.w }, (nt_f4v *)p); }
 struct V3 { float x, y, z; };
 __device__ __forceinline__ float dot3(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ V3 axpy3(float s, const V3 &a, const V3 &b) { return { s * a.x + b.x, s * a.y + b.y, s * a.z + b.z }; }
@@ -386,13 +394,13 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	const float m10 = ac0.w, m01 = ac1.x, opac = rq1.y;
 	const float g_px = -opac * (rq0.z * m10 + rq0.w * m01) * (0.5f * a.W), g_py = -opac * (rq1.x * m01 + rq0.w * m10) * (0.5f * a.H);
 	const float gA = -0.5f * opac * ac1.y, gB = -0.5f * opac * ac1.z, gC = -0.5f * opac * ac1.w;
-	a.dL_dmean2D[3 * orow] = g_px; a.dL_dmean2D[3 * orow + 1] = g_py;
+	FR_ST(a.dL_dmean2D + 3 * orow, g_px); FR_ST(a.dL_dmean2D + 3 * orow + 1, g_py);
 	if (a.row_sparse) a.dL_dmean2D[3 * orow + 2] = 0.0f; // (the dense tensors get their zeros from the fill)
 	// (raw parameters: through the sigmoid, o (1 - o), and below through exp and the normalisation -- what k_activate_bwd does
 	// for all P Gaussians, here only for the rows that are not zero anyway)
-	a.dL_dopacity[orow] = ac2.x;
-	if (a.dL_dcolor != nullptr) { a.dL_dcolor[3 * orow] = g_col[0]; a.dL_dcolor[3 * orow + 1] = g_col[1]; a.dL_dcolor[3 * orow + 2] = g_col[2]; }
-	if (a.dL_dconic != nullptr) { a.dL_dconic[4 * orow] = gA; a.dL_dconic[4 * orow + 1] = gB; a.dL_dconic[4 * orow + 3] = gC; if (a.row_sparse) a.dL_dconic[4 * orow + 2] = 0.0f; }
+	FR_ST(a.dL_dopacity + orow, a.raw ? ac2.x * opac * (1.0f - opac) : ac2.x);
+	if (a.dL_dcolor != nullptr) { FR_ST(a.dL_dcolor + 3 * orow, g_col[0]); FR_ST(a.dL_dcolor + 3 * orow + 1, g_col[1]); FR_ST(a.dL_dcolor + 3 * orow + 2, g_col[2]); }
+	if (a.dL_dconic != nullptr) { FR_ST(a.dL_dconic + 4 * orow, gA); FR_ST(a.dL_dconic + 4 * orow + 1, gB); FR_ST(a.dL_dconic + 4 * orow + 3, gC); if (a.row_sparse) a.dL_dconic[4 * orow + 2] = 0.0f; }
 
 	// rows of the camera rotation: t = R mean + translation, R[i][r] = vm[4 r + i]
 	const V3 Rx = { vm[0], vm[4], vm[8] }, Ry = { vm[1], vm[5], vm[9] }, Rz = { vm[2], vm[6], vm[10] };
@@ -410,7 +418,6 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	// H = -Q Ghat Q with the conic Q the forward pass stored
 	const float4 rc0 = rq0, rc1 = rq1; // (..., conic a, conic b), (conic c, opacity, ...)
 	const float qa = rc0.z, qb = rc0.w, qc = rc1.x;
-	if (a.raw) a.dL_dopacity[orow] = ac2.x * rc1.y * (1.0f - rc1.y);
 	const float k00 = qa * gA + qb * gB, k01 = qa * gB + qb * gC, k10 = qb * gA + qc * gB, k11 = qb * gB + qc * gC; // Q Ghat
 	const float detq = qa * qc - qb * qb;                     // = 1 / det M
 	const float guard = -1.0f / (1.0f + 0.0000001f * detq * detq); // -(det^2 / (det^2 + 1e-7)), backward.cu:190
@@ -428,7 +435,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	if (a.dL_dcov3D != nullptr)
 	{
 #pragma unroll
-		for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * orow + i] = gSigma[i];
+		for (int i = 0; i < 6; i++) FR_ST(a.dL_dcov3D + 6 * orow + i, gSigma[i]);
 	}
 	// dL/dU = 2 Y Sigma (rows w0, w1); dL/dJac[i][k] = dL/dU row i . R row k
 	const V3 w0 = symv(Sigma, y0), w1 = symv(Sigma, y1);
@@ -476,7 +483,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 #pragma unroll
 		for (int k = 0; k < 16; k++) { bas[k] = 0.f; grd[k] = { 0, 0, 0 }; }
 		sh_basis_grad(a.D, dir.x, dir.y, dir.z, bas, grd);
-		dsh0[0] = bas[0] * g[0]; dsh0[1] = bas[0] * g[1]; dsh0[2] = bas[0] * g[2];
+		FR_ST(dsh0, bas[0] * g[0]); FR_ST(dsh0 + 1, bas[0] * g[1]); FR_ST(dsh0 + 2, bas[0] * g[2]);
 		V3 g_dir = { 0, 0, 0 };
 		if (sh_row != nullptr)
 		{
@@ -541,9 +548,9 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		g_mean.y += (g_dir.y - along * dir.y) * ilen;
 		g_mean.z += (g_dir.z - along * dir.z) * ilen;
 	}
-	a.dL_dmean3D[3 * orow] = g_mean.x;
-	a.dL_dmean3D[3 * orow + 1] = g_mean.y;
-	a.dL_dmean3D[3 * orow + 2] = g_mean.z;
+	FR_ST(a.dL_dmean3D + 3 * orow, g_mean.x);
+	FR_ST(a.dL_dmean3D + 3 * orow + 1, g_mean.y);
+	FR_ST(a.dL_dmean3D + 3 * orow + 2, g_mean.z);
 	// ---- 3D covariance: Sigma = A^T A, A = diag(s) B(q), B the matrix forward.cu:127-137 builds from the quaternion
 	// (backward.cu:278-341). With Gs the symmetric gradient matrix (off-diagonals halved): dL/dA = 2 A Gs,
 	// dL/ds_i = B_i . (dL/dA)_i, dL/dB_i = s_i (dL/dA)_i (rows), then through the quadratic entries of B.
@@ -587,12 +594,12 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 			}
 			else gq = make_float4(gq.x * -inv, gq.y * -inv, gq.z * -inv, gq.w * -inv); // clamped denominator: x / 1e-12
 		}
-		a.dL_dscale[3 * orow] = gs[0]; a.dL_dscale[3 * orow + 1] = gs[1]; a.dL_dscale[3 * orow + 2] = gs[2];
-		((float4 *)a.dL_drot)[orow] = gq;
+		FR_ST(a.dL_dscale + 3 * orow, gs[0]); FR_ST(a.dL_dscale + 3 * orow + 1, gs[1]); FR_ST(a.dL_dscale + 3 * orow + 2, gs[2]);
+		st_f4((float4 *)a.dL_drot + orow, gq);
 	}
 }
 
-// Zero-fill of the gradient tensors: every workgroup takes a contiguous share of every tensor (16-byte stores).
+// Zero-fill of the gradient tensors: every workgroup takes a contiguous share of every tensor (16-byte non-temporal stores, see FR_ST).
 #define FR_FILL_MAX 12
 #ifndef FR_FILL_BLOCKS
 #define FR_FILL_BLOCKS 1024
@@ -600,12 +607,11 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 struct FillArgs { int n; float *p[FR_FILL_MAX]; size_t words[FR_FILL_MAX]; };
 __global__ void __launch_bounds__(256) k_fill_zero(const FillArgs a)
 {
-	const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 	for (int t = 0; t < a.n; t++)
 	{
 		const size_t quads = a.words[t] / 4, tail = a.words[t] - 4 * quads;
-		float4 *q = (float4 *)a.p[t];
-		for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) q[i] = z;
+		nt_f4v *q = (nt_f4v *)a.p[t];
+		for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store((nt_f4v){ 0.f, 0.f, 0.f, 0.f }, q + i);
 		if (blockIdx.x == 0 && threadIdx.x < tail) a.p[t][4 * quads + threadIdx.x] = 0.0f;
 	}
 }
@@ -700,7 +706,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 				{
 					const float *w = &s_rows[wv][r * ROWF + 3 * part];
 					float *q = dst + (size_t)o * src_stride + src_off + 3 * part;
-					q[0] = w[0]; q[1] = w[1]; q[2] = w[2];
+					FR_ST(q, w[0]); FR_ST(q + 1, w[1]); FR_ST(q + 2, w[2]);
 				}
 			}
 			FR_WAVE_LDS_SYNC(); // the rows and tables are rewritten by the next round
