@@ -299,6 +299,20 @@ __global__ void __launch_bounds__(64, 6) k_render_bwd(const BwdRenderArgs a)
 //   and dL/dt through the four non-constant entries of Jac. The reference writes the same chain out per matrix entry
 //   (backward.cu:144-274) with the quotient rule on the recomputed covariance; its 1e-7 guard on det^2 is kept as the
 //   factor `guard` below.
+// The NARROW dense gradient tensors (4-16 bytes a row: positions, opacity, scales, rotations, the DC coefficients of split SH storage).
+// A visible Gaussian's row in such a tensor is a fraction of a 64-byte memory transaction, and with one Gaussian in three visible the
+// rows of a wave are 64 partial transactions per tensor over zeros the fill had just written: 124 us of k_preprocess_bwd's 516 for 6 %
+// of its payload (timed by leaving the stores out). So the rows of these tensors are written TOGETHER WITH THE ZEROS AROUND THEM, as
+// whole lines, by the kernel that has the rows: the tensors are cut into groups of 32 rows; a group without a visible Gaussian
+// (radii > 0) is cleared by k_fill_groups beside k_render_bwd like everything else; in any other group every visible row's owner writes
+// the zeros in front of it (back to the previous visible row of the group) and, when it is the group's last, those behind it -- a
+// wave's 64 consecutive visible rows and their zeros are one contiguous range, put together in LDS and stored 256 bytes an instruction.
+// off: where the tensor's row sits in a lane's staging row of FR_SMALL_ROW floats.
+#define FR_SMALL_MAX 6
+#define FR_SMALL_ROW 17      // 3 mean2D + 1 opacity + 3 mean3D + 3 scale + 4 rotation + 3 DC (odd: lanes' rows start in different LDS banks)
+#define FR_SMALL_GROUPS 16   // 32-row groups (512 rows) a wave puts together at a time; a wave whose rows span more takes several turns
+struct SmallSet { int n; float *p[FR_SMALL_MAX]; int w[FR_SMALL_MAX]; int off[FR_SMALL_MAX]; };
+
 struct BwdPreArgs {
 	int P, D, M, W, H;
 	float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
@@ -316,6 +330,7 @@ struct BwdPreArgs {
 	int raw;                   // dL_dscale / dL_drot / dL_dopacity w.r.t. the model's raw parameters (fr_backward_args.raw_activations)
 	int row_sparse;            // the outputs are COMPACT: row i belongs to the Gaussian vis_list[i] (fr_backward_args.row_sparse)
 	int M0;                    // coefficients in dL_dsh's rows ([., M0, 3]): M, or 1 with split SH storage
+	SmallSet small;            // dense tensors: the narrow ones this kernel writes in whole lines (n == 0: every row on its own)
 };
 
 // The gradient rows are written once and read by nobody in this library, and so are the zeros of k_fill_zero: both leave with
@@ -366,7 +381,8 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 // (xyz | raw scale | rotation | 3D covariance) the forward pass left there: one coalesced row instead of four gathers)
 // sh_row: the Gaussian's 45 rest coefficients in LDS (k_preprocess_bwd fetched the wave's rows together), replaced in place by
 // their gradients (stored together as well); null: read / written here, per lane
-__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx, const int slot, const float4 *stash, float *sh_row)
+// sv: the lane's staging row of the narrow tensors (BwdPreArgs.small; null: every row stored on its own)
+__device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const int idx, const int slot, const float4 *stash, float *sh_row, float *sv)
 {
 	const size_t orow = a.row_sparse ? (size_t)slot : (size_t)idx; // the row of the gradient tensors this Gaussian's gradients go to
 	const float *vm = a.viewmatrix, *pm = a.projmatrix;
@@ -394,11 +410,15 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 	const float m10 = ac0.w, m01 = ac1.x, opac = rq1.y;
 	const float g_px = -opac * (rq0.z * m10 + rq0.w * m01) * (0.5f * a.W), g_py = -opac * (rq1.x * m01 + rq0.w * m10) * (0.5f * a.H);
 	const float gA = -0.5f * opac * ac1.y, gB = -0.5f * opac * ac1.z, gC = -0.5f * opac * ac1.w;
-	FR_ST(a.dL_dmean2D + 3 * orow, g_px); FR_ST(a.dL_dmean2D + 3 * orow + 1, g_py);
+	if (sv) { sv[0] = g_px; sv[1] = g_py; sv[2] = 0.0f; }
+	else { FR_ST(a.dL_dmean2D + 3 * orow, g_px); FR_ST(a.dL_dmean2D + 3 * orow + 1, g_py); }
 	if (a.row_sparse) a.dL_dmean2D[3 * orow + 2] = 0.0f; // (the dense tensors get their zeros from the fill)
 	// (raw parameters: through the sigmoid, o (1 - o), and below through exp and the normalisation -- what k_activate_bwd does
 	// for all P Gaussians, here only for the rows that are not zero anyway)
-	FR_ST(a.dL_dopacity + orow, a.raw ? ac2.x * opac * (1.0f - opac) : ac2.x);
+	{
+		const float g_op = a.raw ? ac2.x * opac * (1.0f - opac) : ac2.x;
+		if (sv) sv[3] = g_op; else FR_ST(a.dL_dopacity + orow, g_op);
+	}
 	if (a.dL_dcolor != nullptr) { FR_ST(a.dL_dcolor + 3 * orow, g_col[0]); FR_ST(a.dL_dcolor + 3 * orow + 1, g_col[1]); FR_ST(a.dL_dcolor + 3 * orow + 2, g_col[2]); }
 	if (a.dL_dconic != nullptr) { FR_ST(a.dL_dconic + 4 * orow, gA); FR_ST(a.dL_dconic + 4 * orow + 1, gB); FR_ST(a.dL_dconic + 4 * orow + 3, gC); if (a.row_sparse) a.dL_dconic[4 * orow + 2] = 0.0f; }
 
@@ -483,7 +503,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 #pragma unroll
 		for (int k = 0; k < 16; k++) { bas[k] = 0.f; grd[k] = { 0, 0, 0 }; }
 		sh_basis_grad(a.D, dir.x, dir.y, dir.z, bas, grd);
-		FR_ST(dsh0, bas[0] * g[0]); FR_ST(dsh0 + 1, bas[0] * g[1]); FR_ST(dsh0 + 2, bas[0] * g[2]);
+		if (sv && split) { sv[14] = bas[0] * g[0]; sv[15] = bas[0] * g[1]; sv[16] = bas[0] * g[2]; }
+		else { FR_ST(dsh0, bas[0] * g[0]); FR_ST(dsh0 + 1, bas[0] * g[1]); FR_ST(dsh0 + 2, bas[0] * g[2]); }
 		V3 g_dir = { 0, 0, 0 };
 		if (sh_row != nullptr)
 		{
@@ -548,9 +569,13 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 		g_mean.y += (g_dir.y - along * dir.y) * ilen;
 		g_mean.z += (g_dir.z - along * dir.z) * ilen;
 	}
-	FR_ST(a.dL_dmean3D + 3 * orow, g_mean.x);
-	FR_ST(a.dL_dmean3D + 3 * orow + 1, g_mean.y);
-	FR_ST(a.dL_dmean3D + 3 * orow + 2, g_mean.z);
+	if (sv) { sv[4] = g_mean.x; sv[5] = g_mean.y; sv[6] = g_mean.z; }
+	else
+	{
+		FR_ST(a.dL_dmean3D + 3 * orow, g_mean.x);
+		FR_ST(a.dL_dmean3D + 3 * orow + 1, g_mean.y);
+		FR_ST(a.dL_dmean3D + 3 * orow + 2, g_mean.z);
+	}
 	// ---- 3D covariance: Sigma = A^T A, A = diag(s) B(q), B the matrix forward.cu:127-137 builds from the quaternion
 	// (backward.cu:278-341). With Gs the symmetric gradient matrix (off-diagonals halved): dL/dA = 2 A Gs,
 	// dL/ds_i = B_i . (dL/dA)_i, dL/dB_i = s_i (dL/dA)_i (rows), then through the quadratic entries of B.
@@ -594,15 +619,19 @@ __device__ __forceinline__ void preprocess_bwd_one(const BwdPreArgs &a, const in
 			}
 			else gq = make_float4(gq.x * -inv, gq.y * -inv, gq.z * -inv, gq.w * -inv); // clamped denominator: x / 1e-12
 		}
-		FR_ST(a.dL_dscale + 3 * orow, gs[0]); FR_ST(a.dL_dscale + 3 * orow + 1, gs[1]); FR_ST(a.dL_dscale + 3 * orow + 2, gs[2]);
-		st_f4((float4 *)a.dL_drot + orow, gq);
+		if (sv) { sv[7] = gs[0]; sv[8] = gs[1]; sv[9] = gs[2]; sv[10] = gq.x; sv[11] = gq.y; sv[12] = gq.z; sv[13] = gq.w; }
+		else
+		{
+			FR_ST(a.dL_dscale + 3 * orow, gs[0]); FR_ST(a.dL_dscale + 3 * orow + 1, gs[1]); FR_ST(a.dL_dscale + 3 * orow + 2, gs[2]);
+			st_f4((float4 *)a.dL_drot + orow, gq);
+		}
 	}
 }
 
 // Zero-fill of the gradient tensors: every workgroup takes a contiguous share of every tensor (16-byte non-temporal stores, see FR_ST).
 #define FR_FILL_MAX 12
 #ifndef FR_FILL_BLOCKS
-#define FR_FILL_BLOCKS 1024
+#define FR_FILL_BLOCKS 4096
 #endif
 struct FillArgs { int n; float *p[FR_FILL_MAX]; size_t words[FR_FILL_MAX]; };
 __global__ void __launch_bounds__(256) k_fill_zero(const FillArgs a)
@@ -614,6 +643,71 @@ __global__ void __launch_bounds__(256) k_fill_zero(const FillArgs a)
 		for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store((nt_f4v){ 0.f, 0.f, 0.f, 0.f }, q + i);
 		if (blockIdx.x == 0 && threadIdx.x < tail) a.p[t][4 * quads + threadIdx.x] = 0.0f;
 	}
+}
+
+// The narrow tensors' share of the fill (SmallSet): the 32-row groups WITHOUT a visible Gaussian. One wave per 64 rows (two groups):
+// their radii as one coalesced load, a ballot, and the zeros of an empty group as 16-byte (both groups) or 4-byte stores.
+__global__ void __launch_bounds__(256) k_fill_groups(const int P, const int *radii, const SmallSet ss)
+{
+	const int lane = threadIdx.x & 63;
+	const int nblk = (P + 63) / 64;
+	for (int b = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); b < nblk; b += (int)gridDim.x * 4)
+	{
+		const int row = 64 * b + lane;
+		const unsigned long long m = __ballot(row < P && radii[row] > 0);
+		const bool e0 = (uint32_t)m == 0u, e1 = (uint32_t)(m >> 32) == 0u;
+		if (!e0 && !e1) continue;
+		for (int t = 0; t < ss.n; t++)
+		{
+			const int w = ss.w[t];
+			float *base = ss.p[t] + (size_t)64 * b * w; // (64 rows of w floats: a multiple of 16 bytes from the tensor's start)
+			if (e0 && e1 && 64 * b + 64 <= P)
+			{
+				for (int q = lane; q < 16 * w; q += 64) __builtin_nontemporal_store((nt_f4v){ 0.f, 0.f, 0.f, 0.f }, (nt_f4v *)base + q);
+				continue;
+			}
+			for (int o = lane; o < 64 * w; o += 64)
+			{
+				const int r = w == 1 ? o : (w == 3 ? o / 3 : o >> 2);
+				if ((r < 32 ? e0 : e1) && 64 * b + r < P) __builtin_nontemporal_store(0.0f, base + o);
+			}
+		}
+	}
+}
+
+// One narrow tensor's rows lo .. lo + n - 1 (the wave's visible rows and the zeros between / around them), put together as an image
+// of the range in LDS and stored 16 bytes a lane: the image starts `pad` words into img so that LDS word and global word are aligned
+// alike (the tensors are 16-byte aligned); the first and the last quad of the range may be partial and go word by word.
+// vals: the lanes' staging rows; mine: this lane holds a visible row of the range (row `idx`).
+template <int W>
+__device__ __forceinline__ void expand_rows(float *dst, const int off, const int lo, const int n, float *img, const float *vals,
+	const bool mine, const int idx, const int lane)
+{
+	const int first_word = lo * W, pad = first_word & 3, total = n * W, nq = (pad + total + 3) >> 2;
+	float4 *img4 = (float4 *)img;
+	for (int q = lane; q < nq; q += 64) img4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+	FR_WAVE_LDS_SYNC();
+	if (mine)
+	{
+#pragma unroll
+		for (int c = 0; c < W; c++) img[pad + (idx - lo) * W + c] = vals[lane * FR_SMALL_ROW + off + c];
+	}
+	FR_WAVE_LDS_SYNC();
+	float *base = dst + ((size_t)first_word - pad); // 16-byte aligned
+	for (int q = lane; q < nq; q += 64)
+	{
+		const float4 v = img4[q];
+		const int o = 4 * q - pad; // the range's word index of v.x
+		if (o >= 0 && o + 3 < total) __builtin_nontemporal_store((nt_f4v){ v.x, v.y, v.z, v.w }, (nt_f4v *)(base + 4 * q));
+		else
+		{
+			if (o >= 0 && o < total) __builtin_nontemporal_store(v.x, base + 4 * q);
+			if (o + 1 >= 0 && o + 1 < total) __builtin_nontemporal_store(v.y, base + 4 * q + 1);
+			if (o + 2 >= 0 && o + 2 < total) __builtin_nontemporal_store(v.z, base + 4 * q + 2);
+			if (o + 3 >= 0 && o + 3 < total) __builtin_nontemporal_store(v.w, base + 4 * q + 3);
+		}
+	}
+	FR_WAVE_LDS_SYNC(); // the image is the next tensor's
 }
 
 // Grid-stride over the forward pass's visible list: dense waves instead of one thread per Gaussian with ~70 % of the
@@ -630,9 +724,14 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 	// with 16-byte accesses -- 64 different rows per instruction -- spent 100 us on these reads and 175 us on the writes of a
 	// 0.5 ms kernel (both measured by leaving them out).
 	constexpr int ROWF = 45;              // rest floats of a degree-3 row
-	__shared__ float s_rows[4][64 * ROWF];
+	__shared__ __attribute__((aligned(16))) float s_rows[4][64 * ROWF];
 	__shared__ int s_idx[4][64];          // per lane of the wave: its Gaussian, or -1
 	__shared__ long long s_orow[4][64];   // ... and the row of the gradient tensors it writes, or -1
+	// the narrow tensors written in whole lines (SmallSet): the lanes' staging rows (the image of a range is put together in the wave's
+	// s_rows, free again by then: 32 * FR_SMALL_GROUPS rows of at most 4 floats + 3 of padding fit its 64 * 45)
+	__shared__ float s_small[4][64 * FR_SMALL_ROW];
+	static_assert(32 * FR_SMALL_GROUPS * 4 + 8 <= 64 * ROWF, "the image of a range lives in the wave's SH rows");
+	const bool expand = a.small.n != 0;
 	const int V = (int)*a.vis_count;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const bool have_sh = a.colors_precomp == nullptr && a.shs != nullptr;
@@ -678,7 +777,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 				}
 			FR_WAVE_LDS_SYNC();
 		}
-		if (alive) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i, coop ? &s_rows[wv][lane * ROWF] : nullptr);
+		if (alive) preprocess_bwd_one(a, idx, i, a.cov3D_precomp ? nullptr : (const float4 *)a.cov3D_ws + 4 * (size_t)i, coop ? &s_rows[wv][lane * ROWF] : nullptr,
+			expand ? &s_small[wv][lane * FR_SMALL_ROW] : nullptr);
 		else if (a.row_sparse && i < V)
 		{
 			// a candidate that landed in no tile: its compact row is all zeros (every row of the compact tensors is written)
@@ -711,6 +811,37 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 			}
 			FR_WAVE_LDS_SYNC(); // the rows and tables are rewritten by the next round
 		}
+		if (expand)
+		{
+			// the wave's visible rows (ascending) in turns of at most FR_SMALL_GROUPS groups -- one turn unless the rows are far apart
+			FR_WAVE_LDS_SYNC();
+			for (unsigned long long am = __ballot(alive); am != 0ull;)
+			{
+				const int l0 = __ffsll((long long)am) - 1;
+				const int first = __builtin_amdgcn_readlane(idx, l0), g0 = first >> 5;
+				const unsigned long long sm = __ballot(alive && (idx >> 5) - g0 < FR_SMALL_GROUPS) & am;
+				const int l1 = 63 - __clzll((long long)sm);
+				const int last = __builtin_amdgcn_readlane(idx, l1), g1 = last >> 5;
+				// the visibility bits (radii > 0) of the first and of the last group: one load, one ballot
+				const int brow = lane < 32 ? 32 * g0 + lane : 32 * g1 + (lane - 32);
+				const unsigned long long bm = __ballot(brow < a.P && a.radii[brow] > 0);
+				// the range: back to the row behind the previous visible one of the first group, on to the end of the last group
+				// unless another visible row follows in it (that row's owner writes the zeros in front of it)
+				const uint32_t below = (uint32_t)bm & ((1u << (first & 31)) - 1u);
+				const int lo = below != 0u ? 32 * g0 + (31 - __clz((int)below)) + 1 : 32 * g0;
+				const uint32_t above = (last & 31) == 31 ? 0u : (uint32_t)(bm >> 32) >> ((last & 31) + 1);
+				const int hi = above != 0u ? last : min(32 * g1 + 31, a.P - 1);
+				const bool mine = ((sm >> lane) & 1ull) != 0ull;
+				for (int t = 0; t < a.small.n; t++)
+				{
+					const int w = a.small.w[t];
+					if (w == 1) expand_rows<1>(a.small.p[t], a.small.off[t], lo, hi - lo + 1, s_rows[wv], s_small[wv], mine, idx, lane);
+					else if (w == 3) expand_rows<3>(a.small.p[t], a.small.off[t], lo, hi - lo + 1, s_rows[wv], s_small[wv], mine, idx, lane);
+					else expand_rows<4>(a.small.p[t], a.small.off[t], lo, hi - lo + 1, s_rows[wv], s_small[wv], mine, idx, lane);
+				}
+				am &= ~sm;
+			}
+		}
 	}
 }
 
@@ -736,9 +867,26 @@ static int launch_render_bwd(const fr_backward_args *a, const GeomWS &geom, cons
 
 // the dense gradient tensors of a backward call cleared by ONE kernel on stream `fs` (seven fill commands in a row ran at 2.7 TB/s
 // beside k_render_bwd, the small ones at 1 TB/s, and outlasted it by 50 us); tensors are 16-byte aligned and their sizes multiples of 4
+// the narrow tensors of a dense backward call (SmallSet): written in whole lines by k_preprocess_bwd + k_fill_groups instead of fill + rows
+static SmallSet small_set(const fr_backward_args *a)
+{
+	SmallSet ss; ss.n = 0;
+#ifdef FR_NO_EXPAND // (developer switch for A / B timing: every row stored on its own, everything cleared by k_fill_zero)
+	return ss;
+#endif
+	if (a->row_sparse || a->outputs_zeroed || a->radii == nullptr) return ss;
+	auto add = [&](float *p, int w, int off) { if (p && ((uintptr_t)p & 15) == 0) { ss.p[ss.n] = p; ss.w[ss.n] = w; ss.off[ss.n] = off; ss.n++; } };
+	add(a->dL_dmean2D, 3, 0); add(a->dL_dopacity, 1, 3); add(a->dL_dmean3D, 3, 4);
+	if (a->cov3D_precomp == nullptr && a->scales != nullptr && a->dL_dscale && a->dL_drot) { add(a->dL_dscale, 3, 7); add(a->dL_drot, 4, 10); }
+	if (a->colors_precomp == nullptr && a->shs != nullptr && a->shs_rest != nullptr) add(a->dL_dsh, 3, 14);
+	return ss;
+}
+
 int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events)
 {
 	if (a->row_sparse) return FR_OK; // (compact rows: k_preprocess_bwd writes every row it is handed, nothing to clear)
+	const SmallSet ss = small_set(a);
+	auto narrow = [&](const void *p) { for (int t = 0; t < ss.n; t++) if (ss.p[t] == p) return true; return false; };
 	const bool have_sh = a->colors_precomp == nullptr && a->shs != nullptr;
 	const size_t P = (size_t)a->P;
 	const size_t m0 = have_sh ? (a->shs_rest ? 1 : (size_t)a->M) : 0;
@@ -748,7 +896,7 @@ int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events)
 		{ a->dL_dcolor, 12 * P }, { a->dL_dconic, 16 * P }, { a->dL_dcov3D, 24 * P } };
 	FillArgs fa; fa.n = 0;
 	for (auto &f : fills)
-		if (f.p && f.bytes)
+		if (f.p && f.bytes && !narrow(f.p))
 		{
 			if (((uintptr_t)f.p & 15) != 0 || fa.n == FR_FILL_MAX)
 			{
@@ -758,12 +906,22 @@ int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events)
 			}
 			fa.p[fa.n] = (float *)f.p; fa.words[fa.n] = f.bytes / 4; fa.n++;
 		}
-	if (fa.n)
+	if (fa.n || ss.n)
 	{
-		// (optional events 3 / 4: around the fill kernel, on the stream it runs on)
+		// (optional events 3 / 4: around the fill kernels, on the stream they run on)
 		if (events && a->stage_events && a->stage_events[3]) (void)hipEventRecord((hipEvent_t)a->stage_events[3], fs);
-		hipLaunchKernelGGL(k_fill_zero, dim3(FR_FILL_BLOCKS), dim3(256), 0, fs, fa);
-		const int rcf = check_launch("fill_zero", fs, a->debug);
+		int rcf = FR_OK;
+		if (fa.n)
+		{
+			hipLaunchKernelGGL(k_fill_zero, dim3(FR_FILL_BLOCKS), dim3(256), 0, fs, fa);
+			rcf = check_launch("fill_zero", fs, a->debug);
+		}
+		if (!rcf && ss.n)
+		{
+			const int nblk = (a->P + 63) / 64;
+			hipLaunchKernelGGL(k_fill_groups, dim3((unsigned)min((nblk + 3) / 4, 8192)), dim3(256), 0, fs, a->P, a->radii, ss);
+			rcf = check_launch("fill_groups", fs, a->debug);
+		}
 		if (events && a->stage_events && a->stage_events[4]) (void)hipEventRecord((hipEvent_t)a->stage_events[4], fs);
 		if (rcf) return rcf;
 	}
@@ -826,6 +984,7 @@ int launch_backward(const fr_backward_args *a)
 	p.dL_dmean2D = a->dL_dmean2D; p.dL_dconic = a->dL_dconic; p.dL_dcolor = a->dL_dcolor; p.dL_dopacity = a->dL_dopacity;
 	p.dL_dmean3D = a->dL_dmean3D; p.dL_dcov3D = a->dL_dcov3D; p.dL_dsh = a->dL_dsh; p.dL_dsh_rest = a->dL_dsh_rest; p.dL_dscale = a->dL_dscale; p.dL_drot = a->dL_drot;
 	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1; p.lrange = geom.lrange; p.raw = a->raw_activations;
+	p.small = small_set(a);
 	p.row_sparse = a->row_sparse; p.M0 = (a->colors_precomp == nullptr && a->shs != nullptr) ? (a->shs_rest ? 1 : a->M) : 0;
 	const int pblocks = (a->P + 255) / 256;
 	hipLaunchKernelGGL(k_preprocess_bwd, dim3(pblocks < 2048 ? pblocks : 2048), dim3(256), 0, stream, p);

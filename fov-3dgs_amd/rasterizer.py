@@ -424,6 +424,11 @@ def _forward_native(*args, **kw):
     return _forward_begin(*args, **kw).finish()
 
 
+# Test switch: the gradient tensors handed to fr_backward hold NaN instead of whatever the allocator had (an element the library fails
+# to write -- it writes every one, zeros included -- then shows in any comparison). The GPU test session sets it (tests/conftest.py).
+POISON_GRADIENTS = False
+
+
 def _alloc_gradients(z, P, M0, Mrest, has_cov, has_col):
     """The dense gradient tensors of one backward call, in _backward_native's order; z(*shape) allocates."""
     return (z(P, 3), z(P, 3), z(P, 1), z(P, 6) if has_cov else None, z(P, 3) if has_col else None, z(P, M0, 3), z(P, 3), z(P, 4),
@@ -521,6 +526,8 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
         # zero-fills 1.8 GB per step at 6 M Gaussians); P == 0 never reaches the library, hence zeros for that case
         z = (lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)) if P != 0 else \
             (lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev))
+        if POISON_GRADIENTS and P != 0:
+            z = lambda *shape: torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
         # outputs only when the 3D covariances / colours are inputs; otherwise intermediates the library keeps per
         # visible Gaussian in its geometry workspace
         has_cov = want_cov3D_grad or (cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0)

@@ -397,6 +397,58 @@ def test_row_sparse_gradients_equal_the_dense_ones(sh_degree):
             assert not sp[k][:, (sh_degree + 1) ** 2 - 1:].any()  # coefficients beyond the active degree: zeros, written explicitly
 
 
+@pytest.mark.parametrize("P", (20_037, 64, 33))
+def test_narrow_gradient_tensors_with_clustered_visibility(P):
+    """The narrow dense gradient tensors (positions, opacity, scales, rotations, DC coefficients of split SH storage) are written in whole
+    lines: k_preprocess_bwd stores a wave's visible rows TOGETHER WITH the zeros between them, k_fill_groups clears the 32-row groups
+    without a visible Gaussian (csrc/backward.hip SmallSet). A model whose visible Gaussians come in index runs -- thousands of rows
+    behind the camera, runs of exactly one group, single visible rows far apart (a wave's 64 rows then span more than the 512 it puts
+    together at a time), a last group cut off by P -- against the row-sparse call of the same step, which stores every row on its own.
+    The tensors start as NaN (tests/conftest.py): every element has to be written by exactly the right kernel."""
+    _need_gpu()
+    from fov3dgs_amd.gaussian_renderer import render
+    dev = "cuda:0"
+    cam = syn.camera_1k(200, 136).to(dev)
+    bg = torch.tensor([0.1, 0.0, 0.2], device=dev)
+
+    class Pipe:
+        debug = False
+    hidden = np.zeros(P, bool)
+    if P > 1000:
+        hidden[:3000] = True            # the head of every tensor: empty groups only
+        hidden[5000:5032] = True        # exactly one group (5000 = 32 * 156.25: it straddles two)
+        hidden[5056:5088] = True        # exactly one aligned group
+        hidden[9000:17000] = True       # a long run ...
+        hidden[9000:17000:701] = False  # ... with single visible rows 701 apart
+        hidden[P - 50:P - 3] = True     # the cut-off last group holds three visible rows at its end
+    else:
+        hidden[P // 2:] = True          # P = 64: one empty group behind a visible one; P = 33: the one-row last group is empty
+    w = None
+    res = []
+    for sparse in (False, True):
+        cloud = small_cloud(P=max(P, 8), seed=31)
+        with torch.no_grad():
+            cloud._xyz[torch.from_numpy(hidden)[: cloud._xyz.shape[0]], 2] = -6.0  # behind the camera
+        cloud = cloud.to(dev).requires_grad_(True)
+        cloud.fuse_activations = True
+        cloud.row_sparse_grads = sparse
+        out = render(cam, cloud, Pipe(), bg, cuda_type="pcheck_obb_sum")
+        if w is None:
+            w = torch.randn_like(out["render"])
+        (out["render"] * w).sum().backward()
+        grads = dict(xyz=cloud._xyz.grad, scaling=cloud._scaling.grad, rotation=cloud._rotation.grad, opacity=cloud._opacity.grad,
+                     f_dc=cloud._features_dc.grad, f_rest=cloud._features_rest.grad, screen=out["viewspace_points"].grad)
+        res.append(({k: (g.to_dense() if g.is_sparse else g).cpu().numpy() for k, g in grads.items()}, out["radii"].cpu().numpy()))
+    (dense, radii), (sp, radii2) = res
+    np.testing.assert_array_equal(radii, radii2)
+    assert not (radii[hidden] > 0).any() and (radii[~hidden] > 0).sum() > (~hidden).sum() // 8
+    for k in dense:
+        assert np.isfinite(dense[k]).all(), k
+        check_grad(dense[k], sp[k], "clustered visibility, dense vs row-sparse " + k)
+        assert not np.abs(dense[k].reshape(P, -1))[radii == 0].any(), k
+        assert np.abs(dense[k]).max() > 0, k
+
+
 @pytest.mark.parametrize("variant", ["original", "pcheck_obb_sum"])
 def test_raw_parameters_in_the_kernels_match_activate_then_render(variant):
     """fr_forward_args.raw_activations: exp / normalize / sigmoid applied inside the kernels give the image of
