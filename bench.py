@@ -166,9 +166,13 @@ def training_bytes(n, sh_coeffs=16):
       preprocess_bwd   276 V + 256 V       (backward.cu:144-396: inputs re-read, gradients written)
       fill_zero        what RasterizeGaussiansBackwardCUDA's torch::zeros clear of the tensors this call returns
                        (RS/rasterize_points.cu:171-179): dL_dmeans3D 12 + dL_dmeans2D 12 + dL_dopacity 4 + dL_dscales 12 +
-                       dL_drotations 16 + dL_dsh 12 M bytes per Gaussian"""
+                       dL_drotations 16 + dL_dsh 12 M bytes per Gaussian
+    The same bytes split the way the library's kernels write them (csrc/backward.hip SmallSet; split SH storage, as the step here
+    uses): the zeros of the five narrow tensors and of the DC coefficients (56 + 12 = 68 bytes per Gaussian without a gradient row)
+    leave with the rows, from k_preprocess_bwd; k_fill_zero clears the rest coefficients' tensor (12 (M - 1) bytes per Gaussian)."""
+    narrow = 56 + 12
     return {"render": 40 * n["D"] + 20 * n["Px"], "render_bwd": 40 * n["D"] + 20 * n["Px"] + 80 * n["V"],
-            "preprocess_bwd": 532 * n["V"], "fill_zero": (56 + 12 * sh_coeffs) * n["P"]}
+            "preprocess_bwd": 532 * n["V"] + narrow * (n["P"] - n["V"]), "fill_zero": 12 * (sh_coeffs - 1) * n["P"]}
 
 
 def main():
@@ -487,8 +491,8 @@ def main():
                             frac_traffic=None if not tr_b else round(tr_b / max(ms_, 1e-9) / 1e6 / HBM_PEAK_GBS, 5))
         roofline["train"] = dict(unit="GB/s", peak=HBM_PEAK_GBS, counts=n_tr, kernels=rows,
                                  note="training step (pcheck_obb_sum, raw parameters, fused L1 + SSIM): median of 10 instrumented steps, HIP events "
-                                      "recorded by the library on the streams the kernels run on (fill_zero: the gradient tensors' zero fill, enqueued at the "
-                                      "end of the forward call on a side stream -- it runs beside the loss kernels and the head of render_bwd); bytes: "
+                                      "recorded by the library on the streams the kernels run on (fill_zero: the zero fill of the rest coefficients' gradient tensor + the empty "
+                                      "groups of the narrow ones, on a helper stream beside render_bwd); bytes: "
                                       "training_bytes() / algorithmic_bytes() of the plain frame; traffic: " + str(prof.train_source()))
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
