@@ -15,7 +15,8 @@
 // lanes, which add them with ONE atomic instruction into ONE 64-byte row per Gaussian (`acc`, indexed by the
 // Gaussian's position in the forward pass's visible list: dense, zeroed by the forward pass, read back coalesced).
 // k_preprocess_bwd then walks the visible list and writes every visible Gaussian's gradient rows: the mean2D / conic / opacity
-// gradients from the moments, then the fused cov2D / projection / SH / cov3D chain rule (see there).
+// gradients from the moments, then the fused cov2D / projection / SH / cov3D chain rule (see there). All gradient stores and the
+// zero fill beside k_render_bwd are non-temporal (FR_ST); the narrow tensors are written in whole lines (SmallSet).
 #include "common.h"
 
 namespace fr {
@@ -713,7 +714,9 @@ __device__ __forceinline__ void expand_rows(float *dst, const int off, const int
 // Grid-stride over the forward pass's visible list: dense waves instead of one thread per Gaussian with ~70 % of the
 // lanes returning immediately. Entries culled after projection (radii reset to 0) are skipped. The rows of all other
 // Gaussians are zero: launch_backward clears the output tensors on a helper stream WHILE k_render_bwd runs (that kernel
-// is bound by arithmetic and atomics, the fill by HBM writes), so the caller need not zero-fill them. (Tried: one
+// is bound by arithmetic and atomics, the fill by HBM writes), so the caller need not zero-fill them -- the wide tensor (rest
+// coefficients) in full, of the narrow ones (SmallSet) the 32-row groups without a visible Gaussian; the zeros of the other groups
+// leave this kernel together with the rows. (Tried: one
 // kernel that walks all Gaussians in index order, clears every chunk's rows with coalesced stores and works the
 // chunk's visible ones off from an LDS list -- every row written once, no fill at all: 722 us against 539 + fill; at
 // 158 registers the kernel does not have the occupancy to stream 1.5 GB of zeros.)
