@@ -8,6 +8,8 @@ from tests.gpu_helpers import hip_forward, hip_backward
 from tests.checks import grad_stats
 from oracle import oracle as orc
 
+from fov3dgs_amd import rasterizer as _rz
+_rz.POISON_GRADIENTS = True  # every gradient tensor starts as NaN: an element the library fails to write shows in the comparisons
 only = int(os.environ.get("STRESS_ONLY", "-1"))  # replay the sweep's random numbers but run just this round, with per-tensor detail
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -12,6 +12,7 @@ from fov3dgs_amd import rasterizer as rz
 from fov3dgs_amd.activations import activate
 from fov3dgs_amd.diff_gaussian_rasterization_pcheck_obb_sum import GaussianRasterizationSettings, GaussianRasterizer
 
+rz.POISON_GRADIENTS = True  # every gradient tensor starts as NaN: an element the library fails to write shows in the comparisons
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = "cuda:0"
@@ -25,6 +26,8 @@ for r in range(rounds):
     cam = small_camera(W, H).to(dev)
     rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.tensor([0.1, 0.2, 0.3], device=dev),
                                        float(rng.choice([1.0, 0.5, 2.0])), cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center, False, False)
+    if int(os.environ.get("STRESS_ONLY", "-1")) not in (-1, r):  # replay one round of a sweep (the random numbers above are drawn for all)
+        continue
     w = torch.randn(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(seed & 0xffff))
 
     def run(form):
@@ -54,6 +57,13 @@ for r in range(rounds):
         return out, grads
     base, gb = run("split")
     ok, notes = True, []
+    # for context: the SAME form once more. Two backward passes differ by the order their float atomics retire in, and the near-camera
+    # splats of some scenes turn that into 1e-4 of a tensor's norm (scales, positions, rotations: the covariance chain) -- between two
+    # FORMS, whose other kernels shift the waves' timing, rather than between two runs of one form (1e-5: the order then nearly repeats;
+    # seeds 71 / 72, rounds 66, 342, 354: which forms land 1.2-1.8e-4 away changes from run to run). Hence 5e-4 on the norm: a wrong
+    # row is 1e-2 and more.
+    _, g2 = run("split")
+    noise = {n: grad_stats(g2[n].cpu().numpy(), gb[n].cpu().numpy(), rtol=1e-4) for n in gb}
     for form in ("cat", "raw", "raw_sparse", "nostats", "packed"):
         o, g = run(form)
         same = torch.equal(o[0], base[0]) and torch.equal(o[1], base[1])
@@ -66,9 +76,10 @@ for r in range(rounds):
         if g is not None:
             for n in g:
                 st = grad_stats(g[n].cpu().numpy(), gb[n].cpu().numpy(), rtol=1e-4)
-                if not (st["frac_bad"] <= max(5e-3, 10.0 / max(st["rows_with_gradient"], 1)) and st["rel_l2"] <= 1e-4 and np.isfinite(g[n].cpu().numpy()).all()):
+                if not (st["frac_bad"] <= max(5e-3, 10.0 / max(st["rows_with_gradient"], 1), 3.0 * noise[n]["frac_bad"]) and
+                        st["rel_l2"] <= max(5e-4, 3.0 * noise[n]["rel_l2"]) and np.isfinite(g[n].cpu().numpy()).all()):
                     ok = False
-                    notes.append(f"{form} {n}: rows outside 1e-4 {st['frac_bad']:.1e}, rel L2 {st['rel_l2']:.1e}")
+                    notes.append(f"{form} {n}: rows outside 1e-4 {st['frac_bad']:.1e}, rel L2 {st['rel_l2']:.1e} (the same form twice: {noise[n]['frac_bad']:.1e}, {noise[n]['rel_l2']:.1e})")
     print(f"{r:3d} P={P:6d} {W}x{H} deg={deg} visible {int((base[1] > 0).sum()):6d} -> {'ok' if ok else 'MISMATCH'} {'; '.join(notes)}", flush=True)
     bad += 0 if ok else 1
 print("mismatches:", bad)
