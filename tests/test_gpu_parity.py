@@ -135,6 +135,34 @@ def test_backward_matches_oracle(variant):
         check_grad(got[k].reshape(want[k].shape), want[k], k)
 
 
+@pytest.mark.parametrize("variant", ("original", "pcheck_obb_sum"))
+def test_backward_with_precomputed_colours_and_covariances(variant):
+    """colors_precomp + cov3D_precomp instead of SH coefficients, scales and rotations (the rasterizer's other input form,
+    diff_gaussian_rasterization/__init__.py:60-75): the backward pass then returns dL_dcolors / dL_dcov3D (backward.cu:346-396 writes
+    them either way) and zeros for the tensors of the absent inputs. Every output starts as NaN (tests/conftest.py): positions and
+    opacity go out in whole lines, colours and covariances row by row over the fill, scales / rotations are the fill's alone."""
+    _need_gpu()
+    from tests.gpu_helpers import hip_backward, hip_forward
+    scene, cam = small_case(variant)
+    w0 = orc.forward(variant, scene, cam)
+    pre = dict(scene)
+    pre["colors_precomp"] = np.random.default_rng(3).random((scene["means3D"].shape[0], 3)).astype(np.float32)
+    pre["cov3D_precomp"] = w0["cov3D"]
+    for k in ("shs", "scales", "rotations"):
+        pre.pop(k)
+    want_f = orc.forward(variant, pre, cam)
+    dpix = np.random.default_rng(8).normal(size=want_f["color"].shape).astype(np.float32)
+    want = orc.backward(variant, pre, cam, want_f, dpix)
+    got_f = hip_forward(variant, pre, cam)
+    np.testing.assert_array_equal(got_f["point_list"], want_f["point_list"])
+    got = hip_backward(variant, got_f, dpix)
+    for k in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D"):
+        check_grad(got[k].reshape(want[k].shape), want[k], k + " (precomputed inputs)")
+    for k in ("dL_dsh", "dL_dscale", "dL_drot"):
+        assert got[k].size == 0 or not np.abs(got[k]).any(), k  # (NaN != 0: unwritten elements fail here too)
+        assert np.isfinite(got[k]).all(), k
+
+
 @pytest.mark.parametrize("sh_degree", (0, 1, 2))
 def test_backward_at_lower_sh_degrees(sh_degree):
     """Active SH degree below the allocated one (early training, scene/gaussian_model.py oneupSHdegree): only the coefficients of
