@@ -477,7 +477,7 @@ int fr_backward_prefill(const fr_backward_args *a, void *fill_stream)
 {
 	if (!a) { set_error("null args"); return FR_ERR_INVALID; }
 	if (a->P <= 0) return FR_OK;
-	return launch_gradient_fill(a, (hipStream_t)fill_stream, false);
+	return launch_gradient_fill(a, (hipStream_t)fill_stream, false, true);
 }
 
 int fr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present, void *stream)

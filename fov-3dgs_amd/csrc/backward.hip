@@ -885,10 +885,11 @@ static SmallSet small_set(const fr_backward_args *a)
 	return ss;
 }
 
-int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events)
+int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events, bool whole)
 {
 	if (a->row_sparse) return FR_OK; // (compact rows: k_preprocess_bwd writes every row it is handed, nothing to clear)
-	const SmallSet ss = small_set(a);
+	SmallSet ss = small_set(a);
+	if (whole) ss.n = 0;
 	auto narrow = [&](const void *p) { for (int t = 0; t < ss.n; t++) if (ss.p[t] == p) return true; return false; };
 	const bool have_sh = a->colors_precomp == nullptr && a->shs != nullptr;
 	const size_t P = (size_t)a->P;
@@ -953,7 +954,7 @@ int launch_backward(const fr_backward_args *a)
 		}
 		if (!a->outputs_zeroed)
 		{
-			const int rcf = launch_gradient_fill(a, fs, true);
+			const int rcf = launch_gradient_fill(a, fs, true, false);
 			if (rcf)
 			{
 				// (whatever was enqueued on the helper stream is joined before the caller gets its tensors back)

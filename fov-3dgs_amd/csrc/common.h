@@ -455,7 +455,9 @@ int launch_emit(FwdCtx &c);
 int launch_tile_sort(FwdCtx &c);
 int launch_render(FwdCtx &c);
 int launch_backward(const fr_backward_args *a);
-int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events);
+// whole: clear every tensor in full (fr_backward_prefill: the caller's zeros come before a backward call that is told about them);
+// else the narrow tensors only where no 32-row group holds a visible Gaussian (the rest of them is k_preprocess_bwd's, backward.hip)
+int launch_gradient_fill(const fr_backward_args *a, hipStream_t fs, bool events, bool whole);
 int launch_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present, hipStream_t s);
 
 } // namespace fr

@@ -452,17 +452,21 @@ def _side_stream(dev):
     return st
 
 
-def prefill_gradients(dev, P, M0, Mrest, has_cov, has_col, has_sh):
+def prefill_gradients(dev, P, M0, Mrest, has_cov, has_col, has_sh, radii=None):
     """-> (tensors in _alloc_gradients' order, event): allocated on the current stream, zero-filled by ONE kernel on the side stream
-    behind everything the current stream holds now; the event marks the end of the fill."""
+    behind everything the current stream holds now; the event marks the end of the fill. radii: handed on as a C host filling in the
+    whole of fr_backward_args would (fr_backward_prefill clears every tensor in full whatever the struct holds)."""
     lib = _native.load()
     with torch.cuda.device(dev):
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        if POISON_GRADIENTS:
+            z = lambda *shape: torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
         g = _alloc_gradients(z, P, M0, Mrest, has_cov, has_col)
         a = _native.BackwardArgs()
         a.P, a.M = P, M0 + (Mrest or 0)
+        a.radii = radii.data_ptr() if radii is not None else None
         # (fr_backward_prefill only looks at which of shs / shs_rest / colors_precomp are given, not at what they hold)
         a.shs = g[5].data_ptr() if has_sh else None
         a.shs_rest = g[8].data_ptr() if Mrest is not None else None
@@ -670,7 +674,7 @@ def _make_plain(variant_id, with_counts, has_backward, takes_loss_map=False):
                 has_sh = sh.numel() != 0
                 M0 = sh.size(1) if has_sh else 0
                 ctx.prezero = prefill_gradients(means3D.device, means3D.size(0), M0, sh_rest.size(1) if sh_rest is not None else None,
-                                                cov3Ds_precomp.numel() != 0, colors_precomp.numel() != 0, has_sh)
+                                                cov3Ds_precomp.numel() != 0, colors_precomp.numel() != 0, has_sh, radii=radii)
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                                   geomBuffer, binningBuffer, imgBuffer,
                                   sh_rest if sh_rest is not None else torch.empty(0, device=means3D.device))
