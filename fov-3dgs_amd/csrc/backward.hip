@@ -878,10 +878,14 @@ static SmallSet small_set(const fr_backward_args *a)
 	return ss;
 #endif
 	if (a->row_sparse || a->outputs_zeroed || a->radii == nullptr) return ss;
-	auto add = [&](float *p, int w, int off) { if (p && ((uintptr_t)p & 15) == 0) { ss.p[ss.n] = p; ss.w[ss.n] = w; ss.off[ss.n] = off; ss.n++; } };
+	// (all of them or none: k_preprocess_bwd stages every narrow row once the set is not empty. The 16-byte stores of the ranges want
+	// 16-byte aligned tensors -- what any allocator hands out; a host with odd pointers gets the rows stored one by one)
+	bool usable = true;
+	auto add = [&](float *p, int w, int off) { if (!p || ((uintptr_t)p & 15) != 0) usable = false; else { ss.p[ss.n] = p; ss.w[ss.n] = w; ss.off[ss.n] = off; ss.n++; } };
 	add(a->dL_dmean2D, 3, 0); add(a->dL_dopacity, 1, 3); add(a->dL_dmean3D, 3, 4);
-	if (a->cov3D_precomp == nullptr && a->scales != nullptr && a->dL_dscale && a->dL_drot) { add(a->dL_dscale, 3, 7); add(a->dL_drot, 4, 10); }
+	if (a->cov3D_precomp == nullptr && a->scales != nullptr) { add(a->dL_dscale, 3, 7); add(a->dL_drot, 4, 10); }
 	if (a->colors_precomp == nullptr && a->shs != nullptr && a->shs_rest != nullptr) add(a->dL_dsh, 3, 14);
+	if (!usable) ss.n = 0;
 	return ss;
 }
 
