@@ -12,6 +12,18 @@ W, H = cam.image_width, cam.image_height
 with torch.no_grad():
     xyz, sc, rot = cloud.get_xyz, cloud.get_scaling.contiguous(), cloud.get_rotation.contiguous()
     rest = cloud.get_rest_features.contiguous()
+    if "ordered" in sys.argv[1:]:
+        # the model sorted by the screen region (8 x 8 tiles) of its projected centres, the off-screen Gaussians last (tools/region_order_price.py)
+        hom = torch.cat([xyz, torch.ones_like(xyz[:, :1])], 1) @ cam.full_proj_transform
+        w_ = 1.0 / (hom[:, 3] + 1e-7)
+        px, py = ((hom[:, 0] * w_ + 1) * W - 1) * 0.5, ((hom[:, 1] * w_ + 1) * H - 1) * 0.5
+        z = xyz @ cam.world_view_transform[:3, 2] + cam.world_view_transform[3, 2]
+        gxr, gyr = (W + 127) // 128, (H + 127) // 128
+        reg = torch.clamp((py / 128).floor().long(), 0, gyr - 1) * gxr + torch.clamp((px / 128).floor().long(), 0, gxr - 1)
+        offs = (z <= 0.2) | (px < -200) | (px > W + 200) | (py < -200) | (py > H + 200)
+        perm = torch.sort(torch.where(offs, torch.full_like(reg, gxr * gyr), reg), stable=True).indices
+        xyz, sc, rot, rest = xyz[perm].contiguous(), sc[perm].contiguous(), rot[perm].contiguous(), rest[perm].contiguous()
+        fov = [t[perm].contiguous() for t in fov]
     rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev),
                                           1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
     E = torch.Tensor([])
@@ -30,3 +42,9 @@ print("first chunk done after us pct 10/50/90:", np.percentile(first, [10, 50, 9
 print("wave total us pct 10/50/90/100:", np.percentile(tot, [10, 50, 90, 100]).round(1))
 print("end us pct 50/90/100:", np.percentile(st + tot, [50, 90, 100]).round(1))
 print("per chunk after the first us: %.2f" % ((tot - first).mean() / (d[:, 3].mean() - 1)))
+
+# by stretch of the cloud (tenths of the waves in index order): when its waves start, how long they take, what they end with
+n = len(d)
+for k in range(10):
+    sl = slice(k * n // 10, (k + 1) * n // 10)
+    print(f"waves {sl.start:5d}..{sl.stop:5d}: start {np.median(st[sl]):6.1f} us, wave time {np.median(tot[sl]):6.1f} (max {tot[sl].max():6.1f}), end {np.median((st + tot)[sl]):6.1f} (max {(st + tot)[sl].max():6.1f})")
