@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(64, 6) k_render_bwd(const BwdRenderArgs a)
 // whole lines, by the kernel that has the rows: the tensors are cut into groups of 32 rows; a group without a visible Gaussian
 // (radii > 0) is cleared by k_fill_groups beside k_render_bwd like everything else; in any other group every visible row's owner writes
 // the zeros in front of it (back to the previous visible row of the group) and, when it is the group's last, those behind it -- a
-// wave's 64 consecutive visible rows and their zeros are one contiguous range, put together in LDS and stored 256 bytes an instruction.
+// wave's 64 consecutive visible rows and their zeros are one contiguous range, put together in LDS and stored 16 bytes a lane.
 // off: where the tensor's row sits in a lane's staging row of FR_SMALL_ROW floats.
 #define FR_SMALL_MAX 6
 #define FR_SMALL_ROW 17      // 3 mean2D + 1 opacity + 3 mean3D + 3 scale + 4 rotation + 3 DC (odd: lanes' rows start in different LDS banks)
