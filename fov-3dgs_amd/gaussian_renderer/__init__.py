@@ -4,6 +4,7 @@ Same signature and result dict; `pc` is anything exposing the GaussianModel gett
 (get_xyz, get_opacity, get_scaling, get_rotation, get_features, get_features_detach_rest,
 active_sh_degree), `viewpoint_camera` anything with the Camera/MiniCam fields.
 """
+import inspect
 import math
 
 import torch
@@ -15,17 +16,74 @@ from ..rasterizer import GaussianRasterizationSettings, zero_points_leaf, zero_p
 # The reference's GaussianModel keeps its raw parameter tensors and its three activation functions as plain attributes
 # (scene/gaussian_model.py:33-41: scaling_activation = torch.exp, opacity_activation = torch.sigmoid, rotation_activation =
 # torch.nn.functional.normalize; :43-50: _features_dc, _features_rest, _scaling, _rotation, _opacity) and its getters are one-line
-# expressions of them (:200-240). render() recognises such a model by exactly those attributes and then hands the rasterizer what the
-# getters would have been computed FROM: the two SH tensors as they are stored (get_features is their torch.cat: 1.15 GB written and
-# read back per step at 6 M Gaussians, and split again by autograd) and the raw parameters (the kernels apply exp / normalize / sigmoid
-# themselves and return the gradients w.r.t. the raw tensors) -- 4.7 -> 2.3 ms per training step on the S-6M cloud with no change to
-# the model class. Same values up to the last bit of the device's exp / sigmoid. Set to False to go through the getters only.
+# expressions of them (:200-240). render() recognises such a model and then hands the rasterizer what the getters would have been
+# computed FROM: the two SH tensors as they are stored (get_features is their torch.cat: 1.15 GB written and read back per step at
+# 6 M Gaussians, and split again by autograd) and the raw parameters (the kernels apply exp / normalize / sigmoid themselves and return
+# the gradients w.r.t. the raw tensors) -- 4.7 -> 2.3 ms per training step on the S-6M cloud with no change to the model class. Same
+# values up to the last bit of the device's exp / sigmoid. Set to False to go through the getters only.
+#
+# Recognition is by what the getters DO, not by what the object carries (a duck-typed model or a subclass that keeps the attributes
+# but overrides a getter -- opacity times a learned mask, clamped scales, another feature concat -- must get ITS getters):
+#   1. the three activation attributes are exactly torch.exp / torch.sigmoid / torch.nn.functional.normalize and the raw tensors have
+#      the reference's shapes;
+#   2. every getter render() would have called resolves, through the class's MRO, to a property whose code is the reference's
+#      one-liner: it touches exactly the names that one-liner touches and no constants of its own (_getter_fingerprint_ok, per class);
+#   3. once per class, the getters' outputs are compared with activation(raw) / torch.cat(dc, rest) bit for bit (_self_check).
+# Anything else goes through its getters.
 FAST_REFERENCE_MODEL = True
+
+# names each reference getter touches (scene/gaussian_model.py:200-240) and the constants it may hold
+_REFERENCE_GETTERS = {
+    "get_xyz": ({"_xyz"}, (None,)),
+    "get_scaling": ({"scaling_activation", "_scaling"}, (None,)),
+    "get_rotation": ({"rotation_activation", "_rotation"}, (None,)),
+    "get_opacity": ({"opacity_activation", "_opacity"}, (None,)),
+    "get_features": ({"_features_dc", "_features_rest", "torch", "cat"}, (None, 1, ("dim",))),
+    "get_features_detach_rest": ({"_features_dc", "_features_rest", "detach", "torch", "cat"}, (None, 1, ("dim",))),
+}
+_class_verdict = {}   # class -> bool: fingerprints ok (None entry never stored)
+_class_checked = {}   # class -> bool: numeric self-check passed
+
+
+def _getter_fingerprint_ok(cls):
+    """True when every getter of `cls` that render() replaces is, as found through the MRO, a property whose function touches exactly
+    the names of the reference's one-line getter and carries no constant of its own (a factor, a clamp bound, another dim)."""
+    hit = _class_verdict.get(cls)
+    if hit is not None:
+        return hit
+    ok = True
+    for name, (names, consts) in _REFERENCE_GETTERS.items():
+        attr = inspect.getattr_static(cls, name, None)
+        code = getattr(getattr(attr, "fget", None), "__code__", None)
+        if not isinstance(attr, property) or code is None:
+            ok = False
+            break
+        own = [c for c in code.co_consts if c != attr.fget.__doc__]   # (a docstring is the function's first constant)
+        if set(code.co_names) != names or code.co_argcount != 1 or any(inspect.iscode(c) or c not in consts for c in own):
+            ok = False
+            break
+    _class_verdict[cls] = ok
+    return ok
+
+
+def _self_check(pc, f):
+    """Once per class: what the getters return IS activation(raw) / the concatenation, to the last bit."""
+    cls = type(pc)
+    hit = _class_checked.get(cls)
+    if hit is not None:
+        return hit
+    with torch.no_grad():
+        ok = (pc.get_xyz is pc._xyz or torch.equal(pc.get_xyz, pc._xyz)) and torch.equal(pc.get_scaling, torch.exp(f[0])) \
+            and torch.equal(pc.get_rotation, torch.nn.functional.normalize(f[1])) and torch.equal(pc.get_opacity, torch.sigmoid(f[2])) \
+            and torch.equal(pc.get_features, torch.cat((f[3], f[4]), dim=1))
+    _class_checked[cls] = bool(ok)
+    return _class_checked[cls]
 
 
 def _reference_model_fields(pc):
-    """-> (raw scaling, raw rotation, raw opacity, features_dc, features_rest) of a model shaped like the reference's GaussianModel,
-    or None when `pc` is anything else (a subclass with other activations, a wrapper exposing only getters, ...)."""
+    """-> (raw scaling, raw rotation, raw opacity, features_dc, features_rest) of a model that IS the reference's GaussianModel as far as
+    render() can tell (see above), or None when `pc` is anything else (a subclass that overrides a getter, other activations, a
+    wrapper exposing only getters, ...)."""
     if not FAST_REFERENCE_MODEL:
         return None
     try:
@@ -33,12 +91,17 @@ def _reference_model_fields(pc):
                 and pc.rotation_activation is torch.nn.functional.normalize):
             return None
         f = (pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc._features_rest)
+        xyz = pc._xyz
     except AttributeError:
         return None
-    P = pc.get_xyz.shape[0]
+    if not _getter_fingerprint_ok(type(pc)):
+        return None
+    P = xyz.shape[0]
     if not all(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() >= 2 and t.shape[0] == P for t in f):
         return None
     if tuple(f[0].shape) != (P, 3) or tuple(f[1].shape) != (P, 4) or f[2].numel() != P or f[3].shape[1] != 1 or f[3].shape[2:] != f[4].shape[2:]:
+        return None
+    if not _self_check(pc, f):
         return None
     return f
 

@@ -154,6 +154,45 @@ class ReferenceShapedModel(ReferenceGetterModel):
         self.scaling_activation, self.opacity_activation = torch.exp, torch.sigmoid
         self.rotation_activation = torch.nn.functional.normalize
 
+    # the getters as the reference's class has them (scene/gaussian_model.py:200-240): one-line expressions of the attributes above;
+    # render() checks that this is what they are before it bypasses them (gaussian_renderer._getter_fingerprint_ok)
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return self.scaling_activation(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_features_detach_rest(self):
+        return torch.cat((self._features_dc, self._features_rest.detach()), dim=1)
+
+
+class MaskedOpacityModel(ReferenceShapedModel):
+    """A subclass that keeps every attribute of the reference's model but overrides ONE getter (opacity times a learned mask, as the
+    reference's masking experiments do with get_mask, scene/gaussian_model.py:212-214): render() must not bypass its getters."""
+
+    def __init__(self, cloud, mask_logit):
+        super().__init__(cloud)
+        self._mask = mask_logit
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity) * torch.sigmoid(self._mask)
+
 
 def _gen(seed):
     g = torch.Generator(device="cpu")

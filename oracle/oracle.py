@@ -23,16 +23,41 @@ VARIANTS = {"original": 0, "pcheck_obb_sum": 1, "pcheck_obb": 2, "fov_pcheck_obb
 FOV_NUM = 4
 
 
+def _host_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+# The three flavours of the ONE source file:
+#   f32      float, -ffp-contract=off: the literal reading of the reference's fp32 expressions (the checker of the parity tests);
+#   f64      double (-DORC_DOUBLE): finite-difference pins, arithmetic-noise yardstick;
+#   f32_fma  float, -ffp-contract=fast -mfma: every multiply whose result feeds an add / subtract is fused into it, within and
+#            across statements -- what nvcc's default -fmad=true does to the reference's .cu files (its setup.py sets no
+#            -fmad=false: R0/setup.py:12-29). gcc and nvcc need not pick the same product of `a*b + c*d`, so this flavour is not
+#            "the reference binary"; it measures how far contraction CAN move radii, lists and pixels (tools/fma_envelope.py,
+#            tests/test_second_derivation.py). Needs a host with FMA3 (the MI355X box's EPYC and this container have it).
+FLAVOURS = {"f32": ("liboracle_f32.so", ["-ffp-contract=off"]), "f64": ("liboracle_f64.so", ["-ffp-contract=off", "-DORC_DOUBLE"]),
+            "f32_fma": ("liboracle_f32_fma.so", ["-ffp-contract=fast", "-mfma"])}
+
+
 def build(force=False):
-    """Compile the C restatement (float and double flavours) with gcc."""
+    """Compile the C restatement (float, double and contracted-float flavours) with gcc."""
     os.makedirs(BUILD, exist_ok=True)
     outs = []
-    for name, flags in (("liboracle_f32.so", []), ("liboracle_f64.so", ["-DORC_DOUBLE"])):
+    for key, (name, flags) in FLAVOURS.items():
+        if key == "f32_fma" and not _host_has_fma():
+            continue
         out = os.path.join(BUILD, name)
         outs.append(out)
         if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(SRC):
             continue
-        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-Wall", *flags, "-o", out, SRC, "-lm"]
+        cmd = ["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-Wall", *flags, "-o", out, SRC, "-lm"]
         subprocess.check_call(cmd)
     return outs
 
@@ -50,15 +75,24 @@ def set_threads(n):
         lib.orc_set_threads(_THREADS)
 
 
-def _lib(dtype):
-    key = np.dtype(dtype).itemsize
+def has_fma_flavour():
+    return _host_has_fma()
+
+
+def _lib(dtype, fma=False):
+    size = np.dtype(dtype).itemsize
+    key = "f64" if size == 8 else ("f32_fma" if fma else "f32")
+    if fma and size != 4:
+        raise ValueError("the contracted flavour exists in float only")
     if key not in _LIBS:
+        if key == "f32_fma" and not _host_has_fma():
+            raise RuntimeError("oracle: the contracted flavour needs a host with FMA3")
         build()
-        lib = C.CDLL(os.path.join(BUILD, "liboracle_f32.so" if key == 4 else "liboracle_f64.so"))
+        lib = C.CDLL(os.path.join(BUILD, FLAVOURS[key][0]))
         lib.orc_forward.restype = C.c_int64
         lib.orc_backward.restype = C.c_int
         lib.orc_sizeof_real.restype = C.c_int
-        assert lib.orc_sizeof_real() == key
+        assert lib.orc_sizeof_real() == size
         lib.orc_set_threads(_THREADS)
         _LIBS[key] = lib
     return _LIBS[key]
@@ -163,9 +197,9 @@ def _alloc_outputs(OrcOut, P, W, H, dtype, capacity):
     return out, o
 
 
-def forward(variant, scene, cam, dtype=np.float32):
-    """Run the oracle forward. Returns a dict with every stage's outputs."""
-    lib = _lib(dtype)
+def forward(variant, scene, cam, dtype=np.float32, fma=False):
+    """Run the oracle forward. Returns a dict with every stage's outputs. fma: the contracted float flavour (see FLAVOURS)."""
+    lib = _lib(dtype, fma)
     keep = []
     inp, OrcOut, _, P, M, vi = _prep_inputs(variant, scene, cam, dtype, keep)
     W, H = inp.W, inp.H
@@ -186,9 +220,9 @@ def forward(variant, scene, cam, dtype=np.float32):
     return o
 
 
-def backward(variant, scene, cam, fwd, dL_dpix, dtype=np.float32):
+def backward(variant, scene, cam, fwd, dL_dpix, dtype=np.float32, fma=False):
     """Run the oracle backward (R0 / RS only) given the dict returned by forward()."""
-    lib = _lib(dtype)
+    lib = _lib(dtype, fma)
     keep = []
     inp, OrcOut, OrcGrads, P, M, vi = _prep_inputs(variant, scene, cam, dtype, keep)
     out = OrcOut()

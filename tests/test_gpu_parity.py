@@ -1279,6 +1279,46 @@ def test_reference_shaped_model_takes_the_fast_path():
         check_grad(gc[n].cpu().numpy(), ga[n].cpu().numpy(), "reference-shaped model " + n)
 
 
+def test_a_subclass_that_overrides_a_getter_keeps_its_getters():
+    """a model that carries every attribute of the reference's GaussianModel but overrides get_opacity (opacity x a learned
+    mask) must be rendered through ITS getters -- render() recognises the reference's class by what its getters do
+    (gaussian_renderer._getter_fingerprint_ok + the one-time numeric self-check), not by the attributes alone. Image and gradients are
+    those of a getters-only model with the same override (bit for bit), not the unmasked fast path's; the mask gets its gradient."""
+    _need_gpu()
+    from fov3dgs_amd import gaussian_renderer as gr
+    dev = "cuda:0"
+    cam = syn.camera_1k(200, 136).to(dev)
+
+    class Pipe:
+        debug = False
+
+    class GetterOnlyMasked(syn.ReferenceGetterModel):
+        def __init__(self, cloud, mask):
+            super().__init__(cloud)
+            self._mask = mask
+
+        @property
+        def get_opacity(self):
+            return torch.sigmoid(self._c._opacity) * torch.sigmoid(self._mask)
+    bg = torch.tensor([0.3, 0.1, 0.2], device=dev)
+    w = torch.randn(3, 136, 200, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    res = {}
+    for name in ("masked_subclass", "masked_getters", "unmasked"):
+        cloud = syn.scene_1k(P=3000, seed=12).to(dev).requires_grad_(True)
+        mask = torch.linspace(-2, 2, 3000, device=dev).reshape(-1, 1).requires_grad_(True)
+        model = {"masked_subclass": lambda: syn.MaskedOpacityModel(cloud, mask), "masked_getters": lambda: GetterOnlyMasked(cloud, mask),
+                 "unmasked": lambda: syn.ReferenceShapedModel(cloud)}[name]()
+        out = gr.render(cam, model, Pipe(), bg, cuda_type="pcheck_obb_sum")
+        (out["render"] * w).sum().backward()
+        torch.cuda.synchronize()
+        res[name] = (out["render"].detach(), cloud._opacity.grad.clone(), None if mask.grad is None else mask.grad.clone())
+    assert gr._getter_fingerprint_ok(syn.ReferenceShapedModel) and not gr._getter_fingerprint_ok(syn.MaskedOpacityModel)
+    a, b, c = res["masked_subclass"], res["masked_getters"], res["unmasked"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[2] is not None and float(a[2].abs().max()) > 0
+    assert float((a[0] - c[0]).abs().max()) > 1e-2  # the mask matters: the fast path would have rendered another image
+
+
 def test_gradient_tensors_cleared_at_the_end_of_the_forward_call():
     """rasterizer.PREZERO_GRADIENTS (opt-in; fr_backward_prefill + fr_backward_args.outputs_zeroed): the dense gradient tensors are
     allocated and zero-filled on a side stream at the end of the forward call instead of beside k_render_bwd. Same gradients as with the fill

@@ -149,3 +149,41 @@ def test_cuda_type_table_matches_the_reference_strings():
     from fov3dgs_amd.gaussian_wrapper import rasterizer_class
     for name in ("original", "pcheck_obb", "pcheck_obb_max", "pcheck_obb_sum", "pcheck_obb_loss_weighted_max_count"):
         assert rasterizer_class(name).__name__ == "GaussianRasterizer"
+
+
+def test_fast_path_recognises_the_reference_getters_only():
+    """gaussian_renderer._getter_fingerprint_ok: the raw-parameter fast path of render() is taken only for classes whose
+    getters are the reference's one-liners (scene/gaussian_model.py:200-240) as resolved through the MRO; a subclass that overrides one
+    getter, adds a factor or a clamp, or a wrapper with other code keeps its getters."""
+    import torch
+    from fov3dgs_amd import gaussian_renderer as gr
+    from fov3dgs_amd import synthetic as syn
+
+    class Clamped(syn.ReferenceShapedModel):
+        @property
+        def get_scaling(self):
+            return self.scaling_activation(self._scaling).clamp(max=1.0)
+
+    class Doubled(syn.ReferenceShapedModel):
+        @property
+        def get_opacity(self):
+            return 0.5 * self.opacity_activation(self._opacity)
+
+    class OtherConcat(syn.ReferenceShapedModel):
+        @property
+        def get_features(self):
+            return torch.cat((self._features_dc, self._features_rest), dim=2)
+
+    class Plain(syn.ReferenceShapedModel):
+        """A subclass that overrides nothing render() bypasses."""
+        def extra(self):
+            return 1
+
+    class NotAProperty(syn.ReferenceShapedModel):
+        def get_rotation(self):
+            return self.rotation_activation(self._rotation)
+    assert gr._getter_fingerprint_ok(syn.ReferenceShapedModel) and gr._getter_fingerprint_ok(Plain)
+    for cls in (Clamped, Doubled, OtherConcat, NotAProperty, syn.MaskedOpacityModel, syn.ReferenceGetterModel, syn.GaussianCloud):
+        assert not gr._getter_fingerprint_ok(cls), cls.__name__
+    # CPU tensors never take the fast path (and nothing is rendered on the CPU)
+    assert gr._reference_model_fields(syn.ReferenceShapedModel(syn.scene_1k(P=10))) is None
