@@ -86,6 +86,16 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+class Timed(tuple):
+    """(seconds of K frames with the nine gazes weighted equally -- the median repeat, [min, max] over the repeats, {stage: mean ms})
+    + .raw: the same repeat's wall clock between the two barrier + synchronize brackets (gaze i % 9: K % 9 gazes weigh one frame more)."""
+
+    def __new__(cls, seconds, spread, stages, raw):
+        self = super().__new__(cls, (seconds, spread, stages))
+        self.raw = raw
+        return self
+
+
 def launch_ranks(args):
     """--gpus N > 1 outside torchrun: start the N ranks as a child process tree (this process never touches a GPU)."""
     import socket
@@ -262,7 +272,7 @@ def main():
         Only the boundaries of `event_stages` are recorded inside the timed frames (every event record is a command on the
         stream, ~3 us: all eight cost 3.5 % of the frame). -> (median seconds, [min, max] seconds, {stage: mean ms})"""
         pending = None
-        times, per_stage = [], {k: [] for k in event_stages}
+        times, balanced, per_stage = [], [], {k: [] for k in event_stages}
         with torch.no_grad():
             for i in range(Wm):
                 out = frame(GAZES[i % 9], packed)
@@ -271,7 +281,8 @@ def main():
             for rep in range(max(1, args.repeats if repeats is None else repeats)):
                 barrier_sync()
                 timer = StageTimer(K, stages=event_stages)
-                t_start = time.perf_counter()
+                slots = np.zeros(K)
+                t_start = t_prev = time.perf_counter()
                 with timer:
                     for i in range(K):
                         out = frame(GAZES[i % 9], packed)
@@ -279,21 +290,31 @@ def main():
                             if pending is not None:
                                 pending[0].wait()
                             pending = multiview.gather_images(out["render"], dst=0, async_op=True) + (out["render"],)
+                        t_now = time.perf_counter()
+                        slots[i], t_prev = t_now - t_prev, t_now
                     if pending is not None:
                         pending[0].wait()
                         pending = None
                 barrier_sync()
-                elapsed = time.perf_counter() - t_start
+                t_end = time.perf_counter()
+                elapsed = t_end - t_start
+                # a call returns once its instance count is in: slot i holds frame i's head and frame i - 1's tail. The last frame's
+                # tail (drained by the synchronize above) goes to slot 0, which had no tail in front of it: sum(slots) == elapsed.
+                slots[0] += t_end - t_prev
+                per_gaze = [float(np.mean(slots[g::9])) for g in range(min(9, K))]
+                bal = float(np.mean(per_gaze)) * K   # seconds K frames take when every gaze has the same weight
                 if world > 1:
-                    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+                    t = torch.tensor([elapsed, bal], device=dev, dtype=torch.float64)
                     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                    elapsed = float(t.item())
+                    elapsed, bal = float(t[0].item()), float(t[1].item())
                 times.append(elapsed)
+                balanced.append(bal)
                 for row in timer.stage_ms():
                     for k in event_stages:
                         per_stage[k].append(row[k])
                 timer.close()
-        return float(np.median(times)), [min(times), max(times)], {k: float(np.mean(v)) for k, v in per_stage.items()}
+        mid = int(np.argsort(balanced)[len(balanced) // 2])
+        return Timed(balanced[mid], [min(balanced), max(balanced)], {k: float(np.mean(v)) for k, v in per_stage.items()}, times[mid])
 
     def timed_run_pipelined(depth=2):
         """The same K frames per repeat with `depth` frames in flight (render_begin / finish, one stream per slot)."""
@@ -346,10 +367,13 @@ def main():
     dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: pre[k])
     ev_stages = tuple(dict.fromkeys((dominant, "render")))
     if args.packed_only:
-        elapsed_p, spread_p, timed_ms_p = timed_run("auto", ev_stages)
-        elapsed, spread, timed_ms = elapsed_p, spread_p, timed_ms_p
+        headline = timed_run("auto", ev_stages)
+        elapsed_p, spread_p, timed_ms_p = headline
+        elapsed, spread, timed_ms, elapsed_raw = elapsed_p, spread_p, timed_ms_p, headline.raw
     else:
-        elapsed, spread, timed_ms = timed_run(None, ev_stages)        # the reference's tensor interface: the headline
+        headline = timed_run(None, ev_stages)                         # the reference's tensor interface: the headline
+        elapsed, spread, timed_ms = headline
+        elapsed_raw = headline.raw
         if args.headline_only:
             elapsed_p, spread_p, timed_ms_p = elapsed, spread, timed_ms
         else:
@@ -387,8 +411,8 @@ def main():
             vm = cam.world_view_transform
             z = pc_.get_xyz @ vm[:3, 2] + vm[3, 2]
             v_in = int((z > 0.2).sum().item())
-        # timed step i uses gaze i % 9: weight the per-gaze statistics accordingly
-        wts = np.array([len(range(g, K, 9)) for g in range(9)], dtype=np.float64)
+        # `value` weighs the gazes the timed steps cover equally (timed_run): so do the per-gaze statistics
+        wts = np.array([1.0 if g < K else 0.0 for g in range(9)], dtype=np.float64)
         mean = {k: float(np.sum([s_[k] * w for s_, w in zip(per, wts)]) / wts.sum()) for k in per[0]}
         return mean, per, v_in
     st, stats, V_in = gaze_stats(scene)
@@ -427,6 +451,8 @@ def main():
     extra = {}
     if world == 1 and not args.no_extra:
         extra = extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H, W)
+    if world == 1:
+        extra["canary"] = canary(torch, dev, mean_ms, ms_step)
 
     # ---- S-6M-T: the same frames and the same training step on a cloud that CONSUMES its lists (synthetic.scene_translucent: same
     # geometry, seeds and SH, opacity logits ~ N(-3.5, 1): the blend fetches 0.9 of a foveated frame's instances and 0.7 of the
@@ -504,6 +530,10 @@ def main():
     line = {
         "metric": "frames/sec at 1080p foveated (bicycle-scale)", "value": round(world * K / elapsed, 3), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_step, 4),
+        "value_raw": round(world * K / elapsed_raw, 3), "ms_per_step_raw": round(elapsed_raw / K * 1e3, 4),
+        "value_note": "value / ms_per_step: the K timed frames (barrier + synchronize on both sides) with the nine gazes weighted EQUALLY -- "
+                      "mean over the gazes of the mean time of that gaze's frames inside the region -- so that it does not depend on steps % 9; "
+                      "value_raw / ms_per_step_raw: K / the region's wall clock (gaze i % 9: steps % 9 gazes weigh one frame more)",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "repeats": max(1, args.repeats), "value_spread": [round(world * K / spread[1], 3), round(world * K / spread[0], 3)],
         "value_packed": round(world * K / elapsed_p, 3), "ms_per_step_packed": round(elapsed_p / K * 1e3, 4),
@@ -530,6 +560,38 @@ def main():
         "extra": dict(extra, **multi),
     }
     print(json.dumps(_finite(line)), flush=True)
+
+
+CANARY_PROJECT_US = 75.0  # k_project on a box in the faster of the two memory states the pool shows (75 / 81 us)
+
+
+def canary(torch, dev, stages_ms, ms_step):
+    """What state this box's memory system is in (boxes of the pool, and one box before / after minutes of load, run the memory-bound
+    stages 4-7 % apart): a 1-GiB device-to-device copy (streaming read + write, HIP events) and the cull pass's kernel time,
+    the frame's own streaming kernel. `value_normalised`: frames/s had the two memory-bound stages (project, bin) run at the reference
+    state's speed -- both scaled by CANARY_PROJECT_US / this run's k_project time; a yardstick for comparing lines across boxes, never `value`."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.zero_()
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    proj_us = stages_ms["project"] * 1e3
+    scale = CANARY_PROJECT_US / max(proj_us, 1e-9)
+    ms_norm = ms_step - (stages_ms["project"] + stages_ms["bin"]) * (1.0 - scale)
+    return dict(copy_1GiB_GBs=round(2 * n / (ms * 1e-3) / 1e9, 1), copy_ms=round(ms, 4), k_project_us=round(proj_us, 2),
+                reference_k_project_us=CANARY_PROJECT_US, value_normalised=round(1e3 / ms_norm, 1),
+                note="value_normalised = 1000 / (ms_per_step - (project + bin) * (1 - 75 us / k_project_us)): the headline with the two "
+                     "memory-bound stages scaled to the pool's faster memory state; compare lines of different boxes by it, report `value`")
 
 
 def _finite(x):
