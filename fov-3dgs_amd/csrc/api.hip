@@ -1,6 +1,7 @@
 // extern "C" entry points of libfovraster_hip.so (see include/fovraster.h for the contract and
 // for the reference interfaces each one replaces).
 #include "common.h"
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -136,29 +137,33 @@ const float *fr_image_tile_levels(int32_t W, int32_t H, const char *image) { ret
 
 namespace fr {
 
-// 64 bytes of pinned, device-mapped host memory per frame in flight: k_tile_scan writes the frame's totals and its sequence
-// number there, the host polls (a copy command after the kernel costs ~10 us more of an idle GPU). A small pool per host
-// thread; the device address of mapped host memory belongs to the device that was current when it was asked for.
+// 64 bytes of pinned, device-mapped host memory per frame in flight: the tile scan writes the frame's totals and its sequence
+// number there, the host polls (a copy command after the kernel costs ~10 us more of an idle GPU). One pool per PROCESS behind a
+// mutex (a frame handle may be dropped by another thread than the one that made it -- a garbage collector's finalizer -- or after
+// its thread has gone); the device address of mapped host memory belongs to the device that was current when it was asked for.
 struct PinnedBlock
 {
 	uint32_t *host = nullptr, *dev = nullptr; int device = -1; bool busy = false;
-	hipEvent_t quarantine = nullptr; bool quarantined = false; // an ABANDONED frame's tile scan may still be on its way to the block
+	hipEvent_t quarantine = nullptr; bool quarantined = false; // a DROPPED frame's tile scan may still be on its way to the block
 };
+static std::mutex g_pinned_mu;
+static PinnedBlock g_pinned_pool[64];
 static PinnedBlock *take_pinned(int device)
 {
-	static thread_local PinnedBlock pool[16];
+	std::lock_guard<std::mutex> lock(g_pinned_mu);
 	PinnedBlock *spare = nullptr;
-	for (PinnedBlock &b : pool)
+	for (PinnedBlock &b : g_pinned_pool)
 	{
+		if (b.busy) continue;
 		if (b.quarantined)
 		{
 			if (hipEventQuery(b.quarantine) != hipSuccess) { (void)hipGetLastError(); continue; }
 			b.quarantined = false;
 		}
-		if (!b.busy && b.host && b.device == device) { b.busy = true; return &b; }
-		if (!b.busy && !spare && (!b.host || b.device != device)) spare = &b;
+		if (b.host && b.device == device) { b.busy = true; return &b; }
+		if (!spare) spare = &b;
 	}
-	if (!spare) return nullptr; // sixteen frames in flight in one thread: the frame falls back to a copy + stream wait
+	if (!spare) return nullptr; // every block of the pool in flight: the frame falls back to a copy + stream wait
 	if (spare->host) (void)hipHostFree(spare->host);
 	spare->host = spare->dev = nullptr; spare->device = device;
 	void *h = nullptr, *d = nullptr;
@@ -169,6 +174,24 @@ static PinnedBlock *take_pinned(int device)
 	if (!spare->host) return nullptr;
 	spare->busy = true;
 	return spare;
+}
+// A frame gives its block back. unread: its tile scan was enqueued and the host never read the totals (an error return between the
+// scan and the count, fr_forward_abandon, a handle dropped by a finalizer): the write may still be on its way, so the block is not
+// handed to another frame before an event on the frame's stream has passed.
+static void release_pinned(PinnedBlock *b, bool unread, hipStream_t stream)
+{
+	if (!b) return;
+	bool drained = !unread;
+	if (unread)
+	{
+		std::lock_guard<std::mutex> lock(g_pinned_mu);
+		if (!b->quarantine && hipEventCreateWithFlags(&b->quarantine, hipEventDisableTiming) != hipSuccess) b->quarantine = nullptr;
+		if (b->quarantine && hipEventRecord(b->quarantine, stream) == hipSuccess) { b->quarantined = true; b->busy = false; return; }
+		(void)hipGetLastError();
+	}
+	if (!drained) (void)hipStreamSynchronize(stream); // (no event to be had: wait the write out)
+	std::lock_guard<std::mutex> lock(g_pinned_mu);
+	b->busy = false;
 }
 
 // what the next frame of a kind (variant, P, W, H) asks its binning workspace for before its count is in
@@ -184,11 +207,13 @@ struct fr_frame
 	AuxStream *ax = nullptr;       // the frame's helper streams (null: everything on the launch stream)
 	bool aux_pending = false;      // work on ax->s2 that the launch stream has not waited for yet
 	PinnedBlock *pin = nullptr;
+	bool scan_enqueued = false;    // the kernel that writes the pinned totals block is on the stream ...
+	bool totals_read = false;      // ... and the host has read what it wrote
 	bool empty = false;            // P == 0: nothing left to do
 	// every exit that abandons the frame joins the helper stream first: the caller may free or reuse out_color / the
 	// statistics arrays / the workspaces as soon as the call has returned
 	void join_aux() { if (aux_pending && ax) (void)hipStreamWaitEvent(c.stream, ax->join2, 0); aux_pending = false; }
-	~fr_frame() { join_aux(); if (pin) pin->busy = false; }
+	~fr_frame() { join_aux(); release_pinned(pin, scan_enqueued && !totals_read, c.stream); }
 };
 
 extern "C" {
@@ -273,14 +298,16 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 	if (is_fov(a->variant)) { rc = launch_tile_levels(c); if (rc) return rc; }
 	mark(FR_STAGE_PROJECT);
 	rc = launch_project(c); if (rc) return rc;
-	mark(FR_STAGE_BIN);
-	rc = launch_bin(c); if (rc) return rc;
 	int cur_dev = 0;
 	(void)hipGetDevice(&cur_dev);
 	f->pin = a->debug ? nullptr : take_pinned(cur_dev);
 	c.totals_host_dev = f->pin ? f->pin->dev : nullptr;
+	c.scan_fused = 0;
+	mark(FR_STAGE_BIN);
+	f->scan_enqueued = true; // (from here on a dropped frame quarantines its block: ~fr_frame)
+	rc = launch_bin(c); if (rc) return rc;
 	mark(FR_STAGE_TILE_SCAN);
-	rc = launch_tile_scan(c); if (rc) return rc;
+	if (!c.scan_fused) { rc = launch_tile_scan(c); if (rc) return rc; } // (else: k_bin's last workgroup did it)
 	*out = f; guard.f = nullptr;
 	return FR_OK;
 }
@@ -333,6 +360,7 @@ int fr_forward_finish(fr_frame *f)
 		for (int i = 0; i < 4; i++) totals[i] = v[i];
 		totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7]; candidates = v[8];
 	}
+	f->totals_read = true;
 	// reference auxiliary.h:156-160: a point behind the near plane although the caller said the cloud was prefiltered
 	// (there: printf + __trap, which kills the context; here an error code)
 	if (a->prefiltered && totals[7] != 0)
@@ -370,15 +398,7 @@ int fr_forward_finish(fr_frame *f)
 int fr_forward_abandon(fr_frame *f)
 {
 	if (!f) { set_error("null frame"); return FR_ERR_INVALID; }
-	if (f->pin && !f->empty)
-	{
-		// the frame's tile scan has not necessarily written its totals yet: the block is not handed to another frame before it has
-		PinnedBlock *b = f->pin;
-		if (!b->quarantine && hipEventCreateWithFlags(&b->quarantine, hipEventDisableTiming) != hipSuccess) b->quarantine = nullptr;
-		if (b->quarantine && hipEventRecord(b->quarantine, f->c.stream) == hipSuccess) b->quarantined = true;
-		else { (void)hipGetLastError(); (void)hipStreamSynchronize(f->c.stream); }
-	}
-	delete f; // ~fr_frame joins the helper stream and releases the pinned block
+	delete f; // ~fr_frame joins the helper stream and quarantines the pinned block (the frame's tile scan may not have written its totals yet)
 	return FR_OK;
 }
 

@@ -18,10 +18,10 @@
 
 namespace fr {
 
-constexpr int FR_TILE_SCAN_THREADS = 512;
 __global__ void __launch_bounds__(FR_TILE_SCAN_THREADS) k_tile_scan(const TileScanArgs ts)
 {
-	if (ts.T <= FR_SCAN_MAX_TILES) tile_scan_body<FR_TILE_SCAN_THREADS>(ts);
+	__shared__ uint32_t lds[tile_scan_lds_words<FR_TILE_SCAN_THREADS>()];
+	if (ts.T <= FR_SCAN_MAX_TILES) tile_scan_body<FR_TILE_SCAN_THREADS>(ts, lds);
 	else tile_scan_atomics<FR_TILE_SCAN_THREADS>(ts);
 }
 

@@ -421,6 +421,7 @@ struct FwdCtx {
 	int fov_split;      // RF: the two level states of a two-level tile go to different waves (out_color was zero-filled)
 	int bin_wgs;        // workgroups k_bin ran with (k_emit replays the same number)
 	int hist_mode;      // k_bin / k_emit: 0 = global tile counters, 1 = LDS histogram of 32-bit counts, 2 = of 16-bit counts (launch_bin decides)
+	int scan_fused;     // the tile scan ran as the tail of k_bin (launch_bin decides): no k_tile_scan launch
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
 	int heavy8;         // tiles with >= 4096 instances
 	int n_items;        // entries of ImageWS::render_items

@@ -16,6 +16,7 @@
 // and re-evaluated in emit (no bitmap, no per-Gaussian scan); instances are bucketed by tile
 // at emission time through per-tile cursors, so no global 64-bit radix sort is needed.
 #include "common.h"
+#include "tile_scan.h"
 #include <cstdlib>
 
 namespace fr {
@@ -293,6 +294,8 @@ struct PreArgs {
 	int prefiltered; // fr_forward_args.prefiltered: a Gaussian behind the near plane is an error (slab_ctr[0] reports it)
 	int proj_waves, proj_cpw; // the cull pass's grid in waves and the chunks each of them took (k_bin finds the regions from them)
 	int wbase_lds;            // k_bin keeps its copy of the cull pass's running counts in LDS (launch_bin: when it fits)
+	int fuse_scan;            // k_bin: the LAST workgroup to finish runs the tile scan (ts) as the kernel's tail -- no k_tile_scan launch
+	TileScanArgs ts;
 };
 
 // Projection of one Gaussian: everything up to the tile rectangle.
@@ -1437,6 +1440,21 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 #pragma unroll
 			for (int k = 0; k < 4; k++) { const int t = t0 + k * FR_BIN_THREADS; if (t < a.T && h[k]) out[t] = o[k]; }
 		}
+		// The tile scan as the tail of this kernel (round 6; a kernel of its own it was 15 us + a 9-us launch gap of pure latency on
+		// the frame's critical path): the LAST workgroup to get here -- found with a counter, as in k_project -- has every
+		// workgroup's share in the tile counters (the shares left as RETURNING device-scope atomics: performed at the memory side
+		// before their values came back and were stored above, so no fence is needed; the counts are read back with device-scope
+		// loads) and scans them with its first eight waves in the LDS the histogram and the staging rows lived in; the other
+		// four waves leave (a finished wave no longer counts at the workgroup barrier).
+		if (LDSH == 1 && a.fuse_scan)
+		{
+			__shared__ uint32_t s_last_wg;
+			__syncthreads();
+			if (threadIdx.x == 0) s_last_wg = atomicAdd(a.geom.slab_ctr + 4, 1u) == gridDim.x - 1 ? 1u : 0u;
+			__syncthreads();
+			if (!s_last_wg || threadIdx.x >= FR_TILE_SCAN_THREADS) return;
+			tile_scan_body<FR_TILE_SCAN_THREADS, true>(a.ts, lds_hist);
+		}
 	}
 }
 #undef BUMP_TILE
@@ -1856,6 +1874,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 	p.write_cov3D = has_backward(a->variant) ? 1 : 0;
 	p.prefiltered = a->prefiltered;
 	p.proj_waves = c.proj_waves; p.proj_cpw = c.proj_cpw;
+	p.fuse_scan = 0;
 	return p;
 }
 
@@ -1934,7 +1953,17 @@ int launch_bin(FwdCtx &c)
 		(size_t)FR_BIN_THREADS * (4 * sizeof(float4) + sizeof(int));
 	const size_t wbase_bytes = (size_t)(c.proj_waves + 1) * sizeof(uint32_t);
 	p.wbase_lds = lds_fixed + wbase_bytes <= 156u * 1024u ? 1 : 0; // (a 4K grid's 16-bit histogram + a large cloud's 32 KiB of counts do not both fit)
-	const size_t lds = lds_fixed + (p.wbase_lds ? wbase_bytes : 0);
+	size_t lds = lds_fixed + (p.wbase_lds ? wbase_bytes : 0);
+	// the tile scan as this kernel's tail (k_bin): 32-bit LDS histograms, a frame that publishes its totals through the pinned block
+	// (c.totals_host_dev / c.totals_seq are set), at most FR_SCAN_MAX_TILES tiles; FOVRASTER_FUSE_SCAN=0 keeps the kernel of its own
+	static const bool fuse_ok = []() { const char *e = getenv("FOVRASTER_FUSE_SCAN"); return !(e && e[0] == '0'); }();
+	c.scan_fused = fuse_ok && c.hist_mode == 1 && c.T <= FR_SCAN_MAX_TILES && !a->debug;
+	if (c.scan_fused)
+	{
+		p.fuse_scan = 1; p.ts = make_tile_scan_args(c);
+		const size_t scan_bytes = (size_t)tile_scan_lds_words<FR_TILE_SCAN_THREADS>() * sizeof(uint32_t);
+		if (lds < scan_bytes) lds = scan_bytes;
+	}
 	// Never more workgroups than the device keeps resident (one per CU: a second one doubles the histogram flushes -- one returning
 	// atomic per workgroup and touched tile -- and the table prologues for slabs that one workgroup's sixteen waves already cover).
 	auto launch = [&](const void *fn, void (*kern)(const PreArgs), size_t dyn) {

@@ -12,6 +12,9 @@ struct TileScanArgs {
 	const float *tile_blend; uint32_t *render_items; const uint32_t *prefilter_flag;
 };
 
+struct FwdCtx;
+TileScanArgs make_tile_scan_args(FwdCtx &c); // binning.hip
+
 // Single workgroup: exclusive scan of tile_count[T] -> ranges, reset the counters to serve as
 // emission cursors, publish {total, max}.
 // Also lays out the blend kernel's work items (render_items): one per wave that has something to do -- two bands per
@@ -28,6 +31,7 @@ struct TileScanArgs {
 // counts alone (stable: tile index ascending inside a bin), not of the order atomics retire in.
 // A word packs {tiles: low 16 bits, two-level tiles: high 16 bits}: good for T <= 65535 (the 8K case, 129 600 tiles,
 // takes tile_scan_atomics below).
+constexpr int FR_TILE_SCAN_THREADS = 512; // threads of the scan (k_tile_scan's workgroup; the first eight waves of k_bin's last workgroup)
 constexpr int FR_SCAN_BINS = 18;
 constexpr int FR_SCAN_ROWS = 19; // one empty row: an odd stride for the linear scan (no LDS bank conflicts)
 constexpr int FR_SCAN_MAX_TILES = 65535;
@@ -65,8 +69,15 @@ __device__ __forceinline__ void publish_totals(const TileScanArgs &ts, const uin
 // the runs are cut out of / put together in LDS (run r at word 17 r: conflict-free both ways):
 //   counts + blend flags -> LDS -> registers;  starts -> LDS -> ranges;  (tile, item offset) at its place -> LDS -> lists.
 // Images above one chunk keep the coalesced loads and ranges and scatter the placement from the threads.
+// LDS words the scan of THREADS threads needs (the caller provides them: k_tile_scan a static array, k_bin's last workgroup the
+// dynamic LDS its histogram and staging rows lived in).
 template <int THREADS>
-__device__ __forceinline__ void tile_scan_body(const TileScanArgs &ts)
+constexpr int tile_scan_lds_words() { return FR_SCAN_ROWS * THREADS + 2 * (16 * THREADS + THREADS) + 3 * (THREADS / 64); }
+
+// MEMSIDE: the counts are read with device-scope atomic loads -- the scan runs as the tail of the kernel whose other workgroups
+// ADDED to them (returning atomics, performed at the memory side), not behind a kernel boundary.
+template <int THREADS, bool MEMSIDE = false>
+__device__ __forceinline__ void tile_scan_body(const TileScanArgs &ts, uint32_t *const lds)
 {
 	constexpr int RUN = 16;
 	constexpr int CHUNK = RUN * THREADS;
@@ -76,12 +87,12 @@ __device__ __forceinline__ void tile_scan_body(const TileScanArgs &ts)
 	uint32_t *const tile_order = ts.tile_order, *const render_items = ts.render_items;
 	const float *const tile_blend = ts.tile_blend;
 	constexpr int NW = THREADS / 64;
-	__shared__ uint32_t hist[FR_SCAN_ROWS * THREADS];
-	__shared__ uint32_t la[PADDED]; // counts (bit 31: two-level tile), later: the tile at each place of the order
-	__shared__ uint32_t lb[PADDED]; // list starts, later: the item offset of each place
-	__shared__ uint32_t wave_sum[NW];
-	__shared__ uint32_t wave_hist[NW];
-	__shared__ uint32_t wave_max[NW];
+	uint32_t *const hist = lds;                          // [FR_SCAN_ROWS * THREADS]
+	uint32_t *const la = hist + FR_SCAN_ROWS * THREADS;  // [PADDED] counts (bit 31: two-level tile), later: the tile at each place of the order
+	uint32_t *const lb = la + PADDED;                    // [PADDED] list starts, later: the item offset of each place
+	uint32_t *const wave_sum = lb + PADDED;              // [NW]
+	uint32_t *const wave_hist = wave_sum + NW;           // [NW]
+	uint32_t *const wave_max = wave_hist + NW;           // [NW]
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #ifdef FR_SCAN_TIMERS
 	const uint64_t tm0 = wall_clock64(); uint64_t tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0, tm5 = 0, tm6 = 0;
@@ -99,7 +110,11 @@ __device__ __forceinline__ void tile_scan_body(const TileScanArgs &ts)
 		uint32_t v[RUN]; float bl[RUN];
 #pragma unroll
 		// (clamped addresses, not predicated loads: all 32 in flight together)
-		for (int k = 0; k < RUN; k++) { const int i = base + k * THREADS + tid; v[k] = tile_count[min(i, T - 1)]; }
+		for (int k = 0; k < RUN; k++)
+		{
+			const int i = base + k * THREADS + tid;
+			v[k] = MEMSIDE ? __hip_atomic_load(tile_count + min(i, T - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tile_count[min(i, T - 1)];
+		}
 		const float *const blend = tile_blend ? tile_blend : (const float *)tile_count;
 #pragma unroll
 		for (int k = 0; k < RUN; k++) { const int i = base + k * THREADS + tid; bl[k] = blend[min(i, T - 1)]; }

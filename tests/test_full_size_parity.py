@@ -423,7 +423,7 @@ def test_training_step_full_size_translucent(s6mt):
 
 def budget_kw(s6m, tensor):
     """check_grad's outlier budget of a whole-frame tensor (tests/checks.py FULL_FRAME_GRAD_BUDGETS); the default budget on a window."""
-    b = FULL_FRAME_GRAD_BUDGETS.get(s6m.name, {}).get(tensor) if WHOLE else None
+    b = FULL_FRAME_GRAD_BUDGETS.get(s6m.name + (" ring" if s6m.view else ""), {}).get(tensor) if WHOLE else None
     if os.environ.get("FOVRASTER_MEASURE_BUDGETS") == "1":
         return dict(outlier_frac=1.0, gross_frac=1.0, rel_l2=1.0, cosine=1.0)  # calibration run: record, do not judge
     return {} if b is None else dict(outlier_frac=b, rel_l2=FULL_FRAME_GRAD_REL_L2, gross_frac=FULL_FRAME_GRAD_GROSS)
