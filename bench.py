@@ -360,6 +360,17 @@ def main():
 
     # which stage is the slowest is found first (untimed); the timed frames then carry the events of that stage and of the
     # blend stage (the kernel north_star names) only
+    from fov3dgs_amd import rasterizer as rz_mod
+    overlap_default = bool(rz_mod.OVERLAP_SUCCESSIVE_FRAMES)
+    _stage_pass = stage_pass
+
+    def stage_pass(*a_, **k_):
+        """(per-stage kernel times are a frame's own: one frame on the GPU at a time)"""
+        rz_mod.OVERLAP_SUCCESSIVE_FRAMES = False
+        try:
+            return _stage_pass(*a_, **k_)
+        finally:
+            rz_mod.OVERLAP_SUCCESSIVE_FRAMES = overlap_default
     with torch.no_grad():
         for i in range(3):
             frame(GAZES[i % 9], "auto" if args.packed_only else None)
@@ -367,12 +378,19 @@ def main():
     dominant = max(("project", "bin", "render", "tile_sort", "emit"), key=lambda k: pre[k])
     ev_stages = tuple(dict.fromkeys((dominant, "render")))
     if args.packed_only:
-        headline = timed_run("auto", ev_stages)
+        headline = serial = timed_run("auto", ev_stages)
         elapsed_p, spread_p, timed_ms_p = headline
         elapsed, spread, timed_ms, elapsed_raw = elapsed_p, spread_p, timed_ms_p, headline.raw
+        timed_ms_overlapped = timed_ms
     else:
-        headline = timed_run(None, ev_stages)                         # the reference's tensor interface: the headline
-        elapsed, spread, timed_ms = headline
+        # one frame on the GPU at a time (rasterizer.OVERLAP_SUCCESSIVE_FRAMES off): a kernel's duration is its own -- the roofline's
+        # timed region -- and `value_serial`
+        rz_mod.OVERLAP_SUCCESSIVE_FRAMES = False
+        serial = timed_run(None, ev_stages)
+        rz_mod.OVERLAP_SUCCESSIVE_FRAMES = overlap_default
+        headline = timed_run(None, ev_stages) if overlap_default else serial   # render() as a caller gets it: the headline
+        elapsed, spread, timed_ms_overlapped = headline
+        timed_ms = serial[2]
         elapsed_raw = headline.raw
         if args.headline_only:
             elapsed_p, spread_p, timed_ms_p = elapsed, spread, timed_ms
@@ -429,7 +447,10 @@ def main():
         ach = alg_bytes[stage] / (roof_ms[stage] * 1e-3) / 1e9
         d = dict(kernel=stage, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
                  algorithmic_bytes=int(alg_bytes[stage]), kernel_ms=round(roof_ms[stage], 4),
-                 measured_in="timed region (HIP events on the launch stream)" if stage in timed_ms else "untimed all-stage pass of the same frames")
+                 measured_in=("timed region of value_serial (HIP events on the launch stream; one frame on the GPU at a time: the kernel's duration is its own)"
+                              if stage in timed_ms else "untimed all-stage pass of the same frames"))
+        if stage in timed_ms_overlapped and overlap_default:
+            d["kernel_ms_overlapped"] = round(timed_ms_overlapped[stage], 4)  # the same kernel in the timed region of `value`, sharing the GPU with the neighbouring frame's tail / head
         d["traffic"], d["traffic_source"] = prof.traffic(stage, packed=args.packed_only)
         if d["traffic"]:
             # the formula charges bytes this build never moves (SH rows of culled Gaussians) or moves twice: the PMC bytes over the
@@ -452,7 +473,7 @@ def main():
     if world == 1 and not args.no_extra:
         extra = extras(args, torch, np, syn, dev, cam, pc, cloud, bg, frame, render_plain, H, W)
     if world == 1:
-        extra["canary"] = canary(torch, dev, mean_ms, ms_step)
+        extra["canary"] = canary(torch, dev, mean_ms, serial[0] / K * 1e3)
 
     # ---- S-6M-T: the same frames and the same training step on a cloud that CONSUMES its lists (synthetic.scene_translucent: same
     # geometry, seeds and SH, opacity logits ~ N(-3.5, 1): the blend fetches 0.9 of a foveated frame's instances and 0.7 of the
@@ -531,6 +552,13 @@ def main():
         "metric": "frames/sec at 1080p foveated (bicycle-scale)", "value": round(world * K / elapsed, 3), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_step, 4),
         "value_raw": round(world * K / elapsed_raw, 3), "ms_per_step_raw": round(elapsed_raw / K * 1e3, 4),
+        "value_serial": round(world * K / serial[0], 3), "ms_per_step_serial": round(serial[0] / K * 1e3, 4),
+        "value_serial_spread": [round(world * K / serial[1][1], 3), round(world * K / serial[1][0], 3)],
+        "overlap_note": "value: render() as a caller gets it -- one call at a time, each returning its instance count; successive inference calls whose inputs "
+                        "are provably unchanged (same tensor objects, addresses, autograd versions) run on two internal streams in turn, so the head of call "
+                        "n + 1 (cull, projection, counts) runs beside the tail of call n (emission, sort, blend): rasterizer.OVERLAP_SUCCESSIVE_FRAMES = "
+                        + str(overlap_default) + "; images bit-identical. value_serial: the same K frames with that switch off (every kernel of a frame alone on the GPU: "
+                        "the roofline's kernel durations are measured there)",
         "value_note": "value / ms_per_step: the K timed frames (barrier + synchronize on both sides) with the nine gazes weighted EQUALLY -- "
                       "mean over the gazes of the mean time of that gaze's frames inside the region -- so that it does not depend on steps % 9; "
                       "value_raw / ms_per_step_raw: K / the region's wall clock (gaze i % 9: steps % 9 gazes weigh one frame more)",
@@ -568,7 +596,7 @@ CANARY_PROJECT_US = 75.0  # k_project on a box in the faster of the two memory s
 def canary(torch, dev, stages_ms, ms_step):
     """What state this box's memory system is in (boxes of the pool, and one box before / after minutes of load, run the memory-bound
     stages 4-7 % apart): a 1-GiB device-to-device copy (streaming read + write, HIP events) and the cull pass's kernel time,
-    the frame's own streaming kernel. `value_normalised`: frames/s had the two memory-bound stages (project, bin) run at the reference
+    the frame's own streaming kernel. `value_serial_normalised`: frames/s of the one-frame-at-a-time run had the two memory-bound stages (project, bin) run at the reference
     state's speed -- both scaled by CANARY_PROJECT_US / this run's k_project time; a yardstick for comparing lines across boxes, never `value`."""
     n = 1 << 30
     a = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -589,8 +617,8 @@ def canary(torch, dev, stages_ms, ms_step):
     scale = CANARY_PROJECT_US / max(proj_us, 1e-9)
     ms_norm = ms_step - (stages_ms["project"] + stages_ms["bin"]) * (1.0 - scale)
     return dict(copy_1GiB_GBs=round(2 * n / (ms * 1e-3) / 1e9, 1), copy_ms=round(ms, 4), k_project_us=round(proj_us, 2),
-                reference_k_project_us=CANARY_PROJECT_US, value_normalised=round(1e3 / ms_norm, 1),
-                note="value_normalised = 1000 / (ms_per_step - (project + bin) * (1 - 75 us / k_project_us)): the headline with the two "
+                reference_k_project_us=CANARY_PROJECT_US, value_serial_normalised=round(1e3 / ms_norm, 1),
+                note="value_serial_normalised = 1000 / (ms_per_step_serial - (project + bin) * (1 - 75 us / k_project_us)): value_serial with the two "
                      "memory-bound stages scaled to the pool's faster memory state; compare lines of different boxes by it, report `value`")
 
 

@@ -1,4 +1,5 @@
 """render() for the foveated rasterizer (reference: fov3dgs/gaussian_renderer_fov/__init__.py:19-105)."""
+import contextlib
 import math
 import weakref
 
@@ -6,7 +7,7 @@ import torch
 
 from ..diff_gaussian_rasterization_fov_pcheck_obb import GaussianRasterizationSettings, GaussianRasterizer
 from .. import _native
-from ..rasterizer import PackedModel, _forward_begin, pack_model, zero_points_like
+from ..rasterizer import PackedModel, _forward_begin, pack_model, serial_frames, zero_points_like
 
 
 class _PackState:
@@ -105,10 +106,13 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, a
         packed = _auto_packed(pc, means3D, scales, rotations, opacity, shs_rest, shs_dcs, highest_levels)
     if starter is not None:
         starter.record()
-    rendered_image, radii = rasterizer(
-        means3D=means3D, means2D=means2D, shs_rest=shs_rest, colors_precomp=None, opacities=opacity, scales=scales,
-        rotations=rotations, cov3D_precomp=None, shs_dcs=shs_dcs, highest_levels=highest_levels,
-        gazeArray=gazeArray, alpha=alpha, blending=blending, packed=packed)
+    # (successive inference calls overlap on the GPU -- rasterizer.OVERLAP_SUCCESSIVE_FRAMES; a caller that brackets the call with its
+    # own events measures the call's own kernels: that call runs on the caller's stream alone)
+    with (serial_frames() if (starter is not None or ender is not None) else contextlib.nullcontext()):
+        rendered_image, radii = rasterizer(
+            means3D=means3D, means2D=means2D, shs_rest=shs_rest, colors_precomp=None, opacities=opacity, scales=scales,
+            rotations=rotations, cov3D_precomp=None, shs_dcs=shs_dcs, highest_levels=highest_levels,
+            gazeArray=gazeArray, alpha=alpha, blending=blending, packed=packed)
     if ender is not None:
         ender.record()
 

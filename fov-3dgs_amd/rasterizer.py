@@ -12,6 +12,7 @@ All tensors must live on a ROCm device; there is no CPU path. Output / workspace
 allocated here with torch (the C library never allocates device memory).
 """
 import ctypes as C
+import os
 import threading
 from typing import NamedTuple
 
@@ -418,9 +419,111 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
     return FrameInFlight(lib, a, keep, color, radii, ws, lease, counts, contribs, handle, dev, stream)
 
 
+# ---- successive inference frames overlap on the GPU -------------------------------------------------------------------------------
+# A frame is seven dependent stages bound by seven different units (HBM streaming, latency, HBM random access, the address unit, LDS,
+# VALU: DESIGN 4); inside one frame nothing overlaps, and a host that renders one frame per call leaves every unit idle most of the
+# time. The call itself cannot return before its instance count is in (the reference's contract: num_rendered), but nothing says the
+# GPU must have finished frame n's sort and blend before it starts frame n + 1's cull pass. So an INFERENCE call (no autograd graph,
+# persistent workspaces) runs on one of two internal streams in turn, each with its own workspace set: the head of call n + 1 is
+# enqueued behind call n - 1 on ITS stream and runs beside the tail of call n on the other. The caller's stream waits (on the GPU,
+# not the host) for the frame's last kernel before anything enqueued after the call, so every use of the outputs is ordered as if
+# the frame had run on the caller's stream.
+# What makes this safe is the dependency on the INPUTS: a frame may only skip waiting for the caller's stream if nothing the caller
+# enqueued since the previous call can have written what it reads. That is decided per call from the inputs' identity: the same tensor
+# objects, storage addresses and autograd version counters as at the previous call of this (device, stream, thread) => unchanged, no
+# wait; anything else (a model whose getters build new tensors per call, an optimiser step, another camera object) => the internal
+# stream first waits for an event recorded on the caller's stream now -- the frame is then serialised behind whatever the caller
+# enqueued, exactly as without this scheme. Writes the version counter cannot see (`.data` writes, raw-pointer kernels, DLPack /
+# numpy aliases) are the caller's to announce: invalidate_overlap() (or OVERLAP_SUCCESSIVE_FRAMES = False).
+# Images, radii and lists are bit-identical with and without (tested); only WHEN the kernels run changes.
+OVERLAP_SUCCESSIVE_FRAMES = os.environ.get("FOVRASTER_OVERLAP", "1") != "0"  # (FOVRASTER_OVERLAP=0: developer A / B runs of single kernels)
+_overlap_state = {}
+_overlap_tls = threading.local()
+
+
+class serial_frames:
+    """with serial_frames(): ... -- calls inside run on the caller's stream alone (a caller that brackets the call with its own
+    events -- render(starter=, ender=) -- measures the call's own kernels, not a neighbour's)."""
+
+    def __enter__(self):
+        _overlap_tls.off = getattr(_overlap_tls, "off", 0) + 1
+
+    def __exit__(self, *exc):
+        _overlap_tls.off -= 1
+
+
+def invalidate_overlap():
+    """The next inference call of every stream waits for its caller's stream (after a write to an input that bypassed the
+    autograd version counter)."""
+    for st in _overlap_state.values():
+        st.sig = None
+
+
+class _OverlapState:
+    def __init__(self, dev):
+        self.streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        self.done = [None, None]      # event behind the last frame of each internal stream
+        self.must_wait = [None, None]  # event on the caller's stream each internal stream still has to wait for
+        self.turn = 0
+        self.sig = None
+        self.refs = None
+
+
+def _input_signature(tensors):
+    return tuple((id(t), t._version, t.data_ptr(), tuple(t.shape), t.stride()) for t in tensors)
+
+
+def _forward_overlapped(args, kw):
+    """_forward_begin + finish of an inference call on the next internal stream (see above). -> the result tuple of _forward_native."""
+    rs, tensors = args[1], [t for t in args if isinstance(t, torch.Tensor) and t.numel() > 0]
+    tensors += [t for t in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos, kw.get("loss_map"), kw.get("sh_rest")) if isinstance(t, torch.Tensor)]
+    dev = args[2].device
+    cur = torch.cuda.current_stream(dev)
+    key = (dev, cur.cuda_stream, threading.get_ident())
+    st = _overlap_state.get(key)
+    if st is None:
+        if len(_overlap_state) > 16:
+            _overlap_state.clear()
+        st = _overlap_state[key] = _OverlapState(dev)
+    sig = _input_signature(tensors)
+    # (a caller-supplied OUTPUT -- the diagnostics list_consumed / blend_pairs -- may still be read by something the caller enqueued
+    # after the previous call: such a frame always waits for the caller's stream)
+    outputs = kw.get("list_consumed") is not None or kw.get("blend_pairs") is not None
+    same = (not outputs and st.sig == sig and st.refs is not None and len(st.refs) == len(tensors)
+            and all(r() is t for r, t in zip(st.refs, tensors)))
+    if not same:
+        # new or modified inputs: both internal streams wait for the caller's stream as it stands now before they read them
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        st.must_wait = [ev, ev]
+        st.sig = None if outputs else sig
+        import weakref
+        st.refs = [weakref.ref(t) for t in tensors]
+    i = st.turn
+    st.turn ^= 1
+    own = st.streams[i]
+    if st.must_wait[i] is not None:
+        own.wait_event(st.must_wait[i])
+        st.must_wait[i] = None
+    with torch.cuda.stream(own):
+        res = _forward_begin(*args, **kw).finish()
+        done = torch.cuda.Event()
+        done.record(own)
+    st.done[i] = done
+    cur.wait_event(done)  # everything the caller enqueues from here on sees the finished frame
+    for t in res:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(cur)
+    return res
+
+
 def _forward_native(*args, **kw):
     """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease):
-    both halves of the forward call back to back (arguments: _forward_begin)."""
+    both halves of the forward call back to back (arguments: _forward_begin). Inference calls (persistent workspaces, no debug
+    mode, no stream capture) of successive frames overlap on the GPU (OVERLAP_SUCCESSIVE_FRAMES, see above)."""
+    if (OVERLAP_SUCCESSIVE_FRAMES and kw.get("persistent") and not getattr(_overlap_tls, "off", 0) and not args[1].debug
+            and args[2].is_cuda and not torch.cuda.is_current_stream_capturing()):
+        return _forward_overlapped(args, kw)
     return _forward_begin(*args, **kw).finish()
 
 

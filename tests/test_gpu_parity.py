@@ -1422,3 +1422,74 @@ def test_tiles_whose_level_is_nan(variant):
         np.testing.assert_array_equal(got["ranges"], want["ranges"])
         np.testing.assert_array_equal(got["point_list"], want["point_list"])
         check_image(got["color"], want["color"], name=f"{variant}: {nan_tiles} tiles with a NaN level")
+
+
+def test_successive_inference_frames_overlap_and_stay_identical():
+    """rasterizer.OVERLAP_SUCCESSIVE_FRAMES (round 6): inference calls run on two internal streams in turn, so that the head of call
+    n + 1 runs beside the tail of call n -- when the inputs are the same unmodified tensor objects as at the previous call; otherwise the
+    frame waits for the caller's stream. Images and radii are those of the serial path bit for bit: (a) a static model over a gaze
+    sweep; (b) a model modified IN PLACE between two calls (version counter) and (c) through a NEW tensor made by a kernel still
+    pending on the caller's stream -- the frame must see the new values; (d) the caller's stream sees finished outputs without a host
+    synchronisation (a dependent kernel enqueued right after the call reads the final image)."""
+    _need_gpu()
+    from fov3dgs_amd import rasterizer as rz
+    from fov3dgs_amd.gaussian_renderer_fov import render as render_fov
+    dev = "cuda:0"
+    cloud = syn.scene_1k(P=20000, seed=4).to(dev)
+    cam = syn.camera_1k(640, 360).to(dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    highest, shs_dcs, opac = [t.to(dev) for t in syn.foveation_layers(cloud, seed=5)]
+
+    class Frozen:
+        def __init__(self, c):
+            with torch.no_grad():
+                self.get_xyz, self.get_scaling, self.get_rotation = c.get_xyz.detach(), c.get_scaling.detach(), c.get_rotation.detach()
+                self.get_opacity, self.get_rest_features = c.get_opacity.detach(), c.get_rest_features.detach().contiguous()
+            self.active_sh_degree = 3
+    pc = Frozen(cloud)
+    gazes = [(0.1 + 0.04 * i, 0.9 - 0.035 * i) for i in range(20)]
+
+    def sweep(op):
+        outs = []
+        with torch.no_grad():
+            for g in gazes:
+                o = render_fov(cam, pc, bg, alpha=0.05, gazeArray=g, blending=True, highest_levels=highest, shs_dcs=shs_dcs, opacities=op)
+                outs.append((o["render"], o["radii"], o["render"].sum()))  # (d): a kernel on the caller's stream right behind the call
+        torch.cuda.synchronize()
+        return outs
+    assert rz.OVERLAP_SUCCESSIVE_FRAMES
+    a = sweep(opac)
+    rz.OVERLAP_SUCCESSIVE_FRAMES = False
+    try:
+        b = sweep(opac)
+    finally:
+        rz.OVERLAP_SUCCESSIVE_FRAMES = True
+    for (ia, ra, sa), (ib, rb, sb) in zip(a, b):
+        assert torch.equal(ia, ib) and torch.equal(ra, rb) and torch.equal(sa, sb)
+    assert len(rz._overlap_state) >= 1
+    # (b) in-place modification between calls, (c) a fresh tensor whose producer kernel is still on the caller's stream
+    with torch.no_grad():
+        op2 = opac.clone()
+        g = gazes[3]
+        kw = dict(alpha=0.05, gazeArray=g, blending=True, highest_levels=highest, shs_dcs=shs_dcs)
+        first = render_fov(cam, pc, bg, opacities=op2, **kw)["render"]
+        second = render_fov(cam, pc, bg, opacities=op2, **kw)["render"]       # same inputs: no wait for the caller's stream
+        big = torch.randn(64 << 20, device=dev)
+        for _ in range(3):
+            big = big * 1.0001 + 0.5                                            # work pending on the caller's stream ...
+        op2.mul_(0.25)                                                         # ... in front of the write the next frame must see
+        third = render_fov(cam, pc, bg, opacities=op2, **kw)["render"]
+        op3 = op2 * 2.0                                                        # a new tensor, its kernel pending
+        fourth = render_fov(cam, pc, bg, opacities=op3, **kw)["render"]
+        torch.cuda.synchronize()
+        rz.OVERLAP_SUCCESSIVE_FRAMES = False
+        try:
+            want3 = render_fov(cam, pc, bg, opacities=op2.clone(), **kw)["render"]
+            want4 = render_fov(cam, pc, bg, opacities=op3.clone(), **kw)["render"]
+            want1 = render_fov(cam, pc, bg, opacities=opac.clone(), **kw)["render"]
+        finally:
+            rz.OVERLAP_SUCCESSIVE_FRAMES = True
+        torch.cuda.synchronize()
+    assert torch.equal(first, want1) and torch.equal(second, want1)
+    assert torch.equal(third, want3) and torch.equal(fourth, want4)
+    assert float((third - first).abs().max()) > 1e-3
