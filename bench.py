@@ -396,9 +396,11 @@ def main():
             elapsed_p, spread_p, timed_ms_p = elapsed, spread, timed_ms
         else:
             elapsed_p, spread_p, timed_ms_p = timed_run("auto", ev_stages)  # static-model layout
-    elapsed_pl, spread_pl = (elapsed, spread) if (args.headline_only or args.packed_only) else timed_run_pipelined(2)
     mean_ms = stage_pass("auto" if args.packed_only else None)
     mean_ms_p = mean_ms if args.headline_only else stage_pass("auto")
+    # (last: its two launch streams and their helper pairs stay in existence, and a process with more streams than hardware queues
+    # -- four by default -- shares queues between them)
+    elapsed_pl, spread_pl = (elapsed, spread) if (args.headline_only or args.packed_only) else timed_run_pipelined(2)
     multi = multi_gpu_extras(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, barrier_sync, frame, torch, np) if world > 1 else {}
     if rank != 0:
         return

@@ -147,7 +147,7 @@ class _Workspaces:
 import collections
 
 _persistent_ws = collections.OrderedDict()
-PERSISTENT_WS_SETS = 4  # per device: grow-only inference workspace sets kept alive (least recently used goes first)
+PERSISTENT_WS_SETS = 8  # per device: grow-only inference workspace sets kept alive (least recently used goes first); the caller's stream, the three internal streams of successive-frame overlap and a two-streams-in-flight host together use six
 _pooled_ws = {}  # device -> idle workspace sets of finished training steps
 
 
@@ -424,8 +424,9 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
 # VALU: DESIGN 4); inside one frame nothing overlaps, and a host that renders one frame per call leaves every unit idle most of the
 # time. The call itself cannot return before its instance count is in (the reference's contract: num_rendered), but nothing says the
 # GPU must have finished frame n's sort and blend before it starts frame n + 1's cull pass. So an INFERENCE call (no autograd graph,
-# persistent workspaces) runs on one of two internal streams in turn, each with its own workspace set: the head of call n + 1 is
-# enqueued behind call n - 1 on ITS stream and runs beside the tail of call n on the other. The caller's stream waits (on the GPU,
+# persistent workspaces) runs on one of OVERLAP_SLOTS (3) internal streams in turn, each with its own workspace set: the head of call
+# n + 1 goes to a stream whose last frame (n - 2) is long finished and runs beside the tail of call n (two streams: 1715 -> 1990
+# frames/s on the S-6M bench frames; three, where the head never queues behind the tail of call n - 1: 2080). The caller's stream waits (on the GPU,
 # not the host) for the frame's last kernel before anything enqueued after the call, so every use of the outputs is ordered as if
 # the frame had run on the caller's stream.
 # What makes this safe is the dependency on the INPUTS: a frame may only skip waiting for the caller's stream if nothing the caller
@@ -459,11 +460,15 @@ def invalidate_overlap():
         st.sig = None
 
 
+OVERLAP_SLOTS = max(2, int(os.environ.get("FOVRASTER_OVERLAP_SLOTS", "3")))  # internal streams (and workspace sets) the frames take turns on
+
+
 class _OverlapState:
     def __init__(self, dev):
-        self.streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        self.done = [None, None]      # event behind the last frame of each internal stream
-        self.must_wait = [None, None]  # event on the caller's stream each internal stream still has to wait for
+        n = OVERLAP_SLOTS
+        self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
+        self.done = [None] * n       # event behind the last frame of each internal stream
+        self.must_wait = [None] * n  # event on the caller's stream each internal stream still has to wait for
         self.turn = 0
         self.sig = None
         self.refs = None
@@ -495,12 +500,12 @@ def _forward_overlapped(args, kw):
         # new or modified inputs: both internal streams wait for the caller's stream as it stands now before they read them
         ev = torch.cuda.Event()
         ev.record(cur)
-        st.must_wait = [ev, ev]
+        st.must_wait = [ev] * len(st.streams)
         st.sig = None if outputs else sig
         import weakref
         st.refs = [weakref.ref(t) for t in tensors]
     i = st.turn
-    st.turn ^= 1
+    st.turn = (i + 1) % len(st.streams)
     own = st.streams[i]
     if st.must_wait[i] is not None:
         own.wait_event(st.must_wait[i])
