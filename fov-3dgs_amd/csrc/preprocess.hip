@@ -1047,7 +1047,12 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	__shared__ uint4 s_lvbox[5]; // RF: the five level boxes every candidate's walk rectangle is clipped to (walk_rect)
 	if (FOV && threadIdx.x < 5) s_lvbox[threadIdx.x] = *(const uint4 *)(a.lv_bbox + threadIdx.x * FR_LV_BBOX_STRIDE);
 	if (threadIdx.x < FR_GIANT_MAX) { s_gcount[threadIdx.x] = 0; s_gmask[threadIdx.x] = 0; }
-	if (threadIdx.x == 0) s_ng = 0;
+	// Which slabs a WORKGROUP takes is static (k_emit's workgroup of the same number replays them: the bucket offsets are per
+	// workgroup); which of its waves takes which is not: the waves pull the workgroup's q-th slab from a counter in LDS (round 6: a
+	// wave's five slabs differ by the splats they hold, the slowest wave of a workgroup ran 20 % behind the mean and everybody waited
+	// for it at the barrier in front of the giant splats and the flush).
+	__shared__ uint32_t s_next_slab;
+	if (threadIdx.x == 0) { s_ng = 0; s_next_slab = 0; }
 	__syncthreads();
 	// tile ti against a splat whose filter bound is olim = highest level + 1: does the tile pass, and its level bits
 	// (1 << min(max(int(tile_min), 0), 3), | 16 if it blends two levels) -- from the 4-bit table, or from the floats
@@ -1093,7 +1098,6 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	}
 	const int V = (int)a.geom.slab_ctr[1]; // entries of vis_list (the cull pass's last workgroup)
 	const int nslabs = (V + 63) / 64;
-	const int wave_gid = (int)blockIdx.x * (FR_BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
 	const int nwaves = (int)gridDim.x * (FR_BIN_THREADS / 64);
 	const float *tile_min = FOV ? a.tile_lv + a.T : nullptr;
 	const float *tile_bl = FOV ? a.tile_lv + 4 * (size_t)a.T : nullptr;
@@ -1154,8 +1158,14 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 	// (uniform) the usual SH storage -- coefficients given, all 16 allocated -- is fetched as whole 16-byte pieces
 	const bool rows_ok = a.colors_precomp == nullptr &&
 		(PACKED || (LEVELCOL ? a.M * 3 >= 45 : (a.shs_rest != nullptr ? (a.M - 1) * 3 >= 45 : a.M * 3 >= 48)));
-	for (int slab = wave_gid; slab < nslabs; slab += nwaves)
+	for (;;)
 	{
+	uint32_t q_ = 0;
+	if (lane == 0) q_ = atomicAdd(&s_next_slab, 1u);
+	q_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_);
+	constexpr int BW_ = FR_BIN_THREADS / 64;
+	const int slab = (int)blockIdx.x * BW_ + (int)(q_ % BW_) + (int)(q_ / BW_) * nwaves; // (increasing in q)
+	if (slab >= nslabs) break;
 	const int nv = min(64, V - slab * 64);
 	const int item = slab * 64 + lane;
 	float4 wr[4];
@@ -1548,8 +1558,8 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	// (dynamic LDS behind the cursors and the table, 16-byte aligned: the pair loop's 64-byte owner row per lane, see k_bin)
 	float4 *const s_orec = (float4 *)(lds_cur + ((cur_words + (ldst ? tab_words : 0) + 3) & ~3));
 	__shared__ int s_gidx[FR_GIANT_MAX]; // vis_list positions of the giant splats, walked by the whole workgroup at the end (see k_bin)
-	__shared__ uint32_t s_ng;
-	if (threadIdx.x == 0) s_ng = 0;
+	__shared__ uint32_t s_ng, s_next_slab;
+	if (threadIdx.x == 0) { s_ng = 0; s_next_slab = 0; }
 	__syncthreads();
 #ifdef FR_EMIT_TIMERS
 	tm_pro = wall_clock64() - tm_entry;
@@ -1629,6 +1639,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		}
 		// big splats: whole wave, wave-uniform owner (see k_bin)
 		const bool big = alive && !in_place && !deferred && tnum >= FR_BIG_TNUM;
+#ifdef FR_EMIT_TIMERS
+		const uint64_t tg0 = wall_clock64();
+#endif
 		for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1)
 		{
 			const int L = __ffsll((long long)bigm) - 1;
@@ -1639,6 +1652,9 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			const uint64_t opay = ((uint64_t)(uint32_t)bcast_i((int)depth_bits, L) << 32) | (uint32_t)(slab * 64 + L);
 			walk_uniform(ox0, oy0, ow, (uint32_t)bcast_i((int)tnum, L), ob, bcast_f(hl, L) + 1, opay, 0u, 64u);
 		}
+#ifdef FR_EMIT_TIMERS
+		tm_big += wall_clock64() - tg0;
+#endif
 		const uint32_t my_n = (alive && !in_place && !big && !deferred) ? tnum : 0u;
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
 		const uint32_t excl = incl - my_n;
@@ -1715,27 +1731,32 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	}; // process(slab)
 	{
 		// the slabs k_bin's wave of the same number took (the bucket offsets are per workgroup): wave, wave + waves, ...
-		constexpr int BW = FR_BIN_THREADS / 64, EW = FR_EMIT_THREADS / 64;
+		constexpr int BW = FR_BIN_THREADS / 64;
 		const int bin_waves = (int)gridDim.x * BW;
 		// the workgroup's s-th slab: k_bin's wave (s mod BW) of this workgroup took it in its round s / BW
 		auto slab_of = [&](const int s) { return (int)blockIdx.x * BW + s % BW + (s / BW) * bin_waves; };
 		// one slab AHEAD: the next slab's records are in flight while this one's pairs are walked (the kernel's waves spent 73 %
 		// of their time parked on s_waitcnt: a slab's record loads in front of its walk, its stores behind)
+		// (which wave takes the workgroup's q-th slab: whoever asks first -- a counter in LDS, as in k_bin)
+		auto grab = [&]() -> int {
+			uint32_t q_ = 0;
+			if (lane == 0) q_ = atomicAdd(&s_next_slab, 1u);
+			return slab_of(__builtin_amdgcn_readfirstlane((int)q_)); // (grows with q)
+		};
 		SlabIn cur, nxt;
-		int sq = (int)(threadIdx.x >> 6);
-		int slab = slab_of(sq);
+		int slab = grab();
 		if (slab < nslabs) fetch_slab(slab, cur);
 #ifdef FR_EMIT_TIMERS
 		const uint64_t tl0 = wall_clock64();
 #endif
 		for (; slab < nslabs; )
 		{
-			const int next = slab_of(sq + EW); // (grows with s along a wave's sequence: EW >= BW)
+			const int next = grab();
 			const bool more = next < nslabs;
 			if (more) fetch_slab(next, nxt);
 			process(slab, cur);
 			if (more) cur = nxt;
-			sq += EW; slab = next;
+			slab = next;
 #ifdef FR_EMIT_TIMERS
 			tm_slabs++;
 #endif

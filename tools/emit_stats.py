@@ -31,7 +31,7 @@ t = geom[off:off + nw * 32].view(torch.float32).view(nw, 8).cpu().numpy()
 t[:, [0, 1, 2, 3, 6, 7]] *= 0.01  # 10-ns ticks -> us (columns 4, 5 are counts)
 live = t[:, 4] > 0
 print(f"waves {nw}, with slabs {int(live.sum())}; slabs/wave mean {t[live, 4].mean():.2f} max {t[live, 4].max():.0f}; pair steps/wave mean {t[live, 5].mean():.1f} max {t[live, 5].max():.0f}")
-for name, c in (("total to barrier", 0), ("prologue", 1), ("slab loop", 2), ("pair loop part", 6)):
+for name, c in (("total to barrier", 0), ("prologue", 1), ("slab loop", 2), ("pair loop part", 6), ("big splats part", 7)):
     v = t[live, c]
     print(f"{name:18s} us: mean {v.mean():7.2f} p50 {np.percentile(v, 50):7.2f} p90 {np.percentile(v, 90):7.2f} max {v.max():7.2f}")
 print("per slab us (slab loop / slabs): mean %.2f; per pair step us: %.3f" % ((t[live, 2] / t[live, 4]).mean(), t[live, 6].sum() / max(t[live, 5].sum(), 1)))
