@@ -309,6 +309,8 @@ def main():
                     elapsed, bal = float(t[0].item()), float(t[1].item())
                 times.append(elapsed)
                 balanced.append(bal)
+                if os.environ.get("FOVRASTER_BENCH_DEBUG"):
+                    log(f"[bench] repeat {rep}: {elapsed * 1e3:.3f} ms raw, {bal * 1e3:.3f} balanced, slowest frames {np.sort(slots)[-3:] * 1e3}")
                 for row in timer.stage_ms():
                     for k in event_stages:
                         per_stage[k].append(row[k])
@@ -388,7 +390,10 @@ def main():
         rz_mod.OVERLAP_SUCCESSIVE_FRAMES = False
         serial = timed_run(None, ev_stages)
         rz_mod.OVERLAP_SUCCESSIVE_FRAMES = overlap_default
-        headline = timed_run(None, ev_stages) if overlap_default else serial   # render() as a caller gets it: the headline
+        # render() as a caller gets it: the headline. No stage events inside these frames: an event record is a barrier packet with a
+        # cache write-back on its stream, and three frames share the GPU here (with the two stages' four records per frame the same
+        # frames ran 8 % slower)
+        headline = timed_run(None, ()) if overlap_default else serial
         elapsed, spread, timed_ms_overlapped = headline
         timed_ms = serial[2]
         elapsed_raw = headline.raw
@@ -1065,6 +1070,38 @@ def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, 
     elapsed = time.perf_counter() - t0
     fb = [e[0].elapsed_time(e[1]) for e in evs]
     co = [e[1].elapsed_time(e[2]) for e in evs]
+    # the same steps with the dense exchange STARTED INSIDE the backward pass (multiview.OverlappedGradientExchange: the per-Gaussian
+    # pass in four ranges of rows, each range's all-reduce on a communication stream as soon as it is complete): the step's wall
+    # clock and what of the exchange stayed exposed behind the backward pass's own kernels
+    overlapped = None
+    if world > 1 and tr.fuse_activations and not args.row_sparse:
+        named = {"means3D": tr._xyz, "opacities": tr._opacity, "scales": tr._scaling, "rotations": tr._rotation, "sh": tr._features_dc, "sh_rest": tr._features_rest}
+        exposed = []
+
+        def ostep(timed):
+            for p in params:
+                p.grad = None
+            o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
+            loss = l1_ssim_loss(o["render"], target, 0.2)
+            ex = multiview.OverlappedGradientExchange(named, ranges=4)
+            with ex:
+                loss.backward()
+            if timed:
+                exposed.append(ex)
+        for _ in range(max(Wm, 1)):
+            ostep(False)
+        barrier_sync()
+        t1 = time.perf_counter()
+        for i in range(K):
+            ostep(True)
+        barrier_sync()
+        el_o = time.perf_counter() - t1
+        exp_ms = float(np.median([e.exposed_ms() or 0.0 for e in exposed]))
+        t = torch.tensor([el_o, exp_ms], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        overlapped = dict(ms_per_step=round(float(t[0]) / K * 1e3, 4), collective_exposed_ms=round(float(t[1]), 4), ranges=4,
+                          note="dense all-reduce of every range of rows started behind the k_preprocess_bwd launch that completes it; "
+                               "collective_exposed_ms = from the end of the backward pass's kernels to the end of the exchange, on the compute stream")
     if world > 1:
         t = torch.tensor([elapsed, float(np.median(fb)), float(np.median(co))], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -1083,6 +1120,7 @@ def train_mode(args, rank, world, dev, cloud, cam, bg, multiview, render_plain, 
                                    + (", row-sparse gradients" if args.row_sparse else "") + "), gradient sum over ranks (multiview.allreduce_gradients)", "gaussians": args.points, "width": W, "height": H,
                        "parallelism": f"views{world}"},
             "fwd_bwd_ms": round(fbm, 4), "collective_ms": round(com, 4), "views_per_s": round(world * K / elapsed, 3),
+            "overlapped_exchange": overlapped, "collective_exposed_ms": None if overlapped is None else overlapped["collective_exposed_ms"],
             "collective": dict(info or {}, algbw_GBs=None if algbw is None else round(algbw, 2),
                                busbw_GBs=None if algbw is None else round(algbw * 2 * (world - 1) / world, 2))}
     print(json.dumps(_finite(line)), flush=True)

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # (FOVRASTER_LIB: an experiment build of the library, tools/ab_build.sh -- never a different implementation: same ABI check)
 LIB_PATH = os.environ.get("FOVRASTER_LIB") or os.path.join(HERE, "libfovraster_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 VARIANT_ORIGINAL, VARIANT_PCHECK_OBB_SUM, VARIANT_PCHECK_OBB, VARIANT_FOV_PCHECK_OBB = 0, 1, 2, 3
 VARIANT_PCHECK_OBB_MAX, VARIANT_PCHECK_OBB_LWMC, VARIANT_NAIVE_FOV_PCHECK_OBB, VARIANT_MMFR_PCHECK_OBB = 4, 5, 6, 7
@@ -70,7 +70,13 @@ class BackwardArgs(C.Structure):
         ("row_sparse", C.c_int32),
         ("blend_pairs", _FP),
         ("outputs_zeroed", C.c_int32),
+        ("num_ranges", C.c_int32),
+        ("range_done", C.c_void_p),   # RANGE_FN, set through ctypes.cast (a NULL function pointer is the default)
+        ("range_user", C.c_void_p),
     ]
+
+
+RANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int32)  # fr_backward_args.range_done(user, k, row_lo, row_hi)
 
 
 EXPORTS = ("fr_abi_version", "fr_last_error", "fr_event_create", "fr_event_destroy", "fr_event_elapsed_ms", "fr_forward", "fr_backward", "fr_mark_visible", "fr_pack_geom", "fr_pack_colour", "fr_pack_cull", "fr_activate_forward", "fr_activate_backward", "fr_l1_ssim_blocks", "fr_l1_ssim_forward", "fr_l1_ssim_finish", "fr_l1_ssim_backward",

@@ -332,7 +332,27 @@ struct BwdPreArgs {
 	int row_sparse;            // the outputs are COMPACT: row i belongs to the Gaussian vis_list[i] (fr_backward_args.row_sparse)
 	int M0;                    // coefficients in dL_dsh's rows ([., M0, 3]): M, or 1 with split SH storage
 	SmallSet small;            // dense tensors: the narrow ones this kernel writes in whole lines (n == 0: every row on its own)
+	const uint32_t *range_bounds; // fr_backward_args.num_ranges > 1: [K + 1] first visible-list entry of every range of rows (k_range_bounds) ...
+	int range_k;                  // ... and the range this launch covers; -1: the whole list
 };
+
+// The per-Gaussian pass in pieces (fr_backward_args.num_ranges): range k covers the rows (Gaussian indices) [row_lo(k), row_lo(k + 1)),
+// row_lo(k) = (P k / K) rounded down to a multiple of 32 -- a group of SmallSet's whole-line scheme never straddles two ranges. The
+// visible list is in index order, so a range of rows is a range of list entries: out[k] = first entry whose Gaussian index is
+// >= row_lo(k) (one binary search per range: twenty dependent loads, on the helper stream beside k_render_bwd), out[K] = V.
+#define FR_MAX_RANGES 16
+__host__ __device__ __forceinline__ int range_row_lo(int P, int k, int K) { return k >= K ? P : (int)(((long long)P * k / K) & ~31ll); }
+__global__ void k_range_bounds(const uint32_t *vis_list, const uint32_t *vis_count, int P, int K, uint32_t *out)
+{
+	const int k = threadIdx.x;
+	if (k > K) return;
+	const int V = (int)*vis_count;
+	if (k == K) { out[k] = (uint32_t)V; return; }
+	const uint32_t want = (uint32_t)range_row_lo(P, k, K);
+	int lo = 0, hi = V; // first entry in [0, V] with vis_list[entry] >= want
+	while (lo < hi) { const int mid = (lo + hi) >> 1; if (vis_list[mid] < want) lo = mid + 1; else hi = mid; }
+	out[k] = (uint32_t)lo;
+}
 
 // The gradient rows are written once and read by nobody in this library, and so are the zeros of k_fill_zero: both leave with
 // NON-TEMPORAL stores (`global_store ... nt`: the lines are first to go from L2). Plain stores left 1.5 GB of dirty zero lines and
@@ -735,7 +755,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 	__shared__ float s_small[4][64 * FR_SMALL_ROW];
 	static_assert(32 * FR_SMALL_GROUPS * 4 + 8 <= 64 * ROWF, "the image of a range lives in the wave's SH rows");
 	const bool expand = a.small.n != 0;
-	const int V = (int)*a.vis_count;
+	const int V_all = (int)*a.vis_count;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const bool have_sh = a.colors_precomp == nullptr && a.shs != nullptr;
 	const bool split = a.shs_rest != nullptr;
@@ -746,7 +766,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdPreArgs a)
 	const float *src = split ? a.shs_rest : a.shs;
 	float *dst = split ? a.dL_dsh_rest : a.dL_dsh;
 	const int r_in = lane / 15, part = lane - 15 * r_in; // this lane's row of a group of four and its piece of that row
-	for (int base = (blockIdx.x * blockDim.x + wv * 64); base < V; base += gridDim.x * blockDim.x)
+	// (a range of the list: entries [i_lo, V) with V = its end; the whole list otherwise)
+	const int i_lo = a.range_k >= 0 ? (int)a.range_bounds[a.range_k] : 0;
+	const int V = a.range_k >= 0 ? (int)a.range_bounds[a.range_k + 1] : V_all;
+	for (int base = i_lo + (blockIdx.x * blockDim.x + wv * 64); base < V; base += gridDim.x * blockDim.x)
 	{
 		const int i = base + lane;
 		const int idx = i < V ? (int)a.vis_list[i] : 0;
@@ -945,6 +968,8 @@ int launch_backward(const fr_backward_args *a)
 	BinWS bin = carve_bin(a->R, (char *)a->binning);
 	auto mark = [&](int i) { if (a->stage_events && a->stage_events[i]) (void)hipEventRecord((hipEvent_t)a->stage_events[i], stream); };
 	mark(0);
+	const int K = (a->num_ranges > 1 && a->range_done != nullptr && !a->row_sparse && a->P >= 64 * a->num_ranges)
+		? (a->num_ranges < FR_MAX_RANGES ? a->num_ranges : FR_MAX_RANGES) : 1;
 	// The gradient tensors are written in full by this call: their rows are cleared here, on the helper stream, while
 	// k_render_bwd runs on the caller's (1.5 GB of fills at 6 M Gaussians, ~0.3 ms that the reference -- and round 1 --
 	// spend before the backward pass starts).
@@ -965,6 +990,13 @@ int launch_backward(const fr_backward_args *a)
 				if (ax) { (void)hipEventRecord(ax->join, ax->s); (void)hipStreamWaitEvent(stream, ax->join, 0); }
 				return rcf;
 			}
+		}
+		if (K > 1)
+		{
+			// (where every range of rows starts in the visible list: beside the fills, off the critical path)
+			hipLaunchKernelGGL(k_range_bounds, dim3(1), dim3(64), 0, fs, geom.vis_list, geom.slab_ctr + 1, a->P, K, geom.slab_ctr + 8);
+			const int rcb = check_launch("range_bounds", fs, a->debug);
+			if (rcb) { if (ax) { (void)hipEventRecord(ax->join, ax->s); (void)hipStreamWaitEvent(stream, ax->join, 0); } return rcb; }
 		}
 		if (ax) (void)hipEventRecord(ax->join, ax->s); // waited for below, after k_render_bwd has been launched
 		if (a->R > 0)
@@ -994,9 +1026,28 @@ int launch_backward(const fr_backward_args *a)
 	p.vis_list = geom.vis_list; p.vis_count = geom.slab_ctr + 1; p.lrange = geom.lrange; p.raw = a->raw_activations;
 	p.small = small_set(a);
 	p.row_sparse = a->row_sparse; p.M0 = (a->colors_precomp == nullptr && a->shs != nullptr) ? (a->shs_rest ? 1 : a->M) : 0;
+	p.range_bounds = geom.slab_ctr + 8; p.range_k = -1;
 	const int pblocks = (a->P + 255) / 256;
-	hipLaunchKernelGGL(k_preprocess_bwd, dim3(pblocks < 2048 ? pblocks : 2048), dim3(256), 0, stream, p);
-	int rc2 = check_launch("preprocess_bwd", stream, a->debug);
+	int rc2 = FR_OK;
+	if (K > 1)
+	{
+		// one launch per range of rows; behind each the host is told that those rows of every gradient tensor are complete once the
+		// stream gets here (a multi-GPU host starts summing them over its ranks while the later ranges are computed: fovraster.h)
+		for (int k = 0; k < K && !rc2; k++)
+		{
+			p.range_k = k;
+			const int rows = range_row_lo(a->P, k + 1, K) - range_row_lo(a->P, k, K);
+			const int blocks = (rows + 255) / 256;
+			hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048), dim3(256), 0, stream, p);
+			rc2 = check_launch("preprocess_bwd", stream, a->debug);
+			if (!rc2) a->range_done(a->range_user, k, range_row_lo(a->P, k, K), range_row_lo(a->P, k + 1, K));
+		}
+	}
+	else
+	{
+		hipLaunchKernelGGL(k_preprocess_bwd, dim3(pblocks < 2048 ? pblocks : 2048), dim3(256), 0, stream, p);
+		rc2 = check_launch("preprocess_bwd", stream, a->debug);
+	}
 	mark(2);
 	return rc2;
 }

@@ -75,7 +75,8 @@ struct GeomWS {
 	uint32_t *lrange;   // [P]  per item, written by k_bin: 0xffffffff = the item lands in no tile (culled everywhere), else the packed
 	                    //      level range lo | hi<<8 (RF; 0 for the variants without levels)
 	uint32_t *slab_ctr; // [FR_SLAB_CTR_WORDS] {prefiltered violation flag, number of entries in vis_list, workgroups of the cull pass that
-	                    // are done, odd highest level seen}
+	                    // are done, odd highest level seen, workgroups of k_bin that are done (its last one runs the tile scan)};
+	                    // words 8 .. 8 + 16: the backward pass's range bounds (k_range_bounds, fr_backward_args.num_ranges)
 	uint32_t *vis_list; // [P]  indices of the Gaussians that survive the cull pass, increasing
 	uint32_t *vis_seg;  // [P + FR_CROW_PAD] the same indices as k_project's waves leave them: wave w of the cull pass owns the slots
 	                    //      from w * (its chunks) * 64 on and fills them in the order it meets its survivors (its chunks are consecutive)

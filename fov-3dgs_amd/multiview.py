@@ -213,3 +213,111 @@ def allreduce_gradients(params, visible=None, sparse_below=0.4, check_rows=False
     for w in works:
         w.wait()
     return dict(mode="dense", bytes=sum(g.numel() * g.element_size() for g in grads))
+
+
+class OverlappedGradientExchange:
+    """The dense gradient sum of a multi-view training step, STARTED INSIDE the backward pass (round 6; SURVEY.md 8e: the exchange moves
+    1.42 GB per rank at 6 M Gaussians, 2.5-3 ms over xGMI against a 2.3 ms step, and `allreduce_gradients` only starts it when
+    backward() has returned).
+
+        ex = OverlappedGradientExchange({"means3D": pc._xyz, "opacities": pc._opacity, "scales": pc._scaling, "rotations": pc._rotation,
+                                         "sh": pc._features_dc, "sh_rest": pc._features_rest})
+        with ex:
+            loss.backward()
+        # here every p.grad holds the sum over the ranks; ex.exposed_ms() = what of the exchange was NOT hidden behind the backward pass
+
+    How: the rasterizer runs the per-Gaussian half of its backward call (k_preprocess_bwd: 40 % of the call) in `ranges` pieces over
+    increasing ranges of rows and tells this object behind each piece (rasterizer.GRADIENT_RANGE_HOOK; C ABI:
+    fr_backward_args.num_ranges / range_done). Every gradient tensor's rows of that range are then final on the compute stream, zeros
+    included, and their all-reduce goes out on a communication stream that waits for exactly that point: all but the last range's
+    share of the exchange runs beside the rest of the backward pass (RCCL's own kernels take a few CUs; the per-Gaussian pass is bound
+    by HBM's random-row rate, not by CUs).
+    For models whose rasterizer inputs ARE the leaf parameters (raw activations + split SH storage: the reference-shaped model that
+    render() recognises, GaussianCloud with fuse_activations): the gradient tensors of the call then become p.grad as they are. The
+    keys name the rasterizer's inputs; a parameter may be missing (None). PRECONDITION: p.grad is None on entry (no accumulation: the
+    sum is formed in the tensors the backward call allocates). If autograd copied a tensor instead of adopting it, p.grad is set
+    to the summed tensor on exit. One backward call of one rasterizer per `with` block. Works on CPU tensors / gloo as well
+    (synchronous collectives: the tests)."""
+
+    def __init__(self, params, ranges=4, group=None):
+        self.params = {k: v for k, v in params.items() if v is not None}
+        self.ranges, self.group = int(ranges), group
+        self.comm = None
+        self._tensors, self._works, self._events = None, [], None
+        self.calls = []
+
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def __enter__(self):
+        from . import rasterizer as rz
+        for k, p_ in self.params.items():
+            if p_.grad is not None:
+                raise RuntimeError(f"OverlappedGradientExchange: {k}.grad must be None on entry (the sum is formed in the backward call's own tensors)")
+        self._tensors, self._works, self.calls = None, [], []
+        if self._active():
+            self._saved = (rz.GRADIENT_RANGE_HOOK, rz.GRADIENT_RANGES)
+            rz.GRADIENT_RANGE_HOOK, rz.GRADIENT_RANGES = self._on_range, self.ranges
+        return self
+
+    def _on_range(self, k, lo, hi, grads):
+        """rows [lo, hi) of every tensor of `grads` are complete on the current stream once it gets here: sum them over the ranks"""
+        if self._tensors is None:
+            self._tensors = grads
+        elif self._tensors is not grads and k == 0:
+            raise RuntimeError("OverlappedGradientExchange: a second backward call inside one `with` block")
+        self.calls.append((k, lo, hi))
+        if hi <= lo:
+            return
+        ts = [t for name, t in grads.items() if t is not None and name in self.params]
+        if ts and ts[0].is_cuda:
+            dev = ts[0].device
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(dev)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                for t in ts:
+                    self._works.append(dist.all_reduce(t[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    t.record_stream(self.comm)
+        else:
+            for t in ts:
+                dist.all_reduce(t[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+
+    def __exit__(self, exc_type, exc, tb):
+        from . import rasterizer as rz
+        if self._active():
+            rz.GRADIENT_RANGE_HOOK, rz.GRADIENT_RANGES = self._saved
+        if exc_type is not None or self._tensors is None:
+            for w in self._works:
+                w.wait()
+            return False
+        cuda = any(t is not None and t.is_cuda for t in self._tensors.values())
+        if cuda:
+            dev = next(t.device for t in self._tensors.values() if t is not None)
+            cur = torch.cuda.current_stream(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)                      # the backward pass's own kernels end here ...
+            for w in self._works:
+                w.wait()                        # (the current stream waits for the collective's stream)
+            if self.comm is not None:
+                cur.wait_stream(self.comm)
+            e1.record(cur)                      # ... and here the sums are in: the gap is what the exchange was not hidden behind
+            self._events = (e0, e1)
+        with torch.no_grad():
+            for name, p_ in self.params.items():
+                t = self._tensors.get(name)
+                if t is None or p_.grad is None:
+                    continue
+                if p_.grad.data_ptr() != t.data_ptr():   # autograd made its own copy (possibly before the sum was in): hand it the summed tensor
+                    p_.grad = t.view_as(p_)
+        return False
+
+    def exposed_ms(self):
+        """milliseconds between the end of the backward pass's kernels and the end of the exchange on the compute stream (GPU only;
+        synchronises on the second event)"""
+        if self._events is None:
+            return None
+        self._events[1].synchronize()
+        return float(self._events[0].elapsed_time(self._events[1]))

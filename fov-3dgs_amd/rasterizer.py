@@ -604,6 +604,14 @@ def prefill_gradients(dev, P, M0, Mrest, has_cov, has_col, has_sh, radii=None):
     return g, ev
 
 
+# Extension (multi-GPU training): a callable(k, row_lo, row_hi, grads) that fr_backward calls on the host behind every one of
+# GRADIENT_RANGES pieces of its per-Gaussian pass -- `grads` = {"means3D", "opacities", "scales", "rotations", "sh", "sh_rest"} -> the dense
+# gradient tensors of the call (None where there is none), rows [row_lo, row_hi) of each complete on the current stream once it gets
+# there. Installed by multiview.OverlappedGradientExchange; None = one piece, no calls.
+GRADIENT_RANGE_HOOK = None
+GRADIENT_RANGES = 4
+
+
 def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                      grad_out_color, sh, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest=None,
                      want_cov3D_grad=False, want_color_grad=False, raw_activations=False, row_sparse=False, num_candidates=0, blend_pairs=None,
@@ -682,9 +690,28 @@ def _backward_native(variant, rs, means3D, radii, colors_precomp, opacities, sca
             if blend_pairs is not None:
                 keep.append(blend_pairs)
                 a.blend_pairs = blend_pairs.data_ptr()
+            hook, hook_errors = GRADIENT_RANGE_HOOK, []
+            if hook is not None and not row_sparse:
+                # the per-Gaussian half of the call in pieces over ranges of rows; behind each piece the hook is told that those rows of
+                # every gradient tensor are complete on this stream (fovraster.h: fr_backward_args.range_done) -- multiview's
+                # OverlappedGradientExchange starts their all-reduce on its communication stream while the later pieces run
+                grads = {"means3D": dL_dmeans3D, "opacities": dL_dopacity, "scales": dL_dscales, "rotations": dL_drotations,
+                         "sh": dL_dsh if M else None, "sh_rest": dL_dsh_rest}
+
+                def _range_done(_user, k, lo, hi):
+                    try:
+                        hook(int(k), int(lo), int(hi), grads)
+                    except Exception as ex:  # (never let an exception cross the C frame)
+                        hook_errors.append(ex)
+                cb = _native.RANGE_FN(_range_done)
+                keep.append(cb)
+                a.num_ranges = int(GRADIENT_RANGES)
+                a.range_done = C.cast(cb, C.c_void_p)
             rc = lib.fr_backward(C.byref(a))
             if rc != 0:
                 raise RuntimeError(f"fovraster backward failed ({rc}): {_native.last_error()}")
+            if hook_errors:
+                raise hook_errors[0]
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     return out + (dL_dsh_rest,) if dL_dsh_rest is not None else out
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 8
+#define FR_ABI_VERSION 9
 
 /* rasterizer variants (the reference ships them as separate extensions; `cuda_type` strings of
  * fov3dgs/gaussian_wrapper.py:11-23) */
@@ -225,6 +225,17 @@ typedef struct fr_backward_args {
 	 * 6 M-Gaussian model's gradients beside the work BETWEEN its forward and backward calls (the image loss) instead of beside
 	 * k_render_bwd, which pays 0.11 ms for the company. */
 	int32_t outputs_zeroed;
+	/* optional (extension; multi-GPU training): the per-Gaussian half of the call in `num_ranges` > 1 pieces over
+	 * increasing, disjoint ranges of ROWS (Gaussian indices) that cover [0, P). As soon as the kernels that complete range k are
+	 * enqueued on `stream` -- every gradient tensor's rows [row_lo, row_hi) are then final once the stream gets there, zeros included --
+	 * the HOST function range_done(range_user, k, row_lo, row_hi) is called (from inside fr_backward, on the calling thread): a host
+	 * records an event there and starts summing those rows over its ranks on a communication stream while the later ranges are still
+	 * being computed. The ranges follow the cull pass's per-wave regions of the forward call (the visible list is in index order, so
+	 * a range of rows is a range of list entries): about equal shares of the INDEX range, not of the visible Gaussians. Dense
+	 * gradients only (ignored with row_sparse). 0 / 1 or range_done == NULL: one piece, no call. */
+	int32_t num_ranges;
+	void (*range_done)(void *user, int32_t k, int32_t row_lo, int32_t row_hi);
+	void *range_user;
 } fr_backward_args;
 
 int fr_abi_version(void);

@@ -106,8 +106,10 @@ FULL_FRAME_GRAD_BUDGETS = {
     # budget = measured x 1.25, and at least measured + 3e-5 (the float atomics' order moves a handful of rows from run to run)
     "S-6M": {"dL_dopacity": 1.7e-3, "dL_dmean2D": 5e-5, "dL_dcolor": 3e-5, "dL_dmean3D": 4e-5, "dL_dcov3D": 1.9e-4, "dL_dsh": 5e-5, "dL_dscale": 1.9e-4,
              "dL_drot": 1.2e-4, "contributions": 6e-5},
-    # ring views 2 / 5 / 7 of S-6M (round 6; BASELINE config 5's per-rank frames), worst of the three x 1.25 -- PLACEHOLDER until view 7 is measured
-    "S-6M ring": {"dL_dopacity": 2.0e-3, "dL_dmean2D": 6e-5, "dL_dcolor": 3e-5, "dL_dmean3D": 6e-5, "dL_dcov3D": 1.9e-4, "dL_dsh": 5e-5, "dL_dscale": 2.2e-4,
+    # ring views 2 / 5 / 7 of S-6M (round 6; BASELINE config 5's per-rank frames): measured worst of the three views -- opacity 1.58e-3, cov3D 1.91e-4,
+    # scale 1.74e-4, rot 1.07e-4, contributions 9.2e-5 (view 7, behind its 14 flipped image values), mean2D / mean3D 3.8e-5, sh / colour 7.6e-6 -- x 1.25,
+    # and at least measured + 3e-5 (the float atomics' order moves a handful of rows from run to run)
+    "S-6M ring": {"dL_dopacity": 2.0e-3, "dL_dmean2D": 7e-5, "dL_dcolor": 4e-5, "dL_dmean3D": 7e-5, "dL_dcov3D": 2.4e-4, "dL_dsh": 4e-5, "dL_dscale": 2.2e-4,
                   "dL_drot": 1.4e-4, "contributions": 1.2e-4},
     "S-6M-T": {"dL_dopacity": 2.9e-3, "dL_dmean2D": 8e-5, "dL_dcolor": 3e-5, "dL_dmean3D": 6e-5, "dL_dcov3D": 5e-5, "dL_dsh": 4e-5, "dL_dscale": 7e-5,
                "dL_drot": 8e-5, "contributions": 1.2e-4},

@@ -477,6 +477,64 @@ def test_narrow_gradient_tensors_with_clustered_visibility(P):
         assert np.abs(dense[k]).max() > 0, k
 
 
+@pytest.mark.parametrize("P", (20000, 777))
+def test_backward_in_ranges_of_rows(P):
+    """fr_backward_args.num_ranges / range_done (round 6; rasterizer.GRADIENT_RANGE_HOOK): the per-Gaussian half of the backward call in
+    four pieces over increasing ranges of rows, the host told behind each piece. The ranges tile [0, P) in order, start on multiples of
+    32 (a group of the whole-line scheme never straddles two) and the gradients -- clustered visibility, every tensor NaN before the
+    call -- are those of the call in one piece. A tensor snapshot taken INSIDE the callback (a copy enqueued on the stream right
+    there) already holds the final rows of its range: that is what lets a communication stream start on them."""
+    _need_gpu()
+    from fov3dgs_amd import rasterizer as rz
+    from fov3dgs_amd.gaussian_renderer import render
+    dev = "cuda:0"
+    cam = syn.camera_1k(200, 136).to(dev)
+    bg = torch.tensor([0.1, 0.0, 0.2], device=dev)
+
+    class Pipe:
+        debug = False
+    hidden = np.zeros(P, bool)
+    if P > 1000:
+        hidden[:3000] = True
+        hidden[4990:5100] = True        # a hidden run across the first range's end (P / 4 = 5000 -> 4992)
+        hidden[9000:17000] = True       # two whole ranges with ...
+        hidden[9000:17000:701] = False  # ... single visible rows 701 apart
+    w = None
+    res = []
+    for ranged in (False, True):
+        cloud = small_cloud(P=P, seed=31)
+        with torch.no_grad():
+            cloud._xyz[torch.from_numpy(hidden), 2] = -6.0
+        cloud = cloud.to(dev).requires_grad_(True)
+        cloud.fuse_activations = True
+        out = render(cam, cloud, Pipe(), bg, cuda_type="pcheck_obb_sum")
+        if w is None:
+            w = torch.randn_like(out["render"])
+        calls, snaps = [], []
+
+        def hook(k, lo, hi, grads):
+            calls.append((k, lo, hi))
+            snaps.append({n: t[lo:hi].clone() for n, t in grads.items() if t is not None})
+        rz.GRADIENT_RANGE_HOOK, rz.GRADIENT_RANGES = (hook if ranged else None), 4
+        try:
+            (out["render"] * w).sum().backward()
+        finally:
+            rz.GRADIENT_RANGE_HOOK = None
+        torch.cuda.synchronize()
+        grads = dict(means3D=cloud._xyz.grad, scales=cloud._scaling.grad, rotations=cloud._rotation.grad, opacities=cloud._opacity.grad,
+                     sh=cloud._features_dc.grad, sh_rest=cloud._features_rest.grad)
+        res.append(({k: g.clone() for k, g in grads.items()}, calls, snaps))
+    (one, c0, _), (four, calls, snaps) = res
+    assert c0 == [] and [c[0] for c in calls] == [0, 1, 2, 3]
+    assert calls[0][1] == 0 and calls[-1][2] == P and all(a[2] == b[1] for a, b in zip(calls, calls[1:]))
+    assert all(lo % 32 == 0 for _, lo, _ in calls) and all(hi > lo for _, lo, hi in calls)
+    for k in one:
+        assert torch.isfinite(four[k]).all(), k
+        check_grad(four[k].cpu().numpy(), one[k].cpu().numpy(), "backward in four ranges vs one piece: " + k)
+        for (kk, lo, hi), snap in zip(calls, snaps):
+            assert torch.equal(snap[k], four[k][lo:hi]), (k, kk)   # the rows of a range were final when the host was told
+
+
 @pytest.mark.parametrize("variant", ["original", "pcheck_obb_sum"])
 def test_raw_parameters_in_the_kernels_match_activate_then_render(variant):
     """fr_forward_args.raw_activations: exp / normalize / sigmoid applied inside the kernels give the image of

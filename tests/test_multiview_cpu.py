@@ -73,6 +73,45 @@ def _worker(rank, world, port, q):
     assert torch.equal(sp[0].grad, want0) and torch.equal(sp[1].grad[:, 0, 0], 2 * want0[:, 0])
     # a union that covers most rows falls back to the dense exchange
     assert multiview.allreduce_gradients(sp, visible=torch.ones(40, dtype=torch.bool))["mode"] == "dense"
+    # the exchange STARTED INSIDE the backward pass (OverlappedGradientExchange): the rasterizer reports every range of rows as it
+    # completes it (here the test plays the rasterizer's part: rasterizer.GRADIENT_RANGE_HOOK is what fr_backward's callback calls);
+    # autograd either adopts the call's tensors as p.grad or copies them -- both end with the sum over the ranks, equal to the
+    # dense exchange of the same gradients
+    from fov3dgs_amd import rasterizer as rz
+    Pn = 1000
+    gen = torch.Generator().manual_seed(100 + rank)
+    for adopt in (True, False):
+        named = {"means3D": torch.nn.Parameter(torch.zeros(Pn, 3)), "opacities": torch.nn.Parameter(torch.zeros(Pn, 1)),
+                 "sh": torch.nn.Parameter(torch.zeros(Pn, 1, 3)), "sh_rest": torch.nn.Parameter(torch.zeros(Pn, 15, 3)), "scales": None}
+        grads = {k: (None if v is None else torch.randn(v.shape, generator=gen)) for k, v in named.items()}
+        grads["rotations"] = torch.randn(Pn, 4, generator=gen)  # a tensor of the call that is nobody's parameter here: not exchanged
+        mine = {k: (None if v is None else v.clone()) for k, v in grads.items()}
+        ex = multiview.OverlappedGradientExchange(named, ranges=4)
+        assert rz.GRADIENT_RANGE_HOOK is None
+        with ex:
+            assert rz.GRADIENT_RANGE_HOOK is not None and rz.GRADIENT_RANGES == 4
+            bounds = [0, 224, 480, 736, Pn]
+            for k in range(4):
+                rz.GRADIENT_RANGE_HOOK(k, bounds[k], bounds[k + 1], grads)
+            for k_, p_ in named.items():      # what autograd does when backward() returns
+                if p_ is not None:
+                    p_.grad = grads[k_] if adopt else grads[k_].clone()
+        assert rz.GRADIENT_RANGE_HOOK is None and ex.calls == [(k, bounds[k], bounds[k + 1]) for k in range(4)]
+        ref = [torch.nn.Parameter(torch.zeros_like(v)) for v in named.values() if v is not None]
+        for p_, k_ in zip(ref, [k for k, v in named.items() if v is not None]):
+            p_.grad = mine[k_].clone()
+        multiview.allreduce_gradients(ref)
+        for p_, k_ in zip(ref, [k for k, v in named.items() if v is not None]):
+            assert torch.equal(named[k_].grad, p_.grad), (adopt, k_)
+        assert torch.equal(grads["rotations"], mine["rotations"])
+    try:
+        busy = {"means3D": torch.nn.Parameter(torch.zeros(4, 3))}
+        busy["means3D"].grad = torch.zeros(4, 3)
+        with multiview.OverlappedGradientExchange(busy):
+            pass
+        raise AssertionError("a gradient that exists on entry must be refused")
+    except RuntimeError:
+        pass
     q.put((rank, views, None if gathered is None else [g.mean().item() for g in gathered],
            allg.mean(dim=(1, 2, 3)).tolist(), [p.grad.mean().item() for p in params]))
     dist.barrier()

@@ -75,6 +75,34 @@ def _worker(rank, world, port, q):
                 # float atomics make a view's gradient sums order-dependent in the last bits; nothing else differs
                 assert err < 2e-5, (mode, i, err)
             assert float(want.abs().max()) > 0
+        # the same sum STARTED INSIDE the backward pass (multiview.OverlappedGradientExchange; round 6): a model whose rasterizer inputs
+        # are its leaf parameters (raw activations, split SH), the per-Gaussian pass in four ranges of rows, every range's all-reduce on
+        # a communication stream as soon as the range is complete
+        def fused_view(view, exchange):
+            cloud = cloud_cpu.to(dev).requires_grad_(True)
+            cloud.fuse_activations = True
+            cam = syn.camera_ring(view, 8, W, H).to(dev)
+            target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + view))
+            out = render(cam, cloud, _Pipe(), torch.zeros(3, device=dev), cuda_type="pcheck_obb_sum")
+            loss = l1_ssim_loss(out["render"], target, 0.2)
+            if exchange:
+                ex = multiview.OverlappedGradientExchange({"means3D": cloud._xyz, "opacities": cloud._opacity, "scales": cloud._scaling,
+                                                           "rotations": cloud._rotation, "sh": cloud._features_dc, "sh_rest": cloud._features_rest}, ranges=4)
+                with ex:
+                    loss.backward()
+                assert [c[0] for c in ex.calls] == [0, 1, 2, 3] and ex.calls[-1][2] == cloud._xyz.shape[0], ex.calls
+                assert ex.exposed_ms() is not None
+            else:
+                loss.backward()
+            torch.cuda.synchronize()
+            return cloud
+        summed = fused_view(rank, True)
+        a_, b_ = fused_view(rank, False), fused_view(1 - rank, False)
+        for i, (ps, pa, pb) in enumerate(zip(summed.parameters(), a_.parameters(), b_.parameters())):
+            want = pa.grad + pb.grad
+            err = float((ps.grad - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+            worst = max(worst, err)
+            assert err < 2e-5 and float(want.abs().max()) > 0, ("overlapped", i, err)
         q.put((rank, int(vis.sum()), worst, None))
         dist.barrier()
         dist.destroy_process_group()
