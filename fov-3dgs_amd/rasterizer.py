@@ -11,6 +11,7 @@ Mirrors, per variant, the Python wrapper each reference extension ships
 All tensors must live on a ROCm device; there is no CPU path. Output / workspace tensors are
 allocated here with torch (the C library never allocates device memory).
 """
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -60,7 +61,7 @@ _small_copies = {}
 SMALL_COPY_CACHE = True  # set to False to copy the per-call camera tensors on every call
 
 
-def _f32_small(t, device):
+def _f32_small(t, device, stream_handle=None):
     """_f32 for the per-call camera tensors (viewmatrix, projmatrix, campos, bg: a few floats each). The reference's cameras
     keep world_view_transform as a TRANSPOSED view (scene/cameras.py:54), so `.contiguous()` is a copy kernel on the stream
     at the head of every frame (~6 us of a 0.7 ms frame, twice); the copy is kept for as long as the caller hands over the
@@ -75,7 +76,7 @@ def _f32_small(t, device):
         return t
     if t.numel() > 64 or not SMALL_COPY_CACHE:
         return _f32(t, device)
-    key = (id(t), torch.cuda.current_stream(device).cuda_stream)
+    key = (id(t), torch.cuda.current_stream(device).cuda_stream if stream_handle is None else stream_handle)  # (the lookup costs 6 us of host time)
     ent = _small_copies.get(key)
     sig = (t._version, t.data_ptr(), t.stride(), t.dtype, t.device)
     if ent is not None and ent[0]() is t and ent[1] == sig and (t.is_cuda or torch.equal(ent[3], t)):
@@ -165,7 +166,7 @@ class _Lease:
             pass
 
 
-def _workspaces_for(device, needs_graph):
+def _workspaces_for(device, needs_graph, stream_handle=None):
     """-> (workspaces, lease). Calls without an autograd graph use a persistent grow-only set per (device, current stream, host
     thread) -- the C ABI is thread-compatible and two frames may be in flight on two streams (begin / finish), so neither two
     threads nor two streams ever share buffers; a call is only valid until the next call on the same stream of the same
@@ -179,7 +180,7 @@ def _workspaces_for(device, needs_graph):
         idle = _pooled_ws.get(device)
         ws = idle.pop() if idle else _Workspaces(device)
         return ws, _Lease(ws)
-    key = (device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
+    key = (device, torch.cuda.current_stream(device).cuda_stream if stream_handle is None else stream_handle, threading.get_ident())
     ws = _persistent_ws.get(key)
     if ws is None:
         ws = _persistent_ws[key] = _Workspaces(device)
@@ -302,14 +303,18 @@ class FrameInFlight:
         self.ws, self.lease, self.counts, self.contribs, self.handle = ws, lease, counts, contribs, handle
         self.device, self.stream = device, stream
 
-    def finish(self):
-        """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease)"""
+    def finish(self, on_stream=False):
+        """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer[, gaussians_count, contributions], lease)
+        on_stream: the frame's stream IS the current one (the caller says so: saves two context managers)"""
         handle, self.handle = self.handle, None
         if handle is None:
             raise RuntimeError("fovraster: frame already finished")
         # (the binning workspace callback allocates: on the frame's own stream, whatever stream the caller is on by now)
-        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+        if on_stream:
             rc = self.lib.fr_forward_finish(handle)
+        else:
+            with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                rc = self.lib.fr_forward_finish(handle)
         if rc != 0:
             raise RuntimeError(f"fovraster forward failed ({rc}): {_native.last_error()}")
         ws = self.ws
@@ -329,8 +334,10 @@ class FrameInFlight:
 
 def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
-                   sh_rest=None, packed=None, cur_level=0.0, raw_activations=False, list_consumed=None, no_stats=False, blend_pairs=None):
-    """First half of a forward call on the current stream -> FrameInFlight. persistent=True: the workspaces are the grow-only
+                   sh_rest=None, packed=None, cur_level=0.0, raw_activations=False, list_consumed=None, no_stats=False, blend_pairs=None,
+                   on_stream=None):
+    """First half of a forward call on the current stream -> FrameInFlight. on_stream: the caller HAS made this stream (and its
+    device) current and says so (saves the lookups). persistent=True: the workspaces are the grow-only
     set of this (device, stream, thread) (valid until the next call there); otherwise they stay reserved for as long as the
     `lease` of the result is referenced."""
     lib = _native.load()
@@ -342,19 +349,21 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
     H, W = int(rs.image_height), int(rs.image_width)
     a = _native.ForwardArgs()
     keep = []
+    stream = torch.cuda.current_stream(dev) if on_stream is None else on_stream  # (looked up once: 6 us of host time a call)
+    sh_ = stream.cuda_stream
 
     def put(name, t, small=False):
-        t = _f32_small(t, dev) if small else _f32(t, dev)
+        t = _f32_small(t, dev, sh_) if small else _f32(t, dev)
         keep.append(t)
         setattr(a, name, _ptr(t))
         return t
 
-    with torch.cuda.device(dev):
+    with (contextlib.nullcontext() if on_stream is not None else torch.cuda.device(dev)):
         # both outputs are written in full by the kernels (every pixel by the blend, every radius by the cull pass
         # or the projection kernel; the P == 0 path fills the image itself): no zero-fill kernels at the head of the frame
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        ws, lease = _workspaces_for(dev, not persistent)
+        ws, lease = _workspaces_for(dev, not persistent, sh_)
         counts = contribs = None
         a.variant = variant
         a.P, a.D = P, int(rs.sh_degree)
@@ -368,8 +377,7 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
         a.gaze_x, a.gaze_y, a.alpha = float(gaze[0]), float(gaze[1]), float(alpha)
         a.cur_level = float(cur_level)
         a.raw_activations = int(bool(raw_activations))
-        stream = torch.cuda.current_stream(dev)
-        a.stream = stream.cuda_stream
+        a.stream = sh_
         put("background", rs.bg, small=True)
         put("means3D", means3D)
         put("colors_precomp", colors_precomp)
@@ -469,6 +477,7 @@ class _OverlapState:
         self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
         self.done = [None] * n       # event behind the last frame of each internal stream
         self.must_wait = [None] * n  # event on the caller's stream each internal stream still has to wait for
+        self.events = [torch.cuda.Event() for _ in range(n)]  # (re-recorded every turn: the caller's stream waited for the previous record when it was made)
         self.turn = 0
         self.sig = None
         self.refs = None
@@ -510,10 +519,20 @@ def _forward_overlapped(args, kw):
     if st.must_wait[i] is not None:
         own.wait_event(st.must_wait[i])
         st.must_wait[i] = None
-    with torch.cuda.stream(own):
-        res = _forward_begin(*args, **kw).finish()
-        done = torch.cuda.Event()
-        done.record(own)
+    # (torch.cuda.stream()'s context manager costs 10 us of host time a call, and the host is on this scheme's critical path: the next
+    # frame's head is enqueued only after this call has returned)
+    done = st.events[i]
+    if torch.cuda.current_device() == dev.index:
+        torch.cuda.set_stream(own)
+        try:
+            res = _forward_begin(*args, on_stream=own, **kw).finish(on_stream=True)
+            done.record(own)
+        finally:
+            torch.cuda.set_stream(cur)
+    else:  # (tensors on another device than the current one: the context managers restore both)
+        with torch.cuda.device(dev), torch.cuda.stream(own):
+            res = _forward_begin(*args, **kw).finish()
+            done.record(own)
     st.done[i] = done
     cur.wait_event(done)  # everything the caller enqueues from here on sees the finished frame
     for t in res:
