@@ -335,22 +335,38 @@ class FrameInFlight:
 def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                    shs_dcs=None, highest_levels=None, gaze=(0.5, 0.5), alpha=0.05, persistent=False, loss_map=None,
                    sh_rest=None, packed=None, cur_level=0.0, raw_activations=False, list_consumed=None, no_stats=False, blend_pairs=None,
-                   on_stream=None):
+                   on_stream=None, reuse=None, reuse_key=None):
     """First half of a forward call on the current stream -> FrameInFlight. on_stream: the caller HAS made this stream (and its
     device) current and says so (saves the lookups). persistent=True: the workspaces are the grow-only
     set of this (device, stream, thread) (valid until the next call there); otherwise they stay reserved for as long as the
-    `lease` of the result is referenced."""
+    `lease` of the result is referenced.
+    reuse / reuse_key (the overlapped inference path): `reuse` is a dict the caller keeps per internal stream; when its "key" equals
+    reuse_key -- the caller vouches that every tensor, scalar and flag of the call is what it was at the previous call on that stream --
+    the argument struct made then is used again with only the gaze and the two output tensors replaced (filling it is 20 checked
+    tensor arguments: 40 us of host time on a path where the host is the bottleneck)."""
     lib = _native.load()
-    _require_gpu(means3D)
-    if means3D.dim() != 2 or means3D.size(1) != 3:
-        raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = means3D.device
     P = means3D.size(0)
     H, W = int(rs.image_height), int(rs.image_width)
-    a = _native.ForwardArgs()
-    keep = []
     stream = torch.cuda.current_stream(dev) if on_stream is None else on_stream  # (looked up once: 6 us of host time a call)
     sh_ = stream.cuda_stream
+    if reuse is not None and reuse_key is not None and reuse.get("key") == reuse_key and on_stream is not None:
+        a, keep, ws = reuse["a"], reuse["keep"], reuse["ws"]
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        a.gaze_x, a.gaze_y = float(gaze[0]), float(gaze[1])
+        a.out_color, a.radii = color.data_ptr(), radii.data_ptr()
+        a.stage_events = _stage_events_hook() if _stage_events_hook is not None else None
+        handle = C.c_void_p()
+        rc = lib.fr_forward_begin(C.byref(a), C.byref(handle))
+        if rc != 0:
+            raise RuntimeError(f"fovraster forward failed ({rc}): {_native.last_error()}")
+        return FrameInFlight(lib, a, keep, color, radii, ws, None, None, None, handle, dev, stream)
+    _require_gpu(means3D)
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    a = _native.ForwardArgs()
+    keep = []
 
     def put(name, t, small=False):
         t = _f32_small(t, dev, sh_) if small else _f32(t, dev)
@@ -424,6 +440,10 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
         rc = lib.fr_forward_begin(C.byref(a), C.byref(handle))
         if rc != 0:
             raise RuntimeError(f"fovraster forward failed ({rc}): {_native.last_error()}")
+    if reuse is not None:
+        reuse.clear()
+        if reuse_key is not None and counts is None and lease is None:  # (no per-call outputs beside the image and the radii)
+            reuse.update(key=reuse_key, a=a, keep=keep, ws=ws)
     return FrameInFlight(lib, a, keep, color, radii, ws, lease, counts, contribs, handle, dev, stream)
 
 
@@ -478,6 +498,7 @@ class _OverlapState:
         self.done = [None] * n       # event behind the last frame of each internal stream
         self.must_wait = [None] * n  # event on the caller's stream each internal stream still has to wait for
         self.events = [torch.cuda.Event() for _ in range(n)]  # (re-recorded every turn: the caller's stream waited for the previous record when it was made)
+        self.reuse = [dict() for _ in range(n)]  # per stream: the argument struct of its previous frame (_forward_begin)
         self.turn = 0
         self.sig = None
         self.refs = None
@@ -522,10 +543,15 @@ def _forward_overlapped(args, kw):
     # (torch.cuda.stream()'s context manager costs 10 us of host time a call, and the host is on this scheme's critical path: the next
     # frame's head is enqueued only after this call has returned)
     done = st.events[i]
+    # everything else a call is made of: with the same tensors AND the same scalars as the previous call on this internal stream the
+    # argument struct is used again
+    rkey = None if outputs else (sig, args[0], int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
+                                 int(rs.sh_degree), bool(rs.prefiltered), tuple(sorted((k, v) for k, v in kw.items() if isinstance(v, (int, float, bool)))),
+                                 args[-1] if isinstance(args[-1], float) else None, id(kw.get("packed")))
     if torch.cuda.current_device() == dev.index:
         torch.cuda.set_stream(own)
         try:
-            res = _forward_begin(*args, on_stream=own, **kw).finish(on_stream=True)
+            res = _forward_begin(*args, on_stream=own, reuse=st.reuse[i], reuse_key=rkey, **kw).finish(on_stream=True)
             done.record(own)
         finally:
             torch.cuda.set_stream(cur)
@@ -971,6 +997,12 @@ def _make_fov():
     def rasterize_gaussians(means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations,
                             cov3Ds_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha, blending,
                             packed=None):
+        if not torch.is_grad_enabled() and not raster_settings.debug:
+            # (inference: no graph to build -- the autograd machinery around an inference-only extension is 15 us of host time a
+            # frame on a path where the host sets the pace, see OVERLAP_SUCCESSIVE_FRAMES)
+            res = _forward_native(variant_id, raster_settings, means3D, shs_rest, colors_precomp, opacities, scales, rotations,
+                                  cov3Ds_precomp, shs_dcs, highest_levels, _gaze_pair(gazeArray), float(alpha), persistent=True, packed=packed)
+            return res[1], res[2]
         return _RasterizeGaussians.apply(means3D, means2D, shs_rest, colors_precomp, opacities, scales, rotations,
                                          cov3Ds_precomp, raster_settings, shs_dcs, highest_levels, gazeArray, alpha,
                                          blending, packed)
