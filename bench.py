@@ -36,6 +36,7 @@ Besides `value` the line carries
 gradients are summed over ranks; reports fwd_bwd_ms and collective_ms.
 """
 import argparse
+import gc
 import hashlib
 import json
 import math
@@ -289,6 +290,9 @@ def main():
                 barrier_sync()
                 timer = StageTimer(K, stages=event_stages)
                 slots = np.zeros(K)
+                gc_was = gc.isenabled()
+                if os.environ.get("FOVRASTER_BENCH_GC") != "1":
+                    gc.disable()  # (as timeit does: a collection of this process's many objects in the middle of a frame is not the rasterizer's time)
                 t_start = t_prev = time.perf_counter()
                 with timer:
                     for i in range(K):
@@ -304,6 +308,8 @@ def main():
                         pending = None
                 barrier_sync()
                 t_end = time.perf_counter()
+                if gc_was:
+                    gc.enable()
                 elapsed = t_end - t_start
                 # a call returns once its instance count is in: slot i holds frame i's head and frame i - 1's tail. The last frame's
                 # tail (drained by the synchronize above) goes to slot 0, which had no tail in front of it: sum(slots) == elapsed.

@@ -48,6 +48,7 @@ class ForwardArgs(C.Structure):
         ("list_consumed", _FP),
         ("no_stats", C.c_int32),
         ("blend_pairs", _FP),
+        ("no_helper_streams", C.c_int32),
     ]
 
 

@@ -261,7 +261,7 @@ int fr_forward_begin(fr_forward_args *a, fr_frame **out)
 	// image (RF) and the training variants' two statistics arrays (7 + 6 us at the head of a 1080p foveated frame when they ran in
 	// front of it) -- beside the cull / binning kernels; only the blend kernel at the END of the frame needs them and waits
 	// (fr_forward_finish).
-	f->ax = !a->debug ? aux_stream(stream) : nullptr;
+	f->ax = (!a->debug && !a->no_helper_streams) ? aux_stream(stream) : nullptr;
 	hipStream_t fill_stream = stream;
 	const bool stats = has_stats(a->variant) && !a->no_stats;
 	if (f->ax && (c.fov_split || stats))

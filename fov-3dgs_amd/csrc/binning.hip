@@ -164,7 +164,7 @@ int launch_tile_sort(FwdCtx &c)
 	const int h4 = c.heavy4, h8 = c.heavy8;
 	const int longest = c.a->max_tile_instances;
 	// long lists exist: the short ones are sorted meanwhile on the helper stream
-	AuxStream *ax = (h4 > 0 && !serial && !c.a->debug) ? aux_stream(c.stream) : nullptr;
+	AuxStream *ax = (h4 > 0 && !serial && !c.a->debug && !c.a->no_helper_streams) ? aux_stream(c.stream) : nullptr;
 	// (measured on the S-6M frames, stage time: this split 88 us; the 2048..4095 class on the helper stream too 94; on a third
 	// stream 96; the 8192..16383 class -- a handful of workgroups that need a whole CU's LDS each -- on a third stream 95: the
 	// stage is bound by the sum of the work, not by a chain)

@@ -172,6 +172,11 @@ typedef struct fr_forward_args {
 	 * counted per level state. Cleared by the call. The unit the blend kernels' VALU time is proportional to (bench.py /
 	 * profiles: vector instructions per blended pair). */
 	uint32_t *blend_pairs;
+	/* != 0: every kernel and fill of the frame goes to `stream` itself -- no helper streams (by default the library forks the image /
+	 * statistics fills and the sort of the short lists onto two helper streams of its own per launch stream, which pays off for ONE
+	 * frame at a time). A host that keeps several frames in flight on several streams sets it: a process's streams share a handful of
+	 * hardware queues (four by default), and a frame's helper stream that lands in another frame's queue serialises the two. */
+	int32_t no_helper_streams;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,
@@ -230,9 +235,9 @@ typedef struct fr_backward_args {
 	 * enqueued on `stream` -- every gradient tensor's rows [row_lo, row_hi) are then final once the stream gets there, zeros included --
 	 * the HOST function range_done(range_user, k, row_lo, row_hi) is called (from inside fr_backward, on the calling thread): a host
 	 * records an event there and starts summing those rows over its ranks on a communication stream while the later ranges are still
-	 * being computed. The ranges follow the cull pass's per-wave regions of the forward call (the visible list is in index order, so
-	 * a range of rows is a range of list entries): about equal shares of the INDEX range, not of the visible Gaussians. Dense
-	 * gradients only (ignored with row_sparse). 0 / 1 or range_done == NULL: one piece, no call. */
+	 * being computed. Range k starts at row (P k / num_ranges) rounded down to a multiple of 32 (the visible list is in index order,
+	 * so a range of rows is a range of list entries): equal shares of the INDEX range, not of the visible Gaussians. Dense
+	 * gradients only (ignored with row_sparse); at most 16 ranges. 0 / 1 or range_done == NULL: one piece, no call. */
 	int32_t num_ranges;
 	void (*range_done)(void *user, int32_t k, int32_t row_lo, int32_t row_hi);
 	void *range_user;
