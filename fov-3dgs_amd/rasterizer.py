@@ -430,8 +430,11 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
             a.packed_cull = _ptr(packed.cull)
             keep.append(packed)
         a.no_stats = int(bool(no_stats))
-        # (a frame that shares the GPU with other frames on other streams keeps to its own stream: fovraster.h)
-        a.no_helper_streams = int(on_stream is not None and OVERLAP_NO_HELPER_STREAMS)
+        # Inference frames keep to their own stream (fovraster.h): frames of successive calls share the GPU on several internal streams, a
+        # process's streams share four hardware queues, and the library's helper streams -- even idle ones, even those of the caller's
+        # own stream -- cost the overlapped frames 12 % (2170 -> 1870-1920 frames/s, tools/overlap9.py) for the 1 % they give a frame
+        # that has the GPU to itself (fills and the short lists' sort beside the main stream: 1725 against 1718 frames/s).
+        a.no_helper_streams = int(persistent and INFERENCE_NO_HELPER_STREAMS)
         if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC) and not no_stats:
             counts = torch.empty((P,), dtype=torch.int32, device=dev)      # zeroed by fr_forward itself
             contribs = torch.empty((P,), dtype=torch.float32, device=dev)
@@ -491,7 +494,7 @@ def invalidate_overlap():
         st.sig = None
 
 
-OVERLAP_NO_HELPER_STREAMS = os.environ.get("FOVRASTER_OVERLAP_HELPERS", "0") != "1"
+INFERENCE_NO_HELPER_STREAMS = os.environ.get("FOVRASTER_INFERENCE_HELPERS", "0") != "1"  # (=1: developer A / B runs)
 OVERLAP_SLOTS = max(2, int(os.environ.get("FOVRASTER_OVERLAP_SLOTS", "3")))  # internal streams (and workspace sets) the frames take turns on
 
 
