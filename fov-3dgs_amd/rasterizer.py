@@ -498,45 +498,10 @@ INFERENCE_NO_HELPER_STREAMS = os.environ.get("FOVRASTER_INFERENCE_HELPERS", "0")
 OVERLAP_SLOTS = max(2, int(os.environ.get("FOVRASTER_OVERLAP_SLOTS", "3")))  # internal streams (and workspace sets) the frames take turns on
 
 
-def _concurrent_streams(dev, n, caller):
-    """n streams that really run side by side. A process's HIP streams share a handful of hardware queues (four by default), a queue
-    executes its packets in order, and which queue a stream gets is the runtime's business: two of the internal streams on one queue
-    serialise their frames, and one that shares the caller's queue stalls behind the caller's waits (measured: 1870 against 2140
-    frames/s, depending on which streams a process happened to create first). So the streams are CHOSEN: candidates from torch's
-    pool, a 0.15-ms spin kernel on two of them at a time -- together they take one spin's time or two -- until n are found that are
-    pairwise concurrent and concurrent with the caller's stream. Once per (device, caller stream); ~10 ms."""
-    cands = [torch.cuda.Stream(dev) for _ in range(16)]
-    if os.environ.get("FOVRASTER_OVERLAP_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
-        return cands[:n]
-    cycles = 300_000
-
-    def spin_ms(streams):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for s_ in streams:
-            with torch.cuda.stream(s_):
-                torch.cuda._sleep(cycles)
-        for s_ in streams:
-            s_.synchronize()
-        return (time.perf_counter() - t0) * 1e3
-    try:
-        spin_ms([cands[0]])
-        one = min(spin_ms([cands[0]]) for _ in range(3))
-        chosen = []
-        for c in cands:
-            if all(spin_ms([c, k]) < 1.5 * one for k in chosen + [caller]):
-                chosen.append(c)
-                if len(chosen) == n:
-                    return chosen
-    except Exception:  # (a runtime without the spin kernel: take what comes)
-        pass
-    return cands[:n]
-
-
 class _OverlapState:
     def __init__(self, dev, caller):
         n = OVERLAP_SLOTS
-        self.streams = _concurrent_streams(dev, n, caller)
+        self.streams = [torch.cuda.Stream(dev) for _ in range(n)]
         self.done = [None] * n       # event behind the last frame of each internal stream
         self.must_wait = [None] * n  # event on the caller's stream each internal stream still has to wait for
         self.events = [torch.cuda.Event() for _ in range(n)]  # (re-recorded every turn: the caller's stream waited for the previous record when it was made)
