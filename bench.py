@@ -49,7 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GAZES = [(0.25 * i, 0.25 * j) for i in range(1, 4) for j in range(1, 4)]  # render_compose_gazes_fps.py:26
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 def parse_args(argv=None):
@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--headline-only", action="store_true",
                     help="time only the headline frames (the reference's tensors, one frame at a time): no packed-layout and no "
                          "two-frames-in-flight runs (profiling passes: one workload per kernel-stats file)")
+    ap.add_argument("--serial-only", action="store_true",
+                    help="one frame on the GPU at a time for the whole run (rasterizer.OVERLAP_SUCCESSIVE_FRAMES off): value == value_serial. "
+                         "The profiling passes: a kernel's duration and counters are then its own (tools/make_profiles.sh)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also collect every rank's frame on rank 0 (asynchronous RCCL gather overlapped with the next "
                          "frame). Off by default: the views are independent and the path has no exchange step.")
@@ -376,6 +379,8 @@ def main():
     # which stage is the slowest is found first (untimed); the timed frames then carry the events of that stage and of the
     # blend stage (the kernel north_star names) only
     from fov3dgs_amd import rasterizer as rz_mod
+    if args.serial_only:
+        rz_mod.OVERLAP_SUCCESSIVE_FRAMES = False
     overlap_default = bool(rz_mod.OVERLAP_SUCCESSIVE_FRAMES)
     _stage_pass = stage_pass
 

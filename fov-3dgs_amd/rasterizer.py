@@ -81,12 +81,21 @@ def _f32_small(t, device, stream_handle=None):
     ent = _small_copies.get(key)
     sig = (t._version, t.data_ptr(), t.stride(), t.dtype, t.device)
     if ent is not None and ent[0]() is t and ent[1] == sig and (t.is_cuda or torch.equal(ent[3], t)):
+        # (a stream handle may be a NEW stream's -- handles of destroyed streams are reused --, which is not ordered behind the copy
+        # kernel the old stream ran: until that kernel is known to be over the reader waits for its event)
+        if not ent[4][0]:
+            if ent[5].query():
+                ent[4][0] = True
+            else:
+                torch.cuda.current_stream(device).wait_event(ent[5])
         return ent[2]
     c = _f32(t, device)
     if len(_small_copies) > 256:
         _small_copies.clear()
     import weakref
-    _small_copies[key] = (weakref.ref(t), sig, c, None if t.is_cuda else t.detach().clone())
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _small_copies[key] = (weakref.ref(t), sig, c, None if t.is_cuda else t.detach().clone(), [False], ev)
     return c
 
 
@@ -96,20 +105,28 @@ class _Produced:
     use there (record_stream), so the buffer is neither read half-written nor recycled under a running kernel."""
 
     def __init__(self, device, tensors):
-        self.stream = torch.cuda.current_stream(device)
+        self.stream = torch.cuda.current_stream(device)  # (kept alive: its handle cannot be handed to another stream meanwhile)
         self.event = torch.cuda.Event()
         self.event.record(self.stream)
         self.tensors = [t for t in tensors if t is not None]
-        self.seen = {self.stream.cuda_stream}
+        self.complete = False
+        self.seen = set()
 
     def wait_on_current(self, device):
         cur = torch.cuda.current_stream(device)
-        if cur.cuda_stream in self.seen:
+        if cur.cuda_stream == self.stream.cuda_stream:
             return
-        cur.wait_event(self.event)
+        # Stream handles are reused once a stream is destroyed (a host that makes a stream per frame): `seen` only short-cuts the
+        # WAIT, and only until the producer's event is known to be over -- after that no stream has anything to wait for. The
+        # allocator is told about every consumer stream on every call (a set insertion per tensor).
+        if not self.complete:
+            if self.event.query():
+                self.complete = True
+            elif cur.cuda_stream not in self.seen:
+                cur.wait_event(self.event)
+                self.seen.add(cur.cuda_stream)
         for t in self.tensors:
             t.record_stream(cur)
-        self.seen.add(cur.cuda_stream)
 
 
 def _require_gpu(means3D):

@@ -192,7 +192,8 @@ typedef struct fr_backward_args {
 	void *stream;
 	const float *background, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations,
 		*cov3D_precomp, *viewmatrix, *projmatrix, *campos;
-	const int32_t *radii;        /* [P] from forward */
+	const int32_t *radii;        /* [P] from forward: the forward call's output UNMODIFIED (the whole-line stores of the narrow gradient
+	                              * tensors take `radii > 0` for "this row is written by the per-Gaussian pass": a clamped or edited copy leaves rows unwritten) */
 	/* the three workspaces filled by fr_forward. The call accumulates into the geometry workspace's per-Gaussian gradient
 	 * sums and clears them again before it ends: calling fr_backward twice over one forward state gives the same
 	 * gradients twice (the reference: fresh torch::zeros per call), but two calls must not run concurrently on it. */

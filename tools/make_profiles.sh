@@ -12,15 +12,18 @@
 #                                    the k_pack_* launches (known byte counts) of the packed pass
 # 3) r05_render_sq.json              SQ counter passes (tools/sq_counters.sh)
 # The sha of the library build is recorded: bench.py quotes PMC bytes only for the build they were measured on.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is unset)}"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles; mkdir -p $OUT
 SHA=$(sha256sum fov-3dgs_amd/libfovraster_hip.so | cut -c1-16)
-rm -rf /tmp/prof_h /tmp/prof_a /tmp/prof_t /tmp/prof_f /tmp/prof_w /tmp/prof_pf /tmp/prof_pw /tmp/prof_tf /tmp/prof_tw
-HEAD="--headline-only --no-extra --no-cpu-baseline"
+rm -rf /tmp/prof_h /tmp/prof_o /tmp/prof_a /tmp/prof_t /tmp/prof_f /tmp/prof_w /tmp/prof_pf /tmp/prof_pw /tmp/prof_tf /tmp/prof_tw
+# (--serial-only: one frame on the GPU at a time -- a kernel's duration and counters are its own; the default run overlaps successive frames)
+HEAD="--headline-only --no-extra --no-cpu-baseline --serial-only"
 TRAIN="--mode train --steps 20 --warmup 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_h -o h -- python3 bench.py $HEAD > /tmp/prof_h.log 2>&1
 cp /tmp/prof_h/h_kernel_stats.csv $OUT/${TAG}_headline_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_o -o o -- python3 bench.py --headline-only --no-extra --no-cpu-baseline > /tmp/prof_o.log 2>&1
+cp /tmp/prof_o/o_kernel_stats.csv $OUT/${TAG}_overlapped_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_a -o b -- python3 bench.py --no-cpu-baseline > /tmp/prof_a.log 2>&1
 cp /tmp/prof_a/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 grep '^{"metric"' /tmp/prof_a.log | tail -1 > $OUT/${TAG}_bench_line_profiled.json
@@ -29,8 +32,8 @@ cp /tmp/prof_t/t_kernel_stats.csv $OUT/${TAG}_train_kernel_stats.csv
 grep '^{"metric"' /tmp/prof_t.log | tail -1 > $OUT/${TAG}_train_line_profiled.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o p -- python3 bench.py $HEAD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o p -- python3 bench.py $HEAD > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_pf -o p -- python3 bench.py --packed-only --no-extra --no-cpu-baseline --steps 18 --repeats 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_pw -o p -- python3 bench.py --packed-only --no-extra --no-cpu-baseline --steps 18 --repeats 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_pf -o p -- python3 bench.py --packed-only --serial-only --no-extra --no-cpu-baseline --steps 18 --repeats 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_pw -o p -- python3 bench.py --packed-only --serial-only --no-extra --no-cpu-baseline --steps 18 --repeats 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_tf -o p -- python3 bench.py $TRAIN > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_tw -o p -- python3 bench.py $TRAIN > /dev/null 2>&1
 python3 - "$TAG" "$SHA" <<'PY'
@@ -88,8 +91,8 @@ def pmc_pass(dirs, frames_kernel, group_by_base):
     return out
 
 
-head = pmc_pass((("/tmp/prof_f", "FETCH_SIZE"), ("/tmp/prof_w", "WRITE_SIZE")), "k_tile_scan", True)
-packed = pmc_pass((("/tmp/prof_pf", "FETCH_SIZE"), ("/tmp/prof_pw", "WRITE_SIZE")), "k_tile_scan", True)
+head = pmc_pass((("/tmp/prof_f", "FETCH_SIZE"), ("/tmp/prof_w", "WRITE_SIZE")), "k_emit", True)
+packed = pmc_pass((("/tmp/prof_pf", "FETCH_SIZE"), ("/tmp/prof_pw", "WRITE_SIZE")), "k_emit", True)
 train = pmc_pass((("/tmp/prof_tf", "FETCH_SIZE"), ("/tmp/prof_tw", "WRITE_SIZE")), "k_render_bwd", False)
 # un-counted durations of the same workloads (pass 1)
 hs, ts = stats_ns("/tmp/prof_h/h_kernel_stats.csv"), stats_ns("/tmp/prof_t/t_kernel_stats.csv")
@@ -119,14 +122,14 @@ calibration = {"launches": cal,
                "note": "fetch_factor from the 16-byte-per-lane streaming reads of k_pack_geom / k_pack_cull (gfx950 FETCH_SIZE counts those at half size, MI355X_MICROARCH.md); k_pack_colour's mix of 4- and 16-byte reads shows a smaller factor: for gather-heavy kernels 2 x FETCH is an upper bound"}
 doc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate WRITE_SIZE pass) -- python3 bench.py --headline-only --no-extra --no-cpu-baseline  |  --packed-only ... --steps 18 --repeats 1  |  --mode train --steps 20 --warmup 5",
        "lib_sha16": sha, "layout": "kernels = the headline frames (the reference's tensors; template instances of one kernel added up); *_packed = the static-model instances; train = the training step's kernels by full name",
-       "note": "KiB as rocprofv3 reports them: per-launch averages and per-frame totals (a frame = one k_tile_scan launch; a training step = one k_render_bwd launch); avg_ns = average kernel duration of the same workload WITHOUT counters (r05_headline_kernel_stats.csv / r05_train_kernel_stats.csv), avg_ns_pmc = inside the counter pass",
+       "note": "KiB as rocprofv3 reports them: per-launch averages and per-frame totals (a frame = one k_emit launch; a training step = one k_render_bwd launch); avg_ns = average kernel duration of the same workload WITHOUT counters (r05_headline_kernel_stats.csv / r05_train_kernel_stats.csv), avg_ns_pmc = inside the counter pass",
        "calibration": calibration, "kernels": kernels, "train": train}
 json.dump(doc, open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "profiles", f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps(calibration)[:400])
 for n in ("k_project", "k_bin", "k_emit", "k_render_fov"):
     print(n, kernels.get(n))
 PY
-tools/sq_counters.sh $TAG --steps 27 --warmup 9 --no-extra --no-cpu-baseline --headline-only --repeats 1 | tail -3
+tools/sq_counters.sh $TAG --steps 27 --warmup 9 --no-extra --no-cpu-baseline --headline-only --serial-only --repeats 1 | tail -3
 # 4) the same on S-6M-T (the list-consuming cloud): kernel stats of its foveated frames and of its training step, the whole bench line
 #    on it (counts: blend pairs of every blend kernel), SQ passes over both -> ${TAG}_valu_per_pair.json: vector instructions per
 #    blended (band, entry) pair of k_render_fov, k_render<1,2> and k_render_bwd on both clouds
@@ -136,7 +139,7 @@ cp /tmp/prof_th/h_kernel_stats.csv $OUT/${TAG}_translucent_headline_kernel_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tt -o t -- python3 bench.py --cloud S-6M-T $TRAIN > /tmp/prof_tt.log 2>&1
 cp /tmp/prof_tt/t_kernel_stats.csv $OUT/${TAG}_translucent_train_kernel_stats.csv
 python3 bench.py --cloud S-6M-T --no-cpu-baseline 2> /dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_line_translucent.json
-tools/sq_counters.sh ${TAG}T --cloud S-6M-T --steps 27 --warmup 9 --no-extra --no-cpu-baseline --headline-only --repeats 1 | tail -1
+tools/sq_counters.sh ${TAG}T --cloud S-6M-T --steps 27 --warmup 9 --no-extra --no-cpu-baseline --headline-only --serial-only --repeats 1 | tail -1
 tools/sq_counters.sh ${TAG}train --mode train --steps 12 --warmup 4 | tail -1
 tools/sq_counters.sh ${TAG}Ttrain --cloud S-6M-T --mode train --steps 12 --warmup 4 | tail -1
 python3 - "$TAG" <<'PY'
