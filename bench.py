@@ -580,7 +580,7 @@ def main():
         "value_serial": round(world * K / serial[0], 3), "ms_per_step_serial": round(serial[0] / K * 1e3, 4),
         "value_serial_spread": [round(world * K / serial[1][1], 3), round(world * K / serial[1][0], 3)],
         "overlap_note": "value: render() as a caller gets it -- one call at a time, each returning its instance count; successive inference calls whose inputs "
-                        "are provably unchanged (same tensor objects, addresses, autograd versions) run on two internal streams in turn, so the head of call "
+                        "are provably unchanged (same tensor objects, addresses, autograd versions) run on three internal streams in turn, so the head of call "
                         "n + 1 (cull, projection, counts) runs beside the tail of call n (emission, sort, blend): rasterizer.OVERLAP_SUCCESSIVE_FRAMES = "
                         + str(overlap_default) + "; images bit-identical. value_serial: the same K frames with that switch off (every kernel of a frame alone on the GPU: "
                         "the roofline's kernel durations are measured there)",
