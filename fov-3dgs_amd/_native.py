@@ -49,6 +49,7 @@ class ForwardArgs(C.Structure):
         ("no_stats", C.c_int32),
         ("blend_pairs", _FP),
         ("no_helper_streams", C.c_int32),
+        ("emit_regions", C.c_int32),
     ]
 
 

@@ -335,12 +335,13 @@ int fr_forward_finish(fr_frame *f)
 	const int64_t early_cap = (same_kind && !a->debug) ? gs.capacity : 0;
 	if (early_cap > 0) early_bin = a->binning_resize(a->resize_user[1], carve_bin(early_cap, nullptr, c.T).bytes);
 
-	uint32_t totals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, candidates = 0;
+	uint32_t totals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, candidates = 0, region_overflow = 0;
 	uint32_t *const pinned = f->pin ? f->pin->host : nullptr;
 	if (!pinned)
 	{
 		FR_HIP(hipMemcpyAsync(totals, c.img.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
 		FR_HIP(hipMemcpyAsync(&candidates, c.geom.slab_ctr + 1, sizeof(candidates), hipMemcpyDeviceToHost, stream));
+		FR_HIP(hipMemcpyAsync(&region_overflow, c.geom.slab_ctr + 5, sizeof(region_overflow), hipMemcpyDeviceToHost, stream));
 		FR_HIP(hipStreamSynchronize(stream));
 	}
 	else
@@ -358,8 +359,9 @@ int fr_forward_finish(fr_frame *f)
 				if (__atomic_load_n(&pinned[4], __ATOMIC_ACQUIRE) != c.totals_seq) { set_error("tile scan did not publish its totals"); return FR_ERR_HIP; }
 			}
 		for (int i = 0; i < 4; i++) totals[i] = v[i];
-		totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7]; candidates = v[8];
+		totals[5] = v[5]; totals[6] = v[6]; totals[7] = v[7]; candidates = v[8]; region_overflow = v[9];
 	}
+	c.regions_ok = region_overflow == 0 ? 1 : 0;
 	f->totals_read = true;
 	// reference auxiliary.h:156-160: a point behind the near plane although the caller said the cloud was prefiltered
 	// (there: printf + __trap, which kills the context; here an error code)

@@ -85,8 +85,17 @@ struct GeomWS {
 	                       // every wave's region; [waves] = the number of items
 	float4 *crow;       // [3 (P + FR_CROW_PAD)] foveated variants' candidate rows (xyz, scale | scale.yz, rotation.xy | rotation.zw, highest
 	                    //      level, index), same slots as vis_seg ...
+	// region-major emission (round 6, k_emit_regions): the screen is cut into regions of 8 x 8 tiles; every binning workgroup leaves,
+	// sorted by region, the items whose walk rectangle reaches the region (an item is listed once per region it reaches)
+	uint2 *rtab;        // [FR_BIN_BLOCKS][FR_MAX_REGIONS] (offset inside the workgroup's segment of wlist, count) of (workgroup, region)
+	uint32_t *wlist;    // [wlist_cap(P)] the workgroups' segments, one after the other (each: capacity / workgroups entries)
+	uint32_t *rtotal;   // [FR_MAX_REGIONS] list entries of every region (zeroed by k_project's last workgroup, added up by k_bin's)
+	uint32_t *rchunk;   // [FR_MAX_REGIONS + 1] first chunk (of FR_ER_CHUNK entries) of every region's list, [regions] = all chunks (k_bin's last workgroup)
 	size_t bytes;
 };
+#define FR_REGION_TILES 8    // tiles per side of a region
+#define FR_MAX_REGIONS 256   // region-major emission for tile grids of at most this many regions (1080p: 15 x 9 = 135; 1440p: 20 x 12)
+__host__ __device__ inline size_t wlist_cap(size_t P) { return 2 * P + 65536; }
 __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 {
 	GeomWS g; size_t off = 0;
@@ -110,6 +119,10 @@ __host__ __device__ inline GeomWS carve_geom(int variant, size_t P, char *base)
 	// training frames need not carry
 	g.crow = nullptr;
 	if (is_fov(variant)) { g.crow = (float4 *)(base + off); off = align_up(off + (P + FR_CROW_PAD) * 3 * sizeof(float4)); }
+	g.rtab = (uint2 *)(base + off); off = align_up(off + (size_t)FR_BIN_BLOCKS * FR_MAX_REGIONS * sizeof(uint2));
+	g.wlist = (uint32_t *)(base + off); off = align_up(off + wlist_cap(P) * sizeof(uint32_t));
+	g.rtotal = (uint32_t *)(base + off); off = align_up(off + FR_MAX_REGIONS * sizeof(uint32_t));
+	g.rchunk = (uint32_t *)(base + off); off = align_up(off + (FR_MAX_REGIONS + 1) * sizeof(uint32_t));
 	g.bytes = off + 256;
 	return g;
 }
@@ -423,6 +436,8 @@ struct FwdCtx {
 	int bin_wgs;        // workgroups k_bin ran with (k_emit replays the same number)
 	int hist_mode;      // k_bin / k_emit: 0 = global tile counters, 1 = LDS histogram of 32-bit counts, 2 = of 16-bit counts (launch_bin decides)
 	int scan_fused;     // the tile scan ran as the tail of k_bin (launch_bin decides): no k_tile_scan launch
+	int regions_ok;               // ... and no binning workgroup's segment overflowed (the host's copy of slab_ctr[5], read with the totals)
+	int regions, region_rx, wcap; // region-major emission (launch_bin decides): regions of the tile grid (0 = off), regions per row, entries of a workgroup's segment
 	int heavy4, heavy2; // tiles with >= 2048 / 512..2047 instances (leading entries of tile_order)
 	int heavy8;         // tiles with >= 4096 instances
 	int n_items;        // entries of ImageWS::render_items

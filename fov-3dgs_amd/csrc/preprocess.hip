@@ -273,6 +273,7 @@ __device__ __forceinline__ float4 nt_load4(const float *p)
 // raw per-Gaussian inputs of the projection
 struct RawGaussian { float p[3], sc[3]; float4 q; float hl; };
 
+#define FR_ER_CHUNK 512 // region-major emission: list entries of a region a workgroup of k_emit_regions takes at a time (two slabs of 64 per wave)
 struct PreArgs {
 	int P, D, M, W, H, gx, gy;
 	float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
@@ -296,6 +297,8 @@ struct PreArgs {
 	int wbase_lds;            // k_bin keeps its copy of the cull pass's running counts in LDS (launch_bin: when it fits)
 	int fuse_scan;            // k_bin: the LAST workgroup to finish runs the tile scan (ts) as the kernel's tail -- no k_tile_scan launch
 	TileScanArgs ts;
+	int regions, region_rx;   // region-major emission: regions of the tile grid (0 = off) and regions per row (GeomWS::rtab / wlist)
+	int wcap;                 // ... entries of a workgroup's segment of wlist
 };
 
 // Projection of one Gaussian: everything up to the tile rectangle.
@@ -748,6 +751,7 @@ __global__ void __launch_bounds__(FR_PROJ_THREADS) k_project(const PreArgs a)
 		for (int k = 0; k < FR_PROJ_MAX_WAVES / FR_PROJ_THREADS; k++)
 			if (w0 + k < w1) { a.geom.wbase[w0 + k] = run; run += cv[k]; }
 		if (w1 == nwaves && w0 < w1) { a.geom.wbase[nwaves] = run; a.geom.slab_ctr[1] = run; }
+		if (threadIdx.x < FR_MAX_REGIONS) a.geom.rtotal[threadIdx.x] = 0; // (the regions' list lengths: added up by k_bin's workgroups, the kernel behind this one)
 	}
 #ifdef FR_PROJ_TIMERS
 	if (lane == 0)
@@ -1426,6 +1430,65 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			else { a.geom.rec[3 * (size_t)gitem + 1] = r[1]; a.geom.rec[3 * (size_t)gitem + 2] = r[2]; }
 		}
 	}
+	if (LDSH == 1 && a.regions)
+	{
+		// Region-major emission (k_emit_regions): the workgroup lists its items BY SCREEN REGION (8 x 8 tiles) -- an item once per region
+		// its walk rectangle reaches -- in a segment of its own, sorted by region: a counting pass over its items' dense words and walk
+		// records (written a moment ago: they come from L2), a scan over the regions, an appending pass. k_emit_regions then has
+		// workgroups that own a region's tile buckets, where k_emit's own a share of every tile's.
+		__shared__ uint32_t s_rneed[FR_MAX_REGIONS], s_roff[FR_MAX_REGIONS], s_rsum[4], s_rok;
+		constexpr int BW_ = FR_BIN_THREADS / 64;
+		const int R = a.regions, RX = a.region_rx;
+		__syncthreads(); // (the giant splats' dense words are in)
+		for (int t = threadIdx.x; t < R; t += FR_BIN_THREADS) s_rneed[t] = 0;
+		__syncthreads();
+		auto each_region = [&](auto &&fn) __attribute__((always_inline))
+		{
+			for (int q = (int)(threadIdx.x >> 6); ; q += BW_)
+			{
+				const int slab = (int)blockIdx.x * BW_ + q % BW_ + (q / BW_) * nwaves;
+				if (slab >= nslabs) break;
+				const int item = slab * 64 + lane;
+				if (item >= V || a.geom.lrange[item] == FR_ITEM_NONE) continue;
+				const float4 w2 = a.geom.wrec[4 * (size_t)item + 2];
+				const uint32_t xy = __float_as_uint(w2.z);
+				const int x0 = (int)(xy & 0xffffu), y0 = (int)(xy >> 16), w = max((int)__float_as_uint(w2.w), 1);
+				const int h = max((int)(__float_as_uint(a.geom.wrec[4 * (size_t)item + 3].x) / (uint32_t)w), 1);
+				const int rx0 = x0 / FR_REGION_TILES, rx1 = (x0 + w - 1) / FR_REGION_TILES, ry0 = y0 / FR_REGION_TILES, ry1 = (y0 + h - 1) / FR_REGION_TILES;
+				for (int ry = ry0; ry <= ry1; ry++)
+					for (int rx = rx0; rx <= rx1; rx++) fn(item, ry * RX + rx);
+			}
+		};
+		each_region([&](const int, const int r) { atomicAdd(&s_rneed[r], 1u); });
+		__syncthreads();
+		{
+			const uint32_t v = (int)threadIdx.x < R ? s_rneed[threadIdx.x] : 0u; // (R <= 256 <= FR_BIN_THREADS)
+			const uint32_t incl = wave_incl_scan_u32(v, lane);
+			if (threadIdx.x < 256 && lane == 63) s_rsum[threadIdx.x >> 6] = incl;
+			__syncthreads();
+			uint32_t off = 0, total = 0;
+#pragma unroll
+			for (int w = 0; w < 4; w++) { const uint32_t ws = s_rsum[w]; if (w < (int)(threadIdx.x >> 6)) off += ws; total += ws; }
+			if ((int)threadIdx.x < R)
+			{
+				s_roff[threadIdx.x] = off + incl - v;
+				s_rneed[threadIdx.x] = 0; // (the appending pass's cursors)
+				a.geom.rtab[(size_t)blockIdx.x * FR_MAX_REGIONS + threadIdx.x] = make_uint2(off + incl - v, total <= (uint32_t)a.wcap ? v : 0u);
+				if (v != 0 && total <= (uint32_t)a.wcap) atomicAdd(a.geom.rtotal + threadIdx.x, v); // (the region's list length: k_emit_regions' chunks)
+			}
+			if (threadIdx.x == 0)
+			{
+				s_rok = total <= (uint32_t)a.wcap ? 1u : 0u;
+				if (total > (uint32_t)a.wcap) atomicOr(a.geom.slab_ctr + 5, 1u); // the segment is too small: the frame is emitted the other way
+			}
+		}
+		__syncthreads();
+		if (s_rok)
+		{
+			uint32_t *const seg = a.geom.wlist + (size_t)blockIdx.x * a.wcap;
+			each_region([&](const int item, const int r) { seg[s_roff[r] + atomicAdd(&s_rneed[r], 1u)] = (uint32_t)item; });
+		}
+	}
 	if (LDSH)
 	{
 		// The workgroup's share of every tile's bucket: its histogram is ADDED to the tile's global counter, and what the
@@ -1464,6 +1527,22 @@ __global__ void __launch_bounds__(FR_BIN_THREADS) k_bin(const PreArgs a)
 			__syncthreads();
 			if (!s_last_wg || threadIdx.x >= FR_TILE_SCAN_THREADS) return;
 			tile_scan_body<FR_TILE_SCAN_THREADS, true>(a.ts, lds_hist);
+			if (a.regions)
+			{
+				// chunks of every region's list (k_emit_regions pulls them from a counter): rchunk[r] = first chunk of region r, [R] = all
+				__syncthreads();
+				const int t = (int)threadIdx.x;
+				const uint32_t nr = t < a.regions ? __hip_atomic_load(a.geom.rtotal + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				const uint32_t ch = (nr + FR_ER_CHUNK - 1) / FR_ER_CHUNK;
+				const uint32_t incl = wave_incl_scan_u32(ch, lane);
+				if (t < 256 && lane == 63) lds_hist[t >> 6] = incl;
+				__syncthreads();
+				uint32_t off = 0, tot = 0;
+#pragma unroll
+				for (int w = 0; w < 4; w++) { const uint32_t ws = lds_hist[w]; if (w < (t >> 6)) off += ws; tot += ws; }
+				if (t < a.regions) a.geom.rchunk[t] = off + incl - ch;
+				if (t == 0) a.geom.rchunk[a.regions] = tot;
+			}
 		}
 	}
 }
@@ -1794,6 +1873,256 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 #undef NEXT_SLOT
 #undef TILE_PASSES
 
+// ---- region-major emission (round 6) --------------------------------------------------------------------------------------------
+// k_emit's workgroups own a SHARE of every tile's bucket: a workgroup contributes 2.4-2.9 entries per tile, 6 M eight-byte stores each
+// dirty a partial line (WRITE_SIZE 3.7 x the payload), and with 84 KiB of LDS per workgroup (cursors of all 8160 tiles + the owner rows)
+// one workgroup of twelve waves is all a CU holds: the kernel is latency-bound at 2.2 waves per SIMD. Here a workgroup owns a REGION
+// (8 x 8 tiles) -- one of G workgroups per region, each taking the lists a group of binning workgroups left for it (GeomWS::rtab /
+// wlist, k_bin's tail) -- so its stores fall into 64 buckets whose lines it fills within microseconds; a wave stages the pairs that
+// pass in LDS, counts them per tile, reserves its share of the 64 buckets with ONE returning atomic per tile and flush, and writes.
+// No table of 8160 cursors, no prologue, no big / giant splats (an item is cut to the region: at most 64 tiles, every item goes through
+// the pair loop), ~1000 small workgroups that the hardware places as CUs fall free. The order inside a bucket is arbitrary, as before.
+struct EmitRegArgs {
+	int gx, gy, T, RX, R, bin_wgs, wcap;
+	GeomWS geom;
+	const float *tile_lv;
+	const uint2 *ranges;
+	uint32_t *cursor;       // ImageWS::tile_count: zero behind the tile scan
+	uint64_t *entries;
+	const uint32_t *totals;
+	uint32_t capacity, items_cap;
+};
+#define FR_ER_THREADS 256
+#define FR_ER_WAVES (FR_ER_THREADS / 64)
+#define FR_ER_STAGE 384 // pairs a wave stages between two flushes
+// The work is handed out in CHUNKS of a region's list (all binning workgroups' lists for the region strung together): GeomWS::rchunk
+// (k_bin's last workgroup) says how many chunks every region has, the workgroups pull chunk numbers from one counter -- the regions
+// around the gaze hold ten times the entries of those at the rim, and a grid of one workgroup per (region, fixed share) ended with
+// its densest regions (243 us; 94 with 8192 small shares).
+template <int VARIANT>
+__global__ void __launch_bounds__(FR_ER_THREADS) k_emit_regions(const EmitRegArgs a)
+{
+	constexpr bool CULL = VARIANT != FR_VARIANT_ORIGINAL;
+	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
+	constexpr int RT = FR_REGION_TILES;
+	if (a.totals[0] > a.capacity || a.totals[5] > a.items_cap) return;
+	__shared__ uint32_t s_rchunk[FR_MAX_REGIONS + 1];
+	__shared__ uint32_t s_pre[FR_BIN_BLOCKS + 1], s_src[FR_BIN_BLOCKS], s_part[FR_ER_WAVES], s_chunk;
+	__shared__ float s_tmin[RT * RT];
+	__shared__ __attribute__((aligned(16))) float4 s_orec[FR_ER_WAVES][64 * 4];
+	__shared__ int s_own[FR_ER_WAVES][64];
+	__shared__ __attribute__((aligned(8))) uint64_t s_pay[FR_ER_WAVES][FR_ER_STAGE];
+	__shared__ uint8_t s_tl[FR_ER_WAVES][FR_ER_STAGE];
+	__shared__ uint32_t s_cnt[FR_ER_WAVES][RT * RT], s_base[FR_ER_WAVES][RT * RT];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int t = threadIdx.x; t <= a.R; t += FR_ER_THREADS) s_rchunk[t] = a.geom.rchunk[t];
+	__syncthreads();
+	const uint32_t nchunks = s_rchunk[a.R];
+	float4 *const orec = s_orec[wv];
+	uint64_t *const pay = s_pay[wv];
+	uint8_t *const stl = s_tl[wv];
+	int cur_r = -1, tx0 = 0, ty0 = 0, n = 0, npre = 1;
+	uint32_t n_staged = 0; // (wave-uniform)
+#ifdef FR_ER_TIMERS
+	const uint64_t tm_start = wall_clock64(); uint64_t tm_pro = 0, tm_fetch = 0, tm_proc = 0, tm_flush = 0; int tm_chunks = 0, tm_flushes = 0, tm_regions = 0;
+#define ERT(x) x
+#else
+#define ERT(x)
+#endif
+	// a wave's staged pairs leave: counted per tile, the wave's share of every bucket reserved with one returning atomic, written
+	auto flush = [&]() __attribute__((always_inline))
+	{
+		ERT(const uint64_t tf0 = wall_clock64(); tm_flushes++;)
+		s_cnt[wv][lane] = 0;
+		FR_WAVE_LDS_SYNC();
+		uint32_t rank[FR_ER_STAGE / 64];
+#pragma unroll
+		for (int k = 0; k < FR_ER_STAGE / 64; k++)
+		{
+			const uint32_t i = (uint32_t)k * 64u + (uint32_t)lane;
+			rank[k] = i < n_staged ? atomicAdd(&s_cnt[wv][stl[i]], 1u) : 0u;
+		}
+		FR_WAVE_LDS_SYNC();
+		{
+			const uint32_t c = s_cnt[wv][lane];
+			const int x = tx0 + (lane & (RT - 1)), y = ty0 + (lane >> 3);
+			uint32_t base = 0;
+			if (c != 0) { const int ti = y * a.gx + x; base = a.ranges[ti].x + atomicAdd(&a.cursor[ti], c); }
+			s_base[wv][lane] = base;
+		}
+		FR_WAVE_LDS_SYNC();
+#pragma unroll
+		for (int k = 0; k < FR_ER_STAGE / 64; k++)
+		{
+			const uint32_t i = (uint32_t)k * 64u + (uint32_t)lane;
+			if (i < n_staged) a.entries[s_base[wv][stl[i]] + rank[k]] = pay[i];
+		}
+		FR_WAVE_LDS_SYNC(); // (the staging rows are written again)
+		n_staged = 0;
+		ERT(tm_flush += wall_clock64() - tf0;)
+	};
+	struct SlabIn { int item; float4 w0, w1, w2, w3; bool valid; };
+	auto fetch = [&](const int jbase, const int jend, SlabIn &in) __attribute__((always_inline))
+	{
+		const int j = jbase + lane;
+		in.valid = j < jend;
+		// which binning workgroup's list entry j comes from: the last b with s_pre[b] <= j
+		const uint32_t jj = (uint32_t)min(j, n - 1);
+		int lo = 0, hi = npre;
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= jj) lo = mid; else hi = mid; }
+		in.item = (int)a.geom.wlist[s_src[lo] + (jj - s_pre[lo])];
+		const float4 *wr = a.geom.wrec + 4 * (size_t)in.item;
+		in.w0 = wr[0]; in.w1 = wr[1]; in.w2 = wr[2]; in.w3 = wr[3];
+	};
+	auto process = [&](const SlabIn &in) __attribute__((always_inline))
+	{
+		const int item = in.item;
+		const float4 w0 = in.w0, w1 = in.w1, w2 = in.w2, w3 = in.w3;
+		const uint32_t idf = __float_as_uint(w2.x), xy = __float_as_uint(w2.z);
+		const bool boxtest = ((idf >> 31) & 1u) != 0;
+		const float cx = w0.x, cy = w0.y;
+		const float4 ev = make_float4(w0.z, w0.w, w1.x, w1.y);
+		const float2 el = make_float2(w1.z, w1.w);
+		const uint32_t depth_bits = __float_as_uint(w2.y);
+		// the walk rectangle, cut to the region
+		const int x0 = (int)(xy & 0xffffu), y0 = (int)(xy >> 16), rw = max((int)__float_as_uint(w2.w), 1);
+		const int rh = max((int)(__float_as_uint(w3.x) / (uint32_t)rw), 1);
+		const int qx0 = max(x0, tx0), qx1 = min(x0 + rw, min(tx0 + RT, a.gx)), qy0 = max(y0, ty0), qy1 = min(y0 + rh, min(ty0 + RT, a.gy));
+		const int qw = max(qx1 - qx0, 0), qh = max(qy1 - qy0, 0);
+		const uint32_t my_n = in.valid ? (uint32_t)(qw * qh) : 0u;
+		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
+		const uint32_t excl = incl - my_n;
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		if (total == 0) return;
+		{
+			const Obb ob = make_obb(cx, cy, ev, el);
+			float4 *mine = orec + 4 * lane;
+			mine[0] = make_float4(cx, cy, ev.x, ev.y);
+			mine[1] = make_float4(ev.z, ev.w, el.x, el.y);
+			mine[2] = make_float4(ob.vxmin, ob.vxmax, ob.vymin, ob.vymax);
+			// (bit 16 of the width word: the box test applies -- a one-tile rectangle, or a variant without culling, skips it)
+			mine[3] = make_float4(__uint_as_float((uint32_t)qx0 | ((uint32_t)qy0 << 16)), __int_as_float(max(qw, 1) | (boxtest ? 0x10000 : 0)), __uint_as_float(excl), w3.y + 1);
+			FR_WAVE_LDS_SYNC();
+		}
+		for (uint32_t k = 0; k < total; k += 64)
+		{
+			if (n_staged + 64u > (uint32_t)FR_ER_STAGE) flush();
+			const uint32_t jp = k + lane;
+			const bool pv = jp < total;
+			const int seg_a = (int)max((long long)excl - (long long)k, 0ll);
+			const int seg_b = (int)min((long long)incl - (long long)k, 64ll);
+			const int owner = max(pair_owner_scan(s_own[wv], lane, seg_a, seg_b), 0);
+			const float4 *orow = orec + 4 * owner;
+			const float4 o3 = orow[3];
+			const uint32_t oxy = __float_as_uint(o3.x);
+			const int owf = __float_as_int(o3.y), ow = owf & 0xffff;
+			const bool obox = (owf & 0x10000) != 0;
+			const uint32_t local = (pv ? jp : total - 1) - __float_as_uint(o3.z);
+			int qy = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)ow));
+			int rx = (int)local - qy * ow;
+			if (rx < 0) { qy--; rx += ow; } else if (rx >= ow) { qy++; rx -= ow; }
+			const int x = (int)(oxy & 0xffffu) + rx, y = (int)(oxy >> 16) + qy;
+			const int tl = ((y - ty0) & (RT - 1)) * RT + ((x - tx0) & (RT - 1));
+			bool pass = pv;
+			if (CULL)
+			{
+				const float4 o0 = orow[0], o1 = orow[1], o2 = orow[2];
+				if (FOV) pass = pass && s_tmin[tl] < o3.w;
+				{
+					// obb_hits_tile() without its early returns (same expressions, same comparisons: a NaN fails no test)
+					const float tpx = (float)x * (float)FR_TILE + (float)FR_TILE / 2.0f, tpy = (float)y * (float)FR_TILE + (float)FR_TILE / 2.0f;
+					const bool cx_ok = !((o2.y - tpx) < -8.0f || (o2.x - tpx) > 8.0f);
+					const bool cy_ok = !((o2.w - tpy) < -8.0f || (o2.z - tpy) > 8.0f);
+					const float xp = tpx + 8.0f - o0.x, xm = tpx - 8.0f - o0.x, yp = tpy + 8.0f - o0.y, ym = tpy - 8.0f - o0.y;
+					const float a1p = xp * o0.z, a1m = xm * o0.z, b1p = yp * o0.w, b1m = ym * o0.w;
+					const float mn1 = fminf(a1p, a1m) + fminf(b1p, b1m), mx1 = fmaxf(a1p, a1m) + fmaxf(b1p, b1m);
+					const bool e1_ok = !(o1.z < mn1 || -o1.z > mx1);
+					const float a2p = xp * o1.x, a2m = xm * o1.x, b2p = yp * o1.y, b2m = ym * o1.y;
+					const float mn2 = fminf(a2p, a2m) + fminf(b2p, b2m), mx2 = fmaxf(a2p, a2m) + fmaxf(b2p, b2m);
+					const bool e2_ok = !(o1.w < mn2 || -o1.w > mx2);
+					pass = pass && (!obox || (cx_ok && cy_ok && e1_ok && e2_ok));
+				}
+			}
+			const uint64_t opay = ((uint64_t)(uint32_t)__shfl((int)depth_bits, owner) << 32) | (uint32_t)__shfl(item, owner);
+			const unsigned long long m = __ballot(pass);
+			if (pass)
+			{
+				const uint32_t pos = n_staged + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+				pay[pos] = opay;
+				stl[pos] = (uint8_t)tl;
+			}
+			n_staged += (uint32_t)__popcll(m);
+		}
+		// the rows are rewritten by the next slab: everyone is done reading
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	};
+	for (;;)
+	{
+		ERT(const uint64_t tp0 = wall_clock64();)
+		__syncthreads(); // (everybody is done with the previous chunk's tables)
+		if (threadIdx.x == 0) s_chunk = atomicAdd(a.geom.slab_ctr + 6, 1u);
+		__syncthreads();
+		const uint32_t chunk = s_chunk;
+		if (chunk >= nchunks) break;
+		int r;
+		{
+			int lo = 0, hi = a.R; // the last region with s_rchunk[r] <= chunk
+			while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rchunk[mid] <= chunk) lo = mid; else hi = mid; }
+			r = lo;
+		}
+		if (r != cur_r)
+		{
+			// the region's list = the binning workgroups' lists for it, strung together: two of them per thread, a scan over the workgroup
+			cur_r = r; tx0 = (r % a.RX) * RT; ty0 = (r / a.RX) * RT; ERT(tm_regions++;)
+			const int b = 2 * (int)threadIdx.x;
+			const uint2 e0 = b < a.bin_wgs ? a.geom.rtab[(size_t)b * FR_MAX_REGIONS + r] : make_uint2(0u, 0u);
+			const uint2 e1 = b + 1 < a.bin_wgs ? a.geom.rtab[(size_t)(b + 1) * FR_MAX_REGIONS + r] : make_uint2(0u, 0u);
+			const uint32_t both = e0.y + e1.y;
+			const uint32_t incl = wave_incl_scan_u32(both, lane);
+			if (lane == 63) s_part[wv] = incl;
+			if (FOV && threadIdx.x >= FR_ER_THREADS - 64)
+			{
+				const int x = tx0 + (lane & (RT - 1)), y = ty0 + (lane >> 3);
+				s_tmin[lane] = (x < a.gx && y < a.gy) ? a.tile_lv[a.T + y * a.gx + x] : __int_as_float(0x7fc00000); // (NaN: no Gaussian passes)
+			}
+			__syncthreads();
+			uint32_t off = 0, tot = 0;
+#pragma unroll
+			for (int w = 0; w < FR_ER_WAVES; w++) { const uint32_t ws = s_part[w]; if (w < wv) off += ws; tot += ws; }
+			const uint32_t ex = off + incl - both;
+			if (b < FR_BIN_BLOCKS) { s_pre[b] = ex; s_src[b] = (uint32_t)b * (uint32_t)a.wcap + e0.x; }
+			if (b + 1 < FR_BIN_BLOCKS) { s_pre[b + 1] = ex + e0.y; s_src[b + 1] = (uint32_t)(b + 1) * (uint32_t)a.wcap + e1.x; }
+			if (threadIdx.x == 0) s_pre[FR_BIN_BLOCKS] = tot;
+			__syncthreads();
+			n = (int)s_pre[FR_BIN_BLOCKS];
+			npre = min(a.bin_wgs, FR_BIN_BLOCKS);
+		}
+		const int j0 = (int)(chunk - s_rchunk[r]) * FR_ER_CHUNK, jend = min(n, j0 + FR_ER_CHUNK);
+		// two slabs per wave, both fetched before the first is walked
+		ERT(const uint64_t tq0 = wall_clock64(); tm_pro += tq0 - tp0; tm_chunks++;)
+		SlabIn sa, sb;
+		const int ja = j0 + wv * 64, jb = ja + FR_ER_WAVES * 64;
+		const bool has_a = ja < jend, has_b = jb < jend; // (wave-uniform)
+		if (has_a) fetch(ja, jend, sa);
+		if (has_b) fetch(jb, jend, sb);
+		ERT(if (has_a) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const uint64_t tq1 = wall_clock64(); tm_fetch += tq1 - tq0; const uint64_t fl0 = tm_flush;)
+		if (has_a) process(sa);
+		if (has_b) process(sb);
+		if (n_staged != 0) flush(); // (the next chunk may belong to another region)
+		ERT(tm_proc += (wall_clock64() - tq1) - (tm_flush - fl0);)
+	}
+#ifdef FR_ER_TIMERS
+	if (lane == 0)
+	{
+		float *d = a.geom.cov3D + (size_t)((int)blockIdx.x * FR_ER_WAVES + wv) * 8; // (developer build: the covariance rows the inference variants do not use)
+		d[0] = (float)(wall_clock64() - tm_start); d[1] = (float)tm_pro; d[2] = (float)tm_fetch; d[3] = (float)tm_proc; d[4] = (float)tm_flush;
+		d[5] = (float)tm_chunks; d[6] = (float)tm_flushes; d[7] = (float)tm_regions;
+	}
+#endif
+#undef ERT
+}
+
 __global__ void k_mark_visible(int P, const float *means3D, const float *vm, uint8_t *present)
 {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1896,6 +2225,7 @@ static PreArgs make_pre_args(FwdCtx &c)
 	p.prefiltered = a->prefiltered;
 	p.proj_waves = c.proj_waves; p.proj_cpw = c.proj_cpw;
 	p.fuse_scan = 0;
+	p.regions = 0; p.region_rx = 0; p.wcap = 0;
 	return p;
 }
 
@@ -2005,6 +2335,8 @@ int launch_bin(FwdCtx &c)
 			if (ncache < 48) { cache[ncache].fn = fn; cache[ncache].dyn = dyn; cache[ncache].wgs = wgs; ncache++; }
 		}
 		nblk = nblk < wgs ? nblk : wgs;
+		p.regions = c.regions; p.region_rx = c.region_rx; p.wcap = (int)(wlist_cap((size_t)a->P) / (size_t)nblk);
+		c.wcap = p.wcap;
 		hipLaunchKernelGGL(kern, dim3(nblk), block, dyn, c.stream, p);
 		return FR_OK;
 	};
@@ -2012,6 +2344,14 @@ int launch_bin(FwdCtx &c)
 	// the packed model layout and the candidate rows are compile-time variants of the kernel (run-time tests on the pointers cost
 	// the ordinary path 5 %): packed needs both packed tensors; the rows exist when k_project stored them (foveated variants,
 	// unpacked cull pass, scales + rotations given)
+	// region-major emission: the workgroups also list their items by screen region (k_emit_regions)
+	{
+		static const int env_mode = []() { const char *e = getenv("FOVRASTER_EMIT_REGIONS"); return e ? atoi(e) : 0; }(); // (developer A / B runs)
+		const int mode = a->emit_regions | env_mode;
+		const int rx = (c.gx + FR_REGION_TILES - 1) / FR_REGION_TILES, ry = (c.gy + FR_REGION_TILES - 1) / FR_REGION_TILES;
+		c.regions = (mode != 0 && c.hist_mode == 1 && c.scan_fused && rx * ry <= FR_MAX_REGIONS && !a->debug) ? rx * ry : 0; // (the chunk table is made behind the fused scan)
+		c.region_rx = rx;
+	}
 	const bool packed = a->packed_geom && a->packed_colour;
 	const bool crow = !packed && is_fov(a->variant) && a->packed_cull == nullptr && a->cov3D_precomp == nullptr;
 #define LAUNCH_BIN_PC(V, PK, CR) do { if (c.hist_mode == 2) lrc = launch((const void *)k_bin<V, 2, PK, CR>, k_bin<V, 2, PK, CR>, lds); \
@@ -2035,9 +2375,41 @@ int launch_bin(FwdCtx &c)
 	return check_launch("bin", c.stream, a->debug);
 }
 
+static int launch_emit_regions(FwdCtx &c)
+{
+	const fr_forward_args *a = c.a;
+	EmitRegArgs e;
+	e.gx = c.gx; e.gy = c.gy; e.T = c.T; e.RX = c.region_rx; e.R = c.regions; e.bin_wgs = c.bin_wgs; e.wcap = c.wcap;
+	e.geom = c.geom; e.tile_lv = c.img.tile_lv; e.ranges = c.img.ranges; e.cursor = c.img.tile_count; e.entries = c.bin.entries;
+	e.totals = c.img.totals; e.capacity = (uint32_t)c.capacity; e.items_cap = (uint32_t)c.items_cap;
+	// as many workgroups as the device keeps resident (four of 37 KiB of LDS per CU): they pull the chunks from a counter
+	static thread_local int wgs = 0;
+	if (wgs == 0)
+	{
+		int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_emit_regions<FR_VARIANT_FOV_PCHECK_OBB>, FR_ER_THREADS, 0) != hipSuccess || per_cu < 1)
+		{ per_cu = 4; prop.multiProcessorCount = 256; (void)hipGetLastError(); }
+		wgs = per_cu * prop.multiProcessorCount;
+	}
+	const dim3 grid((unsigned)wgs), block(FR_ER_THREADS);
+	switch (a->variant)
+	{
+	case FR_VARIANT_ORIGINAL: hipLaunchKernelGGL((k_emit_regions<FR_VARIANT_ORIGINAL>), grid, block, 0, c.stream, e); break;
+	case FR_VARIANT_FOV_PCHECK_OBB:
+	case FR_VARIANT_MMFR_PCHECK_OBB:
+	case FR_VARIANT_NAIVE_FOV_PCHECK_OBB: hipLaunchKernelGGL((k_emit_regions<FR_VARIANT_FOV_PCHECK_OBB>), grid, block, 0, c.stream, e); break;
+	default: hipLaunchKernelGGL((k_emit_regions<FR_VARIANT_PCHECK_OBB>), grid, block, 0, c.stream, e); break;
+	}
+	return check_launch("emit_regions", c.stream, a->debug);
+}
+
 int launch_emit(FwdCtx &c)
 {
 	const fr_forward_args *a = c.a;
+	// region-major emission when k_bin listed the items by region and every workgroup's segment held them (c.regions_ok: the host's copy
+	// of slab_ctr[5]); the share-per-workgroup kernel below otherwise
+	if (c.regions && c.regions_ok) return launch_emit_regions(c);
 	EmitArgs e;
 	e.P = a->P; e.gx = c.gx; e.gy = c.gy; e.T = c.T; e.radii = a->radii; e.geom = c.geom;
 	e.highest_levels = a->highest_levels; e.tile_lv = c.img.tile_lv; e.lv_bbox = c.img.lv_bbox; e.ranges = c.img.ranges;

@@ -57,6 +57,9 @@ __device__ __forceinline__ void publish_totals(const TileScanArgs &ts, const uin
 		totals_host[0] = total; totals_host[1] = longest; totals_host[2] = h4; totals_host[3] = mid;
 		totals_host[5] = nitems; totals_host[6] = h8; totals_host[7] = pf;
 		totals_host[8] = ts.prefilter_flag[1]; // slab_ctr[1]: the number of cull-pass survivors (fr_forward_args.num_candidates)
+		// slab_ctr[5]: a binning workgroup's region list did not fit its segment (raised with device-scope atomics by workgroups that may
+		// sit on another XCD: read from the memory side)
+		totals_host[9] = __hip_atomic_load(ts.prefilter_flag + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		__threadfence_system();
 		__hip_atomic_store(&totals_host[4], ts.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}

@@ -452,6 +452,7 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
         # own stream -- cost the overlapped frames 12 % (2170 -> 1870-1920 frames/s, tools/overlap9.py) for the 1 % they give a frame
         # that has the GPU to itself (fills and the short lists' sort beside the main stream: 1725 against 1718 frames/s).
         a.no_helper_streams = int(persistent and INFERENCE_NO_HELPER_STREAMS)
+        a.emit_regions = int(bool(EMIT_REGIONS))
         if variant in (_native.VARIANT_PCHECK_OBB_SUM, _native.VARIANT_PCHECK_OBB_MAX, _native.VARIANT_PCHECK_OBB_LWMC) and not no_stats:
             counts = torch.empty((P,), dtype=torch.int32, device=dev)      # zeroed by fr_forward itself
             contribs = torch.empty((P,), dtype=torch.float32, device=dev)
@@ -511,6 +512,9 @@ def invalidate_overlap():
         st.sig = None
 
 
+# Experimental (fovraster.h: fr_forward_args.emit_regions): region-major emission -- same lists, 1.5 x instead of 3.7 x the payload written,
+# slower at present. Off by default.
+EMIT_REGIONS = False
 INFERENCE_NO_HELPER_STREAMS = os.environ.get("FOVRASTER_INFERENCE_HELPERS", "0") != "1"  # (=1: developer A / B runs)
 OVERLAP_SLOTS = max(2, int(os.environ.get("FOVRASTER_OVERLAP_SLOTS", "3")))  # internal streams (and workspace sets) the frames take turns on
 
@@ -571,7 +575,7 @@ def _forward_overlapped(args, kw):
     # argument struct is used again
     rkey = None if outputs else (sig, args[0], int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
                                  int(rs.sh_degree), bool(rs.prefiltered), tuple(sorted((k, v) for k, v in kw.items() if isinstance(v, (int, float, bool)))),
-                                 args[-1] if isinstance(args[-1], float) else None, id(kw.get("packed")))
+                                 args[-1] if isinstance(args[-1], float) else None, id(kw.get("packed")), bool(EMIT_REGIONS))
     if torch.cuda.current_device() == dev.index:
         torch.cuda.set_stream(own)
         try:

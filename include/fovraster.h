@@ -177,6 +177,12 @@ typedef struct fr_forward_args {
 	 * frame at a time). A host that keeps several frames in flight on several streams sets it: a process's streams share a handful of
 	 * hardware queues (four by default), and a frame's helper stream that lands in another frame's queue serialises the two. */
 	int32_t no_helper_streams;
+	/* != 0 (experimental, off by default): region-major emission. The binning kernel also lists its items by screen region (8 x 8 tiles),
+	 * and the instances are placed by workgroups that own a region's tile buckets (k_emit_regions) instead of workgroups that own a
+	 * share of every tile's. Same lists (the order inside a bucket is arbitrary either way; the per-tile sort fixes it). Writes 1.5 x
+	 * the instance payload to HBM where the default kernel writes 3.7 x, and is slower at present; needs 8 P + 1 MB more of
+	 * the geometry workspace (always reserved), tile grids of at most 256 regions, the 32-bit LDS histograms. */
+	int32_t emit_regions;
 } fr_forward_args;
 
 enum { FR_STAGE_TILE_LEVELS = 0, FR_STAGE_PROJECT = 1, FR_STAGE_BIN = 2, FR_STAGE_TILE_SCAN = 3, FR_STAGE_EMIT = 4,

@@ -319,6 +319,16 @@ def _foveated_forward(s6m, gaze_id, layouts=None):
             against_the_contracted_flavour(s6m, "fov_pcheck_obb", s6m.scene_fov, s6m.cam_dict(gaze=gaze, window=owin), got, want, tag)
 
 
+def test_foveated_forward_full_size_region_emission(s6m):
+    """fr_forward_args.emit_regions (experimental): the whole S-6M foveated frame with the instances placed region by region
+    (k_emit_regions) -- radii, every tile's sorted list and the image against the oracle, as for the default emission."""
+    s6m.rz.EMIT_REGIONS = True
+    try:
+        _foveated_forward(s6m, "bench2" if WHOLE else "centre", layouts=(False,))
+    finally:
+        s6m.rz.EMIT_REGIONS = False
+
+
 def _native_lists(s6m, vid, res):
     D, color, radii, geom, binb, img = res[:6]
     view = lambda buf, ptr, count, dtype: buf[ptr - buf.data_ptr():ptr - buf.data_ptr() + 4 * count].view(dtype)

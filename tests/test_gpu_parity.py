@@ -1551,3 +1551,51 @@ def test_successive_inference_frames_overlap_and_stay_identical():
     assert torch.equal(first, want1) and torch.equal(second, want1)
     assert torch.equal(third, want3) and torch.equal(fourth, want4)
     assert float((third - first).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("variant", ["original", "pcheck_obb_sum", "fov_pcheck_obb"])
+def test_region_major_emission_gives_the_same_frame(variant):
+    """fr_forward_args.emit_regions (experimental; rasterizer.EMIT_REGIONS): the instances placed by workgroups that own a screen
+    region's tile buckets (k_emit_regions, from the per-region item lists k_bin's tail leaves) instead of workgroups that own a share of
+    every tile's (k_emit). The order inside a bucket is arbitrary either way and the per-tile sort fixes it: ranges, sorted lists, image
+    and radii are those of the default path bit for bit -- on a cloud with frame-filling splats (an item is listed in every region it
+    reaches), sub-tile splats and a ragged tile grid."""
+    _need_gpu()
+    from fov3dgs_amd import _native, rasterizer as rz
+    dev = torch.device("cuda", 0)
+    cloud = small_cloud(P=40000, seed=23, big_fraction=0.05)
+    with torch.no_grad():
+        cloud._scaling[:40] += 3.0  # frame-filling splats: every region
+    cam = syn.camera_1k(1000, 600).to(dev)   # 63 x 38 tiles: 8 x 5 regions, the last ones cut off
+    W, H = 1000, 600
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    fov = syn.foveation_layers(cloud, seed=24)
+    cloud = cloud.to(dev)
+    rs = rz.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.tensor([0.1, 0.2, 0.3], device=dev), 1.0,
+                                          cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
+    vid, E = _native.VARIANT_IDS[variant], torch.Tensor([])
+    lib = _native.load()
+    res = []
+    for regions in (False, True):
+        rz.EMIT_REGIONS = regions
+        try:
+            with torch.no_grad():
+                if variant == "fov_pcheck_obb":
+                    hl, dcs, op4 = [t.to(dev) for t in fov]
+                    r = rz._forward_native(vid, rs, cloud.get_xyz, cloud.get_rest_features.contiguous(), E, op4, cloud.get_scaling, cloud.get_rotation, E, dcs, hl,
+                                           (0.4, 0.55), 0.05)
+                else:
+                    r = rz._forward_native(vid, rs, cloud.get_xyz, cloud.get_features, E, cloud.get_opacity, cloud.get_scaling, cloud.get_rotation, E)
+                torch.cuda.synchronize()
+        finally:
+            rz.EMIT_REGIONS = False
+        D, color, radii, geom, binb, img = r[:6]
+        off = lib.fr_image_ranges(vid, W, H, img.data_ptr()) - img.data_ptr()
+        ranges = img[off:off + 8 * T].view(torch.int32).clone()
+        poff = lib.fr_binning_point_list(vid, D, binb.data_ptr()) - binb.data_ptr()
+        plist = binb[poff:poff + 4 * D].view(torch.int32).clone()
+        res.append((D, color.clone(), radii.clone(), ranges, plist))
+    a, b = res
+    assert a[0] == b[0] and a[0] > 200_000
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
