@@ -1019,6 +1019,33 @@ def multi_gpu_extras(args, rank, world, dev, cloud, cam, bg, multiview, render_p
     t = torch.tensor([el, fb, co], device=dev, dtype=torch.float64)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     el, fb, co = [float(x) for x in t.tolist()]
+    # the same steps with the dense exchange started INSIDE the backward pass (multiview.OverlappedGradientExchange): the step's
+    # forward-to-summed-gradients time and what of the exchange stayed exposed behind the backward pass's own kernels
+    overlapped = None
+    try:
+        named = {"means3D": tr._xyz, "opacities": tr._opacity, "scales": tr._scaling, "rotations": tr._rotation, "sh": tr._features_dc, "sh_rest": tr._features_rest}
+        oev, exps = [], []
+        for it in range(2 + n_train):
+            for p_ in params:
+                p_.grad = None
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o = render_plain(cam, tr, Pipe(), bg, cuda_type="pcheck_obb_sum")
+            loss = l1_ssim_loss(o["render"], target, 0.2)
+            ex = multiview.OverlappedGradientExchange(named, ranges=4)
+            with ex:
+                loss.backward()
+            e1.record()
+            if it >= 2:
+                oev.append((e0, e1))
+                exps.append(ex)
+        barrier_sync()
+        t2 = torch.tensor([float(np.median([a_.elapsed_time(b_) for a_, b_ in oev])), float(np.median([x_.exposed_ms() or 0.0 for x_ in exps]))],
+                          device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
+        overlapped = dict(step_ms=round(float(t2[0]), 4), collective_exposed_ms=round(float(t2[1]), 4), ranges=4)
+    except Exception as e:  # (a diagnosis must not take the line down)
+        overlapped = f"failed: {e}"
     for p_ in params:
         p_.grad = None
     tr.requires_grad_(False)
@@ -1045,8 +1072,10 @@ def multi_gpu_extras(args, rank, world, dev, cloud, cam, bg, multiview, render_p
     out["multiview_train"] = dict(fwd_bwd_ms=round(fb, 4), collective_ms=round(co, 4), backend=torch.distributed.get_backend(),
                                   collective=dict(info or {}, algbw_GBs=None if algbw is None else round(algbw, 2),
                                                   busbw_GBs=None if algbw is None else round(algbw * 2 * (world - 1) / world, 2)),
+                                  overlapped_exchange=overlapped,
                                   note=f"median of {n_train} steps: pcheck_obb_sum forward + fused L1+SSIM + backward of this rank's camera, then "
-                                       "multiview.allreduce_gradients over the ranks (max over ranks)")
+                                       "multiview.allreduce_gradients over the ranks (max over ranks); overlapped_exchange: the dense sum started inside the "
+                                       "backward pass (step_ms = forward to summed gradients; fwd_bwd_ms + collective_ms is the same span without it)")
     return out
 
 
