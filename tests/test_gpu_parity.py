@@ -1551,6 +1551,29 @@ def test_successive_inference_frames_overlap_and_stay_identical():
     assert torch.equal(first, want1) and torch.equal(second, want1)
     assert torch.equal(third, want3) and torch.equal(fourth, want4)
     assert float((third - first).abs().max()) > 1e-3
+    # (e) a caller on a stream of its own, two models taking turns (every call sees other inputs than the call before it: each waits
+    # for the caller's stream), and two image sizes taking turns (the internal streams' workspaces grow under them)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    cam_small = syn.camera_1k(320, 200).to(dev)
+    with torch.no_grad(), torch.cuda.stream(side):
+        seq = []
+        for i in range(12):
+            op = opac if i % 2 == 0 else op3
+            c = cam if i % 3 else cam_small
+            o = render_fov(c, pc, bg, opacities=op, alpha=0.05, gazeArray=gazes[i], blending=True, highest_levels=highest, shs_dcs=shs_dcs)
+            seq.append((i, o["render"], o["radii"]))
+        side.synchronize()
+        rz.OVERLAP_SUCCESSIVE_FRAMES = False
+        try:
+            for i, img, rad in seq:
+                op = opac if i % 2 == 0 else op3
+                c = cam if i % 3 else cam_small
+                o = render_fov(c, pc, bg, opacities=op, alpha=0.05, gazeArray=gazes[i], blending=True, highest_levels=highest, shs_dcs=shs_dcs)
+                assert torch.equal(o["render"], img) and torch.equal(o["radii"], rad), i
+        finally:
+            rz.OVERLAP_SUCCESSIVE_FRAMES = True
+        side.synchronize()
 
 
 @pytest.mark.parametrize("variant", ["original", "pcheck_obb_sum", "fov_pcheck_obb"])
