@@ -1575,6 +1575,13 @@ struct EmitArgs {
 #endif
 // LDSH == 2 (see k_bin): the LDS cursors are 16-bit offsets inside the workgroup's share, two tiles per word; where the share
 // starts comes from global memory with every entry
+#ifdef FR_EMIT_NOSTORE
+#define FR_EMIT_ST(slot, v) do { if ((slot) == 0xffffffffu) a.entries[0] = (v); } while (0) // (timing experiment: the cursors are bumped, nothing is stored)
+#elif defined(FR_EMIT_COALESCED)
+#define FR_EMIT_ST(slot, v) do { (void)(slot); a.entries[(size_t)blockIdx.x * 20000 + (threadIdx.x & ~63u) * 26u + ((uint32_t)tm_seq++ * 64u + lane) % 1600u] = (v); } while (0) // (timing experiment: a wave's entries to consecutive slots of its own)
+#else
+#define FR_EMIT_ST(slot, v) a.entries[(slot)] = (v)
+#endif
 #define NEXT_SLOT(ti) (LDSH == 2 ? a.ranges[(ti)].x + pre_row[(ti)] + ((atomicAdd(&lds_cur[(ti) >> 1], 1u << (16 * ((ti) & 1))) >> (16 * ((ti) & 1))) & 0xffffu) \
 	: LDSH ? atomicAdd(&lds_cur[(ti)], 1u) : a.ranges[(ti)].x + atomicAdd(&a.cursor[(ti)], 1u))
 template <int VARIANT, int LDSH>
@@ -1584,12 +1591,15 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	constexpr bool FOV = VARIANT == FR_VARIANT_FOV_PCHECK_OBB;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
 #ifdef FR_EMIT_TIMERS
-	const uint64_t tm_entry = wall_clock64(); uint64_t tm_pro = 0, tm_loop = 0, tm_walk = 0, tm_big = 0; int tm_slabs = 0, tm_steps = 0;
+	const uint64_t tm_entry = wall_clock64(); uint64_t tm_pro = 0, tm_loop = 0, tm_walk = 0, tm_big = 0, tm_drain = 0, tm_pre = 0, tm_mid = 0, tm_ta = 0; int tm_slabs = 0, tm_steps = 0;
 #endif
 	// launched before the host knows the frame's instance count (fr_forward): when the binning workspace turns out too
 	// small nothing is emitted, the host replays the stage with a larger one
 	if (a.totals[0] > a.capacity || a.totals[5] > a.items_cap) return;
 	const int lane = threadIdx.x & 63;
+#ifdef FR_EMIT_COALESCED
+	uint32_t tm_seq = 0;
+#endif
 	// RF: the tiles' levels as k_bin keeps them: four bits per tile, min(max(int(tile_min), 0), 7) (the filter compares
 	// with an integer; exact for highest levels 0..3, k_project says if it saw another: then the floats in global memory)
 	const int cur_words = LDSH == 2 ? (a.T + 1) / 2 : (LDSH ? a.T : 0);
@@ -1663,7 +1673,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 				if (FOV) pass = pass && TILE_PASSES(ti, olim);
 				pass = pass && obb_hits_tile(ob, x, y);
 			}
-			if (pass) a.entries[NEXT_SLOT(ti)] = opay;
+			if (pass) FR_EMIT_ST(NEXT_SLOT(ti), opay);
 		}
 	};
 	const int V = (int)a.geom.slab_ctr[1];
@@ -1708,7 +1718,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 	// so the per-tile sort by (depth bits, item) gives the reference's stable order
 	const uint64_t payload = ((uint64_t)depth_bits << 32) | (uint32_t)item;
 	const bool in_place = alive && tnum == 1 && !boxtest; // survived k_bin's level test, no box test (single-tile splat)
-	if (in_place) a.entries[NEXT_SLOT(y0 * a.gx + x0)] = payload;
+	if (in_place) FR_EMIT_ST(NEXT_SLOT(y0 * a.gx + x0), payload);
 	{
 		bool deferred = false;
 		if (alive && !in_place && tnum >= FR_GIANT_TNUM)
@@ -1719,7 +1729,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		// big splats: whole wave, wave-uniform owner (see k_bin)
 		const bool big = alive && !in_place && !deferred && tnum >= FR_BIG_TNUM;
 #ifdef FR_EMIT_TIMERS
-		const uint64_t tg0 = wall_clock64();
+		const uint64_t tg0 = wall_clock64(); tm_pre += tg0 - tm_ta;
 #endif
 		for (unsigned long long bigm = __ballot(big); bigm; bigm &= bigm - 1)
 		{
@@ -1732,7 +1742,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 			walk_uniform(ox0, oy0, ow, (uint32_t)bcast_i((int)tnum, L), ob, bcast_f(hl, L) + 1, opay, 0u, 64u);
 		}
 #ifdef FR_EMIT_TIMERS
-		tm_big += wall_clock64() - tg0;
+		const uint64_t tg1 = wall_clock64(); tm_big += tg1 - tg0;
 #endif
 		const uint32_t my_n = (alive && !in_place && !big && !deferred) ? tnum : 0u;
 		const uint32_t incl = wave_incl_scan_u32(my_n, lane);
@@ -1744,7 +1754,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		// pulled thirteen registers through ds_bpermute, divided twice and rebuilt the box per pair: 60 of the kernel's 104 us)
 		float4 *const orec = s_orec + 4 * (threadIdx.x & ~63);
 #ifdef FR_EMIT_TIMERS
-		const uint64_t tw0 = wall_clock64(); tm_steps += (int)((total + 63) / 64);
+		const uint64_t tw0 = wall_clock64(); tm_steps += (int)((total + 63) / 64); tm_mid += tw0 - tg1;
 #endif
 		if (total != 0)
 		{
@@ -1795,7 +1805,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 					pass = pass && cx_ok && cy_ok && e1_ok && e2_ok;
 				}
 			}
-			if (pass) a.entries[NEXT_SLOT(ti)] = opay;
+			if (pass) FR_EMIT_ST(NEXT_SLOT(ti), opay);
 		}
 		if (total != 0)
 		{
@@ -1830,10 +1840,16 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 #endif
 		for (; slab < nslabs; )
 		{
+#ifdef FR_EMIT_TIMERS
+			tm_ta = wall_clock64();
+#endif
 			const int next = grab();
 			const bool more = next < nslabs;
 			if (more) fetch_slab(next, nxt);
 			process(slab, cur);
+#ifdef FR_EMIT_TIMERS
+			{ const uint64_t td0 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tm_drain += wall_clock64() - td0; }
+#endif
 			if (more) cur = nxt;
 			slab = next;
 #ifdef FR_EMIT_TIMERS
@@ -1855,7 +1871,7 @@ __global__ void __launch_bounds__(FR_EMIT_THREADS) k_emit(const EmitArgs a)
 		// covariance rows the inference variants do not use
 		float *d = a.geom.cov3D + (size_t)((int)blockIdx.x * (FR_EMIT_THREADS / 64) + (int)(threadIdx.x >> 6)) * 8;
 		d[0] = (float)(wall_clock64() - tm_entry); d[1] = (float)tm_pro; d[2] = (float)tm_loop; d[3] = (float)(wall_clock64() - tb0);
-		d[4] = (float)tm_slabs; d[5] = (float)tm_steps; d[6] = (float)tm_walk; d[7] = (float)tm_big;
+		d[4] = (float)tm_slabs; d[5] = (float)tm_steps; d[6] = (float)tm_walk; d[7] = (float)tm_big; d[3] = (float)tm_drain; d[1] = (float)tm_pre; d[4] = (float)tm_mid; // (developer layout: d[1] grab + fetch issue + unpack + single-tile stores, d[3] the wait for the slab's stores / the next records, d[4] scan + owner rows)
 	}
 #endif
 	const int ng = min((int)s_ng, FR_GIANT_MAX);

@@ -28,12 +28,12 @@ geom = r[3]
 off = (P * 48 + 255) // 256 * 256
 nw = 256 * 12
 t = geom[off:off + nw * 32].view(torch.float32).view(nw, 8).cpu().numpy()
-t[:, [0, 1, 2, 3, 6, 7]] *= 0.01  # 10-ns ticks -> us (columns 4, 5 are counts)
-live = t[:, 4] > 0
-print(f"waves {nw}, with slabs {int(live.sum())}; slabs/wave mean {t[live, 4].mean():.2f} max {t[live, 4].max():.0f}; pair steps/wave mean {t[live, 5].mean():.1f} max {t[live, 5].max():.0f}")
-for name, c in (("total to barrier", 0), ("prologue", 1), ("slab loop", 2), ("pair loop part", 6), ("big splats part", 7)):
+t[:, [0, 1, 2, 3, 4, 6, 7]] *= 0.01  # 10-ns ticks -> us (column 5 is a count)
+live = t[:, 5] > 0
+print(f"waves {nw}; pair steps/wave mean {t[live, 5].mean():.1f} max {t[live, 5].max():.0f}")
+for name, c in (("total to barrier", 0), ("grab+fetch+unpack+single-tile stores", 1), ("scan + owner rows", 4), ("slab loop", 2), ("pair loop part", 6), ("big splats part", 7), ("vmcnt(0) at slab end", 3)):
     v = t[live, c]
     print(f"{name:18s} us: mean {v.mean():7.2f} p50 {np.percentile(v, 50):7.2f} p90 {np.percentile(v, 90):7.2f} max {v.max():7.2f}")
-print("per slab us (slab loop / slabs): mean %.2f; per pair step us: %.3f" % ((t[live, 2] / t[live, 4]).mean(), t[live, 6].sum() / max(t[live, 5].sum(), 1)))
+print("per pair step us: %.3f" % (t[live, 6].sum() / max(t[live, 5].sum(), 1)))
 wg = t[:, 0].reshape(256, 12)
 print("workgroup time to barrier: slowest wave per workgroup mean %.1f max %.1f; mean over waves %.1f" % (wg.max(1).mean(), wg.max(), wg.mean()))
