@@ -386,9 +386,14 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
     a = _native.ForwardArgs()
     keep = []
 
+    own = []  # the tensors this call MADE (converted copies): what the argument struct must keep alive if it is used again
+
     def put(name, t, small=False):
+        src = t
         t = _f32_small(t, dev, sh_) if small else _f32(t, dev)
         keep.append(t)
+        if t is not None and t is not src:
+            own.append(t)
         setattr(a, name, _ptr(t))
         return t
 
@@ -467,7 +472,9 @@ def _forward_begin(variant, rs, means3D, sh, colors_precomp, opacities, scales, 
     if reuse is not None:
         reuse.clear()
         if reuse_key is not None and counts is None and lease is None:  # (no per-call outputs beside the image and the radii)
-            reuse.update(key=reuse_key, a=a, keep=keep, ws=ws)
+            # (the caller's own tensors are NOT kept: the key vouches that the caller still holds the very objects the pointers
+            # belong to; keeping them here would pin a dropped model's gigabytes until the next call)
+            reuse.update(key=reuse_key, a=a, keep=own, ws=ws)
     return FrameInFlight(lib, a, keep, color, radii, ws, lease, counts, contribs, handle, dev, stream)
 
 
@@ -536,6 +543,11 @@ def _input_signature(tensors):
     return tuple((id(t), t._version, t.data_ptr(), tuple(t.shape), t.stride()) for t in tensors)
 
 
+def _packed_key(pk):
+    """what a PackedModel is to a reused argument struct: its three buffers' addresses (an id() could be another object's by now)"""
+    return None if pk is None else tuple(None if t is None else t.data_ptr() for t in (pk.geom, pk.colour, pk.cull))
+
+
 def _forward_overlapped(args, kw):
     """_forward_begin + finish of an inference call on the next internal stream (see above). -> the result tuple of _forward_native."""
     rs, tensors = args[1], [t for t in args if isinstance(t, torch.Tensor) and t.numel() > 0]
@@ -575,7 +587,7 @@ def _forward_overlapped(args, kw):
     # argument struct is used again
     rkey = None if outputs else (sig, args[0], int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
                                  int(rs.sh_degree), bool(rs.prefiltered), tuple(sorted((k, v) for k, v in kw.items() if isinstance(v, (int, float, bool)))),
-                                 args[-1] if isinstance(args[-1], float) else None, id(kw.get("packed")), bool(EMIT_REGIONS))
+                                 args[-1] if isinstance(args[-1], float) else None, _packed_key(kw.get("packed")), bool(EMIT_REGIONS))
     if torch.cuda.current_device() == dev.index:
         torch.cuda.set_stream(own)
         try:
