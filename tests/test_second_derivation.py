@@ -106,3 +106,28 @@ def test_fma_contraction_envelope_small_frames(variant):
     assert tot["radii_differ"] <= 1e-3 * tot["gaussians"], tot
     assert tot["instances_in_one_only"] <= 1e-3 * tot["instances_a"], tot
     assert tot["values_gt_1e4"] <= 1e-4 * tot["values"], tot
+
+
+def test_numpy_twin_random_sweep():
+    """Thirty random small frames -- cloud size, seed, image shape (ragged tile grids down to 3 x 3 tiles), gaze inside and outside
+    the frame, alpha 0.02 / 0.05 / 0.2, SH degree 0..3, scale modifier -- through both derivations: radii, tile counts, ranges,
+    sorted lists (and, foveated, tile_min and the level ranges) array-equal in float32, images within last-bit rounding."""
+    rng = np.random.default_rng(2026)
+    for it in range(30):
+        variant = ("pcheck_obb", "pcheck_obb_sum", "fov_pcheck_obb")[it % 3]
+        P, seed = int(rng.integers(200, 3000)), int(rng.integers(0, 10000))
+        w, h = int(rng.integers(40, 400)), int(rng.integers(40, 300))
+        gaze = (float(rng.uniform(-0.2, 1.2)), float(rng.uniform(-0.2, 1.2)))
+        alpha = float(rng.choice([0.02, 0.05, 0.2]))
+        scene, cam = small_case(variant, P=P, seed=seed, gaze=gaze, alpha=alpha, width=w, height=h)
+        cam["sh_degree"] = int(rng.integers(0, 4))
+        cam["scale_modifier"] = float(rng.choice([1.0, 0.5, 1.7]))
+        o, n = orc.forward(variant, scene, cam), npr.rasterize(variant, scene, cam, np.float32)
+        tag = f"case {it}: {variant} P={P} seed={seed} {w}x{h} gaze={gaze} alpha={alpha} deg={cam['sh_degree']} mod={cam['scale_modifier']}"
+        for k in ("radii", "tiles_touched", "ranges", "point_list"):
+            np.testing.assert_array_equal(n[k], o[k], err_msg=tag + " " + k)
+        if variant == "fov_pcheck_obb":
+            vis = o["radii"] > 0
+            np.testing.assert_array_equal(n["tile_min"], o["tile_min"], err_msg=tag)
+            np.testing.assert_array_equal(n["level_ranges"][vis], o["level_ranges"][vis], err_msg=tag)
+        assert np.abs(n["color"] - o["color"]).max() <= 5e-6, tag
