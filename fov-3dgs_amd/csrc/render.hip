@@ -117,13 +117,11 @@ __device__ __forceinline__ void blend2(Px2 &s, bool in_x, bool in_y, v2f e, floa
 // `ok` = the two skip tests of the reference that do not depend on T (outside the support, alpha < 1/255) as ONE comparison made by
 // the caller. Two compares + four selects per pixel instead of four + three: a v_cmp costs two plain VALU slots on gfx950.
 struct Px2k { v2f T, Tk, C0, C1, C2; };
-// ALPHATEST: `ok` only holds the support test, the alpha < 1/255 skip is made here (the _max flavour counts pixels between the two)
-template <bool CLAMP, bool ALPHATEST = false>
+template <bool CLAMP>
 __device__ __forceinline__ void blend2k(Px2k &s, bool ok_x, bool ok_y, v2f e, float4 c, v2f &w_out, bool &acc_xo, bool &acc_yo)
 {
 	v2f alpha = c.w * e;
 	if (CLAMP) { alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y); }
-	if (ALPHATEST) { ok_x = ok_x && !(alpha.x < 1.0f / 255.0f); ok_y = ok_y && !(alpha.y < 1.0f / 255.0f); }
 	const v2f tt = s.T * (1.0f - alpha);
 	v2f w = alpha * s.T;
 	const bool sat_x = tt.x < 0.0001f, sat_y = tt.y < 0.0001f;
@@ -211,6 +209,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 	__shared__ float4 s1[64];
 	__shared__ float2 s2[64];   // b, tq: the threshold on q = -power below which a pixel takes part (see the staging)
 	__shared__ int sid[NEEDID ? 64 : 1];
+	__shared__ int stqa[PMAX ? 64 : 1]; // _max: the alpha test's threshold on q beside the support's (see the staging)
 
 	const int st = threadIdx.x; // lane = staging slot
 	if (blockIdx.x >= a.totals[5] || a.totals[0] > a.capacity || a.totals[5] > gridDim.x) return;
@@ -301,7 +300,9 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		// power > 0, (CUTOFF) power < -4.5, and alpha = o e^-q < 1/255 <=> q > ln(255 o): a pixel takes part iff 0 <= q <= tq with
 		// tq = min(4.5, ln(255 o)), one unsigned comparison on q's bits. ln(255 o) to an ulp (logf): the decision then differs from the
 		// reference's own fp32 evaluation of o * exp(power) < 1/255 only inside that expression's rounding, like the exp2-based test it
-		// replaces. The _max flavour counts pixels between the support test and the alpha test: its threshold is the support's alone.
+		// replaces. The _max flavour counts pixels between the support test and the alpha test: tq is the support's alone there, and the
+		// alpha test is a second threshold of the same form (stqa; -1 = no pixel passes, compared as signed integers: q >= 0 inside the
+		// support) -- the one k_render_bwd applies, so both passes blend the same pairs in this variant too.
 		const float lq = logf(255.0f * p1.y);
 		// (lq >= 0 is false for the NaN of a negative opacity: such an entry takes part nowhere, as alpha < 1/255 says in the reference)
 		const float tq = PMAX ? 4.5f : (lq >= 0.0f ? (CUTOFF ? fminf(4.5f, lq) : lq) : 0.0f);
@@ -309,6 +310,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		{
 			s0[st] = p0; s1[st] = p1; s2[st] = make_float2(p2, tq);
 			if (NEEDID) sid[st] = (int)pgid;
+			if (PMAX) stqa[st] = __float_as_int(lq >= 0.0f ? fminf(4.5f, lq) : -1.0f);
 		}
 		unsigned long long reach_own;
 		{
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 		// Entries are taken FR_RENDER_GROUP_PLAIN at a time: the part that does not depend on the running transmittance
 		// (record fetch, power, support test, exp) is evaluated for all of them before the first one is blended,
 		// so their dependency chains overlap (see k_render_fov).
-		struct Ent { v2f e[HP]; bool inx[HP], iny[HP]; float4 col; int j; };
+		struct Ent { v2f e[HP]; bool inx[HP], iny[HP], okx[HP], oky[HP]; float4 col; int j; };
 		auto prepare = [&](const int j, const bool valid)
 		{
 			Ent t;
@@ -355,6 +357,9 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 				const v2f q = qform2(g0.y - pyp[h], g1.x, adx2, bdx);
 				t.inx[h] = valid && __float_as_uint(q.x) <= tqb; // 0 <= q <= tq
 				t.iny[h] = valid && __float_as_uint(q.y) <= tqb;
+				// (_max: inx / iny = inside the support, what the count takes; okx / oky = ... and alpha >= 1/255, what is blended)
+				t.okx[h] = PMAX ? t.inx[h] && __float_as_int(q.x) <= stqa[j] : t.inx[h];
+				t.oky[h] = PMAX ? t.iny[h] && __float_as_int(q.y) <= stqa[j] : t.iny[h];
 				t.e[h] = exp_neg_pair(q);
 			}
 			t.col = make_float4(g1.z, g1.w, g2.x, g1.y); // r, g, b, opacity
@@ -378,7 +383,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderArgs a)
 			for (int h = 0; h < HP; h++)
 			{
 				v2f w; bool ax, ay;
-				blend2k<true, PMAX>(S[h], t.inx[h], t.iny[h], t.e[h], t.col, w, ax, ay);
+				blend2k<true>(S[h], t.okx[h], t.oky[h], t.e[h], t.col, w, ax, ay);
 				if (AUX)
 				{
 					last[2 * h] = ax ? (uint32_t)(base + j + 1) : last[2 * h];

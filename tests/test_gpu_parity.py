@@ -120,6 +120,38 @@ def test_pruning_metric_variants(variant):
         check_grad(gb[k].reshape(wb[k].shape), wb[k], k)
 
 
+def test_max_variant_blends_the_pairs_the_backward_pass_takes():
+    """pcheck_obb_max counts pixels BEFORE the alpha test, so its forward blend kept the reference's own form of that test
+    while k_render_bwd (shared by the training variants) decides by the threshold on q. Now the _max blend applies the same threshold
+    (a second one beside the support's): its image, final_T and n_contrib are the training variant's BIT FOR BIT on a cloud whose
+    opacities crowd the 1/255 line, and its gradients those of the training variant. (A guard on the structure -- one test, one blend
+    function, entries that pass nowhere -- more than on the rounding: a flip needs a pair within an ulp of the line, a few per whole
+    1080p frame, and the previous library happens to pass on this scene too.)"""
+    _need_gpu()
+    from tests.gpu_helpers import hip_backward, hip_forward
+    scene, cam = small_case("pcheck_obb_max", P=30000, seed=21, width=960, height=544)
+    rng = np.random.default_rng(3)
+    op = np.asarray(scene["opacities"], np.float32).copy()
+    low = rng.random(op.shape[0]) < 0.6
+    op[low, 0] = rng.uniform(0.5 / 255.0, 6.0 / 255.0, int(low.sum())).astype(np.float32)   # alpha = o e^-q crosses 1/255 inside the splat
+    op[rng.random(op.shape[0]) < 0.02, 0] = -0.1                                            # ... and a few that pass nowhere
+    scene = dict(scene, opacities=op)
+    a = hip_forward("pcheck_obb_max", scene, cam)
+    b = hip_forward("pcheck_obb_sum", scene, cam)
+    assert a["num_rendered"] == b["num_rendered"] > 100_000
+    np.testing.assert_array_equal(a["point_list"], b["point_list"])
+    np.testing.assert_array_equal(a["color"], b["color"])
+    np.testing.assert_array_equal(a["final_T"], b["final_T"])
+    np.testing.assert_array_equal(a["n_contrib"], b["n_contrib"])
+    want = orc.forward("pcheck_obb_max", scene, cam)
+    check_image(a["color"], want["color"])
+    assert np.mean(a["gaussians_count"] != want["gaussians_count"]) <= 2e-3   # the support count is untouched by the alpha threshold
+    dpix = rng.normal(size=a["color"].shape).astype(np.float32)
+    ga, gb = hip_backward("pcheck_obb_max", a, dpix), hip_backward("pcheck_obb_sum", b, dpix)
+    for k in ("dL_dmean3D", "dL_dsh", "dL_dscale", "dL_drot", "dL_dopacity"):
+        check_grad(ga[k], gb[k], k + " (_max against _sum)")
+
+
 @pytest.mark.parametrize("variant", ("original", "pcheck_obb_sum"))
 def test_backward_matches_oracle(variant):
     _need_gpu()
